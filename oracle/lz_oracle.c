@@ -1,0 +1,339 @@
+/*
+ * lz_oracle.c — CPU restatement of the LZ-ANI pairwise parse (TEST INFRASTRUCTURE ONLY).
+ *
+ * Reference call site: vclust.py:1142-1181 (`lz-ani all2all --mal 11 --msl 7 --mrd 40
+ * --mqd 40 --reg 35 --aw 15 --am 7 --ar 3`).  The native source (3rd_party/lz-ani,
+ * .gitmodules:4-6) is absent from the checkout, so this file restates the published
+ * LZ-ANI algorithm and was fitted, rule by rule, to the 5 693 golden regions of
+ * example/output/ani.aln.tsv (see DESIGN.md "LZ parse rules" for the evidence per rule):
+ *
+ *   R1  reference = forward strand | N | reverse complement (query is never reversed).
+ *   R2  at every query position i (left to right) look for an ANCHOR: the longest exact
+ *       match >= mal over all occurrences of the mal-mer q[i..] in the reference, ties ->
+ *       smallest reference position.  The anchor search runs whether or not a prediction
+ *       is alive; an anchor within +-mrd of the prediction continues the region, any
+ *       other anchor closes the region and opens a new one.
+ *   R3  if no anchor and a prediction is alive, look for a SEED: exact match >= msl whose
+ *       reference position p satisfies  pred0 <= p  and  p - pred < mrd, where pred0 is
+ *       the reference end of the previous match and pred = pred0 + literals skipped;
+ *       longest wins, ties -> smallest position.
+ *   R4  after every match an approximate extension walks the diagonal while the last aw
+ *       symbols hold <= am mismatches and is cut back to the end of the last run of >= ar
+ *       matches.
+ *   R5  a new region is first extended to the left by the maximal exact match, then by the
+ *       same approximate rule, never crossing the end of the last KEPT region.
+ *   R6  more than mqd literals without a match drop the prediction.
+ *   R7  query symbols between two chained matches are scored on the old diagonal.
+ *   R8  a region is kept when its query span >= reg; nt_mismatch = span - nt_match.
+ */
+#include "vclust_oracle.h"
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+
+struct vo_ref_index {
+    int64_t  len;        /* forward length */
+    int64_t  n_rr;       /* total RR symbols incl. padding */
+    int64_t  rc_off;     /* start of reverse complement part */
+    uint8_t* rr;         /* fwd | N*sep | rc | N*pad */
+    int      mal, msl;
+    /* anchor table: open addressing, positions in insertion (ascending) order */
+    uint32_t  a_mask;
+    int32_t*  a_tab;     /* -1 = empty */
+    uint64_t* a_code;    /* per position mal-mer code or UINT64_MAX */
+    /* seed table: CSR over 4^msl */
+    int32_t*  s_off;     /* 4^msl + 1 */
+    int32_t*  s_pos;
+};
+
+void vo_lz_default_variant(vo_lz_variant* v) {
+    memset(v, 0, sizeof(*v));
+    v->sep_len = 1;
+    v->anchor_while_predicting = 2;  /* R2: anchor search first, always */
+    v->bwd_bound_kept = 1;           /* R5 */
+    v->bwd_exact_first = 1;          /* R5 */
+    v->seed_window = 2;              /* R3 */
+    v->seed_back = 0;
+    v->seed_fwd = -1;                /* -1: mrd - 1 */
+    v->seed_choice = 0;
+    v->lit_reset_ge = 0;             /* R6: '>' */
+    v->gap_mode = 0;                 /* R7 */
+    v->fwd_after_close = 1;
+    v->loop_le = 0;
+    v->anchor_tie = 0;
+    v->reg_on_span = 1;
+    v->rend_mode = 2;
+    v->trace = 0;
+}
+
+static inline uint64_t mix64(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33;
+    x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33; return x;
+}
+
+/* per-position codes of all w-mers of s (UINT64_MAX where a symbol > 3 occurs) */
+static void kmer_codes(const uint8_t* s, int64_t n, int w, uint64_t* out) {
+    uint64_t mask = (w >= 32) ? ~0ULL : ((1ULL << (2 * w)) - 1);
+    uint64_t code = 0; int valid = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (s[i] > 3) { valid = 0; code = 0; }
+        else { code = ((code << 2) | s[i]) & mask; ++valid; }
+        if (i >= w - 1) out[i - w + 1] = (valid >= w) ? code : UINT64_MAX;
+    }
+    for (int64_t i = (n - w + 1 > 0 ? n - w + 1 : 0); i < n; ++i) out[i] = UINT64_MAX;
+}
+
+vo_ref_index* vo_lz_build_index(const uint8_t* ref, int64_t len,
+                                const vo_lz_params* p, const vo_lz_variant* v) {
+    vo_ref_index* ix = (vo_ref_index*)calloc(1, sizeof(*ix));
+    int sep = v->sep_len > 0 ? v->sep_len : 1;
+    int pad = p->mrd + p->mal + 8;
+    ix->len = len; ix->mal = p->mal; ix->msl = p->msl;
+    ix->rc_off = len + sep;
+    ix->n_rr = 2 * len + sep + pad;
+    ix->rr = (uint8_t*)malloc(ix->n_rr);
+    memset(ix->rr, VO_NREF, ix->n_rr);
+    for (int64_t i = 0; i < len; ++i) {
+        uint8_t c = ref[i] > 3 ? VO_NREF : ref[i];
+        ix->rr[i] = c;
+        ix->rr[ix->rc_off + (len - 1 - i)] = c > 3 ? VO_NREF : (uint8_t)(3 - c);
+    }
+    int64_t n = ix->n_rr;
+    /* anchors */
+    ix->a_code = (uint64_t*)malloc(sizeof(uint64_t) * n);
+    kmer_codes(ix->rr, n, p->mal, ix->a_code);
+    int64_t cnt = 0;
+    for (int64_t i = 0; i < n; ++i) cnt += ix->a_code[i] != UINT64_MAX;
+    uint32_t sz = 16; while (sz < (uint64_t)cnt * 3) sz <<= 1;
+    ix->a_mask = sz - 1;
+    ix->a_tab = (int32_t*)malloc(sizeof(int32_t) * sz);
+    memset(ix->a_tab, 0xff, sizeof(int32_t) * sz);
+    for (int64_t i = 0; i < n; ++i) {
+        if (ix->a_code[i] == UINT64_MAX) continue;
+        uint32_t h = (uint32_t)mix64(ix->a_code[i]) & ix->a_mask;
+        while (ix->a_tab[h] >= 0) h = (h + 1) & ix->a_mask;
+        ix->a_tab[h] = (int32_t)i;
+    }
+    /* seeds */
+    if (p->msl > 12) { fprintf(stderr, "oracle: msl > 12 unsupported\n"); abort(); }
+    int64_t nb = 1LL << (2 * p->msl);
+    uint64_t* sc = (uint64_t*)malloc(sizeof(uint64_t) * n);
+    kmer_codes(ix->rr, n, p->msl, sc);
+    ix->s_off = (int32_t*)calloc(nb + 1, sizeof(int32_t));
+    for (int64_t i = 0; i < n; ++i) if (sc[i] != UINT64_MAX) ix->s_off[sc[i] + 1]++;
+    for (int64_t b = 0; b < nb; ++b) ix->s_off[b + 1] += ix->s_off[b];
+    ix->s_pos = (int32_t*)malloc(sizeof(int32_t) * (ix->s_off[nb] + 1));
+    int32_t* cur = (int32_t*)malloc(sizeof(int32_t) * nb);
+    memcpy(cur, ix->s_off, sizeof(int32_t) * nb);
+    for (int64_t i = 0; i < n; ++i) if (sc[i] != UINT64_MAX) ix->s_pos[cur[sc[i]]++] = (int32_t)i;
+    free(cur); free(sc);
+    return ix;
+}
+
+void vo_lz_free_index(vo_ref_index* ix) {
+    if (!ix) return;
+    free(ix->rr); free(ix->a_tab); free(ix->a_code); free(ix->s_off); free(ix->s_pos); free(ix);
+}
+
+int64_t vo_rr_to_fwd1(const vo_ref_index* ix, int64_t p) {
+    if (p < ix->len) return p + 1;
+    return ix->len - (p - ix->rc_off);   /* 1-based forward coordinate of an rc position */
+}
+int vo_rr_is_rev(const vo_ref_index* ix, int64_t p) { return p >= ix->rc_off; }
+
+typedef struct {
+    const vo_ref_index* ix;
+    const uint8_t* q; int64_t qn;
+    const vo_lz_params* p; const vo_lz_variant* v;
+} pctx;
+
+static inline int64_t equal_len(const pctx* c, int64_t rpos, int64_t qpos) {
+    int64_t m = c->ix->n_rr - rpos; if (c->qn - qpos < m) m = c->qn - qpos;
+    int64_t l = 0;
+    while (l < m && c->ix->rr[rpos + l] == c->q[qpos + l]) ++l;
+    return l;
+}
+
+/* R4: approximate extension to the right of (qpos, rpos); returns accepted length */
+static int64_t ext_fwd(const pctx* c, int64_t qpos, int64_t rpos) {
+    const vo_lz_params* p = c->p;
+    int win[64]; memset(win, 0, sizeof(win));
+    int nm = 0, run = 0; int64_t last = 0, e;
+    for (e = 0; qpos + e < c->qn && rpos + e < c->ix->n_rr; ++e) {
+        int mm = c->ix->rr[rpos + e] != c->q[qpos + e];
+        nm -= win[e % p->aw]; win[e % p->aw] = mm; nm += mm;
+        if (!mm) { if (++run >= p->ar) last = e + 1; } else run = 0;
+        if (nm > p->am) break;
+    }
+    return last;
+}
+
+/* R5: approximate extension to the left of (qpos, rpos), at most max_len symbols */
+static int64_t ext_bwd(const pctx* c, int64_t qpos, int64_t rpos, int64_t max_len) {
+    const vo_lz_params* p = c->p;
+    int win[64]; memset(win, 0, sizeof(win));
+    int nm = 0, run = 0; int64_t last = 0, e;
+    for (e = 0; e < max_len && qpos - 1 - e >= 0 && rpos - 1 - e >= 0; ++e) {
+        int mm = c->ix->rr[rpos - 1 - e] != c->q[qpos - 1 - e];
+        nm -= win[e % p->aw]; win[e % p->aw] = mm; nm += mm;
+        if (!mm) { if (++run >= p->ar) last = e + 1; } else run = 0;
+        if (nm > p->am) break;
+    }
+    return last;
+}
+
+static inline int64_t count_eq(const pctx* c, int64_t qpos, int64_t rpos, int64_t n) {
+    int64_t m = 0;
+    for (int64_t j = 0; j < n; ++j)
+        if (rpos + j >= 0 && rpos + j < c->ix->n_rr && c->ix->rr[rpos + j] == c->q[qpos + j]) ++m;
+    return m;
+}
+
+typedef struct { vo_region* r; int n, cap; } rvec;
+static void rpush(rvec* v, vo_region x) {
+    if (v->n == v->cap) { v->cap = v->cap ? v->cap * 2 : 64; v->r = (vo_region*)realloc(v->r, sizeof(vo_region) * v->cap); }
+    v->r[v->n++] = x;
+}
+
+int vo_lz_parse(const vo_ref_index* ix, const uint8_t* qry, int64_t qn,
+                const vo_lz_params* p, const vo_lz_variant* v,
+                vo_region** out, int* n_out) {
+    pctx c = { ix, NULL, qn, p, v };
+    uint8_t* q = (uint8_t*)malloc(qn > 0 ? qn : 1);
+    for (int64_t i = 0; i < qn; ++i) q[i] = qry[i] > 3 ? VO_NQRY : qry[i];
+    c.q = q;
+    uint64_t* ql = (uint64_t*)malloc(sizeof(uint64_t) * (qn + 1));
+    uint64_t* qs = (uint64_t*)malloc(sizeof(uint64_t) * (qn + 1));
+    kmer_codes(q, qn, p->mal, ql);
+    kmer_codes(q, qn, p->msl, qs);
+
+    rvec regs = { NULL, 0, 0 };
+    int in_region = 0;
+    vo_region cur; memset(&cur, 0, sizeof(cur));
+
+    int64_t pred = -1;        /* predicted RR position for q[i]; <0: none */
+    int64_t lit = 0;          /* literals since the last match */
+    int64_t i = 0;
+    int64_t kept_end = 0;     /* query end (exclusive) of the last kept region */
+    int64_t lim = v->loop_le ? qn - p->mal + 1 : qn - p->mal;
+    const int64_t seed_fwd = v->seed_fwd >= 0 ? v->seed_fwd : p->mrd - 1;
+
+#define CLOSE_REGION() do { if (in_region) { \
+        cur.n_mismatch = (cur.qend - cur.qstart + 1) - cur.n_match; \
+        int keep = v->reg_on_span ? (cur.qend - cur.qstart + 1 >= p->reg) : (cur.n_match >= p->reg); \
+        if (keep) { rpush(&regs, cur); kept_end = cur.qend + 1; } in_region = 0; } } while (0)
+
+    while (i < lim) {
+        int64_t best_pos = 0, best_len = 0;
+        int is_close = 0;
+        int do_long = (pred < 0) || v->anchor_while_predicting == 2;
+        int do_close = (pred >= 0);
+        for (int pass = 0; pass < 2; ++pass) {
+            if (pass == 1) {
+                if (v->anchor_while_predicting == 1 && pred >= 0 && best_len == 0) { do_long = 1; do_close = 0; }
+                else break;
+            }
+            if (do_long && best_len == 0) {          /* R2 */
+                if (ql[i] != UINT64_MAX) {
+                    uint32_t h = (uint32_t)mix64(ql[i]) & ix->a_mask;
+                    for (; ix->a_tab[h] >= 0; h = (h + 1) & ix->a_mask) {
+                        int64_t rp = ix->a_tab[h];
+                        if (ix->a_code[rp] != ql[i]) continue;
+                        int64_t l = equal_len(&c, rp, i);
+                        if (l < p->mal) continue;
+                        if (l > best_len || (l == best_len && (v->anchor_tie ? rp > best_pos : rp < best_pos))) {
+                            best_len = l; best_pos = rp;
+                        }
+                    }
+                }
+                if (best_len > 0) {
+                    int64_t d = best_pos - pred;
+                    is_close = (pred >= 0 && d >= -p->mrd && d <= p->mrd);
+                }
+            }
+            if (do_close && best_len == 0) {         /* R3 */
+                if (qs[i] != UINT64_MAX) {
+                    int32_t b0 = ix->s_off[qs[i]], b1 = ix->s_off[qs[i] + 1];
+                    int64_t best_d = 0;
+                    for (int32_t j = b0; j < b1; ++j) {
+                        int64_t rp = ix->s_pos[j];
+                        int64_t d = rp - pred; int ok;
+                        if (v->seed_window == 2) ok = (rp - (pred - lit) >= -v->seed_back && d <= seed_fwd);
+                        else if (v->seed_window == 1) ok = (rp - (pred - lit) >= -v->seed_back && rp - (pred - lit) <= seed_fwd);
+                        else ok = (d >= -p->mrd && d <= p->mrd);
+                        if (!ok) continue;
+                        int64_t l = equal_len(&c, rp, i);
+                        if (l < p->msl) continue;
+                        int64_t ad = d < 0 ? -d : d;
+                        int take = 0;
+                        if (best_len == 0) take = 1;
+                        else if (v->seed_choice == 0) take = l > best_len;
+                        else if (v->seed_choice == 1) take = (ad < best_d) || (ad == best_d && l > best_len);
+                        else if (v->seed_choice == 2) take = 0;
+                        else take = (l > best_len) || (l == best_len && ad < best_d);
+                        if (take) { best_len = l; best_pos = rp; best_d = ad; }
+                    }
+                }
+                if (best_len > 0) is_close = 1;
+            }
+        }
+
+        if (best_len > 0) {
+            if (v->trace) fprintf(stderr, "i=%lld %s pos=%lld len=%lld pred=%lld lit=%lld\n", (long long)i + 1,
+                                  is_close ? "CLOSE" : "DIST", (long long)best_pos, (long long)best_len,
+                                  (long long)pred, (long long)lit);
+            int64_t gap_end_ref = pred - 1;
+            if (!is_close) {
+                /* distant match: close the previous region, open a new one (R5) */
+                CLOSE_REGION();
+                int64_t bound = v->bwd_bound_kept ? i - kept_end : lit;
+                int64_t b = 0;
+                if (v->bwd_exact_first)
+                    while (b < bound && best_pos - 1 - b >= 0 && ix->rr[best_pos - 1 - b] == q[i - 1 - b]) ++b;
+                b += ext_bwd(&c, i - b, best_pos - b, bound - b);
+                cur.qstart = (int32_t)(i - b); cur.rstart = (int32_t)(best_pos - b);
+                cur.n_match = (int32_t)count_eq(&c, i - b, best_pos - b, b);
+                cur.rend = -1;
+                in_region = 1;
+            } else if (lit > 0) {
+                /* chained match: score the literal gap (R7) */
+                int64_t g = lit, m = 0;
+                if (v->gap_mode == 0) m = count_eq(&c, i - g, pred - g, g);
+                else if (v->gap_mode == 1) m = count_eq(&c, i - g, best_pos - g, g);
+                else if (v->gap_mode == 2) {
+                    /* best single split: prefix on the old diagonal, suffix on the new one */
+                    int64_t pre = 0, suf = count_eq(&c, i - g, best_pos - g, g);
+                    m = suf;
+                    for (int64_t s = 0; s < g; ++s) {
+                        int64_t qp = i - g + s, ro = pred - g + s, rn = best_pos - g + s;
+                        if (ro >= 0 && ro < ix->n_rr && ix->rr[ro] == q[qp]) ++pre;
+                        if (rn >= 0 && rn < ix->n_rr && ix->rr[rn] == q[qp]) --suf;
+                        if (pre + suf > m) m = pre + suf;
+                    }
+                }
+                cur.n_match += (int32_t)m;
+            }
+            cur.n_match += (int32_t)best_len;
+            i += best_len; pred = best_pos + best_len; lit = 0;
+            if (!is_close || v->fwd_after_close) {
+                int64_t e = ext_fwd(&c, i, pred);
+                cur.n_match += (int32_t)count_eq(&c, i, pred, e);
+                i += e; pred += e;
+            }
+            cur.qend = (int32_t)(i - 1);
+            if (is_close && v->rend_mode) {
+                if (pred - 1 > cur.rend) cur.rend = (int32_t)(pred - 1);
+                if (v->rend_mode == 2 && gap_end_ref > cur.rend) cur.rend = (int32_t)gap_end_ref;
+            } else cur.rend = (int32_t)(pred - 1);
+        } else {
+            ++i; ++lit;
+            if (pred >= 0) ++pred;
+            if (v->lit_reset_ge ? (lit >= p->mqd) : (lit > p->mqd)) pred = -1;   /* R6 */
+        }
+    }
+    CLOSE_REGION();
+#undef CLOSE_REGION
+    free(q); free(ql); free(qs);
+    *out = regs.r; *n_out = regs.n;
+    return 0;
+}

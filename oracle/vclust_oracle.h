@@ -1,0 +1,115 @@
+/*
+ * vclust_oracle.h — CPU restatement (TEST INFRASTRUCTURE ONLY) of the
+ * prefilter -> align hot path of refresh-bio/vclust.
+ *
+ * This oracle is the checker for the HIP product path.  It must never be
+ * imported, linked or executed by anything except tests/, bench.py's
+ * cpu_baseline leg and __graft_entry__.smoke().
+ *
+ * The native sources of the reference path (3rd_party/kmer-db, 3rd_party/lz-ani;
+ * reference .gitmodules:1-6) are ABSENT from /root/reference, and their pinned
+ * versions are not recoverable.  The restatement therefore
+ * follows the published algorithm of those tools as far as it can be
+ * reconstructed, and is pinned on the reference's golden vectors
+ * example/output/{fltr.txt,ani.tsv,ani.ids.tsv,ani.aln.tsv}; the achieved
+ * agreement is reported by tests/test_oracle_golden.py and in DESIGN.md.
+ */
+#ifndef VCLUST_ORACLE_H
+#define VCLUST_ORACLE_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------- symbols ---------- */
+enum { VO_A = 0, VO_C = 1, VO_G = 2, VO_T = 3, VO_NREF = 4, VO_NQRY = 5 };
+
+/* ---------- genome set ---------- */
+typedef struct {
+    char*    name;      /* first header token */
+    uint8_t* seq;       /* codes 0..3, 4 = non-ACGT */
+    int64_t  len;
+    int32_t  n_parts;   /* contigs joined into this genome (directory mode) */
+} vo_genome;
+
+typedef struct {
+    vo_genome* g;
+    int32_t    n;
+    int32_t    cap;
+} vo_genome_set;
+
+/* Read FASTA / FASTA.gz.  multisample != 0: one genome per record (vclust.py:962-963,
+ * 1159-1160); else one genome per file (records concatenated as parts). */
+int  vo_read_fasta(const char* path, int multisample, vo_genome_set* out);
+void vo_free_genomes(vo_genome_set* s);
+
+/* ---------- prefilter (kmer-db build / all2all-sp / distance; vclust.py:953-1055) ---------- */
+/* distinct canonical k-mers of one genome, sorted ascending; returns count */
+int64_t vo_kmer_set(const uint8_t* seq, int64_t len, int k, uint64_t** out_sorted);
+/* |A ∩ B| for sorted distinct arrays */
+int64_t vo_shared(const uint64_t* a, int64_t na, const uint64_t* b, int64_t nb);
+/* ani-shorter transform */
+double  vo_ani_shorter(int64_t shared, int64_t na, int64_t nb, int k);
+/* whole prefilter: writes fltr.txt. */
+int vo_prefilter(const vo_genome_set* s, int k, int min_kmers, double min_ident,
+                 int n_threads, const char* out_path);
+
+/* ---------- LZ-ANI parse (lz-ani all2all; vclust.py:1142-1181) ---------- */
+typedef struct {
+    int mal, msl, mrd, mqd, reg, aw, am, ar;
+} vo_lz_params;
+
+/* Knobs for the rules the goldens had to decide.  The defaults (vo_lz_default_variant) are the
+ * fitted rules R1-R8 documented in lz_oracle.c; the alternatives are kept so that the fit can
+ * be re-run with oracle/lzfit when new evidence (e.g. the upstream binary) appears. */
+typedef struct {
+    int sep_len;                 /* N symbols between forward strand and reverse complement */
+    int anchor_while_predicting; /* 0 never, 1 after a failed seed search, 2 before the seed search */
+    int bwd_bound_kept;          /* left extension bounded by the last kept region (1) or by the literal run (0) */
+    int bwd_exact_first;         /* maximal exact left extension before the approximate one */
+    int seed_window;             /* 0: |p-pred|<=mrd  1: pred0-back<=p<=pred0+fwd  2: pred0-back<=p, p-pred<=fwd */
+    int seed_back, seed_fwd;     /* window bounds (seed_fwd<0: mrd-1) */
+    int seed_choice;             /* 0 longest,first  1 closest  2 first  3 longest,closest */
+    int lit_reset_ge;            /* drop prediction at lit>=mqd (1) or lit>mqd (0) */
+    int gap_mode;                /* 0 old diagonal, 1 new diagonal, 2 best split, 3 none */
+    int fwd_after_close;
+    int loop_le;                 /* main loop bound i+mal<=n (1) or i+mal<n (0) */
+    int anchor_tie;              /* 0 smallest pos, 1 largest pos */
+    int reg_on_span;             /* region kept on query span (1) or on matches (0) */
+    int rend_mode;               /* 0 true end, 1 max with chained ends, 2 also max with the gap end on the old diagonal */
+    int trace;
+} vo_lz_variant;
+
+typedef struct {
+    int32_t qstart, qend;   /* 0-based inclusive, query coordinates */
+    int32_t rstart, rend;   /* 0-based inclusive in RR coordinates (fwd | sep | rc) */
+    int32_t n_match;
+    int32_t n_mismatch;     /* = qend-qstart+1-n_match */
+} vo_region;
+
+typedef struct vo_ref_index vo_ref_index;
+
+void vo_lz_default_variant(vo_lz_variant* v);
+vo_ref_index* vo_lz_build_index(const uint8_t* ref, int64_t len,
+                                const vo_lz_params* p, const vo_lz_variant* v);
+void vo_lz_free_index(vo_ref_index* idx);
+/* parse query against index; regions (already filtered by reg) written to *out (malloc'd). */
+int  vo_lz_parse(const vo_ref_index* idx, const uint8_t* qry, int64_t qlen,
+                 const vo_lz_params* p, const vo_lz_variant* v,
+                 vo_region** out, int* n_out);
+/* forward-strand 1-based coordinates of a region end point in RR space */
+int64_t vo_rr_to_fwd1(const vo_ref_index* idx, int64_t rr_pos);
+int     vo_rr_is_rev(const vo_ref_index* idx, int64_t rr_pos);
+
+/* ---------- formatting ---------- */
+/* writes the LZ-ANI style number into buf (>= 32 bytes), returns length */
+int vo_fmt_num(double x, char* buf);
+int vo_fmt_len_ratio(int64_t a, int64_t b, char* buf);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
