@@ -1,0 +1,214 @@
+/*
+ * prefilter_oracle.c — CPU restatement of the Kmer-db prefilter (TEST INFRASTRUCTURE ONLY).
+ *
+ * Reference call sites: kmer-db build (vclust.py:953-964), all2all-sp/-parts with
+ * `-sparse -min num-kmers:N -min ani-shorter:I [-sample-rows ani-shorter:M]`
+ * (vclust.py:1005-1017), distance ani-shorter (vclust.py:1045-1055).  Native source
+ * (3rd_party/kmer-db, .gitmodules:1-3) is absent; the arithmetic below reproduces
+ * example/output/fltr.txt 13/13 to the last digit:
+ *   K1  per genome: set of distinct canonical k-mers (min of k-mer and reverse complement,
+ *       A<C<G<T), k-mers containing a non-ACGT symbol skipped;
+ *   K2  shared(a,b) = |K_a ∩ K_b|, kept when shared >= min_kmers;
+ *   K3  j = shared / min(|K_a|,|K_b|);  ani_shorter = 1 + ln(2j/(1+j))/k; kept when >= min_ident;
+ *   K4  fltr.txt layout.
+ * Unpinned by any reference fixture (our definition, identical in the HIP path):
+ *   --kmers-fraction f<1 keeps canonical k-mer x iff mix64(x) < f*2^64;
+ *   --max-seqs M keeps, per output row, the M entries of highest ani (ties: lower column).
+ */
+#include "vclust_oracle.h"
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+uint64_t vo_mix64(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33;
+    x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33; return x;
+}
+
+static void radix_sort_u64(uint64_t* a, uint64_t* tmp, int64_t n, int bits) {
+    for (int sh = 0; sh < bits; sh += 8) {
+        int64_t cnt[257]; memset(cnt, 0, sizeof cnt);
+        for (int64_t i = 0; i < n; ++i) cnt[((a[i] >> sh) & 255) + 1]++;
+        for (int b = 0; b < 256; ++b) cnt[b + 1] += cnt[b];
+        for (int64_t i = 0; i < n; ++i) tmp[cnt[(a[i] >> sh) & 255]++] = a[i];
+        uint64_t* t = a; a = tmp; tmp = t;
+    }
+    /* number of passes may be odd: caller passes bits as a multiple of 16 */
+}
+
+int64_t vo_kmer_set_f(const uint8_t* seq, int64_t len, int k, double fraction, uint64_t** out_sorted) {
+    uint64_t mask = (k >= 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
+    uint64_t thr = fraction >= 1.0 ? UINT64_MAX : (uint64_t)ldexp(fraction, 64);
+    uint64_t* a = (uint64_t*)malloc(sizeof(uint64_t) * (len > 0 ? len : 1));
+    int64_t n = 0; uint64_t fw = 0, rc = 0; int valid = 0;
+    for (int64_t i = 0; i < len; ++i) {
+        uint8_t c = seq[i];
+        if (c > 3) { valid = 0; fw = rc = 0; continue; }
+        fw = ((fw << 2) | c) & mask;
+        rc = (rc >> 2) | ((uint64_t)(3 - c) << (2 * (k - 1)));
+        if (++valid >= k) {
+            uint64_t cano = fw < rc ? fw : rc;
+            if (fraction >= 1.0 || vo_mix64(cano) < thr) a[n++] = cano;
+        }
+    }
+    uint64_t* tmp = (uint64_t*)malloc(sizeof(uint64_t) * (n > 0 ? n : 1));
+    int bits = 2 * k; bits = (bits + 15) / 16 * 16;
+    radix_sort_u64(a, tmp, n, bits);
+    free(tmp);
+    int64_t u = 0;
+    for (int64_t i = 0; i < n; ++i) if (i == 0 || a[i] != a[i - 1]) a[u++] = a[i];
+    *out_sorted = a;
+    return u;
+}
+
+int64_t vo_kmer_set(const uint8_t* seq, int64_t len, int k, uint64_t** out_sorted) {
+    return vo_kmer_set_f(seq, len, k, 1.0, out_sorted);
+}
+
+int64_t vo_shared(const uint64_t* a, int64_t na, const uint64_t* b, int64_t nb) {
+    int64_t i = 0, j = 0, s = 0;
+    while (i < na && j < nb) {
+        if (a[i] < b[j]) ++i; else if (a[i] > b[j]) ++j; else { ++s; ++i; ++j; }
+    }
+    return s;
+}
+
+double vo_ani_shorter(int64_t shared, int64_t na, int64_t nb, int k) {
+    int64_t mn = na < nb ? na : nb;
+    if (mn <= 0 || shared <= 0) return 0.0;
+    double j = (double)shared / (double)mn;
+    return 1.0 + log(2.0 * j / (1.0 + j)) / (double)k;
+}
+
+/* ---- sparse all-pairs shared counts through an inverted index ---- */
+typedef struct { uint64_t kmer; uint32_t g; } kg_t;
+
+static void sort_kg(kg_t* a, kg_t* tmp, int64_t n, int bits) {
+    for (int sh = 0; sh < bits; sh += 8) {
+        int64_t cnt[257]; memset(cnt, 0, sizeof cnt);
+        for (int64_t i = 0; i < n; ++i) cnt[((a[i].kmer >> sh) & 255) + 1]++;
+        for (int b = 0; b < 256; ++b) cnt[b + 1] += cnt[b];
+        for (int64_t i = 0; i < n; ++i) tmp[cnt[(a[i].kmer >> sh) & 255]++] = a[i];
+        kg_t* t = a; a = tmp; tmp = t;
+    }
+}
+
+typedef struct { uint64_t key; uint32_t cnt; } pc_t;
+
+int vo_shared_all(const vo_genome_set* s, int k, double fraction,
+                  int64_t* set_sizes, vo_pair_count** out_pairs, int64_t* n_pairs) {
+    int n = s->n;
+    int64_t total = 0;
+    uint64_t** sets = (uint64_t**)calloc(n, sizeof(uint64_t*));
+    #pragma omp parallel for schedule(dynamic) reduction(+:total)
+    for (int g = 0; g < n; ++g) {
+        set_sizes[g] = vo_kmer_set_f(s->g[g].seq, s->g[g].len, k, fraction, &sets[g]);
+        total += set_sizes[g];
+    }
+    kg_t* a = (kg_t*)malloc(sizeof(kg_t) * (total > 0 ? total : 1));
+    kg_t* tmp = (kg_t*)malloc(sizeof(kg_t) * (total > 0 ? total : 1));
+    int64_t o = 0;
+    for (int g = 0; g < n; ++g) {            /* genome order => stable sort keeps genomes ascending in a run */
+        for (int64_t i = 0; i < set_sizes[g]; ++i) { a[o].kmer = sets[g][i]; a[o].g = (uint32_t)g; ++o; }
+        free(sets[g]);
+    }
+    free(sets);
+    int bits = (2 * k + 15) / 16 * 16;
+    sort_kg(a, tmp, total, bits);
+    free(tmp);
+    /* pair counts in an open-addressing table */
+    uint64_t cap = 1 << 16; pc_t* tab = (pc_t*)calloc(cap, sizeof(pc_t)); uint64_t used = 0;
+    for (int64_t i = 0; i < total;) {
+        int64_t j = i + 1;
+        while (j < total && a[j].kmer == a[i].kmer) ++j;
+        for (int64_t x = i; x < j; ++x)
+            for (int64_t y = x + 1; y < j; ++y) {
+                uint64_t key = ((uint64_t)a[y].g << 32) | a[x].g;      /* (row = larger id, col = smaller id) */
+                if ((used + 1) * 2 > cap) {
+                    uint64_t nc = cap * 2; pc_t* nt = (pc_t*)calloc(nc, sizeof(pc_t));
+                    for (uint64_t t = 0; t < cap; ++t) if (tab[t].cnt) {
+                        uint64_t h = vo_mix64(tab[t].key) & (nc - 1);
+                        while (nt[h].cnt) h = (h + 1) & (nc - 1);
+                        nt[h] = tab[t];
+                    }
+                    free(tab); tab = nt; cap = nc;
+                }
+                uint64_t h = vo_mix64(key) & (cap - 1);
+                while (tab[h].cnt && tab[h].key != key) h = (h + 1) & (cap - 1);
+                if (!tab[h].cnt) { tab[h].key = key; ++used; }
+                tab[h].cnt++;
+            }
+        i = j;
+    }
+    free(a);
+    vo_pair_count* pr = (vo_pair_count*)malloc(sizeof(vo_pair_count) * (used > 0 ? used : 1));
+    int64_t m = 0;
+    for (uint64_t t = 0; t < cap; ++t) if (tab[t].cnt) {
+        pr[m].a = (uint32_t)(tab[t].key >> 32); pr[m].b = (uint32_t)tab[t].key; pr[m].shared = tab[t].cnt; ++m;
+    }
+    free(tab);
+    *out_pairs = pr; *n_pairs = m;
+    return 0;
+}
+
+static int cmp_pair(const void* x, const void* y) {
+    const vo_pair_count* a = (const vo_pair_count*)x; const vo_pair_count* b = (const vo_pair_count*)y;
+    if (a->a != b->a) return a->a < b->a ? -1 : 1;
+    return a->b < b->b ? -1 : (a->b > b->b);
+}
+
+typedef struct { uint32_t col; double ani; } ent_t;
+static int cmp_ent_ani(const void* x, const void* y) {
+    const ent_t* a = (const ent_t*)x; const ent_t* b = (const ent_t*)y;
+    if (a->ani != b->ani) return a->ani > b->ani ? -1 : 1;
+    return a->col < b->col ? -1 : (a->col > b->col);
+}
+static int cmp_ent_col(const void* x, const void* y) {
+    const ent_t* a = (const ent_t*)x; const ent_t* b = (const ent_t*)y;
+    return a->col < b->col ? -1 : (a->col > b->col);
+}
+
+int vo_write_fltr(const vo_genome_set* s, int k, double fraction, int min_kmers, double min_ident,
+                  int max_seqs, const int64_t* set_sizes, vo_pair_count* pairs, int64_t n_pairs,
+                  const char* out_path) {
+    FILE* f = fopen(out_path, "w");
+    if (!f) return -1;
+    qsort(pairs, n_pairs, sizeof(vo_pair_count), cmp_pair);
+    fprintf(f, "kmer-length: %d fraction: %g ,", k, fraction);
+    for (int g = 0; g < s->n; ++g) fprintf(f, "%s,", s->g[g].name);
+    fprintf(f, "\n");
+    int64_t p = 0;
+    ent_t* row = (ent_t*)malloc(sizeof(ent_t) * (s->n > 0 ? s->n : 1));
+    for (int g = 0; g < s->n; ++g) {
+        fprintf(f, "%s,", s->g[g].name);
+        int m = 0;
+        while (p < n_pairs && pairs[p].a == (uint32_t)g) {
+            if ((int64_t)pairs[p].shared >= min_kmers) {
+                double ani = vo_ani_shorter(pairs[p].shared, set_sizes[g], set_sizes[pairs[p].b], k);
+                if (ani >= min_ident) { row[m].col = pairs[p].b; row[m].ani = ani; ++m; }
+            }
+            ++p;
+        }
+        if (max_seqs > 0 && m > max_seqs) {
+            qsort(row, m, sizeof(ent_t), cmp_ent_ani); m = max_seqs;
+            qsort(row, m, sizeof(ent_t), cmp_ent_col);
+        }
+        for (int e = 0; e < m; ++e) fprintf(f, "%u:%.6f,", row[e].col + 1, row[e].ani);
+        fprintf(f, "\n");
+    }
+    free(row);
+    fclose(f);
+    return 0;
+}
+
+int vo_prefilter(const vo_genome_set* s, int k, int min_kmers, double min_ident,
+                 int n_threads, const char* out_path) {
+    (void)n_threads;
+    int64_t* sizes = (int64_t*)calloc(s->n > 0 ? s->n : 1, sizeof(int64_t));
+    vo_pair_count* pairs; int64_t np;
+    vo_shared_all(s, k, 1.0, sizes, &pairs, &np);
+    int rc = vo_write_fltr(s, k, 1.0, min_kmers, min_ident, 0, sizes, pairs, np, out_path);
+    free(pairs); free(sizes);
+    return rc;
+}

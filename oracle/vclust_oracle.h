@@ -56,6 +56,15 @@ double  vo_ani_shorter(int64_t shared, int64_t na, int64_t nb, int k);
 /* whole prefilter: writes fltr.txt. */
 int vo_prefilter(const vo_genome_set* s, int k, int min_kmers, double min_ident,
                  int n_threads, const char* out_path);
+uint64_t vo_mix64(uint64_t x);
+int64_t vo_kmer_set_f(const uint8_t* seq, int64_t len, int k, double fraction, uint64_t** out_sorted);
+typedef struct { uint32_t a, b, shared; } vo_pair_count;   /* a > b (row, column of the lower triangle) */
+/* sparse all-pairs shared k-mer counts (only pairs with shared > 0) and per-genome set sizes */
+int vo_shared_all(const vo_genome_set* s, int k, double fraction,
+                  int64_t* set_sizes, vo_pair_count** out_pairs, int64_t* n_pairs);
+int vo_write_fltr(const vo_genome_set* s, int k, double fraction, int min_kmers, double min_ident,
+                  int max_seqs, const int64_t* set_sizes, vo_pair_count* pairs, int64_t n_pairs,
+                  const char* out_path);
 
 /* ---------- LZ-ANI parse (lz-ani all2all; vclust.py:1142-1181) ---------- */
 typedef struct {
@@ -103,6 +112,24 @@ int  vo_lz_parse(const vo_ref_index* idx, const uint8_t* qry, int64_t qlen,
 /* forward-strand 1-based coordinates of a region end point in RR space */
 int64_t vo_rr_to_fwd1(const vo_ref_index* idx, int64_t rr_pos);
 int     vo_rr_is_rev(const vo_ref_index* idx, int64_t rr_pos);
+
+/* ---------- whole align stage (lz-ani all2all) ---------- */
+typedef struct {
+    vo_lz_params lz;
+    double out_tani, out_gani, out_ani, out_qcov, out_rcov;  /* 0 = off (vclust.py:1170-1176) */
+    const char* filter_path; double filter_threshold;        /* NULL = all-vs-all (vclust.py:1165-1166) */
+    const char* out_aln_path;                                /* NULL = none (vclust.py:1167-1168) */
+    const char* const* out_columns; int n_out_columns;       /* ALIGN_OUTFMT[fmt] (vclust.py:38-47) */
+    int n_threads;
+} vo_align_params;
+/* per ordered pair integer result (L5) */
+typedef struct { uint32_t q, r; uint32_t n_match, aln_len, n_regions; } vo_pair_stat;
+/* sorts genomes by length (stable, descending), writes out_path, <out_path minus .tsv>.ids.tsv and
+ * optionally the alignment table */
+int vo_align(const vo_genome_set* s, const char* out_path, const vo_align_params* p);
+/* integer statistics of one ordered pair with the default variant (for parity tests) */
+int vo_lz_pair_stat(const uint8_t* qry, int64_t qlen, const uint8_t* ref, int64_t rlen,
+                    const vo_lz_params* p, uint32_t* n_match, uint32_t* aln_len, uint32_t* n_regions);
 
 /* ---------- formatting ---------- */
 /* writes the LZ-ANI style number into buf (>= 32 bytes), returns length */
