@@ -1,0 +1,159 @@
+/*
+ * vclust_gpu.h — C ABI of libvclust_gpu.so, the MI355X-native replacement of the two native
+ * tools on Vclust's prefilter -> align hot path.
+ *
+ * The reference has no library ABI for this path: vclust.py drives `bin/kmer-db` and
+ * `bin/lz-ani` through subprocess.run() (vclust.py:762-807).  Every entry point below
+ * names the process invocation it replaces:
+ *
+ *   vg_prefilter      <- kmer-db build (vclust.py:953-964) + all2all-sp/-parts
+ *                        (vclust.py:1005-1017) + distance ani-shorter (vclust.py:1045-1055),
+ *                        i.e. the whole body of handle_prefilter (vclust.py:1433-1471)
+ *   vg_align          <- lz-ani all2all (vclust.py:1142-1181, run at vclust.py:1521)
+ *   vg_version        <- `kmer-db -version` / `lz-ani --version` (vclust.py:1323-1331)
+ *
+ * The finer-grained functions (genome sets, integer kernels, writers) are what the two
+ * calls above are made of; they are exported so that (a) the Python front-end can shard the
+ * integer work over one process per GPU and gather rows with torch.distributed (RCCL), and
+ * (b) the parity tests can compare integers with the CPU oracle.
+ *
+ * Conventions: every function returns 0 on success and a negative code on error;
+ * vg_last_error() returns a thread-local, library-owned, NUL-terminated message.  Calls
+ * block.  Paths are UTF-8, owned by the caller.  Arrays returned through `T** out` are
+ * owned by the library and released with vg_free().  No C++ exceptions cross the ABI.
+ * There is NO CPU fallback: without a HIP device every compute call fails with VG_ENODEV.
+ */
+#ifndef VCLUST_GPU_H
+#define VCLUST_GPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    VG_OK = 0, VG_EINVAL = -1, VG_EIO = -2, VG_ENODEV = -3, VG_EHIP = -4, VG_ENOMEM = -5,
+    VG_EOVERFLOW = -6
+};
+
+const char* vg_version(void);
+const char* vg_last_error(void);
+void        vg_free(void* p);
+/* number of visible HIP devices (0 when there is none); selects the device used by this
+ * process for all later calls (one process per GPU) */
+int vg_device_count(void);
+int vg_set_device(int device);
+
+/* ------------------------------------------------------------------ genome sets ------- */
+typedef struct vg_genomes vg_genomes;
+
+/* FASTA / FASTA.gz ingest.  n_paths == 1 && multisample: one genome per record
+ * (`-multisample-fasta`, vclust.py:962-963 / `--multisample-fasta true`, :1159-1160);
+ * otherwise one genome per file, records joined by one N (vclust.py:692-700).
+ * Genome name = first header token (multisample) or file name (directory mode). */
+int vg_genomes_load(const char* const* paths, int n_paths, int multisample, int n_threads,
+                    vg_genomes** out);
+/* synthetic / in-memory input: codes 0..3 = ACGT, >3 = N; genome g = codes[offsets[g] ..
+ * offsets[g+1]); names may be NULL ("g<idx>") */
+int vg_genomes_from_codes(const uint8_t* codes, const int64_t* offsets, int n_genomes,
+                          const char* const* names, vg_genomes** out);
+void        vg_genomes_free(vg_genomes* g);
+int         vg_genomes_count(const vg_genomes* g);
+int64_t     vg_genomes_total_len(const vg_genomes* g);
+int         vg_genomes_lengths(const vg_genomes* g, int64_t* out /* n */);
+const char* vg_genomes_name(const vg_genomes* g, int idx);
+/* 2-bit packed bases + N mask -> HBM of the current device (idempotent) */
+int vg_genomes_to_device(vg_genomes* g);
+
+/* ------------------------------------------------------------------ prefilter --------- */
+typedef struct { uint32_t a, b, shared; } vg_pair_count;   /* a > b (input order ids) */
+
+/* Integer core of the prefilter on the GPU: per-genome distinct canonical k-mer counts and
+ * the sparse all-vs-all shared-k-mer counts (K1+K2 of SURVEY §8a).
+ *   fraction        --kmers-fraction (vclust.py:241-248); 1.0 = all k-mers
+ *   shard/n_shards  k-mer hash range handled by this call (multi-GPU: one shard per rank;
+ *                   set sizes and shared counts of the shards ADD UP)
+ *   min_shared      pairs with fewer shared k-mers are not emitted (use 1 when n_shards>1)
+ * set_sizes: n entries.  pairs: unordered; released with vg_free(). */
+int vg_kmer_shared(vg_genomes* g, int k, double fraction, int shard, int n_shards,
+                   uint32_t min_shared, int64_t* set_sizes, vg_pair_count** pairs,
+                   int64_t* n_pairs);
+/* distinct canonical k-mers of one genome, ascending (parity tests) */
+int vg_kmer_set(vg_genomes* g, int idx, int k, double fraction, uint64_t** out, int64_t* n_out);
+
+/* K3+K4: ani-shorter transform, thresholds, fltr.txt (example/output/fltr.txt layout).
+ * Sums duplicate (a,b) entries first, so concatenated per-shard outputs are accepted. */
+int vg_write_fltr(const vg_genomes* g, int k, double fraction, int min_kmers, double min_ident,
+                  int max_seqs, const int64_t* set_sizes, const vg_pair_count* pairs,
+                  int64_t n_pairs, const char* out_path);
+
+typedef struct {            /* mirrors the prefilter sub-parser, vclust.py:208-262 */
+    int    k;               /* -k, 15..30 */
+    int    min_kmers;       /* --min-kmers */
+    double min_ident;       /* --min-ident */
+    int    batch_size;      /* --batch-size: accepted, results do not depend on it */
+    double kmers_fraction;  /* --kmers-fraction */
+    int    max_seqs;        /* --max-seqs */
+    int    num_threads;     /* host threads for ingest */
+    int    verbosity;
+    int    is_multifasta;   /* args.is_multifasta (vclust.py:689-693) */
+} vg_prefilter_params;
+int vg_prefilter(const char* const* fasta_paths, int n_paths, const char* out_path,
+                 const vg_prefilter_params* p);
+
+/* ------------------------------------------------------------------ align ------------- */
+typedef struct { int mal, msl, mrd, mqd, reg, aw, am, ar; } vg_lz_params;  /* vclust.py:363-418 */
+typedef struct { uint32_t q, r; } vg_task;       /* ordered pair, ids in input order */
+typedef struct { uint32_t n_match, aln_len, n_regions; } vg_pair_stat;     /* L5 integers */
+typedef struct {            /* one local alignment, 0-based inclusive; r* in fwd|N|rc space */
+    uint32_t task; int32_t qstart, qend, rstart, rend; int32_t n_match;
+} vg_region;
+
+/* LZ parse of every task on the GPU.  stats: n_tasks entries (caller-owned).
+ * regions/n_regions may be NULL; otherwise all kept regions (unordered), vg_free(). */
+int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks, const vg_lz_params* p,
+                vg_pair_stat* stats, vg_region** regions, int64_t* n_regions);
+
+/* L1: stable sort by length, descending.  order[rank] = input index. */
+int vg_align_order(const vg_genomes* g, int32_t* order /* n */);
+/* L2: candidate pairs (input-order ids, a > b) from a Kmer-db filter file with value >= thr,
+ * or all pairs when path == NULL */
+int vg_read_filter(const vg_genomes* g, const char* path, double thr,
+                   vg_pair_count** pairs, int64_t* n_pairs);
+
+/* L7: the canonical ordered-pair list of a candidate set: for ranks a < b the couple
+ * (q = b, r = a), (q = a, r = b), couples ascending in (a, b).  ids are input-order ids. */
+int vg_align_tasks(const vg_genomes* g, const vg_pair_count* pairs, int64_t n_pairs,
+                   vg_task** tasks, int64_t* n_tasks);
+/* HBM budget (bytes) for the per-reference indexes of one vg_lz_align batch (default 24 GiB) */
+void vg_set_index_budget(int64_t bytes);
+
+typedef struct {            /* mirrors the align sub-parser and cmd_lzani, vclust.py:290-421, 1142-1181 */
+    vg_lz_params lz;
+    double out_tani, out_gani, out_ani, out_qcov, out_rcov;   /* 0 = off */
+    const char* filter_path; double filter_threshold;         /* NULL = all-vs-all */
+    const char* out_aln_path;                                 /* NULL = none */
+    const char* const* out_columns; int n_out_columns;        /* ALIGN_OUTFMT[fmt] */
+    int num_threads; int verbosity; int is_multifasta;
+} vg_align_params;
+/* L6-L8: rows + ids file (+ alignment table when regions != NULL and out_aln_path set).
+ * tasks/stats: 2 entries per unordered pair, (q=hi-rank, r=lo-rank) then the reverse. */
+int vg_write_ani(const vg_genomes* g, const vg_task* tasks, const vg_pair_stat* stats,
+                 int64_t n_tasks, const vg_region* regions, int64_t n_regions,
+                 const char* out_path, const vg_align_params* p);
+int vg_align(const char* const* fasta_paths, int n_paths, const char* out_path,
+             const vg_align_params* p);
+
+/* ------------------------------------------------------------------ measurement ------- */
+/* per-kernel HIP-event timing on the library's stream (bench.py's roofline leg) */
+void vg_profile_enable(int on);
+void vg_profile_reset(void);
+/* returns number of kernels recorded; fills up to cap entries */
+typedef struct { char name[48]; double total_ms; int64_t launches; double bytes; } vg_kernel_time;
+int  vg_profile_get(vg_kernel_time* out, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,152 @@
+"""Parity of the HIP product path with the CPU oracle (and, through it, the reference goldens).
+
+All tests call through the C ABI of libvclust_gpu.so; integers must be bit-exact.
+"""
+import filecmp
+
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+from vclust_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def example(golden_dir):
+    codes, offsets, names = orc.read_fasta_codes(golden_dir / 'multifasta.fna')
+    gs = api.GenomeSet.load([golden_dir / 'multifasta.fna'], multisample=True)
+    return codes, offsets, names, gs
+
+
+def _pairs_dict(pairs):
+    return {(int(p['a']), int(p['b'])): int(p['shared']) for p in pairs}
+
+
+def test_ingest_matches_oracle_reader(example):
+    codes, offsets, names, gs = example
+    assert gs.names() == names
+    assert list(gs.lengths()) == list(np.diff(offsets))
+
+
+def test_kmer_sets_example(example):
+    codes, offsets, names, gs = example
+    for idx in (0, 5, 11):
+        mine = gs.kmer_set(idx, 25)
+        ref = orc.kmer_set(codes[offsets[idx]:offsets[idx + 1]], 25)
+        assert np.array_equal(mine, ref)
+
+
+@pytest.mark.parametrize('k', [25, 20, 30, 15])
+def test_kmer_shared_example(example, k):
+    codes, offsets, names, gs = example
+    sizes, pairs = gs.kmer_shared(k=k)
+    osizes, opairs = orc.shared_all(codes, offsets, k=k)
+    assert list(sizes) == list(osizes)
+    assert _pairs_dict(pairs) == opairs
+
+
+def test_kmer_shared_shards_add_up(example):
+    codes, offsets, names, gs = example
+    osizes, opairs = orc.shared_all(codes, offsets, k=25)
+    tot_sizes = np.zeros(len(gs), dtype=np.int64)
+    tot = {}
+    for s in range(3):
+        sizes, pairs = gs.kmer_shared(k=25, shard=s, n_shards=3)
+        tot_sizes += sizes
+        for key, v in _pairs_dict(pairs).items():
+            tot[key] = tot.get(key, 0) + v
+    assert list(tot_sizes) == list(osizes)
+    assert tot == opairs
+
+
+def test_kmer_fraction(example):
+    codes, offsets, names, gs = example
+    sizes, pairs = gs.kmer_shared(k=25, fraction=0.2)
+    osizes, opairs = orc.shared_all(codes, offsets, k=25, fraction=0.2)
+    assert list(sizes) == list(osizes)
+    assert _pairs_dict(pairs) == opairs
+
+
+def test_prefilter_file_is_golden(tmp_path, golden_dir):
+    out = tmp_path / 'fltr.txt'
+    api.prefilter([golden_dir / 'multifasta.fna'], out, is_multifasta=True)
+    assert filecmp.cmp(out, golden_dir / 'output' / 'fltr.txt', shallow=False)
+    out2 = tmp_path / 'fltr_gz.txt'
+    api.prefilter([golden_dir / 'multifasta.fna.gz'], out2, is_multifasta=True)
+    assert filecmp.cmp(out2, golden_dir / 'output' / 'fltr.txt', shallow=False)
+
+
+def test_lz_example_all_pairs(example):
+    codes, offsets, names, gs = example
+    tasks = gs.align_tasks(gs.read_filter(None))
+    assert len(tasks) == 132
+    stats = gs.lz_align(tasks)
+    bad = []
+    for t, s in zip(tasks, stats):
+        q, r = int(t['q']), int(t['r'])
+        ref = orc.lz_pair_stat(codes[offsets[q]:offsets[q + 1]], codes[offsets[r]:offsets[r + 1]])
+        if ref != (int(s['n_match']), int(s['aln_len']), int(s['n_regions'])):
+            bad.append((names[q], names[r], ref, tuple(int(x) for x in s)))
+    assert not bad, bad[:10]
+
+
+def test_align_files_equal_oracle(tmp_path, golden_dir):
+    mine = tmp_path / 'ani.tsv'
+    aln = tmp_path / 'ani.aln.tsv'
+    api.align([golden_dir / 'multifasta.fna'], mine, is_multifasta=True, columns=api.ALIGN_FIELDS[:11], out_aln=aln)
+    ref = tmp_path / 'ref.tsv'
+    ref_aln = tmp_path / 'ref.aln.tsv'
+    orc.run_cli('align', '-o', ref, '--out-aln', ref_aln, golden_dir / 'multifasta.fna')
+    assert filecmp.cmp(mine, ref, shallow=False)
+    assert filecmp.cmp(tmp_path / 'ani.ids.tsv', golden_dir / 'output' / 'ani.ids.tsv', shallow=False)
+    assert sorted(open(aln).read().splitlines()) == sorted(open(ref_aln).read().splitlines())
+
+
+@pytest.fixture(scope='module')
+def small_synth():
+    codes, offsets, names = synth.make_families(6, 4, length=6000, seed=7)
+    gs = api.GenomeSet.from_codes(codes, offsets, names)
+    return codes, offsets, names, gs
+
+
+def test_synth_prefilter(small_synth):
+    codes, offsets, names, gs = small_synth
+    sizes, pairs = gs.kmer_shared(k=25)
+    osizes, opairs = orc.shared_all(codes, offsets, k=25)
+    assert list(sizes) == list(osizes)
+    assert _pairs_dict(pairs) == opairs
+
+
+def test_synth_lz(small_synth):
+    codes, offsets, names, gs = small_synth
+    tasks = gs.align_tasks(synth.family_pairs(6, 4))
+    stats = gs.lz_align(tasks)
+    for t, s in zip(tasks, stats):
+        q, r = int(t['q']), int(t['r'])
+        ref = orc.lz_pair_stat(codes[offsets[q]:offsets[q + 1]], codes[offsets[r]:offsets[r + 1]])
+        assert ref == (int(s['n_match']), int(s['aln_len']), int(s['n_regions'])), (names[q], names[r])
+
+
+def test_lz_with_n_and_edges():
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, 4, size=3000, dtype=np.uint8)
+    b = a.copy()
+    b[rng.random(3000) < 0.05] = 0
+    b[500:520] = 4                      # run of N in the reference copy
+    c = a[1000:2200].copy()
+    c[100] = 4
+    tiny = a[:8].copy()                 # shorter than mal
+    empty_like = np.full(40, 4, dtype=np.uint8)
+    seqs = [a, b, c, tiny, empty_like]
+    offsets = np.zeros(len(seqs) + 1, dtype=np.int64)
+    offsets[1:] = np.cumsum([len(s) for s in seqs])
+    codes = np.concatenate(seqs)
+    gs = api.GenomeSet.from_codes(codes, offsets)
+    tasks = gs.align_tasks(gs.read_filter(None))
+    stats = gs.lz_align(tasks)
+    for t, s in zip(tasks, stats):
+        q, r = int(t['q']), int(t['r'])
+        ref = orc.lz_pair_stat(seqs[q], seqs[r])
+        assert ref == (int(s['n_match']), int(s['aln_len']), int(s['n_regions'])), (q, r)

@@ -1,0 +1,619 @@
+// vg_align.hip — LZ-ANI pairwise parse on gfx950.  Replaces `lz-ani all2all`
+// (vclust.py:1142-1181); restates rules R1-R8 of oracle/lz_oracle.c and is
+// parity-checked against it integer for integer.
+//
+// Design: one 64-lane wavefront owns one ordered pair (query -> reference).  The parse is a
+// sequential left-to-right scan with data-dependent jumps, so the wave speculates: lane l
+// probes query position i+l (anchor lookup, then seed lookup under the prediction that no
+// earlier lane matched); a ballot + find-first picks the first hit, which is exactly the
+// sequential result.  Exact extension, the (aw, am, ar) approximate extension and the gap
+// scoring are bit-parallel: every lane compares 32 bases (one u64 of 2-bit codes) and the
+// window rule is evaluated on mismatch bit masks.  Only integers leave the kernel.
+//
+// Reference side: per reference genome, RR = forward | N | reverse complement is materialised
+// 2-bit packed (+ N mask), with two direct-address indexes built on the device: anchors
+// (mal-mers, hashed into 2^B buckets) and seeds (msl-mers, 4^msl buckets).  This is integer,
+// latency-bound work: no MFMA, the levers are occupancy and L2 locality of the reference
+// (tasks are grouped by reference and dealt to workgroups XCD-aware).
+#include "vg_common.h"
+#include <algorithm>
+#include <numeric>
+#include <cstring>
+
+namespace {
+
+constexpr int RR_PAD = 128;     // mask=1 padding bases behind RR
+constexpr uint64_t EVEN = 0x5555555555555555ULL;
+
+struct ref_desc {
+    int64_t rr_w;      // word offset of packed RR
+    int64_t mask_w;    // word offset of RR mask
+    int64_t atab;      // offset into anchor bucket table pool (2^B entries: END of each bucket)
+    int64_t aent;      // offset into anchor entry pool
+    int64_t stab;      // seed bucket table (4^msl entries: END of each bucket)
+    int64_t sent;      // seed entry pool
+    int32_t L;         // forward length
+    int32_t n_rr;      // 2L + 1
+    int32_t B;         // anchor bucket bits
+    int32_t genome;    // genome id
+    int32_t has_n;     // reference genome contains N
+    int32_t pad_;
+};
+
+struct lz_dev_params { int mal, msl, mrd, mqd, reg, aw, am, ar; };
+
+// ------------------------------------------------------------------ bit helpers
+// 32 bases (2-bit codes, first base in the low bits) starting at base position p (p >= 0)
+__device__ __forceinline__ uint64_t load32(const uint32_t* __restrict__ pk, int64_t p) {
+    int64_t w = p >> 4; int sh = 2 * (int)(p & 15);
+    uint64_t lo = (uint64_t)pk[w] | ((uint64_t)pk[w + 1] << 32);
+    if (sh == 0) return lo;
+    return (lo >> sh) | ((uint64_t)pk[w + 2] << (64 - sh));
+}
+// 32 mask bits starting at base position p
+__device__ __forceinline__ uint32_t loadm32(const uint32_t* __restrict__ mk, int64_t p) {
+    int64_t w = p >> 5; int sh = (int)(p & 31);
+    uint64_t m = (uint64_t)mk[w] | ((uint64_t)mk[w + 1] << 32);
+    return (uint32_t)(m >> sh);
+}
+// spread 32 bits to the even bit positions of a u64
+__device__ __forceinline__ uint64_t spread(uint32_t v) {
+    uint64_t x = v;
+    x = (x | (x << 16)) & 0x0000FFFF0000FFFFULL;
+    x = (x | (x << 8)) & 0x00FF00FF00FF00FFULL;
+    x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0FULL;
+    x = (x | (x << 2)) & 0x3333333333333333ULL;
+    x = (x | (x << 1)) & EVEN;
+    return x;
+}
+// even-bit mask of the base slots j in [0,32) with lo <= j < hi
+__device__ __forceinline__ uint64_t slots(int lo, int hi) {
+    if (lo < 0) lo = 0; if (hi > 32) hi = 32;
+    if (hi <= lo) return 0;
+    uint64_t a = (hi == 32) ? ~0ULL : ((1ULL << (2 * hi)) - 1);
+    uint64_t b = (lo == 0) ? 0ULL : ((1ULL << (2 * lo)) - 1);
+    return (a & ~b) & EVEN;
+}
+__device__ __forceinline__ uint64_t rev2(uint64_t x) {
+    x = __brevll(x);
+    return ((x >> 1) & EVEN) | ((x & EVEN) << 1);
+}
+
+struct pair_ctx {
+    const uint32_t* qpk; const uint32_t* qmk; int qlen; int q_has_n;
+    const uint32_t* rpk; const uint32_t* rmk; int n_rr; int L; int r_has_n;
+};
+
+// mismatch mask (even bits) of the 32 positions q[qp+j] vs rr[rp+j]; out-of-range, separator
+// and N positions are mismatches.  qp/rp may be negative or run past the end.
+__device__ __forceinline__ uint64_t mism32(const pair_ctx& c, int qp, int rp) {
+    uint64_t bad = 0;
+    // valid slots: 0 <= qp+j < qlen, 0 <= rp+j < n_rr, rp+j != L
+    int lo = max(-qp, -rp); int hi = min(c.qlen - qp, c.n_rr - rp);
+    uint64_t ok = slots(lo, hi);
+    bad = EVEN & ~ok;
+    int sj = c.L - rp; if (sj >= 0 && sj < 32) bad |= 1ULL << (2 * sj);
+    if (ok == 0) return EVEN;
+    int qs = qp < 0 ? 0 : qp, rs = rp < 0 ? 0 : rp;           // clamp loads; shifted back below
+    uint64_t xq = load32(c.qpk, qs), xr = load32(c.rpk, rs);
+    if (qp < 0) xq <<= 2 * (-qp);
+    if (rp < 0) xr <<= 2 * (-rp);
+    uint64_t d = xq ^ xr;
+    uint64_t mm = (d | (d >> 1)) & EVEN;
+    if (c.q_has_n) { uint32_t m = loadm32(c.qmk, qs); uint64_t s = spread(m); if (qp < 0) s <<= 2 * (-qp); mm |= s; }
+    if (c.r_has_n) { uint32_t m = loadm32(c.rmk, rs); uint64_t s = spread(m); if (rp < 0) s <<= 2 * (-rp); mm |= s; }
+    return (mm | bad) & EVEN;
+}
+
+// exact match length from (qp, rp), lane-local, at most cap bases examined (multiple of 32)
+__device__ __forceinline__ int match_len_lane(const pair_ctx& c, int qp, int rp, int cap) {
+    int l = 0;
+    while (l < cap) {
+        uint64_t mm = mism32(c, qp + l, rp + l);
+        if (mm) return l + (__builtin_ctzll(mm) >> 1);
+        l += 32;
+    }
+    return l;
+}
+
+__device__ __forceinline__ int wave_sum(int v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// exact match length from (qp, rp), whole wave (2048 bases per round); uniform result
+__device__ __forceinline__ int match_len_wave(const pair_ctx& c, int qp, int rp, int lane) {
+    int base = 0;
+    for (;;) {
+        uint64_t mm = mism32(c, qp + base + 32 * lane, rp + base + 32 * lane);
+        unsigned long long b = __ballot(mm != 0);
+        if (b) {
+            int f = __builtin_ctzll(b);
+            uint64_t mf = __shfl(mm, f);
+            return base + 32 * f + (__builtin_ctzll(mf) >> 1);
+        }
+        base += 2048;
+    }
+}
+
+// Approximate extension (R4 / R5) in direction dir = +1 (right of (qp,rp), positions qp+e) or
+// -1 (left: positions qp-1-e), at most `bound` positions.  Returns accepted length; *n_match =
+// matching symbols inside it.  Bit-parallel restatement of the sequential window automaton:
+// stop at the first e whose trailing aw-window holds > am mismatches; accept up to the end of
+// the last run of >= ar matches before that.
+__device__ __forceinline__ int approx_ext(const pair_ctx& c, const lz_dev_params& P, int qp, int rp, int dir, int bound,
+                                           int lane, int* n_match) {
+    int accepted = 0, matches_total = 0;
+    uint64_t carry_mm = 0;        // mismatch bits of the previous 32 positions (0 before e = 0)
+    uint64_t carry_ok = 0;        // match bits of the previous 32 positions (none before e = 0)
+    int base = 0;                 // first position of this round
+    int cum_before = 0;           // matches in [0, base)
+    int lanes_now = 8;            // first round looks at 256 positions only
+    const uint64_t awmask = (P.aw >= 32) ? ~0ULL : ((1ULL << (2 * P.aw)) - 1);
+    for (;;) {
+        uint64_t mm = EVEN;
+        const bool act = lane < lanes_now;
+        if (act) {
+            int e0 = base + 32 * lane;
+            if (e0 < bound) {
+                if (dir > 0) mm = mism32(c, qp + e0, rp + e0);
+                else mm = rev2(mism32(c, qp - e0 - 32, rp - e0 - 32));        // slot j <-> position e0 + j
+                mm &= EVEN;
+                int rem = bound - e0; if (rem < 32) mm |= EVEN & ~slots(0, rem);
+            }
+        }
+        uint64_t prev_mm = __shfl_up(mm, 1); uint64_t okb = (~mm) & EVEN; uint64_t prev_ok = __shfl_up(okb, 1);
+        if (lane == 0) { prev_mm = carry_mm; prev_ok = carry_ok; }
+        // per-position window counts -> first violation in this lane
+        int viol = 32;
+        {
+            // window ending at slot j covers combined bits [64 + 2(j-aw+1), 64 + 2j]
+            for (int j = 0; j < 32; ++j) {
+                int top = 2 * j + 2;                       // exclusive bit index inside `mm`
+                uint64_t hi = (top == 64) ? mm : (mm & ((1ULL << top) - 1));
+                int cnt;
+                if (j + 1 >= P.aw) cnt = __popcll(hi & (awmask << (2 * (j + 1 - P.aw))));
+                else cnt = __popcll(hi) + __popcll(prev_mm >> (64 - 2 * (P.aw - 1 - j)));
+                if (cnt > P.am) { viol = j; break; }
+            }
+        }
+        if (!act) viol = 32;
+        // positions ending a run of >= ar matches
+        uint64_t run = okb;
+        for (int t = 1; t < P.ar; ++t) run &= (okb << (2 * t)) | (prev_ok >> (64 - 2 * t));
+        unsigned long long vb = __ballot(viol < 32);
+        int fv = vb ? __builtin_ctzll(vb) : 64;            // first violating lane
+        int vj = __shfl(viol, fv & 63);
+        // candidate ends strictly before the violation
+        uint64_t cand = run;
+        if (lane > fv || !act) cand = 0;
+        else if (lane == fv) cand &= (vj == 0) ? 0ULL : ((1ULL << (2 * vj)) - 1);
+        unsigned long long cb = __ballot(cand != 0);
+        if (cb) {
+            int hl = 63 - __builtin_clzll(cb);
+            uint64_t ch = __shfl(cand, hl); uint64_t mh = __shfl(mm, hl);
+            int hj = (63 - __builtin_clzll(ch)) >> 1;
+            accepted = base + 32 * hl + hj + 1;
+            // matches inside [0, accepted): lanes below hl fully, lane hl up to hj
+            int part = (lane < hl && act) ? 32 - __popcll(mm) : 0;
+            int tot = wave_sum(part);
+            uint64_t upto = (hj == 31) ? ~0ULL : ((1ULL << (2 * hj + 2)) - 1);
+            tot += (hj + 1) - __popcll(mh & upto);
+            matches_total = cum_before + tot;
+        }
+        if (vb) break;
+        if (base + 32 * lanes_now >= bound) break;
+        // no violation yet: carry masks of the last active lane into the next round
+        int full = wave_sum(act ? 32 - __popcll(mm) : 0);
+        cum_before += full;
+        carry_mm = __shfl(mm, lanes_now - 1); carry_ok = __shfl(okb, lanes_now - 1);
+        base += 32 * lanes_now;
+        lanes_now = 64;
+    }
+    *n_match = matches_total;
+    return accepted;
+}
+
+// number of equal symbols of q[qp..qp+n) vs rr[rp..rp+n) (whole wave, uniform result)
+__device__ __forceinline__ int count_eq_wave(const pair_ctx& c, int qp, int rp, int n, int lane) {
+    int tot = 0;
+    for (int base = 0; base < n; base += 2048) {
+        int e0 = base + 32 * lane; int part = 0;
+        if (e0 < n) {
+            uint64_t mm = mism32(c, qp + e0, rp + e0);
+            int rem = n - e0; if (rem < 32) mm |= EVEN & ~slots(0, rem);
+            part = 32 - __popcll(mm & EVEN);
+        }
+        tot += wave_sum(part);
+    }
+    return tot;
+}
+
+// ------------------------------------------------------------------ index construction
+// RR packed + mask words: one thread per 32 RR positions
+__global__ void __launch_bounds__(256)
+k_build_rr(const ref_desc* __restrict__ refs, int n_refs, const int64_t* __restrict__ chunk_off /* n_refs+1, in 32-base chunks */,
+           const uint32_t* __restrict__ packed, const uint32_t* __restrict__ nmask, const int64_t* __restrict__ base_off,
+           uint32_t* __restrict__ rr_pool, uint32_t* __restrict__ mask_pool) {
+    const int64_t total = chunk_off[n_refs];
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        int lo = 0, hi = n_refs - 1;
+        while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (chunk_off[mid] <= t) lo = mid; else hi = mid - 1; }
+        const ref_desc rd = refs[lo];
+        const int64_t ch = t - chunk_off[lo];
+        const int64_t g0 = base_off[rd.genome];
+        uint64_t bits = 0; uint32_t mask = 0;
+        for (int j = 0; j < 32; ++j) {
+            int64_t p = ch * 32 + j;
+            uint32_t code = 0, m = 1;
+            if (p < rd.L) {
+                int64_t gp = g0 + p;
+                code = (packed[gp >> 4] >> (2 * (gp & 15))) & 3u; m = (nmask[gp >> 5] >> (gp & 31)) & 1u;
+            } else if (p > rd.L && p <= 2 * (int64_t)rd.L) {
+                int64_t gp = g0 + (rd.L - 1 - (p - rd.L - 1));
+                code = 3u - ((packed[gp >> 4] >> (2 * (gp & 15))) & 3u); m = (nmask[gp >> 5] >> (gp & 31)) & 1u;
+            }
+            if (m) code = 0;
+            bits |= (uint64_t)code << (2 * j); mask |= m << j;
+        }
+        rr_pool[rd.rr_w + 2 * ch] = (uint32_t)bits; rr_pool[rd.rr_w + 2 * ch + 1] = (uint32_t)(bits >> 32);
+        mask_pool[rd.mask_w + ch] = mask;
+    }
+}
+
+__device__ __forceinline__ uint32_t anchor_bucket(uint64_t code, int B) {
+    return (uint32_t)((code * 0x9E3779B97F4A7C15ULL) >> (64 - B));
+}
+
+// count (fill == 0) or place (fill == 1) the anchor / seed entries of every RR position
+__global__ void __launch_bounds__(256)
+k_index_pass(const ref_desc* __restrict__ refs, int n_refs, const int64_t* __restrict__ chunk_off,
+             const uint32_t* __restrict__ rr_pool, const uint32_t* __restrict__ mask_pool, int mal, int msl, int fill,
+             uint32_t* __restrict__ atab_pool, uint32_t* __restrict__ aent_pool, uint32_t* __restrict__ stab_pool,
+             uint32_t* __restrict__ sent_pool) {
+    const int64_t total = chunk_off[n_refs] * 32;
+    const uint64_t amask = (mal >= 32) ? ~0ULL : ((1ULL << (2 * mal)) - 1);
+    const uint64_t smask = (1ULL << (2 * msl)) - 1;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        int64_t chunk = t >> 5;
+        int lo = 0, hi = n_refs - 1;
+        while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (chunk_off[mid] <= chunk) lo = mid; else hi = mid - 1; }
+        const ref_desc rd = refs[lo];
+        const int64_t p = t - chunk_off[lo] * 32;
+        if (p >= rd.n_rr) continue;
+        const uint32_t* pk = rr_pool + rd.rr_w; const uint32_t* mk = mask_pool + rd.mask_w;
+        uint64_t x = load32(pk, p);
+        uint64_t m = (uint64_t)mk[p >> 5] | ((uint64_t)mk[(p >> 5) + 1] << 32);
+        m >>= (p & 31);
+        if (p + mal <= rd.n_rr && (m & ((1ULL << mal) - 1)) == 0) {
+            uint32_t b = anchor_bucket(x & amask, rd.B);
+            if (!fill) atomicAdd(&atab_pool[rd.atab + b], 1u);
+            else { uint32_t slot = atomicAdd(&atab_pool[rd.atab + b], 1u); aent_pool[rd.aent + slot] = (uint32_t)p; }
+        }
+        if (p + msl <= rd.n_rr && (m & ((1ULL << msl) - 1)) == 0) {
+            uint32_t b = (uint32_t)(x & smask);
+            if (!fill) atomicAdd(&stab_pool[rd.stab + b], 1u);
+            else { uint32_t slot = atomicAdd(&stab_pool[rd.stab + b], 1u); sent_pool[rd.sent + slot] = (uint32_t)p; }
+        }
+    }
+}
+
+// exclusive scan of each bucket table, one workgroup per (reference, table)
+__global__ void __launch_bounds__(256)
+k_scan_tables(const ref_desc* __restrict__ refs, int msl, uint32_t* __restrict__ atab_pool, uint32_t* __restrict__ stab_pool) {
+    __shared__ uint32_t part[256];
+    __shared__ uint32_t carry;
+    const ref_desc rd = refs[blockIdx.x >> 1];
+    const bool seed = blockIdx.x & 1;
+    uint32_t* tab = seed ? stab_pool + rd.stab : atab_pool + rd.atab;
+    const int64_t n = seed ? (1LL << (2 * msl)) : (1LL << rd.B);
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n; base += 256 * 8) {
+        uint32_t v[8]; uint32_t s = 0;
+        int64_t i0 = base + (int64_t)threadIdx.x * 8;
+        for (int j = 0; j < 8; ++j) { v[j] = (i0 + j < n) ? tab[i0 + j] : 0; s += v[j]; }
+        part[threadIdx.x] = s;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            uint32_t add = threadIdx.x >= (unsigned)o ? part[threadIdx.x - o] : 0;
+            __syncthreads();
+            part[threadIdx.x] += add;
+            __syncthreads();
+        }
+        uint32_t excl = part[threadIdx.x] - s + carry;
+        for (int j = 0; j < 8; ++j) { if (i0 + j < n) tab[i0 + j] = excl; excl += v[j]; }
+        __syncthreads();
+        if (threadIdx.x == 255) carry += part[255];
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------ the parse
+struct task_dev { uint32_t q, r_slot, out_idx, pad; };
+
+__global__ void __launch_bounds__(256)
+k_lz_parse(const task_dev* __restrict__ tasks, int64_t n_tasks, const ref_desc* __restrict__ refs,
+           const uint32_t* __restrict__ packed, const uint32_t* __restrict__ nmask, const int64_t* __restrict__ base_off,
+           const int64_t* __restrict__ glen, const uint8_t* __restrict__ g_has_n,
+           const uint32_t* __restrict__ rr_pool, const uint32_t* __restrict__ mask_pool,
+           const uint32_t* __restrict__ atab_pool, const uint32_t* __restrict__ aent_pool,
+           const uint32_t* __restrict__ stab_pool, const uint32_t* __restrict__ sent_pool,
+           lz_dev_params P, vg_pair_stat* __restrict__ stats,
+           vg_region* __restrict__ regions, unsigned long long* __restrict__ region_cursor, unsigned long long region_cap) {
+    const int lane = threadIdx.x & 63;
+    // XCD-aware dealing: consecutive task groups of one reference stay on one XCD (block b runs on XCD b % 8)
+    const int64_t per_xcd = gridDim.x / 8;           // grid is a multiple of 8 workgroups
+    const int64_t vblk = (int64_t)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    const int64_t t = vblk * 4 + (threadIdx.x >> 6);
+    if (t >= n_tasks) return;
+    const task_dev tk = tasks[t];
+    const ref_desc rd = refs[tk.r_slot];
+    pair_ctx c;
+    const int64_t qb = base_off[tk.q];
+    c.qpk = packed + (qb >> 4); c.qmk = nmask + (qb >> 5); c.qlen = (int)glen[tk.q]; c.q_has_n = g_has_n[tk.q];
+    c.rpk = rr_pool + rd.rr_w; c.rmk = mask_pool + rd.mask_w; c.n_rr = rd.n_rr; c.L = rd.L; c.r_has_n = rd.has_n;
+    const uint32_t* atab = atab_pool + rd.atab; const uint32_t* aent = aent_pool + rd.aent;
+    const uint32_t* stab = stab_pool + rd.stab; const uint32_t* sent = sent_pool + rd.sent;
+    const uint64_t amask = (P.mal >= 32) ? ~0ULL : ((1ULL << (2 * P.mal)) - 1);
+    const uint64_t smask = (1ULL << (2 * P.msl)) - 1;
+
+    int i = 0, lit = 0, pred = 0; bool alive = false;
+    bool in_region = false; int r_qstart = 0, r_rstart = 0, r_qend = 0, r_rend = -1, r_match = 0;
+    int kept_end = 0;
+    uint32_t M = 0, A = 0, NR = 0;
+    const int lim = c.qlen - P.mal;
+
+    auto close_region = [&]() {
+        if (in_region) {
+            int span = r_qend - r_qstart + 1;
+            if (span >= P.reg) {
+                M += (uint32_t)r_match; A += (uint32_t)span; NR += 1; kept_end = r_qend + 1;
+                if (regions && lane == 0) {
+                    unsigned long long o = atomicAdd(region_cursor, 1ULL);
+                    if (o < region_cap) {
+                        vg_region rg; rg.task = tk.out_idx; rg.qstart = r_qstart; rg.qend = r_qend;
+                        rg.rstart = r_rstart; rg.rend = r_rend; rg.n_match = r_match;
+                        regions[o] = rg;
+                    }
+                }
+            }
+            in_region = false;
+        }
+    };
+
+    while (i < lim) {
+        // ---- speculative probe of positions i .. i+63
+        const int qi = i + lane;
+        int best_len = 0, best_pos = 0; bool hit_close = false;
+        if (qi < lim) {
+            const bool alive_l = alive && (lit + lane <= P.mqd);
+            const int pred_l = pred + lane;
+            uint64_t xq = load32(c.qpk, qi);
+            bool q_ok_a = true, q_ok_s = (qi + P.msl <= c.qlen);
+            if (c.q_has_n) {
+                uint64_t m = (uint64_t)c.qmk[qi >> 5] | ((uint64_t)c.qmk[(qi >> 5) + 1] << 32);
+                m >>= (qi & 31);
+                q_ok_a = (m & ((1ULL << P.mal) - 1)) == 0;
+                q_ok_s = q_ok_s && (m & ((1ULL << P.msl) - 1)) == 0;
+            }
+            // R2: anchor = longest exact match >= mal over all occurrences, ties -> smallest position
+            if (q_ok_a) {
+                const uint64_t code = xq & amask;
+                const uint32_t b = anchor_bucket(code, rd.B);
+                const uint32_t s = b ? atab[b - 1] : 0u, e = atab[b];
+                int ncap = 0;
+                for (uint32_t u = s; u < e; ++u) {
+                    const int rp = (int)aent[u];
+                    if ((load32(c.rpk, rp) ^ xq) & amask) continue;
+                    int l = match_len_lane(c, qi, rp, 32);
+                    if (l < P.mal) continue;
+                    if (l >= 32) {
+                        // rare: several long candidates need their exact lengths to be ranked
+                        if (ncap++ > 0 || best_len >= 32) {
+                            l = match_len_lane(c, qi, rp, 1 << 30);
+                            if (best_len == 32) best_len = match_len_lane(c, qi, best_pos, 1 << 30);
+                        }
+                    }
+                    if (l > best_len || (l == best_len && rp < best_pos)) { best_len = l; best_pos = rp; }
+                }
+                if (best_len > 0) {
+                    const int d = best_pos - pred_l;
+                    hit_close = alive_l && d >= -P.mrd && d <= P.mrd;
+                }
+            }
+            // R3: seed near the prediction
+            if (best_len == 0 && alive_l && q_ok_s) {
+                const uint32_t b = (uint32_t)(xq & smask);
+                const uint32_t s = b ? stab[b - 1] : 0u, e = stab[b];
+                const int pred0 = pred - lit;                    // reference end of the previous match
+                int ncap = 0;
+                for (uint32_t u = s; u < e; ++u) {
+                    const int rp = (int)sent[u];
+                    if (rp < pred0 || rp - pred_l > P.mrd - 1) continue;
+                    int l = match_len_lane(c, qi, rp, 32);
+                    if (l < P.msl) continue;
+                    if (l >= 32) {
+                        if (ncap++ > 0 || best_len >= 32) {
+                            l = match_len_lane(c, qi, rp, 1 << 30);
+                            if (best_len == 32) best_len = match_len_lane(c, qi, best_pos, 1 << 30);
+                        }
+                    }
+                    if (l > best_len || (l == best_len && rp < best_pos)) { best_len = l; best_pos = rp; }
+                }
+                if (best_len > 0) hit_close = true;
+            }
+        }
+        const unsigned long long hb = __ballot(best_len > 0);
+        if (!hb) {
+            // 64 literals (or the tail)
+            const int n = min(64, lim - i);
+            i += n; lit += n; if (alive) { pred += n; if (lit > P.mqd) alive = false; }
+            continue;
+        }
+        const int f = __builtin_ctzll(hb);
+        const int ev_pos = __shfl(best_pos, f);
+        const bool ev_close = __shfl((int)hit_close, f) != 0;
+        // literals in front of the event
+        i += f; lit += f; if (alive) { pred += f; if (lit > P.mqd) alive = false; }
+        // exact length of the chosen match, whole wave
+        const int ev_len = match_len_wave(c, i, ev_pos, lane);
+        const int gap_end_ref = pred - 1;
+        if (!ev_close) {
+            // R5: new region, extended to the left (exact, then approximate), not into the last kept region
+            close_region();
+            const int bound = i - kept_end;
+            int b = 0;
+            {   // maximal exact run to the left
+                int base = 0; bool done = false;
+                while (!done && base < bound) {
+                    int e0 = base + 32 * lane; uint64_t mm = EVEN;
+                    if (e0 < bound) {
+                        mm = rev2(mism32(c, i - e0 - 32, ev_pos - e0 - 32)) & EVEN;
+                        int rem = bound - e0; if (rem < 32) mm |= EVEN & ~slots(0, rem);
+                    }
+                    unsigned long long bb = __ballot(mm != 0);
+                    if (bb) { int fl = __builtin_ctzll(bb); uint64_t mf = __shfl(mm, fl); b = base + 32 * fl + (__builtin_ctzll(mf) >> 1); done = true; }
+                    else { base += 2048; b = min(base, bound); }
+                }
+                if (b > bound) b = bound;
+            }
+            int am_cnt = 0;
+            const int ab = approx_ext(c, P, i - b, ev_pos - b, -1, bound - b, lane, &am_cnt);
+            r_qstart = i - b - ab; r_rstart = ev_pos - b - ab; r_match = b + am_cnt; r_rend = -1;
+            in_region = true;
+        } else if (lit > 0) {
+            // R7: literal gap scored on the old diagonal
+            r_match += count_eq_wave(c, i - lit, pred - lit, lit, lane);
+        }
+        r_match += ev_len;
+        i += ev_len; pred = ev_pos + ev_len; lit = 0; alive = true;
+        {   // R4
+            int fm = 0;
+            const int fe = approx_ext(c, P, i, pred, +1, 1 << 30, lane, &fm);
+            r_match += fm; i += fe; pred += fe;
+        }
+        r_qend = i - 1;
+        if (ev_close) { r_rend = max(r_rend, max(pred - 1, gap_end_ref)); }
+        else r_rend = pred - 1;
+    }
+    close_region();
+    if (lane == 0) { vg_pair_stat st; st.n_match = M; st.aln_len = A; st.n_regions = NR; stats[tk.out_idx] = st; }
+}
+
+inline int grid_for(int64_t n, int block = 256, int max_blocks = 256 * 16) {
+    int64_t b = (n + block - 1) / block; if (b < 1) b = 1;
+    return (int)std::min<int64_t>(b, max_blocks);
+}
+
+}  // namespace
+
+static int64_t g_index_budget_bytes = 24LL << 30;
+
+extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks, const vg_lz_params* p,
+                           vg_pair_stat* stats, vg_region** regions, int64_t* n_regions) {
+    VG_API_BEGIN
+    if (!g || (!tasks && n_tasks) || !p || (!stats && n_tasks)) throw vg_error(VG_EINVAL, "vg_lz_align: null argument");
+    if (p->mal < 8 || p->mal > 31 || p->msl < 4 || p->msl > 12 || p->msl > p->mal) throw vg_error(VG_EINVAL, "mal must be 8..31, msl 4..12 and <= mal");
+    if (p->aw < 1 || p->aw > 32 || p->ar < 1 || p->ar > 16 || p->am < 0 || p->mrd < 0 || p->mqd < 0 || p->reg < 0)
+        throw vg_error(VG_EINVAL, "aw must be 1..32, ar 1..16");
+    vg_require_device();
+    int rc = vg_genomes_to_device(g); if (rc) return rc;
+    hipStream_t s = vg_stream();
+    if (regions) { *regions = nullptr; if (n_regions) *n_regions = 0; }
+    if (n_tasks == 0) return VG_OK;
+    for (int64_t t = 0; t < n_tasks; ++t)
+        if (tasks[t].q >= (uint32_t)g->n || tasks[t].r >= (uint32_t)g->n) throw vg_error(VG_EINVAL, "task id out of range");
+    for (int i = 0; i < g->n; ++i) if (g->len[i] > (1 << 29)) throw vg_error(VG_EOVERFLOW, "genome longer than 2^29 bases");
+
+    // group tasks by reference
+    std::vector<int64_t> order((size_t)n_tasks);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int64_t x, int64_t y) { return tasks[x].r < tasks[y].r; });
+    const lz_dev_params P{ p->mal, p->msl, p->mrd, p->mqd, p->reg, p->aw, p->am, p->ar };
+    const int64_t stab_n = 1LL << (2 * p->msl);
+
+    dbuf<vg_pair_stat> d_stats((size_t)n_tasks);
+    const bool want_regions = regions != nullptr;
+    unsigned long long region_cap = want_regions ? std::max<unsigned long long>(1 << 20, (unsigned long long)n_tasks * 64) : 0;
+    dbuf<vg_region> d_regions((size_t)std::max<unsigned long long>(region_cap, 1));
+    dbuf<unsigned long long> d_rcur(1); d_rcur.zero(s);
+
+    int64_t pos = 0;
+    while (pos < n_tasks) {
+        // take references until the index budget is used
+        std::vector<ref_desc> refs; std::vector<int64_t> chunk_off{ 0 };
+        int64_t rr_words = 0, mask_words = 0, atab_n = 0, aent_n = 0, stab_tot = 0, sent_n = 0, bytes = 0;
+        int64_t end = pos;
+        while (end < n_tasks) {
+            const uint32_t r = tasks[order[end]].r;
+            const int64_t L = g->len[r]; const int64_t n_rr = 2 * L + 1;
+            int B = 8; while ((1LL << (B + 1)) <= n_rr && B + 1 <= 2 * p->mal && B < 26) ++B;
+            const int64_t chunks = (n_rr + RR_PAD + 31) / 32 + 2;
+            const int64_t need = chunks * 12 + ((1LL << B) + n_rr + stab_n + n_rr) * 4;
+            if (!refs.empty() && bytes + need > g_index_budget_bytes) break;
+            ref_desc rd; memset(&rd, 0, sizeof rd);
+            rd.rr_w = rr_words; rd.mask_w = mask_words; rd.atab = atab_n; rd.aent = aent_n; rd.stab = stab_tot; rd.sent = sent_n;
+            rd.L = (int32_t)L; rd.n_rr = (int32_t)n_rr; rd.B = B; rd.genome = (int32_t)r; rd.has_n = g->has_n[r];
+            refs.push_back(rd);
+            rr_words += chunks * 2; mask_words += chunks; atab_n += 1LL << B; aent_n += n_rr; stab_tot += stab_n; sent_n += n_rr;
+            chunk_off.push_back(chunk_off.back() + chunks);
+            bytes += need;
+            while (end < n_tasks && tasks[order[end]].r == r) ++end;
+        }
+        const int n_refs = (int)refs.size();
+        std::vector<task_dev> td((size_t)(end - pos));
+        {
+            int slot = -1; uint32_t cur = 0xffffffffu;
+            for (int64_t t = pos; t < end; ++t) {
+                const vg_task& tk = tasks[order[t]];
+                if (tk.r != cur) { cur = tk.r; ++slot; }
+                td[(size_t)(t - pos)] = { tk.q, (uint32_t)slot, (uint32_t)order[t], 0 };
+            }
+        }
+        dbuf<ref_desc> d_refs((size_t)n_refs); d_refs.upload(refs.data(), refs.size(), s);
+        dbuf<int64_t> d_chunk(chunk_off.size()); d_chunk.upload(chunk_off.data(), chunk_off.size(), s);
+        dbuf<uint32_t> rr_pool((size_t)rr_words + 8), mask_pool((size_t)mask_words + 8), atab_pool((size_t)atab_n), aent_pool((size_t)aent_n),
+            stab_pool((size_t)stab_tot), sent_pool((size_t)sent_n);
+        dbuf<task_dev> d_tasks(td.size()); d_tasks.upload(td.data(), td.size(), s);
+        atab_pool.zero(s); stab_pool.zero(s);
+        const int64_t total_chunks = chunk_off.back();
+        {
+            vg_prof_scope ps("lz_build_index", (double)total_chunks * 32 * (0.25 + 0.375 + 16));
+            hipLaunchKernelGGL(k_build_rr, dim3(grid_for(total_chunks)), dim3(256), 0, s, d_refs.p, n_refs, d_chunk.p, g->d_packed.p,
+                               g->d_nmask.p, g->d_base_off.p, rr_pool.p, mask_pool.p);
+            hipLaunchKernelGGL(k_index_pass, dim3(grid_for(total_chunks * 32)), dim3(256), 0, s, d_refs.p, n_refs, d_chunk.p, rr_pool.p,
+                               mask_pool.p, p->mal, p->msl, 0, atab_pool.p, aent_pool.p, stab_pool.p, sent_pool.p);
+            hipLaunchKernelGGL(k_scan_tables, dim3(2 * n_refs), dim3(256), 0, s, d_refs.p, p->msl, atab_pool.p, stab_pool.p);
+            hipLaunchKernelGGL(k_index_pass, dim3(grid_for(total_chunks * 32)), dim3(256), 0, s, d_refs.p, n_refs, d_chunk.p, rr_pool.p,
+                               mask_pool.p, p->mal, p->msl, 1, atab_pool.p, aent_pool.p, stab_pool.p, sent_pool.p);
+        }
+        {
+            const int64_t nt = end - pos;
+            double bytes_alg = 0;
+            for (int64_t t = pos; t < end; ++t) bytes_alg += (double)(g->len[tasks[order[t]].q] + g->len[tasks[order[t]].r]) / 4.0 + 20.0;
+            vg_prof_scope ps("lz_parse", bytes_alg);
+            const int64_t nblk = ((nt + 3) / 4 + 7) / 8 * 8;
+            hipLaunchKernelGGL(k_lz_parse, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p, nt, d_refs.p, g->d_packed.p, g->d_nmask.p,
+                               g->d_base_off.p, g->d_len.p, g->d_has_n.p, rr_pool.p, mask_pool.p, atab_pool.p, aent_pool.p, stab_pool.p,
+                               sent_pool.p, P, d_stats.p, want_regions ? d_regions.p : (vg_region*)nullptr, d_rcur.p, region_cap);
+        }
+        VG_HIP(hipStreamSynchronize(s));
+        VG_HIP(hipGetLastError());
+        pos = end;
+    }
+    d_stats.download(stats, (size_t)n_tasks, s);
+    VG_HIP(hipStreamSynchronize(s));
+    if (want_regions) {
+        unsigned long long nr = 0; d_rcur.download(&nr, 1, s); VG_HIP(hipStreamSynchronize(s));
+        if (nr > region_cap) throw vg_error(VG_EOVERFLOW, "region buffer overflow");
+        vg_region* o = (vg_region*)malloc(sizeof(vg_region) * std::max<size_t>(1, (size_t)nr));
+        if (!o) throw vg_error(VG_ENOMEM, "out of host memory");
+        if (nr) d_regions.download(o, (size_t)nr, s);
+        VG_HIP(hipStreamSynchronize(s));
+        *regions = o; if (n_regions) *n_regions = (int64_t)nr;
+    }
+    VG_API_END
+}
+
+extern "C" void vg_set_index_budget(int64_t bytes) { if (bytes > (64 << 20)) g_index_budget_bytes = bytes; }

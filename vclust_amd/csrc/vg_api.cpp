@@ -1,0 +1,48 @@
+// vg_api.cpp — the two whole-stage entry points the reference's front-end needs:
+//   vg_prefilter  replaces kmer-db build + all2all + distance (vclust.py:1433-1471)
+//   vg_align      replaces lz-ani all2all                    (vclust.py:1497-1521)
+// Both are compositions of the finer C-ABI calls (ingest -> HBM -> integer kernels -> writers).
+#include "vg_common.h"
+#include <stdlib.h>
+#include <vector>
+
+namespace {
+struct genomes_guard { vg_genomes* g = nullptr; ~genomes_guard() { if (g) vg_genomes_free(g); } };
+struct free_guard { void* p = nullptr; ~free_guard() { if (p) vg_free(p); } };
+void check(int rc) { if (rc != VG_OK) throw vg_error(rc, vg_last_error()); }
+}
+
+extern "C" int vg_prefilter(const char* const* fasta_paths, int n_paths, const char* out_path,
+                            const vg_prefilter_params* p) {
+    VG_API_BEGIN
+    if (!fasta_paths || n_paths <= 0 || !out_path || !p) throw vg_error(VG_EINVAL, "vg_prefilter: null argument");
+    if (p->k < 15 || p->k > 30) throw vg_error(VG_EINVAL, "k must be in 15..30");
+    vg_require_device();
+    genomes_guard gg;
+    check(vg_genomes_load(fasta_paths, n_paths, p->is_multifasta, p->num_threads, &gg.g));
+    std::vector<int64_t> sizes((size_t)std::max(1, vg_genomes_count(gg.g)));
+    free_guard pairs; int64_t np = 0;
+    // on a single device the --min-kmers cut can be applied on the GPU already
+    uint32_t min_emit = (uint32_t)std::max(1, p->min_kmers);
+    check(vg_kmer_shared(gg.g, p->k, p->kmers_fraction > 0 ? p->kmers_fraction : 1.0, 0, 1, min_emit, sizes.data(),
+                         (vg_pair_count**)&pairs.p, &np));
+    check(vg_write_fltr(gg.g, p->k, p->kmers_fraction > 0 ? p->kmers_fraction : 1.0, p->min_kmers, p->min_ident, p->max_seqs,
+                        sizes.data(), (const vg_pair_count*)pairs.p, np, out_path));
+    VG_API_END
+}
+
+extern "C" int vg_align(const char* const* fasta_paths, int n_paths, const char* out_path, const vg_align_params* p) {
+    VG_API_BEGIN
+    if (!fasta_paths || n_paths <= 0 || !out_path || !p) throw vg_error(VG_EINVAL, "vg_align: null argument");
+    vg_require_device();
+    genomes_guard gg;
+    check(vg_genomes_load(fasta_paths, n_paths, p->is_multifasta, p->num_threads, &gg.g));
+    free_guard pairs, tasks, regions; int64_t np = 0, nt = 0, nr = 0;
+    check(vg_read_filter(gg.g, p->filter_path, p->filter_threshold, (vg_pair_count**)&pairs.p, &np));
+    check(vg_align_tasks(gg.g, (const vg_pair_count*)pairs.p, np, (vg_task**)&tasks.p, &nt));
+    std::vector<vg_pair_stat> stats((size_t)std::max<int64_t>(1, nt));
+    const bool want_aln = p->out_aln_path != nullptr;
+    check(vg_lz_align(gg.g, (const vg_task*)tasks.p, nt, &p->lz, stats.data(), want_aln ? (vg_region**)&regions.p : nullptr, &nr));
+    check(vg_write_ani(gg.g, (const vg_task*)tasks.p, stats.data(), nt, (const vg_region*)regions.p, nr, out_path, p));
+    VG_API_END
+}

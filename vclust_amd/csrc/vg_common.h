@@ -1,0 +1,87 @@
+// vg_common.h — shared host-side declarations of libvclust_gpu (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <cstdlib>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include <stdexcept>
+#include "../../include/vclust_gpu.h"
+
+// ---------------------------------------------------------------- errors
+void vg_set_error(const char* fmt, ...);
+struct vg_error : std::runtime_error {
+    int code;
+    vg_error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+#define VG_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \
+    throw vg_error(VG_EHIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
+// wraps a C-ABI body: exceptions -> error code + vg_last_error()
+#define VG_API_BEGIN try {
+#define VG_API_END } catch (const vg_error& e) { vg_set_error("%s", e.what()); return e.code; } \
+    catch (const std::bad_alloc&) { vg_set_error("out of host memory"); return VG_ENOMEM; } \
+    catch (const std::exception& e) { vg_set_error("%s", e.what()); return VG_EINVAL; } \
+    return VG_OK;
+
+void vg_require_device();        // throws VG_ENODEV when no HIP device is usable
+hipStream_t vg_stream();         // the library's compute stream on the current device
+
+// ---------------------------------------------------------------- device buffers
+template <class T> struct dbuf {
+    T* p = nullptr; size_t n = 0;
+    dbuf() {}
+    explicit dbuf(size_t count) { alloc(count); }
+    dbuf(const dbuf&) = delete; dbuf& operator=(const dbuf&) = delete;
+    dbuf(dbuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    dbuf& operator=(dbuf&& o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
+    ~dbuf() { release(); }
+    void alloc(size_t count) {
+        release(); n = count;
+        if (count) VG_HIP(hipMalloc((void**)&p, count * sizeof(T)));
+    }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; } n = 0; }
+    size_t bytes() const { return n * sizeof(T); }
+    void zero(hipStream_t s) { if (n) VG_HIP(hipMemsetAsync(p, 0, bytes(), s)); }
+    void upload(const T* h, size_t count, hipStream_t s) { VG_HIP(hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, s)); }
+    void download(T* h, size_t count, hipStream_t s) const { VG_HIP(hipMemcpyAsync(h, p, count * sizeof(T), hipMemcpyDeviceToHost, s)); }
+};
+
+// ---------------------------------------------------------------- profiling (HIP events on vg_stream)
+struct vg_prof_scope {
+    const char* name; double bytes; hipEvent_t e0 = nullptr, e1 = nullptr; bool on;
+    vg_prof_scope(const char* name, double algorithmic_bytes = 0);
+    ~vg_prof_scope();
+};
+bool vg_profile_on();
+
+// ---------------------------------------------------------------- genome set
+// Layout (host and HBM): bases 2-bit packed, 16 per uint32 word, little end first
+// (base i of the padded stream sits in word i/16, bits 2*(i%16)..+1); N mask 1 bit per base,
+// 32 per word.  Every genome starts at a multiple of VG_ALIGN bases of the padded stream;
+// padding bases are A with mask bit 1.
+constexpr int64_t VG_ALIGN = 64;
+struct vg_genomes {
+    int n = 0;
+    std::vector<std::string> names;
+    std::vector<int64_t> len;        // n
+    std::vector<int32_t> n_parts;    // n
+    std::vector<int64_t> base_off;   // n+1, padded base offsets
+    std::vector<uint8_t> has_n;      // n
+    std::vector<uint32_t> packed;    // base_off[n]/16 words (+ slack)
+    std::vector<uint32_t> nmask;     // base_off[n]/32 words (+ slack)
+    // device residency
+    int device = -1;
+    dbuf<uint32_t> d_packed, d_nmask;
+    dbuf<int64_t> d_base_off, d_len;
+    dbuf<uint8_t> d_has_n;
+    int64_t padded_total() const { return base_off.empty() ? 0 : base_off.back(); }
+};
+// append one genome given codes (0..3, >3 = N); used by the FASTA reader and vg_genomes_from_codes
+void vg_genomes_append(vg_genomes* g, const std::string& name, const uint8_t* codes, int64_t len, int n_parts);
+void vg_genomes_finish(vg_genomes* g);
+
+// ---------------------------------------------------------------- host-side helpers shared by writers
+int  vg_fmt_num(double x, char* buf);                 // LZ-ANI number format
+int  vg_fmt_len_ratio(int64_t a, int64_t b, char* buf);
+double vg_ani_shorter(int64_t shared, int64_t na, int64_t nb, int k);

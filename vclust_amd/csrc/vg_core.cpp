@@ -1,0 +1,110 @@
+// vg_core.cpp — error channel, device selection, the library stream and HIP-event profiling.
+#include "vg_common.h"
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <stdlib.h>
+#include <map>
+#include <mutex>
+
+static thread_local char g_err[1024] = "";
+
+void vg_set_error(const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* vg_last_error(void) { return g_err; }
+extern "C" const char* vg_version(void) { return "vclust-mi355x 0.1.0 (gfx950, HIP)"; }
+extern "C" void vg_free(void* p) { free(p); }
+
+static int g_device = -1;
+static hipStream_t g_stream = nullptr;
+
+extern "C" int vg_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int vg_set_device(int device) {
+    VG_API_BEGIN
+    int n = vg_device_count();
+    if (n <= 0) throw vg_error(VG_ENODEV, "no HIP device visible: libvclust_gpu has no CPU fallback");
+    if (device < 0 || device >= n) throw vg_error(VG_EINVAL, "device index out of range");
+    if (g_stream && device != g_device) { (void)hipStreamDestroy(g_stream); g_stream = nullptr; }
+    VG_HIP(hipSetDevice(device));
+    g_device = device;
+    VG_API_END
+}
+
+void vg_require_device() {
+    if (g_device < 0) {
+        int n = vg_device_count();
+        if (n <= 0) throw vg_error(VG_ENODEV, "no HIP device visible: libvclust_gpu has no CPU fallback");
+        VG_HIP(hipSetDevice(0));
+        g_device = 0;
+    }
+}
+
+hipStream_t vg_stream() {
+    vg_require_device();
+    if (!g_stream) VG_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    return g_stream;
+}
+
+// ---------------------------------------------------------------- profiling
+struct prof_entry { double ms = 0; int64_t launches = 0; double bytes = 0; int order = 0; };
+struct pending_ev { std::string name; hipEvent_t e0, e1; double bytes; };
+static bool g_prof = false;
+static std::map<std::string, prof_entry> g_prof_tab;
+static std::vector<pending_ev> g_pending;
+static std::mutex g_prof_mu;
+
+bool vg_profile_on() { return g_prof; }
+
+vg_prof_scope::vg_prof_scope(const char* nm, double b) : name(nm), bytes(b), on(g_prof) {
+    if (!on) return;
+    hipStream_t s = vg_stream();
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { on = false; return; }
+    (void)hipEventRecord(e0, s);
+}
+vg_prof_scope::~vg_prof_scope() {
+    if (!on) return;
+    (void)hipEventRecord(e1, vg_stream());
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_pending.push_back({ name, e0, e1, bytes });
+}
+
+static void prof_drain() {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& p : g_pending) {
+        (void)hipEventSynchronize(p.e1);
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
+            auto& e = g_prof_tab[p.name];
+            if (e.launches == 0) e.order = (int)g_prof_tab.size();
+            e.ms += ms; e.launches++; e.bytes += p.bytes;
+        }
+        (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1);
+    }
+    g_pending.clear();
+}
+
+extern "C" void vg_profile_enable(int on) { g_prof = on != 0; }
+extern "C" void vg_profile_reset(void) { prof_drain(); std::lock_guard<std::mutex> lk(g_prof_mu); g_prof_tab.clear(); }
+extern "C" int vg_profile_get(vg_kernel_time* out, int cap) {
+    prof_drain();
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    int n = 0;
+    for (auto& kv : g_prof_tab) {
+        if (n < cap) {
+            memset(&out[n], 0, sizeof(out[n]));
+            strncpy(out[n].name, kv.first.c_str(), sizeof(out[n].name) - 1);
+            out[n].total_ms = kv.second.ms; out[n].launches = kv.second.launches; out[n].bytes = kv.second.bytes;
+        }
+        ++n;
+    }
+    return n;
+}

@@ -1,0 +1,282 @@
+// vg_io.cpp — host side of the two stages: everything that turns the GPU's integers into the
+// reference's files.  Floating point appears only here (ani-shorter uses log; ANI ratios are
+// fp64 quotients of integers), so file identity with the CPU oracle reduces to integer identity.
+//   fltr.txt            layout of example/output/fltr.txt        
+//   ani.tsv, ids.tsv    layout of example/output/ani{,.ids}.tsv  
+//   ani.aln.tsv         layout of example/output/ani.aln.tsv     
+#include "vg_common.h"
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <unordered_map>
+#include <numeric>
+
+// ---------------------------------------------------------------- numbers
+double vg_ani_shorter(int64_t shared, int64_t na, int64_t nb, int k) {
+    int64_t mn = std::min(na, nb);
+    if (mn <= 0 || shared <= 0) return 0.0;
+    double j = (double)shared / (double)mn;
+    return 1.0 + log(2.0 * j / (1.0 + j)) / (double)k;
+}
+
+// LZ-ANI prints a double with the shortest "%.{1..6}g" that reproduces it exactly, else with six
+// significant digits in fixed notation (zeros kept), exact decimal ties rounded away from zero.
+int vg_fmt_num(double x, char* buf) {
+    for (int prec = 1; prec <= 6; ++prec) {
+        char t[64];
+        snprintf(t, sizeof t, "%.*g", prec, x);
+        if (strtod(t, nullptr) == x) { strcpy(buf, t); return (int)strlen(buf); }
+    }
+    bool neg = x < 0; double ax = neg ? -x : x;
+    char full[400];
+    snprintf(full, sizeof full, "%.150f", ax);                 // exact binary expansion
+    std::string digits; int int_len = 0; bool seen_dot = false;
+    for (char* c = full; *c; ++c) { if (*c == '.') { seen_dot = true; continue; } digits.push_back(*c); if (!seen_dot) ++int_len; }
+    size_t first = 0; while (first < digits.size() && digits[first] == '0') ++first;
+    size_t keep = std::min(digits.size(), first + 6);
+    bool up = keep < digits.size() && digits[keep] >= '5';
+    digits.resize(keep);
+    if (up) {
+        int j = (int)keep - 1;
+        while (j >= 0 && digits[j] == '9') { digits[j] = '0'; --j; }
+        if (j >= 0) digits[j]++; else { digits.insert(digits.begin(), '1'); ++int_len; }
+    }
+    std::string out = neg ? "-" : "";
+    if ((int)digits.size() <= int_len) { out += digits; out.append(int_len - digits.size(), '0'); }
+    else { out += digits.substr(0, int_len); out.push_back('.'); out += digits.substr(int_len); }
+    strcpy(buf, out.c_str());
+    return (int)out.size();
+}
+
+int vg_fmt_len_ratio(int64_t a, int64_t b, char* buf) {
+    if (a == b) { strcpy(buf, "1"); return 1; }
+    return snprintf(buf, 32, "%.4f", (double)std::min(a, b) / (double)std::max(a, b));
+}
+
+// ---------------------------------------------------------------- fltr.txt
+extern "C" int vg_write_fltr(const vg_genomes* g, int k, double fraction, int min_kmers, double min_ident,
+                             int max_seqs, const int64_t* set_sizes, const vg_pair_count* pairs,
+                             int64_t n_pairs, const char* out_path) {
+    VG_API_BEGIN
+    if (!g || !set_sizes || (!pairs && n_pairs) || !out_path) throw vg_error(VG_EINVAL, "vg_write_fltr: null argument");
+    std::vector<vg_pair_count> v(pairs, pairs + n_pairs);
+    for (auto& p : v) if (p.a < p.b) std::swap(p.a, p.b);
+    std::sort(v.begin(), v.end(), [](const vg_pair_count& x, const vg_pair_count& y) { return x.a != y.a ? x.a < y.a : x.b < y.b; });
+    // sum duplicates (per-shard partial counts)
+    size_t u = 0;
+    for (size_t i = 0; i < v.size(); ++i) {
+        if (u && v[u - 1].a == v[i].a && v[u - 1].b == v[i].b) v[u - 1].shared += v[i].shared;
+        else v[u++] = v[i];
+    }
+    v.resize(u);
+    FILE* f = fopen(out_path, "w");
+    if (!f) throw vg_error(VG_EIO, std::string("cannot write ") + out_path);
+    fprintf(f, "kmer-length: %d fraction: %g ,", k, fraction);
+    for (int i = 0; i < g->n; ++i) fprintf(f, "%s,", g->names[i].c_str());
+    fputc('\n', f);
+    size_t p = 0;
+    struct ent { uint32_t col; double ani; };
+    std::vector<ent> row;
+    for (int a = 0; a < g->n; ++a) {
+        fprintf(f, "%s,", g->names[a].c_str());
+        row.clear();
+        for (; p < v.size() && v[p].a == (uint32_t)a; ++p) {
+            if ((int64_t)v[p].shared < min_kmers || v[p].b >= (uint32_t)g->n) continue;
+            double ani = vg_ani_shorter(v[p].shared, set_sizes[a], set_sizes[v[p].b], k);
+            if (ani >= min_ident) row.push_back({ v[p].b, ani });
+        }
+        if (max_seqs > 0 && (int)row.size() > max_seqs) {
+            std::sort(row.begin(), row.end(), [](const ent& x, const ent& y) { return x.ani != y.ani ? x.ani > y.ani : x.col < y.col; });
+            row.resize(max_seqs);
+            std::sort(row.begin(), row.end(), [](const ent& x, const ent& y) { return x.col < y.col; });
+        }
+        for (auto& e : row) fprintf(f, "%u:%.6f,", e.col + 1, e.ani);
+        fputc('\n', f);
+    }
+    if (fclose(f)) throw vg_error(VG_EIO, std::string("write error on ") + out_path);
+    VG_API_END
+}
+
+// ---------------------------------------------------------------- align: order, filter, tasks
+extern "C" int vg_align_order(const vg_genomes* g, int32_t* order) {
+    VG_API_BEGIN
+    if (!g || !order) throw vg_error(VG_EINVAL, "vg_align_order: null argument");
+    std::iota(order, order + g->n, 0);
+    std::stable_sort(order, order + g->n, [&](int32_t x, int32_t y) { return g->len[x] > g->len[y]; });
+    VG_API_END
+}
+
+extern "C" int vg_read_filter(const vg_genomes* g, const char* path, double thr, vg_pair_count** pairs, int64_t* n_pairs) {
+    VG_API_BEGIN
+    if (!g || !pairs || !n_pairs) throw vg_error(VG_EINVAL, "vg_read_filter: null argument");
+    std::vector<vg_pair_count> v;
+    if (!path) {
+        for (uint32_t a = 1; a < (uint32_t)g->n; ++a) for (uint32_t b = 0; b < a; ++b) v.push_back({ a, b, 0 });
+    } else {
+        FILE* f = fopen(path, "r");
+        if (!f) throw vg_error(VG_EIO, std::string("cannot open filter ") + path);
+        std::unordered_map<std::string, uint32_t> by_name;
+        for (int i = 0; i < g->n; ++i) by_name.emplace(g->names[i], (uint32_t)i);
+        std::string data; char buf[1 << 16]; size_t r;
+        while ((r = fread(buf, 1, sizeof buf, f)) > 0) data.append(buf, r);
+        fclose(f);
+        size_t pos = 0; bool header = true; std::vector<int64_t> col_id;
+        while (pos < data.size()) {
+            size_t e = data.find('\n', pos); if (e == std::string::npos) e = data.size();
+            std::string line = data.substr(pos, e - pos); pos = e + 1;
+            if (!line.empty() && line.back() == '\r') line.pop_back();
+            if (header) {
+                header = false;
+                size_t c = line.find(',');
+                while (c != std::string::npos && c + 1 < line.size()) {
+                    size_t n2 = line.find(',', c + 1); if (n2 == std::string::npos) break;
+                    auto it = by_name.find(line.substr(c + 1, n2 - c - 1));
+                    col_id.push_back(it == by_name.end() ? -1 : (int64_t)it->second);
+                    c = n2;
+                }
+                continue;
+            }
+            size_t c = line.find(','); if (c == std::string::npos) continue;
+            auto it = by_name.find(line.substr(0, c));
+            int64_t row = it == by_name.end() ? -1 : (int64_t)it->second;
+            while (c != std::string::npos && c + 1 < line.size()) {
+                size_t n2 = line.find(',', c + 1);
+                std::string field = line.substr(c + 1, (n2 == std::string::npos ? line.size() : n2) - c - 1);
+                size_t colon = field.find(':');
+                if (colon != std::string::npos) {
+                    long ci = atol(field.c_str()) - 1; double val = atof(field.c_str() + colon + 1);
+                    if (row >= 0 && ci >= 0 && ci < (long)col_id.size() && col_id[ci] >= 0 && col_id[ci] != row && val >= thr) {
+                        uint32_t x = (uint32_t)row, y = (uint32_t)col_id[ci];
+                        v.push_back({ std::max(x, y), std::min(x, y), 0 });
+                    }
+                }
+                c = n2;
+            }
+        }
+        std::sort(v.begin(), v.end(), [](const vg_pair_count& x, const vg_pair_count& y) { return x.a != y.a ? x.a < y.a : x.b < y.b; });
+        v.erase(std::unique(v.begin(), v.end(), [](const vg_pair_count& x, const vg_pair_count& y) { return x.a == y.a && x.b == y.b; }), v.end());
+    }
+    vg_pair_count* o = (vg_pair_count*)malloc(sizeof(vg_pair_count) * std::max<size_t>(1, v.size()));
+    if (!o) throw vg_error(VG_ENOMEM, "out of host memory");
+    if (!v.empty()) memcpy(o, v.data(), sizeof(vg_pair_count) * v.size());
+    *pairs = o; *n_pairs = (int64_t)v.size();
+    VG_API_END
+}
+
+extern "C" int vg_align_tasks(const vg_genomes* g, const vg_pair_count* pairs, int64_t n_pairs,
+                              vg_task** tasks, int64_t* n_tasks) {
+    VG_API_BEGIN
+    if (!g || (!pairs && n_pairs) || !tasks || !n_tasks) throw vg_error(VG_EINVAL, "vg_align_tasks: null argument");
+    std::vector<int32_t> order(g->n), rank(g->n);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return g->len[x] > g->len[y]; });
+    for (int i = 0; i < g->n; ++i) rank[order[i]] = i;
+    struct rp { int32_t lo, hi; };
+    std::vector<rp> v((size_t)n_pairs);
+    for (int64_t i = 0; i < n_pairs; ++i) {
+        if (pairs[i].a >= (uint32_t)g->n || pairs[i].b >= (uint32_t)g->n) throw vg_error(VG_EINVAL, "pair id out of range");
+        int32_t x = rank[pairs[i].a], y = rank[pairs[i].b];
+        v[(size_t)i] = { std::min(x, y), std::max(x, y) };
+    }
+    std::sort(v.begin(), v.end(), [](const rp& x, const rp& y) { return x.lo != y.lo ? x.lo < y.lo : x.hi < y.hi; });
+    vg_task* o = (vg_task*)malloc(sizeof(vg_task) * std::max<size_t>(1, 2 * v.size()));
+    if (!o) throw vg_error(VG_ENOMEM, "out of host memory");
+    for (size_t i = 0; i < v.size(); ++i) {
+        o[2 * i] = { (uint32_t)order[v[i].hi], (uint32_t)order[v[i].lo] };       // row (q = b, r = a)
+        o[2 * i + 1] = { (uint32_t)order[v[i].lo], (uint32_t)order[v[i].hi] };   // row (q = a, r = b)
+    }
+    *tasks = o; *n_tasks = (int64_t)(2 * v.size());
+    VG_API_END
+}
+
+// ---------------------------------------------------------------- ani.tsv / ids.tsv / aln.tsv
+extern "C" int vg_write_ani(const vg_genomes* g, const vg_task* tasks, const vg_pair_stat* stats, int64_t n_tasks,
+                            const vg_region* regions, int64_t n_regions, const char* out_path, const vg_align_params* p) {
+    VG_API_BEGIN
+    if (!g || (!tasks && n_tasks) || (!stats && n_tasks) || !out_path || !p) throw vg_error(VG_EINVAL, "vg_write_ani: null argument");
+    if (n_tasks & 1) throw vg_error(VG_EINVAL, "vg_write_ani: tasks must come in (q,r),(r,q) couples");
+    std::vector<int32_t> order(g->n), rank(g->n);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return g->len[x] > g->len[y]; });
+    for (int i = 0; i < g->n; ++i) rank[order[i]] = i;
+    {
+        std::string ids(out_path);
+        if (ids.size() > 4 && ids.compare(ids.size() - 4, 4, ".tsv") == 0) ids.resize(ids.size() - 4);
+        ids += ".ids.tsv";
+        FILE* f = fopen(ids.c_str(), "w");
+        if (!f) throw vg_error(VG_EIO, "cannot write " + ids);
+        fprintf(f, "id\tseq_len\tno_parts\n");
+        for (int i = 0; i < g->n; ++i) fprintf(f, "%s\t%lld\t%d\n", g->names[order[i]].c_str(), (long long)g->len[order[i]], g->n_parts[order[i]]);
+        if (fclose(f)) throw vg_error(VG_EIO, "write error on " + ids);
+    }
+    FILE* f = fopen(out_path, "w");
+    if (!f) throw vg_error(VG_EIO, std::string("cannot write ") + out_path);
+    for (int c = 0; c < p->n_out_columns; ++c) fprintf(f, "%s%s", c ? "\t" : "", p->out_columns[c]);
+    fputc('\n', f);
+    std::vector<char> line;
+    for (int64_t t = 0; t < n_tasks; ++t) {
+        const vg_task& tk = tasks[t]; const vg_pair_stat& x = stats[t]; const vg_pair_stat& rev = stats[t ^ 1];
+        if (tasks[t ^ 1].q != tk.r || tasks[t ^ 1].r != tk.q) { fclose(f); throw vg_error(VG_EINVAL, "vg_write_ani: task couple mismatch"); }
+        int64_t lq = g->len[tk.q], lr = g->len[tk.r];
+        double ani = x.aln_len ? (double)x.n_match / (double)x.aln_len : 0.0;
+        double gani = lq ? (double)x.n_match / (double)lq : 0.0;
+        double qcov = lq ? (double)x.aln_len / (double)lq : 0.0;
+        double rcov = lr ? (double)rev.aln_len / (double)lr : 0.0;
+        double tani = (lq + lr) ? (double)((uint64_t)x.n_match + rev.n_match) / (double)(lq + lr) : 0.0;
+        if (p->out_tani > 0 && tani < p->out_tani) continue;
+        if (p->out_gani > 0 && gani < p->out_gani) continue;
+        if (p->out_ani > 0 && ani < p->out_ani) continue;
+        if (p->out_qcov > 0 && qcov < p->out_qcov) continue;
+        if (p->out_rcov > 0 && rcov < p->out_rcov) continue;
+        char buf[64];
+        for (int c = 0; c < p->n_out_columns; ++c) {
+            const char* col = p->out_columns[c];
+            if (c) fputc('\t', f);
+            if (!strcmp(col, "qidx")) fprintf(f, "%d", rank[tk.q]);
+            else if (!strcmp(col, "ridx")) fprintf(f, "%d", rank[tk.r]);
+            else if (!strcmp(col, "query")) fputs(g->names[tk.q].c_str(), f);
+            else if (!strcmp(col, "reference")) fputs(g->names[tk.r].c_str(), f);
+            else if (!strcmp(col, "tani")) { vg_fmt_num(tani, buf); fputs(buf, f); }
+            else if (!strcmp(col, "gani")) { vg_fmt_num(gani, buf); fputs(buf, f); }
+            else if (!strcmp(col, "ani")) { vg_fmt_num(ani, buf); fputs(buf, f); }
+            else if (!strcmp(col, "qcov")) { vg_fmt_num(qcov, buf); fputs(buf, f); }
+            else if (!strcmp(col, "rcov")) { vg_fmt_num(rcov, buf); fputs(buf, f); }
+            else if (!strcmp(col, "num_alns")) fprintf(f, "%u", x.n_regions);
+            else if (!strcmp(col, "len_ratio")) { vg_fmt_len_ratio(lq, lr, buf); fputs(buf, f); }
+            else if (!strcmp(col, "qlen")) fprintf(f, "%lld", (long long)lq);
+            else if (!strcmp(col, "rlen")) fprintf(f, "%lld", (long long)lr);
+            else if (!strcmp(col, "nt_match")) fprintf(f, "%u", x.n_match);
+            else if (!strcmp(col, "nt_mismatch")) fprintf(f, "%u", x.aln_len - x.n_match);
+            else { fclose(f); throw vg_error(VG_EINVAL, std::string("unknown output column ") + col); }
+        }
+        fputc('\n', f);
+    }
+    if (fclose(f)) throw vg_error(VG_EIO, std::string("write error on ") + out_path);
+
+    if (p->out_aln_path && regions) {
+        std::vector<vg_region> v(regions, regions + n_regions);
+        std::sort(v.begin(), v.end(), [](const vg_region& x, const vg_region& y) {
+            if (x.task != y.task) return x.task < y.task;
+            int lx = x.qend - x.qstart, ly = y.qend - y.qstart;
+            if (lx != ly) return lx > ly;
+            return x.qstart < y.qstart;
+        });
+        FILE* fa = fopen(p->out_aln_path, "w");
+        if (!fa) throw vg_error(VG_EIO, std::string("cannot write ") + p->out_aln_path);
+        fprintf(fa, "query\treference\tpident\talnlen\tqstart\tqend\trstart\trend\tnt_match\tnt_mismatch\n");
+        for (auto& r : v) {
+            if ((int64_t)r.task >= n_tasks) continue;
+            const vg_task& tk = tasks[r.task];
+            int64_t L = g->len[tk.r];
+            auto fwd1 = [&](int64_t rr) { return rr < L ? rr + 1 : L - (rr - (L + 1)); };   // fwd | N | rc space -> 1-based forward
+            int alnlen = r.qend - r.qstart + 1; char buf[64];
+            vg_fmt_num(100.0 * r.n_match / alnlen, buf);
+            fprintf(fa, "%s\t%s\t%s\t%d\t%d\t%d\t%lld\t%lld\t%d\t%d\n", g->names[tk.q].c_str(), g->names[tk.r].c_str(), buf, alnlen,
+                    r.qstart + 1, r.qend + 1, (long long)fwd1(r.rstart), (long long)fwd1(r.rend), r.n_match, alnlen - r.n_match);
+        }
+        if (fclose(fa)) throw vg_error(VG_EIO, std::string("write error on ") + p->out_aln_path);
+    }
+    VG_API_END
+}

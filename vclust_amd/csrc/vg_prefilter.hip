@@ -1,0 +1,426 @@
+// vg_prefilter.hip — Kmer-db prefilter on gfx950: canonical k-mer extraction from 2-bit
+// packed genomes, inverted index by one stable device radix sort, and the sparse
+// genome x genome shared-k-mer matrix as a row-wise SpGEMM (A * A^T) with LDS hash
+// accumulators.  Replaces `kmer-db build` + `all2all-sp` (vclust.py:953-1017); restates
+// SURVEY §8a K1/K2, parity-checked against oracle/prefilter_oracle.c.
+//
+// All kernels are HBM-streaming integer kernels (no MFMA): per padded base position the
+// pipeline reads 3 bits of sequence, writes/reads one u64 key per sort pass and one u64
+// row descriptor for the SpGEMM; the only random traffic is the read of the short genome
+// lists of shared k-mers.
+#include "vg_common.h"
+#include <rocprim/rocprim.hpp>
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace {
+
+constexpr uint64_t SENT = ~0ULL;
+constexpr uint32_t DUP_BIT = 0x80000000u;
+constexpr int RUNLEN_BITS = 24;
+constexpr uint64_t RUNLEN_MASK = (1ull << RUNLEN_BITS) - 1;
+
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33;
+    x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33; return x;
+}
+
+// reverse the order of the 32 two-bit groups of x
+__device__ __forceinline__ uint64_t rev2(uint64_t x) {
+    x = __brevll(x);
+    return ((x >> 1) & 0x5555555555555555ULL) | ((x & 0x5555555555555555ULL) << 1);
+}
+
+// ------------------------------------------------------------------ K1: canonical k-mers
+// One thread per padded base position.  64 consecutive lanes read the same 3-4 packed words
+// (served by one L1 line) and write 64 consecutive u64 keys (512 B, coalesced).
+__global__ void __launch_bounds__(256)
+k_kmer_extract(const uint32_t* __restrict__ packed, const uint32_t* __restrict__ nmask,
+               const uint32_t* __restrict__ blk2g, const int64_t* __restrict__ base_off,
+               const int64_t* __restrict__ len, int64_t P, int k, int use_frac, uint64_t frac_thr,
+               uint32_t shard, uint32_t n_shards, uint64_t* __restrict__ keys,
+               unsigned long long* __restrict__ n_valid) {
+    const uint64_t kmask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
+    unsigned long long local_valid = 0;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t g = blk2g[p >> 6];
+        int64_t local = p - base_off[g];
+        uint64_t key = SENT;
+        if (local + k <= len[g]) {
+            int64_t mw = p >> 5; int msh = (int)(p & 31);
+            uint64_t m = (uint64_t)nmask[mw] | ((uint64_t)nmask[mw + 1] << 32);
+            if (((m >> msh) & ((1ULL << k) - 1)) == 0) {
+                int64_t w = p >> 4; int sh = 2 * (int)(p & 15);
+                uint64_t lo = (uint64_t)packed[w] | ((uint64_t)packed[w + 1] << 32);
+                uint64_t hi = (uint64_t)packed[w + 2] | ((uint64_t)packed[w + 3] << 32);
+                uint64_t x = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;   // first base in the low bits
+                x &= kmask;
+                uint64_t fwd = rev2(x) >> (64 - 2 * k);                     // first base most significant
+                uint64_t rc = (~x) & kmask;                                 // reverse complement, same convention
+                uint64_t cano = fwd < rc ? fwd : rc;
+                bool keep = true;
+                if (use_frac || n_shards > 1) {
+                    uint64_t h = mix64(cano);
+                    if (use_frac && !(h < frac_thr)) keep = false;
+                    if (n_shards > 1 && (uint32_t)(((h & 0xffffffffULL) * n_shards) >> 32) != shard) keep = false;
+                }
+                if (keep) { key = cano; ++local_valid; }
+            }
+        }
+        keys[p] = key;
+    }
+    // one atomic per wave
+    for (int o = 32; o > 0; o >>= 1) local_valid += __shfl_down(local_valid, o);
+    if ((threadIdx.x & 63) == 0 && local_valid) atomicAdd(n_valid, local_valid);
+}
+
+__global__ void k_iota(uint32_t* v, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) v[i] = (uint32_t)i;
+}
+
+// ------------------------------------------------------------------ K2a: runs of the inverted index
+// sorted (key, pos): mark duplicates (same k-mer, same genome), run heads for the max-scan
+__global__ void __launch_bounds__(256)
+k_mark(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos, const uint32_t* __restrict__ blk2g,
+       int64_t n, uint32_t* __restrict__ gen, uint32_t* __restrict__ head) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        uint64_t key = keys[i];
+        uint32_t g = blk2g[pos[i] >> 6];
+        bool is_head = true, dup = false;
+        if (i > 0 && keys[i - 1] == key) { is_head = false; dup = (blk2g[pos[i - 1] >> 6] == g); }
+        gen[i] = g | (dup ? DUP_BIT : 0u);
+        head[i] = is_head ? (uint32_t)i : 0u;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_runlen(const uint32_t* __restrict__ run_start, int64_t n, uint32_t* __restrict__ run_len) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t rs = run_start[i];
+        if (i == n - 1 || run_start[i + 1] != rs) run_len[rs] = (uint32_t)(i - rs + 1);
+    }
+}
+
+// CSR side of the SpGEMM: one descriptor per base position = (run start, run length) of its
+// k-mer in the inverted index; 0 = position holds no distinct k-mer of its genome
+__global__ void __launch_bounds__(256)
+k_rowinfo(const uint32_t* __restrict__ pos, const uint32_t* __restrict__ gen, const uint32_t* __restrict__ run_start,
+          const uint32_t* __restrict__ run_len, int64_t n, uint64_t* __restrict__ rowinfo) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (gen[i] & DUP_BIT) continue;
+        uint32_t rs = run_start[i];
+        uint64_t rl = run_len[rs]; if (rl > RUNLEN_MASK) rl = RUNLEN_MASK;
+        rowinfo[pos[i]] = ((uint64_t)rs << RUNLEN_BITS) | rl;
+    }
+}
+
+// ------------------------------------------------------------------ K2b: row-wise SpGEMM
+// One workgroup per genome a: for every distinct k-mer of a, walk the (ascending) genome list
+// of that k-mer and count partners b < a in an LDS hash table; emit (a, b, shared).
+constexpr int HT_SIZE = 8192;          // LDS hash slots per workgroup (64 KiB)
+constexpr uint32_t HT_EMPTY = 0xffffffffu;
+constexpr int LONG_RUN = 48;           // runs longer than this are walked by the whole workgroup
+constexpr int LQ_CAP = 512;
+
+__device__ __forceinline__ bool ht_add(uint32_t* hk, uint32_t* hc, uint32_t b, uint32_t* n_used) {
+    uint32_t h = (b * 2654435761u) >> (32 - 13);
+    for (int probe = 0; probe < HT_SIZE; ++probe) {
+        uint32_t cur = hk[h];
+        if (cur == b) { atomicAdd(&hc[h], 1u); return true; }
+        if (cur == HT_EMPTY) {
+            uint32_t old = atomicCAS(&hk[h], HT_EMPTY, b);
+            if (old == HT_EMPTY) { atomicAdd(n_used, 1u); atomicAdd(&hc[h], 1u); return true; }
+            if (old == b) { atomicAdd(&hc[h], 1u); return true; }
+        }
+        h = (h + 1) & (HT_SIZE - 1);
+    }
+    return false;
+}
+
+__global__ void __launch_bounds__(256)
+k_spgemm(const uint64_t* __restrict__ rowinfo, const uint32_t* __restrict__ gen, const uint32_t* __restrict__ run_len,
+         const int64_t* __restrict__ base_off, const int64_t* __restrict__ len, int n_genomes, uint32_t min_emit,
+         const uint32_t* __restrict__ row_list, int n_rows,
+         int64_t* __restrict__ set_sizes, vg_pair_count* __restrict__ out, unsigned long long* __restrict__ out_cursor,
+         unsigned long long out_cap, uint32_t* __restrict__ overflow_rows, uint32_t* __restrict__ n_overflow) {
+    __shared__ uint32_t hk[HT_SIZE];
+    __shared__ uint32_t hc[HT_SIZE];
+    __shared__ uint64_t lq[LQ_CAP];
+    __shared__ uint32_t s_used, s_count, s_lq, s_fail;
+    const int row = blockIdx.x;
+    if (row >= n_rows) return;
+    const uint32_t a = row_list ? row_list[row] : (uint32_t)row;
+    for (int i = threadIdx.x; i < HT_SIZE; i += blockDim.x) { hk[i] = HT_EMPTY; hc[i] = 0; }
+    if (threadIdx.x == 0) { s_used = 0; s_count = 0; s_lq = 0; s_fail = 0; }
+    __syncthreads();
+    const int64_t p0 = base_off[a], L = len[a];
+    uint32_t my_count = 0;
+    for (int64_t base = 0; base < L; base += blockDim.x) {
+        int64_t i = base + threadIdx.x;
+        uint64_t r = (i < L) ? rowinfo[p0 + i] : 0;
+        if (r) {
+            ++my_count;
+            uint32_t rl = (uint32_t)(r & RUNLEN_MASK); uint32_t rs = (uint32_t)(r >> RUNLEN_BITS);
+            bool walk = false;
+            if (rl >= 2) {
+                if (rl > LONG_RUN) {
+                    uint32_t slot = atomicAdd(&s_lq, 1u);
+                    if (slot < LQ_CAP) lq[slot] = r; else walk = true;
+                } else walk = true;
+            }
+            if (walk) {
+                if (rl == RUNLEN_MASK) rl = run_len[rs];
+                for (uint32_t e = 0; e < rl; ++e) {
+                    uint32_t g = gen[rs + e];
+                    if (g & DUP_BIT) continue;
+                    if (g >= a) break;
+                    if (!ht_add(hk, hc, g, &s_used)) s_fail = 1;
+                }
+            }
+        }
+        // drain the long-run queue cooperatively when it fills up
+        __syncthreads();
+        if (s_lq >= LQ_CAP - 256 || base + blockDim.x >= L) {
+            uint32_t nq = s_lq < LQ_CAP ? s_lq : LQ_CAP;
+            for (uint32_t qi = 0; qi < nq; ++qi) {
+                uint64_t rr = lq[qi];
+                uint32_t rl = (uint32_t)(rr & RUNLEN_MASK); uint32_t rs = (uint32_t)(rr >> RUNLEN_BITS);
+                if (rl == RUNLEN_MASK) rl = run_len[rs];
+                for (uint32_t e = threadIdx.x; e < rl; e += blockDim.x) {
+                    uint32_t g = gen[rs + e];
+                    if ((g & DUP_BIT) || g >= a) continue;
+                    if (!ht_add(hk, hc, g, &s_used)) s_fail = 1;
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) s_lq = 0;
+            __syncthreads();
+        }
+    }
+    atomicAdd(&s_count, my_count);
+    __syncthreads();
+    if (threadIdx.x == 0) set_sizes[a] = s_count;
+    if (s_fail || s_used > HT_SIZE * 7 / 8) {
+        // too many partners for the LDS table: hand the row to the dense fallback
+        if (threadIdx.x == 0) { uint32_t o = atomicAdd(n_overflow, 1u); overflow_rows[o] = a; }
+        return;
+    }
+    for (int i = threadIdx.x; i < HT_SIZE; i += blockDim.x) {
+        uint32_t b = hk[i];
+        if (b != HT_EMPTY && hc[i] >= min_emit) {
+            unsigned long long o = atomicAdd(out_cursor, 1ULL);
+            if (o < out_cap) { out[o].a = a; out[o].b = b; out[o].shared = hc[i]; }
+        }
+    }
+}
+
+// dense fallback for rows whose partner set does not fit the LDS table: one workgroup per
+// overflowing row, counters in a private global array of n_genomes entries
+__global__ void __launch_bounds__(256)
+k_spgemm_dense(const uint64_t* __restrict__ rowinfo, const uint32_t* __restrict__ gen, const uint32_t* __restrict__ run_len,
+               const int64_t* __restrict__ base_off, const int64_t* __restrict__ len, int n_genomes, uint32_t min_emit,
+               const uint32_t* __restrict__ rows, uint32_t* __restrict__ dense /* gridDim.x * n_genomes, zeroed */,
+               vg_pair_count* __restrict__ out, unsigned long long* __restrict__ out_cursor, unsigned long long out_cap) {
+    const uint32_t a = rows[blockIdx.x];
+    uint32_t* cnt = dense + (size_t)blockIdx.x * n_genomes;
+    const int64_t p0 = base_off[a], L = len[a];
+    for (int64_t i = threadIdx.x; i < L; i += blockDim.x) {
+        uint64_t r = rowinfo[p0 + i];
+        if (!r) continue;
+        uint32_t rl = (uint32_t)(r & RUNLEN_MASK); uint32_t rs = (uint32_t)(r >> RUNLEN_BITS);
+        if (rl == RUNLEN_MASK) rl = run_len[rs];
+        if (rl < 2) continue;
+        for (uint32_t e = 0; e < rl; ++e) {
+            uint32_t g = gen[rs + e];
+            if (g & DUP_BIT) continue;
+            if (g >= a) break;
+            atomicAdd(&cnt[g], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < a; b += blockDim.x) {
+        uint32_t c = cnt[b];
+        if (c >= min_emit && c > 0) {
+            unsigned long long o = atomicAdd(out_cursor, 1ULL);
+            if (o < out_cap) { out[o].a = a; out[o].b = b; out[o].shared = c; }
+        }
+    }
+}
+
+inline int grid_for(int64_t n, int block = 256, int max_blocks = 256 * 16) {
+    int64_t b = (n + block - 1) / block;
+    if (b < 1) b = 1;
+    return (int)std::min<int64_t>(b, max_blocks);
+}
+
+struct max_op { __device__ __host__ uint32_t operator()(uint32_t a, uint32_t b) const { return a > b ? a : b; } };
+
+}  // namespace
+
+// ------------------------------------------------------------------ device residency of the block->genome map
+struct vg_prefilter_dev {
+    dbuf<uint32_t> blk2g;
+};
+static void build_blk2g(const vg_genomes* g, dbuf<uint32_t>& out, hipStream_t s) {
+    std::vector<uint32_t> h((size_t)(g->padded_total() / 64) + 1, 0);
+    for (int i = 0; i < g->n; ++i)
+        for (int64_t b = g->base_off[i] / 64; b < g->base_off[i + 1] / 64; ++b) h[(size_t)b] = (uint32_t)i;
+    out.alloc(h.size());
+    out.upload(h.data(), h.size(), s);
+    VG_HIP(hipStreamSynchronize(s));
+}
+
+// shared pipeline: extract -> (compact) -> sort.  Returns sorted keys/pos of the n_valid real k-mers.
+struct sorted_index {
+    dbuf<uint64_t> keys; dbuf<uint32_t> pos; int64_t n_valid = 0;
+};
+
+static void run_extract_sort(vg_genomes* g, const dbuf<uint32_t>& blk2g, int k, double fraction, int shard, int n_shards,
+                             sorted_index& out) {
+    hipStream_t s = vg_stream();
+    const int64_t P = g->padded_total();
+    if (P >= (1LL << 32)) throw vg_error(VG_EOVERFLOW, "genome set exceeds 2^32 padded bases per call; use --batch-size");
+    dbuf<uint64_t> keys_a((size_t)P), keys_b((size_t)P);
+    dbuf<uint32_t> pos_a((size_t)P), pos_b((size_t)P);
+    dbuf<unsigned long long> d_nvalid(1); d_nvalid.zero(s);
+    const int use_frac = fraction < 1.0;
+    const uint64_t thr = use_frac ? (uint64_t)std::ldexp(fraction, 64) : ~0ULL;
+    {
+        vg_prof_scope ps("kmer_extract", (double)P * (3.0 / 8.0 + 8.0));
+        hipLaunchKernelGGL(k_kmer_extract, dim3(grid_for(P)), dim3(256), 0, s, g->d_packed.p, g->d_nmask.p, blk2g.p,
+                           g->d_base_off.p, g->d_len.p, P, k, use_frac, thr, (uint32_t)shard, (uint32_t)n_shards,
+                           keys_a.p, d_nvalid.p);
+    }
+    hipLaunchKernelGGL(k_iota, dim3(grid_for(P)), dim3(256), 0, s, pos_a.p, P);
+    unsigned long long nv = 0;
+    d_nvalid.download(&nv, 1, s);
+    VG_HIP(hipStreamSynchronize(s));
+    // stable LSD radix sort on the 2k key bits; sentinels (all ones) end up behind every real k-mer
+    size_t tmp_bytes = 0;
+    unsigned int end_bit = (unsigned)(2 * k);
+    VG_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_a.p, keys_b.p, pos_a.p, pos_b.p, (size_t)P, 0u, end_bit, s));
+    dbuf<char> tmp(tmp_bytes);
+    {
+        int passes = (2 * k + 7) / 8;
+        vg_prof_scope ps("radix_sort_pairs", (double)P * 12.0 * 2.0 * passes);
+        VG_HIP(rocprim::radix_sort_pairs((void*)tmp.p, tmp_bytes, keys_a.p, keys_b.p, pos_a.p, pos_b.p, (size_t)P, 0u, end_bit, s));
+    }
+    VG_HIP(hipStreamSynchronize(s));
+    out.keys = std::move(keys_b); out.pos = std::move(pos_b); out.n_valid = (int64_t)nv;
+}
+
+extern "C" int vg_kmer_shared(vg_genomes* g, int k, double fraction, int shard, int n_shards, uint32_t min_shared,
+                              int64_t* set_sizes, vg_pair_count** pairs, int64_t* n_pairs) {
+    VG_API_BEGIN
+    if (!g || !set_sizes || !pairs || !n_pairs) throw vg_error(VG_EINVAL, "vg_kmer_shared: null argument");
+    if (k < 8 || k > 31) throw vg_error(VG_EINVAL, "k out of range (8..31)");
+    if (n_shards < 1 || shard < 0 || shard >= n_shards) throw vg_error(VG_EINVAL, "bad shard");
+    if (!(fraction > 0.0) || fraction > 1.0) throw vg_error(VG_EINVAL, "fraction must be in (0,1]");
+    vg_require_device();
+    int rc = vg_genomes_to_device(g); if (rc) return rc;
+    hipStream_t s = vg_stream();
+    *pairs = nullptr; *n_pairs = 0;
+    const int n = g->n;
+    if (n == 0) return VG_OK;
+    dbuf<uint32_t> blk2g; build_blk2g(g, blk2g, s);
+    sorted_index si;
+    run_extract_sort(g, blk2g, k, fraction, shard, n_shards, si);
+    const int64_t nv = si.n_valid;
+    const int64_t P = g->padded_total();
+    dbuf<uint64_t> rowinfo((size_t)P); rowinfo.zero(s);
+    dbuf<uint32_t> gen((size_t)std::max<int64_t>(nv, 1)), head((size_t)std::max<int64_t>(nv, 1)),
+        run_start((size_t)std::max<int64_t>(nv, 1)), run_len((size_t)std::max<int64_t>(nv, 1));
+    if (nv > 0) {
+        {
+            vg_prof_scope ps("mark_runs", (double)nv * (8 + 4 + 4 + 4));
+            hipLaunchKernelGGL(k_mark, dim3(grid_for(nv)), dim3(256), 0, s, si.keys.p, si.pos.p, blk2g.p, nv, gen.p, head.p);
+        }
+        size_t tb = 0;
+        VG_HIP(rocprim::inclusive_scan(nullptr, tb, head.p, run_start.p, (size_t)nv, max_op(), s));
+        dbuf<char> tmp(tb);
+        {
+            vg_prof_scope ps("run_start_scan", (double)nv * 8);
+            VG_HIP(rocprim::inclusive_scan((void*)tmp.p, tb, head.p, run_start.p, (size_t)nv, max_op(), s));
+        }
+        {
+            vg_prof_scope ps("run_len_rowinfo", (double)nv * (4 + 4 + 4 + 4 + 8));
+            hipLaunchKernelGGL(k_runlen, dim3(grid_for(nv)), dim3(256), 0, s, run_start.p, nv, run_len.p);
+            hipLaunchKernelGGL(k_rowinfo, dim3(grid_for(nv)), dim3(256), 0, s, si.pos.p, gen.p, run_start.p, run_len.p, nv, rowinfo.p);
+        }
+    }
+    si.keys.release();
+    // SpGEMM with a growing output buffer
+    dbuf<int64_t> d_sizes((size_t)n); d_sizes.zero(s);
+    dbuf<unsigned long long> d_cursor(1);
+    dbuf<uint32_t> d_over((size_t)n), d_nover(1);
+    unsigned long long cap = std::max<unsigned long long>(1u << 20, (unsigned long long)n * 16);
+    std::vector<vg_pair_count> host_pairs;
+    for (;;) {
+        dbuf<vg_pair_count> d_out((size_t)cap);
+        d_cursor.zero(s); d_nover.zero(s);
+        {
+            vg_prof_scope ps("spgemm_rows", (double)P * 8.0);
+            hipLaunchKernelGGL(k_spgemm, dim3(n), dim3(256), 0, s, rowinfo.p, gen.p, run_len.p, g->d_base_off.p, g->d_len.p, n,
+                               min_shared, (const uint32_t*)nullptr, n, d_sizes.p, d_out.p, d_cursor.p, cap, d_over.p, d_nover.p);
+        }
+        uint32_t nover = 0; d_nover.download(&nover, 1, s);
+        VG_HIP(hipStreamSynchronize(s));
+        if (nover > 0) {
+            // dense fallback, a few rows at a time
+            std::vector<uint32_t> rows(nover); d_over.download(rows.data(), nover, s); VG_HIP(hipStreamSynchronize(s));
+            const uint32_t batch = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(nover, (int64_t)(1u << 28) / std::max(n, 1)));
+            dbuf<uint32_t> dense((size_t)batch * n), d_rows(batch);
+            for (uint32_t o = 0; o < nover; o += batch) {
+                uint32_t nb = std::min(batch, nover - o);
+                dense.zero(s);
+                d_rows.upload(rows.data() + o, nb, s);
+                vg_prof_scope ps("spgemm_dense_rows", 0);
+                hipLaunchKernelGGL(k_spgemm_dense, dim3(nb), dim3(256), 0, s, rowinfo.p, gen.p, run_len.p, g->d_base_off.p, g->d_len.p,
+                                   n, min_shared, d_rows.p, dense.p, d_out.p, d_cursor.p, cap);
+                VG_HIP(hipStreamSynchronize(s));
+            }
+        }
+        unsigned long long produced = 0; d_cursor.download(&produced, 1, s);
+        VG_HIP(hipStreamSynchronize(s));
+        if (produced <= cap) {
+            host_pairs.resize((size_t)produced);
+            if (produced) d_out.download(host_pairs.data(), (size_t)produced, s);
+            VG_HIP(hipStreamSynchronize(s));
+            break;
+        }
+        cap = produced + produced / 8 + 1024;     // rerun with a buffer that fits
+    }
+    d_sizes.download(set_sizes, (size_t)n, s);
+    VG_HIP(hipStreamSynchronize(s));
+    vg_pair_count* outp = (vg_pair_count*)malloc(sizeof(vg_pair_count) * std::max<size_t>(1, host_pairs.size()));
+    if (!outp) throw vg_error(VG_ENOMEM, "out of host memory");
+    if (!host_pairs.empty()) memcpy(outp, host_pairs.data(), sizeof(vg_pair_count) * host_pairs.size());
+    *pairs = outp; *n_pairs = (int64_t)host_pairs.size();
+    VG_API_END
+}
+
+extern "C" int vg_kmer_set(vg_genomes* g, int idx, int k, double fraction, uint64_t** out, int64_t* n_out) {
+    VG_API_BEGIN
+    if (!g || !out || !n_out || idx < 0 || idx >= g->n) throw vg_error(VG_EINVAL, "vg_kmer_set: bad argument");
+    if (k < 8 || k > 31) throw vg_error(VG_EINVAL, "k out of range (8..31)");
+    vg_require_device();
+    int rc = vg_genomes_to_device(g); if (rc) return rc;
+    hipStream_t s = vg_stream();
+    dbuf<uint32_t> blk2g; build_blk2g(g, blk2g, s);
+    sorted_index si;
+    run_extract_sort(g, blk2g, k, fraction, 0, 1, si);
+    // host-side filter of one genome's keys out of the sorted index (test-only entry point)
+    std::vector<uint64_t> keys((size_t)si.n_valid); std::vector<uint32_t> pos((size_t)si.n_valid);
+    if (si.n_valid) { si.keys.download(keys.data(), keys.size(), s); si.pos.download(pos.data(), pos.size(), s); }
+    VG_HIP(hipStreamSynchronize(s));
+    std::vector<uint64_t> mine;
+    const int64_t lo = g->base_off[idx], hi = g->base_off[idx + 1];
+    for (size_t i = 0; i < keys.size(); ++i)
+        if ((int64_t)pos[i] >= lo && (int64_t)pos[i] < hi && (mine.empty() || mine.back() != keys[i])) mine.push_back(keys[i]);
+    uint64_t* o = (uint64_t*)malloc(sizeof(uint64_t) * std::max<size_t>(1, mine.size()));
+    if (!o) throw vg_error(VG_ENOMEM, "out of host memory");
+    if (!mine.empty()) memcpy(o, mine.data(), sizeof(uint64_t) * mine.size());
+    *out = o; *n_out = (int64_t)mine.size();
+    VG_API_END
+}
