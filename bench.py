@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py — genome pairs/sec through prefilter+align on MI355X (BASELINE.json metric).
+
+One "step" = one full pass of the hot path over the synthetic genome set, inputs already
+resident in HBM: Kmer-db prefilter (k-mer extraction, inverted index, shared-k-mer SpGEMM)
+-> host threshold (min-kmers / ani-shorter) -> LZ-ANI parse of every surviving pair in both
+directions.  value = unordered pairs aligned per second (whole job, all ranks).
+
+  python bench.py --gpus 1 --steps 3 --warmup 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N = 1 workload: configs[1] of BASELINE.json, "phage-1k" = 100 families x 10 members x 40 kb.
+N > 1: weak scaling, N x 100 families; the prefilter is sharded by k-mer hash range (partial
+counts all-gathered over RCCL and summed), the align tasks are dealt in contiguous reference
+groups, and the per-pair integer rows are gathered to rank 0.
+"""
+import argparse
+import json
+import os
+import pathlib
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = pathlib.Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+from vclust_amd import api, synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def candidate_pairs(sizes, pairs, k, min_kmers, min_ident):
+    """K3 thresholds on the summed shared counts (same arithmetic as vg_write_fltr)."""
+    if len(pairs) == 0:
+        return pairs
+    key = pairs['a'].astype(np.uint64) << np.uint64(32) | pairs['b'].astype(np.uint64)
+    uk, inv = np.unique(key, return_inverse=True)
+    shared = np.zeros(len(uk), dtype=np.int64)
+    np.add.at(shared, inv, pairs['shared'].astype(np.int64))
+    a = (uk >> np.uint64(32)).astype(np.int64)
+    b = (uk & np.uint64(0xffffffff)).astype(np.int64)
+    mn = np.minimum(sizes[a], sizes[b]).astype(np.float64)
+    j = shared / np.maximum(mn, 1.0)
+    ani = 1.0 + np.log(2.0 * j / (1.0 + j)) / k
+    keep = (shared >= min_kmers) & (ani >= min_ident)
+    out = np.zeros(int(keep.sum()), dtype=api.PAIR_DTYPE)
+    out['a'], out['b'], out['shared'] = a[keep], b[keep], shared[keep]
+    return out
+
+
+def cpu_baseline(sample_families, members, length, seed, threads):
+    """Time the CPU oracle (own restatement, not upstream) on a bounded sample of the workload."""
+    cli = ROOT / 'oracle' / '_build' / 'oracle_cli'
+    if not cli.exists():
+        subprocess.run(['make', '-C', str(ROOT / 'oracle')], check=True, stdout=subprocess.DEVNULL)
+    codes, offsets, names = synth.make_families(sample_families, members, length=length, seed=seed)
+    with tempfile.TemporaryDirectory() as td:
+        fa = os.path.join(td, 's.fna')
+        synth.write_fasta(fa, codes, offsets, names)
+        fl, ani = os.path.join(td, 'fltr.txt'), os.path.join(td, 'ani.tsv')
+        t0 = time.perf_counter()
+        subprocess.run([str(cli), 'prefilter', '-t', str(threads), '-o', fl, fa], check=True)
+        subprocess.run([str(cli), 'align', '-t', str(threads), '--filter', fl, '0', '-o', ani, fa], check=True)
+        dt = time.perf_counter() - t0
+        rows = sum(1 for _ in open(ani)) - 1
+    pairs = rows // 2
+    return dict(value=pairs / dt, unit='pairs/s', cores=threads, kind='port',
+                sample=f'{sample_families} families x {members} x {length} bp = {pairs} pairs, '
+                       f'oracle_cli prefilter+align incl. FASTA parse, {dt:.1f} s')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--families', type=int, default=100, help='families per GPU')
+    ap.add_argument('--members', type=int, default=10)
+    ap.add_argument('--length', type=int, default=40000)
+    ap.add_argument('--k', type=int, default=25)
+    ap.add_argument('--min-kmers', type=int, default=20)
+    ap.add_argument('--min-ident', type=float, default=0.7)
+    ap.add_argument('--cpu-sample-families', type=int, default=40)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    dist = None
+    import torch
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    if api.device_count() < 1:
+        raise SystemExit('bench.py needs a HIP device: libvclust_gpu has no CPU fallback')
+    api.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+
+    n_fam = args.families * world
+    codes, offsets, names = synth.make_families(n_fam, args.members, length=args.length, seed=1)
+    gs = api.GenomeSet.from_codes(codes, offsets, names)
+    gs.to_device()
+    lens = gs.lengths()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def gather_rows(arr, dtype):
+        """variable-length all-gather of a structured array (RCCL): counts, then padded payload."""
+        if not dist:
+            return arr
+        raw = torch.from_numpy(arr.view(np.uint8).copy()).to(dev)
+        cnt = torch.tensor([raw.numel()], device=dev, dtype=torch.int64)
+        cnts = [torch.zeros_like(cnt) for _ in range(world)]
+        dist.all_gather(cnts, cnt)
+        mx = int(max(int(c) for c in cnts))
+        pad = torch.zeros(mx, device=dev, dtype=torch.uint8)
+        pad[:raw.numel()] = raw
+        bufs = [torch.zeros_like(pad) for _ in range(world)]
+        dist.all_gather(bufs, pad)
+        parts = [bufs[r][:int(cnts[r])].cpu().numpy().view(dtype) for r in range(world)]
+        return np.concatenate(parts)
+
+    state = {}
+
+    def step():
+        # -- prefilter: this rank's k-mer hash range; partial counts add up across ranks
+        sizes, pairs = gs.kmer_shared(k=args.k, shard=rank, n_shards=world, min_shared=1 if world > 1 else args.min_kmers)
+        if dist:
+            st = torch.from_numpy(sizes).to(dev)
+            dist.all_reduce(st)
+            sizes = st.cpu().numpy()
+            pairs = gather_rows(pairs, api.PAIR_DTYPE)
+        cand = candidate_pairs(sizes, pairs, args.k, args.min_kmers, args.min_ident)
+        # -- align: canonical task list, contiguous share per rank (couples stay together)
+        tasks = gs.align_tasks(cand)
+        n_couples = len(tasks) // 2
+        lo = (n_couples * rank // world) * 2
+        hi = (n_couples * (rank + 1) // world) * 2
+        stats = gs.lz_align(tasks[lo:hi])
+        stats = gather_rows(stats, api.STAT_DTYPE)
+        state.update(n_pairs=n_couples, stats=stats, tasks=tasks)
+
+    api.profile_enable(False)
+    for _ in range(args.warmup):
+        step()
+    api.profile_enable(True)
+    api.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    prof = api.profile_get()
+    api.profile_enable(False)
+
+    if rank == 0:
+        n_pairs = state['n_pairs']
+        # roofline of the dominant kernel (HIP events on the library stream, vg_profile_*)
+        dom = max(prof, key=lambda e: e['total_ms']) if prof else None
+        roofline = None
+        if dom and dom['launches']:
+            avg_ms = dom['total_ms'] / dom['launches']
+            alg_bytes = dom['bytes'] / dom['launches']
+            achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+            roofline = dict(bound='hbm', kernel=dom['name'], achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit='GB/s',
+                            frac=round(achieved / HBM_PEAK_GBS, 6), traffic=None,
+                            avg_launch_ms=round(avg_ms, 4), algorithmic_bytes_per_launch=round(alg_bytes),
+                            kernels={e['name']: round(e['total_ms'] / max(e['launches'], 1), 4) for e in prof})
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(min(args.cpu_sample_families, args.families), args.members, args.length, 1,
+                               os.cpu_count() or 1)
+        out = {
+            'metric': 'genome pairs/sec through prefilter+align (ani.tsv)',
+            'value': round(n_pairs * args.steps / dt, 3),
+            'unit': 'pairs/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': round(dt / args.steps * 1e3, 3),
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'u64',
+            'data': 'synthetic',
+            'config': {
+                'workload': f'phage-1k x{world}: {n_fam} families x {args.members} members x {args.length} bp, '
+                            f'k={args.k}, min-kmers={args.min_kmers}, min-ident={args.min_ident}, lz defaults',
+                'genomes': int(len(gs)), 'pairs_per_step': int(n_pairs), 'total_bases': int(lens.sum()),
+                'parallelism': f'kmer-range x{world} prefilter, task-range x{world} align',
+            },
+            'roofline': roofline,
+            'cpu_baseline': cpu,
+        }
+        print(json.dumps(out))
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

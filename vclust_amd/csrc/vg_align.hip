@@ -230,55 +230,150 @@ __device__ __forceinline__ int count_eq_wave(const pair_ctx& c, int qp, int rp, 
 }
 
 // ------------------------------------------------------------------ index construction
-// RR packed + mask words: one thread per 32 RR positions
-__global__ void __launch_bounds__(256)
-k_build_rr(const ref_desc* __restrict__ refs, int n_refs, const int64_t* __restrict__ chunk_off /* n_refs+1, in 32-base chunks */,
-           const uint32_t* __restrict__ packed, const uint32_t* __restrict__ nmask, const int64_t* __restrict__ base_off,
-           uint32_t* __restrict__ rr_pool, uint32_t* __restrict__ mask_pool) {
-    const int64_t total = chunk_off[n_refs];
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        int lo = 0, hi = n_refs - 1;
-        while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (chunk_off[mid] <= t) lo = mid; else hi = mid - 1; }
-        const ref_desc rd = refs[lo];
-        const int64_t ch = t - chunk_off[lo];
-        const int64_t g0 = base_off[rd.genome];
-        uint64_t bits = 0; uint32_t mask = 0;
-        for (int j = 0; j < 32; ++j) {
-            int64_t p = ch * 32 + j;
-            uint32_t code = 0, m = 1;
-            if (p < rd.L) {
-                int64_t gp = g0 + p;
-                code = (packed[gp >> 4] >> (2 * (gp & 15))) & 3u; m = (nmask[gp >> 5] >> (gp & 31)) & 1u;
-            } else if (p > rd.L && p <= 2 * (int64_t)rd.L) {
-                int64_t gp = g0 + (rd.L - 1 - (p - rd.L - 1));
-                code = 3u - ((packed[gp >> 4] >> (2 * (gp & 15))) & 3u); m = (nmask[gp >> 5] >> (gp & 31)) & 1u;
-            }
-            if (m) code = 0;
-            bits |= (uint64_t)code << (2 * j); mask |= m << j;
-        }
-        rr_pool[rd.rr_w + 2 * ch] = (uint32_t)bits; rr_pool[rd.rr_w + 2 * ch + 1] = (uint32_t)(bits >> 32);
-        mask_pool[rd.mask_w + ch] = mask;
+// 32 symbols of RR = forward | N | reverse complement, starting at RR position 32*ch, straight
+// from the genome's packed words (no per-base loop): the reverse-complement part is a
+// 2-bit-group reversal + complement of 32 forward bases.
+__device__ __forceinline__ void rr_chunk(const uint32_t* __restrict__ gpk, const uint32_t* __restrict__ gmk, int L, int64_t ch,
+                                         uint64_t* bits_out, uint32_t* mask_out) {
+    const int64_t p0 = ch * 32;
+    uint64_t bits = 0; uint32_t mask = 0xffffffffu;
+    const int64_t nf = (int64_t)L - p0;
+    if (nf > 0) {
+        uint64_t x = (uint64_t)gpk[p0 >> 4] | ((uint64_t)gpk[(p0 >> 4) + 1] << 32);
+        uint32_t m = gmk[p0 >> 5];
+        if (nf >= 32) { bits = x; mask = m; }
+        else { bits = x & ((1ULL << (2 * nf)) - 1); uint32_t lowm = (1u << nf) - 1; mask = (m & lowm) | ~lowm; }
     }
+    const int64_t jlo = (L + 1 - p0) > 0 ? (L + 1 - p0) : 0;
+    const int64_t jhi = (2 * (int64_t)L - p0) < 31 ? (2 * (int64_t)L - p0) : 31;
+    if (jlo <= jhi) {
+        const int64_t fstart = 2 * (int64_t)L - p0 - 31;
+        uint64_t x; uint32_t m;
+        if (fstart >= 0) { x = load32(gpk, fstart); m = loadm32(gmk, fstart); }
+        else { x = load32(gpk, 0) << (2 * (-fstart)); m = loadm32(gmk, 0) << (-fstart); }
+        const uint64_t r = ~rev2(x);
+        const uint32_t mr = __brev(m);
+        const uint64_t hi2 = (jhi == 31) ? ~0ULL : ((1ULL << (2 * (jhi + 1))) - 1);
+        const uint64_t lo2 = (jlo == 0) ? 0ULL : ((1ULL << (2 * jlo)) - 1);
+        const uint64_t sl2 = hi2 & ~lo2;
+        const uint32_t hi1 = (jhi == 31) ? 0xffffffffu : ((1u << (jhi + 1)) - 1);
+        const uint32_t lo1 = (jlo == 0) ? 0u : ((1u << jlo) - 1);
+        const uint32_t sl1 = hi1 & ~lo1;
+        bits |= r & sl2;
+        mask = (mask & ~sl1) | (mr & sl1);
+    }
+    uint64_t sm = spread(mask); sm |= sm << 1;
+    *bits_out = bits & ~sm; *mask_out = mask;
 }
 
 __device__ __forceinline__ uint32_t anchor_bucket(uint64_t code, int B) {
     return (uint32_t)((code * 0x9E3779B97F4A7C15ULL) >> (64 - B));
 }
 
+// ---- path A (references up to 2^18 RR symbols, msl <= 7): one 1024-thread workgroup per
+// reference builds RR and both bucket indexes by counting sort entirely in LDS (128 KiB table).
+constexpr int LDS_TAB = 32768;
+__device__ __forceinline__ void lds_scan_exclusive(uint32_t* tab, int n, uint32_t* part) {
+    // n <= LDS_TAB, blockDim.x == 1024: each thread owns n/1024 consecutive entries
+    const int per = (n + 1023) / 1024;
+    const int i0 = threadIdx.x * per;
+    uint32_t s = 0;
+    for (int j = 0; j < per; ++j) if (i0 + j < n) s += tab[i0 + j];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        uint32_t add = threadIdx.x >= (unsigned)o ? part[threadIdx.x - o] : 0;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - s;
+    for (int j = 0; j < per; ++j) if (i0 + j < n) { uint32_t v = tab[i0 + j]; tab[i0 + j] = run; run += v; }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(1024)
+k_build_index_lds(const ref_desc* __restrict__ refs, const int* __restrict__ slot_list,
+                  const uint32_t* __restrict__ packed, const uint32_t* __restrict__ nmask, const int64_t* __restrict__ base_off,
+                  uint32_t* __restrict__ rr_pool, uint32_t* __restrict__ mask_pool, int mal, int msl,
+                  uint32_t* __restrict__ atab_pool, uint32_t* __restrict__ aent_pool,
+                  uint32_t* __restrict__ stab_pool, uint32_t* __restrict__ sent_pool) {
+    __shared__ uint32_t tab[LDS_TAB];
+    __shared__ uint32_t part[1024];
+    const ref_desc rd = refs[slot_list[blockIdx.x]];
+    const int64_t g0 = base_off[rd.genome];
+    const uint32_t* gpk = packed + (g0 >> 4); const uint32_t* gmk = nmask + (g0 >> 5);
+    uint32_t* pk = rr_pool + rd.rr_w; uint32_t* mk = mask_pool + rd.mask_w;
+    const int64_t chunks = ((int64_t)rd.n_rr + RR_PAD + 31) / 32 + 2;
+    for (int64_t ch = threadIdx.x; ch < chunks; ch += blockDim.x) {
+        uint64_t bits; uint32_t m;
+        rr_chunk(gpk, gmk, rd.L, ch, &bits, &m);
+        pk[2 * ch] = (uint32_t)bits; pk[2 * ch + 1] = (uint32_t)(bits >> 32); mk[ch] = m;
+    }
+    __threadfence_block();
+    __syncthreads();
+    const uint64_t amask = (mal >= 32) ? ~0ULL : ((1ULL << (2 * mal)) - 1);
+    const uint64_t smask = (1ULL << (2 * msl)) - 1;
+    for (int phase = 0; phase < 2; ++phase) {
+        const int nb = phase == 0 ? (1 << rd.B) : (1 << (2 * msl));
+        const int w = phase == 0 ? mal : msl;
+        uint32_t* gtab = phase == 0 ? atab_pool + rd.atab : stab_pool + rd.stab;
+        uint32_t* gent = phase == 0 ? aent_pool + rd.aent : sent_pool + rd.sent;
+        for (int i = threadIdx.x; i < nb; i += blockDim.x) tab[i] = 0;
+        __syncthreads();
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int p = threadIdx.x; p < rd.n_rr; p += blockDim.x) {
+                if (p + w > rd.n_rr) continue;
+                uint64_t m = (uint64_t)mk[p >> 5] | ((uint64_t)mk[(p >> 5) + 1] << 32);
+                m >>= (p & 31);
+                if (m & ((1ULL << w) - 1)) continue;
+                const uint64_t x = load32(pk, p);
+                const uint32_t b = phase == 0 ? anchor_bucket(x & amask, rd.B) : (uint32_t)(x & smask);
+                const uint32_t slot = atomicAdd(&tab[b], 1u);
+                if (pass == 1) gent[slot] = (uint32_t)p;
+            }
+            __syncthreads();
+            if (pass == 0) lds_scan_exclusive(tab, nb, part);
+        }
+        for (int i = threadIdx.x; i < nb; i += blockDim.x) gtab[i] = tab[i];     // END of every bucket
+        __syncthreads();
+    }
+}
+
+// ---- path B (large references / long seeds): global-memory counting sort
+__global__ void __launch_bounds__(256)
+k_build_rr(const ref_desc* __restrict__ refs, const int* __restrict__ slot_list, int n_list,
+           const int64_t* __restrict__ chunk_off /* n_list+1, in 32-base chunks */,
+           const uint32_t* __restrict__ packed, const uint32_t* __restrict__ nmask, const int64_t* __restrict__ base_off,
+           uint32_t* __restrict__ rr_pool, uint32_t* __restrict__ mask_pool) {
+    const int64_t total = chunk_off[n_list];
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        int lo = 0, hi = n_list - 1;
+        while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (chunk_off[mid] <= t) lo = mid; else hi = mid - 1; }
+        const ref_desc rd = refs[slot_list[lo]];
+        const int64_t ch = t - chunk_off[lo];
+        const int64_t g0 = base_off[rd.genome];
+        uint64_t bits; uint32_t m;
+        rr_chunk(packed + (g0 >> 4), nmask + (g0 >> 5), rd.L, ch, &bits, &m);
+        rr_pool[rd.rr_w + 2 * ch] = (uint32_t)bits; rr_pool[rd.rr_w + 2 * ch + 1] = (uint32_t)(bits >> 32);
+        mask_pool[rd.mask_w + ch] = m;
+    }
+}
+
 // count (fill == 0) or place (fill == 1) the anchor / seed entries of every RR position
 __global__ void __launch_bounds__(256)
-k_index_pass(const ref_desc* __restrict__ refs, int n_refs, const int64_t* __restrict__ chunk_off,
+k_index_pass(const ref_desc* __restrict__ refs, const int* __restrict__ slot_list, int n_list, const int64_t* __restrict__ chunk_off,
              const uint32_t* __restrict__ rr_pool, const uint32_t* __restrict__ mask_pool, int mal, int msl, int fill,
              uint32_t* __restrict__ atab_pool, uint32_t* __restrict__ aent_pool, uint32_t* __restrict__ stab_pool,
              uint32_t* __restrict__ sent_pool) {
-    const int64_t total = chunk_off[n_refs] * 32;
+    const int64_t total = chunk_off[n_list] * 32;
     const uint64_t amask = (mal >= 32) ? ~0ULL : ((1ULL << (2 * mal)) - 1);
     const uint64_t smask = (1ULL << (2 * msl)) - 1;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         int64_t chunk = t >> 5;
-        int lo = 0, hi = n_refs - 1;
+        int lo = 0, hi = n_list - 1;
         while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (chunk_off[mid] <= chunk) lo = mid; else hi = mid - 1; }
-        const ref_desc rd = refs[lo];
+        const ref_desc rd = refs[slot_list[lo]];
         const int64_t p = t - chunk_off[lo] * 32;
         if (p >= rd.n_rr) continue;
         const uint32_t* pk = rr_pool + rd.rr_w; const uint32_t* mk = mask_pool + rd.mask_w;
@@ -287,23 +382,24 @@ k_index_pass(const ref_desc* __restrict__ refs, int n_refs, const int64_t* __res
         m >>= (p & 31);
         if (p + mal <= rd.n_rr && (m & ((1ULL << mal) - 1)) == 0) {
             uint32_t b = anchor_bucket(x & amask, rd.B);
-            if (!fill) atomicAdd(&atab_pool[rd.atab + b], 1u);
-            else { uint32_t slot = atomicAdd(&atab_pool[rd.atab + b], 1u); aent_pool[rd.aent + slot] = (uint32_t)p; }
+            uint32_t slot = atomicAdd(&atab_pool[rd.atab + b], 1u);
+            if (fill) aent_pool[rd.aent + slot] = (uint32_t)p;
         }
         if (p + msl <= rd.n_rr && (m & ((1ULL << msl) - 1)) == 0) {
             uint32_t b = (uint32_t)(x & smask);
-            if (!fill) atomicAdd(&stab_pool[rd.stab + b], 1u);
-            else { uint32_t slot = atomicAdd(&stab_pool[rd.stab + b], 1u); sent_pool[rd.sent + slot] = (uint32_t)p; }
+            uint32_t slot = atomicAdd(&stab_pool[rd.stab + b], 1u);
+            if (fill) sent_pool[rd.sent + slot] = (uint32_t)p;
         }
     }
 }
 
 // exclusive scan of each bucket table, one workgroup per (reference, table)
 __global__ void __launch_bounds__(256)
-k_scan_tables(const ref_desc* __restrict__ refs, int msl, uint32_t* __restrict__ atab_pool, uint32_t* __restrict__ stab_pool) {
+k_scan_tables(const ref_desc* __restrict__ refs, const int* __restrict__ slot_list, int msl,
+              uint32_t* __restrict__ atab_pool, uint32_t* __restrict__ stab_pool) {
     __shared__ uint32_t part[256];
     __shared__ uint32_t carry;
-    const ref_desc rd = refs[blockIdx.x >> 1];
+    const ref_desc rd = refs[slot_list[blockIdx.x >> 1]];
     const bool seed = blockIdx.x & 1;
     uint32_t* tab = seed ? stab_pool + rd.stab : atab_pool + rd.atab;
     const int64_t n = seed ? (1LL << (2 * msl)) : (1LL << rd.B);
@@ -548,7 +644,8 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
         while (end < n_tasks) {
             const uint32_t r = tasks[order[end]].r;
             const int64_t L = g->len[r]; const int64_t n_rr = 2 * L + 1;
-            int B = 8; while ((1LL << (B + 1)) <= n_rr && B + 1 <= 2 * p->mal && B < 26) ++B;
+            const bool small = n_rr <= (1 << 18) && p->msl <= 7;
+            int B = 8; while ((1LL << (B + 1)) <= n_rr && B + 1 <= 2 * p->mal && B < (small ? 15 : 26)) ++B;
             const int64_t chunks = (n_rr + RR_PAD + 31) / 32 + 2;
             const int64_t need = chunks * 12 + ((1LL << B) + n_rr + stab_n + n_rr) * 4;
             if (!refs.empty() && bytes + need > g_index_budget_bytes) break;
@@ -576,17 +673,35 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
         dbuf<uint32_t> rr_pool((size_t)rr_words + 8), mask_pool((size_t)mask_words + 8), atab_pool((size_t)atab_n), aent_pool((size_t)aent_n),
             stab_pool((size_t)stab_tot), sent_pool((size_t)sent_n);
         dbuf<task_dev> d_tasks(td.size()); d_tasks.upload(td.data(), td.size(), s);
-        atab_pool.zero(s); stab_pool.zero(s);
+        // split the batch: LDS counting sort for ordinary references, global path for the rest
+        std::vector<int> small_list, large_list; std::vector<int64_t> large_chunks{ 0 };
+        for (int i = 0; i < n_refs; ++i) {
+            const bool small = refs[i].n_rr <= (1 << 18) && p->msl <= 7;
+            if (small) small_list.push_back(i);
+            else { large_list.push_back(i); large_chunks.push_back(large_chunks.back() + (chunk_off[i + 1] - chunk_off[i])); }
+        }
+        dbuf<int> d_small(std::max<size_t>(1, small_list.size())), d_large(std::max<size_t>(1, large_list.size()));
+        dbuf<int64_t> d_lchunk(large_chunks.size());
+        if (!small_list.empty()) d_small.upload(small_list.data(), small_list.size(), s);
+        if (!large_list.empty()) { d_large.upload(large_list.data(), large_list.size(), s); d_lchunk.upload(large_chunks.data(), large_chunks.size(), s); }
         const int64_t total_chunks = chunk_off.back();
         {
-            vg_prof_scope ps("lz_build_index", (double)total_chunks * 32 * (0.25 + 0.375 + 16));
-            hipLaunchKernelGGL(k_build_rr, dim3(grid_for(total_chunks)), dim3(256), 0, s, d_refs.p, n_refs, d_chunk.p, g->d_packed.p,
-                               g->d_nmask.p, g->d_base_off.p, rr_pool.p, mask_pool.p);
-            hipLaunchKernelGGL(k_index_pass, dim3(grid_for(total_chunks * 32)), dim3(256), 0, s, d_refs.p, n_refs, d_chunk.p, rr_pool.p,
-                               mask_pool.p, p->mal, p->msl, 0, atab_pool.p, aent_pool.p, stab_pool.p, sent_pool.p);
-            hipLaunchKernelGGL(k_scan_tables, dim3(2 * n_refs), dim3(256), 0, s, d_refs.p, p->msl, atab_pool.p, stab_pool.p);
-            hipLaunchKernelGGL(k_index_pass, dim3(grid_for(total_chunks * 32)), dim3(256), 0, s, d_refs.p, n_refs, d_chunk.p, rr_pool.p,
-                               mask_pool.p, p->mal, p->msl, 1, atab_pool.p, aent_pool.p, stab_pool.p, sent_pool.p);
+            vg_prof_scope ps("lz_build_index", (double)total_chunks * 32 * (0.375 + 0.375 + 8));
+            if (!large_list.empty()) { atab_pool.zero(s); stab_pool.zero(s); }
+            if (!small_list.empty())
+                hipLaunchKernelGGL(k_build_index_lds, dim3((unsigned)small_list.size()), dim3(1024), 0, s, d_refs.p, d_small.p, g->d_packed.p,
+                                   g->d_nmask.p, g->d_base_off.p, rr_pool.p, mask_pool.p, p->mal, p->msl, atab_pool.p, aent_pool.p,
+                                   stab_pool.p, sent_pool.p);
+            if (!large_list.empty()) {
+                const int nl = (int)large_list.size(); const int64_t lc = large_chunks.back();
+                hipLaunchKernelGGL(k_build_rr, dim3(grid_for(lc)), dim3(256), 0, s, d_refs.p, d_large.p, nl, d_lchunk.p, g->d_packed.p,
+                                   g->d_nmask.p, g->d_base_off.p, rr_pool.p, mask_pool.p);
+                hipLaunchKernelGGL(k_index_pass, dim3(grid_for(lc * 32)), dim3(256), 0, s, d_refs.p, d_large.p, nl, d_lchunk.p, rr_pool.p,
+                                   mask_pool.p, p->mal, p->msl, 0, atab_pool.p, aent_pool.p, stab_pool.p, sent_pool.p);
+                hipLaunchKernelGGL(k_scan_tables, dim3(2 * nl), dim3(256), 0, s, d_refs.p, d_large.p, p->msl, atab_pool.p, stab_pool.p);
+                hipLaunchKernelGGL(k_index_pass, dim3(grid_for(lc * 32)), dim3(256), 0, s, d_refs.p, d_large.p, nl, d_lchunk.p, rr_pool.p,
+                                   mask_pool.p, p->mal, p->msl, 1, atab_pool.p, aent_pool.p, stab_pool.p, sent_pool.p);
+            }
         }
         {
             const int64_t nt = end - pos;
