@@ -37,7 +37,7 @@ struct ref_desc {
     int32_t B;         // anchor bucket bits
     int32_t genome;    // genome id
     int32_t has_n;     // reference genome contains N
-    int32_t pad_;
+    int32_t pos_bits;  // anchor entry = pos | tag << pos_bits (tag = next hash bits after the bucket)
 };
 
 struct lz_dev_params { int mal, msl, mrd, mqd, reg, aw, am, ar; };
@@ -87,21 +87,29 @@ struct pair_ctx {
 // mismatch mask (even bits) of the 32 positions q[qp+j] vs rr[rp+j]; out-of-range, separator
 // and N positions are mismatches.  qp/rp may be negative or run past the end.
 __device__ __forceinline__ uint64_t mism32(const pair_ctx& c, int qp, int rp) {
-    uint64_t bad = 0;
     // valid slots: 0 <= qp+j < qlen, 0 <= rp+j < n_rr, rp+j != L
-    int lo = max(-qp, -rp); int hi = min(c.qlen - qp, c.n_rr - rp);
-    uint64_t ok = slots(lo, hi);
-    bad = EVEN & ~ok;
-    int sj = c.L - rp; if (sj >= 0 && sj < 32) bad |= 1ULL << (2 * sj);
+    const int lo = max(-qp, -rp); const int hi = min(c.qlen - qp, c.n_rr - rp);
+    const int sj = c.L - rp;
+    if (lo <= 0 && hi >= 32 && (unsigned)sj >= 32u) {
+        // fast path: the whole chunk lies inside both sequences and misses the separator
+        const uint64_t d = load32(c.qpk, qp) ^ load32(c.rpk, rp);
+        uint64_t mm = (d | (d >> 1)) & EVEN;
+        if (c.q_has_n) mm |= spread(loadm32(c.qmk, qp));
+        if (c.r_has_n) mm |= spread(loadm32(c.rmk, rp));
+        return mm;
+    }
+    const uint64_t ok = slots(lo, hi);
     if (ok == 0) return EVEN;
-    int qs = qp < 0 ? 0 : qp, rs = rp < 0 ? 0 : rp;           // clamp loads; shifted back below
+    uint64_t bad = EVEN & ~ok;
+    if (sj >= 0 && sj < 32) bad |= 1ULL << (2 * sj);
+    const int qs = qp < 0 ? 0 : qp, rs = rp < 0 ? 0 : rp;     // clamp loads; shifted back below
     uint64_t xq = load32(c.qpk, qs), xr = load32(c.rpk, rs);
     if (qp < 0) xq <<= 2 * (-qp);
     if (rp < 0) xr <<= 2 * (-rp);
-    uint64_t d = xq ^ xr;
+    const uint64_t d = xq ^ xr;
     uint64_t mm = (d | (d >> 1)) & EVEN;
-    if (c.q_has_n) { uint32_t m = loadm32(c.qmk, qs); uint64_t s = spread(m); if (qp < 0) s <<= 2 * (-qp); mm |= s; }
-    if (c.r_has_n) { uint32_t m = loadm32(c.rmk, rs); uint64_t s = spread(m); if (rp < 0) s <<= 2 * (-rp); mm |= s; }
+    if (c.q_has_n) { uint64_t sp = spread(loadm32(c.qmk, qs)); if (qp < 0) sp <<= 2 * (-qp); mm |= sp; }
+    if (c.r_has_n) { uint64_t sp = spread(loadm32(c.rmk, rs)); if (rp < 0) sp <<= 2 * (-rp); mm |= sp; }
     return (mm | bad) & EVEN;
 }
 
@@ -148,7 +156,7 @@ __device__ __forceinline__ int approx_ext(const pair_ctx& c, const lz_dev_params
     uint64_t carry_ok = 0;        // match bits of the previous 32 positions (none before e = 0)
     int base = 0;                 // first position of this round
     int cum_before = 0;           // matches in [0, base)
-    int lanes_now = 8;            // first round looks at 256 positions only
+    int lanes_now = 64;
     const uint64_t awmask = (P.aw >= 32) ? ~0ULL : ((1ULL << (2 * P.aw)) - 1);
     for (;;) {
         uint64_t mm = EVEN;
@@ -164,20 +172,25 @@ __device__ __forceinline__ int approx_ext(const pair_ctx& c, const lz_dev_params
         }
         uint64_t prev_mm = __shfl_up(mm, 1); uint64_t okb = (~mm) & EVEN; uint64_t prev_ok = __shfl_up(okb, 1);
         if (lane == 0) { prev_mm = carry_mm; prev_ok = carry_ok; }
-        // per-position window counts -> first violation in this lane
+        // first violation in this lane.  A window count can only newly exceed am at a mismatch
+        // position, and never if the chunk plus the aw-1 symbols before it hold <= am mismatches.
         int viol = 32;
-        {
-            // window ending at slot j covers combined bits [64 + 2(j-aw+1), 64 + 2j]
-            for (int j = 0; j < 32; ++j) {
-                int top = 2 * j + 2;                       // exclusive bit index inside `mm`
-                uint64_t hi = (top == 64) ? mm : (mm & ((1ULL << top) - 1));
-                int cnt;
-                if (j + 1 >= P.aw) cnt = __popcll(hi & (awmask << (2 * (j + 1 - P.aw))));
-                else cnt = __popcll(hi) + __popcll(prev_mm >> (64 - 2 * (P.aw - 1 - j)));
-                if (cnt > P.am) { viol = j; break; }
+        if (act) {
+            const uint64_t tail = (P.aw > 1) ? (prev_mm >> (64 - 2 * (P.aw - 1))) : 0ULL;
+            if (__popcll(mm) + __popcll(tail) > P.am) {
+                uint64_t bits = mm;
+                while (bits) {
+                    const int j = __builtin_ctzll(bits) >> 1;
+                    const int top = 2 * j + 2;
+                    const uint64_t hi = (top == 64) ? mm : (mm & ((1ULL << top) - 1));
+                    int cnt;
+                    if (j + 1 >= P.aw) cnt = __popcll(hi & (awmask << (2 * (j + 1 - P.aw))));
+                    else cnt = __popcll(hi) + __popcll(prev_mm >> (64 - 2 * (P.aw - 1 - j)));
+                    if (cnt > P.am) { viol = j; break; }
+                    bits &= bits - 1;
+                }
             }
         }
-        if (!act) viol = 32;
         // positions ending a run of >= ar matches
         uint64_t run = okb;
         for (int t = 1; t < P.ar; ++t) run &= (okb << (2 * t)) | (prev_ok >> (64 - 2 * t));
@@ -266,8 +279,10 @@ __device__ __forceinline__ void rr_chunk(const uint32_t* __restrict__ gpk, const
     *bits_out = bits & ~sm; *mask_out = mask;
 }
 
-__device__ __forceinline__ uint32_t anchor_bucket(uint64_t code, int B) {
-    return (uint32_t)((code * 0x9E3779B97F4A7C15ULL) >> (64 - B));
+__device__ __forceinline__ uint64_t anchor_hash(uint64_t code) { return code * 0x9E3779B97F4A7C15ULL; }
+__device__ __forceinline__ uint32_t anchor_bucket(uint64_t h, int B) { return (uint32_t)(h >> (64 - B)); }
+__device__ __forceinline__ uint32_t anchor_tag(uint64_t h, int B, int pos_bits) {
+    return (uint32_t)((h << B) >> 32) >> pos_bits;          // the (32 - pos_bits) hash bits below the bucket bits
 }
 
 // ---- path A (references up to 2^18 RR symbols, msl <= 7): one 1024-thread workgroup per
@@ -328,9 +343,13 @@ k_build_index_lds(const ref_desc* __restrict__ refs, const int* __restrict__ slo
                 m >>= (p & 31);
                 if (m & ((1ULL << w) - 1)) continue;
                 const uint64_t x = load32(pk, p);
-                const uint32_t b = phase == 0 ? anchor_bucket(x & amask, rd.B) : (uint32_t)(x & smask);
+                uint32_t b, ent = (uint32_t)p;
+                if (phase == 0) {
+                    const uint64_t h = anchor_hash(x & amask);
+                    b = anchor_bucket(h, rd.B); ent |= anchor_tag(h, rd.B, rd.pos_bits) << rd.pos_bits;
+                } else b = (uint32_t)(x & smask);
                 const uint32_t slot = atomicAdd(&tab[b], 1u);
-                if (pass == 1) gent[slot] = (uint32_t)p;
+                if (pass == 1) gent[slot] = ent;
             }
             __syncthreads();
             if (pass == 0) lds_scan_exclusive(tab, nb, part);
@@ -381,9 +400,10 @@ k_index_pass(const ref_desc* __restrict__ refs, const int* __restrict__ slot_lis
         uint64_t m = (uint64_t)mk[p >> 5] | ((uint64_t)mk[(p >> 5) + 1] << 32);
         m >>= (p & 31);
         if (p + mal <= rd.n_rr && (m & ((1ULL << mal) - 1)) == 0) {
-            uint32_t b = anchor_bucket(x & amask, rd.B);
+            const uint64_t h = anchor_hash(x & amask);
+            uint32_t b = anchor_bucket(h, rd.B);
             uint32_t slot = atomicAdd(&atab_pool[rd.atab + b], 1u);
-            if (fill) aent_pool[rd.aent + slot] = (uint32_t)p;
+            if (fill) aent_pool[rd.aent + slot] = (uint32_t)p | (anchor_tag(h, rd.B, rd.pos_bits) << rd.pos_bits);
         }
         if (p + msl <= rd.n_rr && (m & ((1ULL << msl) - 1)) == 0) {
             uint32_t b = (uint32_t)(x & smask);
@@ -495,12 +515,16 @@ k_lz_parse(const task_dev* __restrict__ tasks, int64_t n_tasks, const ref_desc* 
             }
             // R2: anchor = longest exact match >= mal over all occurrences, ties -> smallest position
             if (q_ok_a) {
-                const uint64_t code = xq & amask;
-                const uint32_t b = anchor_bucket(code, rd.B);
+                const uint64_t h = anchor_hash(xq & amask);
+                const uint32_t b = anchor_bucket(h, rd.B);
+                const uint32_t tag = anchor_tag(h, rd.B, rd.pos_bits);
+                const uint32_t posmask = (1u << rd.pos_bits) - 1u;
                 const uint32_t s = b ? atab[b - 1] : 0u, e = atab[b];
                 int ncap = 0;
                 for (uint32_t u = s; u < e; ++u) {
-                    const int rp = (int)aent[u];
+                    const uint32_t ent = aent[u];
+                    if ((ent >> rd.pos_bits) != tag) continue;
+                    const int rp = (int)(ent & posmask);
                     if ((load32(c.rpk, rp) ^ xq) & amask) continue;
                     int l = match_len_lane(c, qi, rp, 32);
                     if (l < P.mal) continue;
@@ -652,6 +676,7 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
             ref_desc rd; memset(&rd, 0, sizeof rd);
             rd.rr_w = rr_words; rd.mask_w = mask_words; rd.atab = atab_n; rd.aent = aent_n; rd.stab = stab_tot; rd.sent = sent_n;
             rd.L = (int32_t)L; rd.n_rr = (int32_t)n_rr; rd.B = B; rd.genome = (int32_t)r; rd.has_n = g->has_n[r];
+            { int pb = 1; while ((1LL << pb) < n_rr) ++pb; rd.pos_bits = pb; }
             refs.push_back(rd);
             rr_words += chunks * 2; mask_words += chunks; atab_n += 1LL << B; aent_n += n_rr; stab_tot += stab_n; sent_n += n_rr;
             chunk_off.push_back(chunk_off.back() + chunks);

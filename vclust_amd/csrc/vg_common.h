@@ -26,6 +26,9 @@ struct vg_error : std::runtime_error {
 
 void vg_require_device();        // throws VG_ENODEV when no HIP device is usable
 hipStream_t vg_stream();         // the library's compute stream on the current device
+void* vg_dev_alloc(size_t bytes); // caching device allocator (throws vg_error)
+void  vg_dev_free(void* p);
+void  vg_dev_trim();             // return all cached blocks to the driver
 
 // ---------------------------------------------------------------- device buffers
 template <class T> struct dbuf {
@@ -36,11 +39,14 @@ template <class T> struct dbuf {
     dbuf(dbuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
     dbuf& operator=(dbuf&& o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
     ~dbuf() { release(); }
+    // blocks come from a caching allocator (vg_core.cpp): every kernel and copy of the library is
+    // issued on one in-order stream, so a released block can be handed out again without a
+    // device synchronisation and the hot path never calls hipMalloc/hipFree.
     void alloc(size_t count) {
         release(); n = count;
-        if (count) VG_HIP(hipMalloc((void**)&p, count * sizeof(T)));
+        if (count) p = (T*)vg_dev_alloc(count * sizeof(T));
     }
-    void release() { if (p) { (void)hipFree(p); p = nullptr; } n = 0; }
+    void release() { if (p) { vg_dev_free(p); p = nullptr; } n = 0; }
     size_t bytes() const { return n * sizeof(T); }
     void zero(hipStream_t s) { if (n) VG_HIP(hipMemsetAsync(p, 0, bytes(), s)); }
     void upload(const T* h, size_t count, hipStream_t s) { VG_HIP(hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, s)); }

@@ -54,6 +54,56 @@ hipStream_t vg_stream() {
     return g_stream;
 }
 
+// ---------------------------------------------------------------- caching device allocator
+namespace {
+std::mutex g_alloc_mu;
+std::multimap<size_t, void*> g_free_blocks;          // size -> block
+std::map<void*, size_t> g_block_size;                // every live or cached block
+size_t g_cached_bytes = 0;
+constexpr size_t ALLOC_GRAN = 1 << 12;
+}
+
+void* vg_dev_alloc(size_t bytes) {
+    vg_require_device();
+    size_t want = (bytes + ALLOC_GRAN - 1) / ALLOC_GRAN * ALLOC_GRAN;
+    {
+        std::lock_guard<std::mutex> lk(g_alloc_mu);
+        auto it = g_free_blocks.lower_bound(want);
+        if (it != g_free_blocks.end() && it->first <= want + want / 4 + (1 << 20)) {
+            void* p = it->second; g_cached_bytes -= it->first; g_free_blocks.erase(it);
+            return p;
+        }
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+        vg_dev_trim();                                // give cached blocks back and retry once
+        e = hipMalloc(&p, want);
+        if (e != hipSuccess) throw vg_error(VG_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    }
+    std::lock_guard<std::mutex> lk(g_alloc_mu);
+    g_block_size[p] = want;
+    return p;
+}
+
+void vg_dev_free(void* p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_alloc_mu);
+    auto it = g_block_size.find(p);
+    if (it == g_block_size.end()) { (void)hipFree(p); return; }
+    g_free_blocks.emplace(it->second, p); g_cached_bytes += it->second;
+}
+
+void vg_dev_trim() {
+    std::vector<void*> blocks;
+    {
+        std::lock_guard<std::mutex> lk(g_alloc_mu);
+        for (auto& kv : g_free_blocks) { blocks.push_back(kv.second); g_block_size.erase(kv.second); }
+        g_free_blocks.clear(); g_cached_bytes = 0;
+    }
+    if (!blocks.empty()) { (void)hipDeviceSynchronize(); for (void* b : blocks) (void)hipFree(b); }
+}
+
 // ---------------------------------------------------------------- profiling
 struct prof_entry { double ms = 0; int64_t launches = 0; double bytes = 0; int order = 0; };
 struct pending_ev { std::string name; hipEvent_t e0, e1; double bytes; };
