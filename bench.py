@@ -29,6 +29,7 @@ ROOT = pathlib.Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 from vclust_amd import api, synth  # noqa: E402
+from vclust_amd import distributed as D  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -84,7 +85,7 @@ def main():
     ap.add_argument('--k', type=int, default=25)
     ap.add_argument('--min-kmers', type=int, default=20)
     ap.add_argument('--min-ident', type=float, default=0.7)
-    ap.add_argument('--cpu-sample-families', type=int, default=40)
+    ap.add_argument('--cpu-sample-families', type=int, default=100)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -114,41 +115,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def gather_rows(arr, dtype):
-        """variable-length all-gather of a structured array (RCCL): counts, then padded payload."""
-        if not dist:
-            return arr
-        raw = torch.from_numpy(arr.view(np.uint8).copy()).to(dev)
-        cnt = torch.tensor([raw.numel()], device=dev, dtype=torch.int64)
-        cnts = [torch.zeros_like(cnt) for _ in range(world)]
-        dist.all_gather(cnts, cnt)
-        mx = int(max(int(c) for c in cnts))
-        pad = torch.zeros(mx, device=dev, dtype=torch.uint8)
-        pad[:raw.numel()] = raw
-        bufs = [torch.zeros_like(pad) for _ in range(world)]
-        dist.all_gather(bufs, pad)
-        parts = [bufs[r][:int(cnts[r])].cpu().numpy().view(dtype) for r in range(world)]
-        return np.concatenate(parts)
-
     state = {}
 
     def step():
-        # -- prefilter: this rank's k-mer hash range; partial counts add up across ranks
-        sizes, pairs = gs.kmer_shared(k=args.k, shard=rank, n_shards=world, min_shared=1 if world > 1 else args.min_kmers)
-        if dist:
-            st = torch.from_numpy(sizes).to(dev)
-            dist.all_reduce(st)
-            sizes = st.cpu().numpy()
-            pairs = gather_rows(pairs, api.PAIR_DTYPE)
+        # -- prefilter: this rank's k-mer hash range; partial counts add up across ranks (RCCL all-gather)
+        if world > 1:
+            sizes, pairs = D.prefilter_counts(gs, dist, dev, rank, world, args.k, 1.0)
+        else:
+            sizes, pairs = gs.kmer_shared(k=args.k, min_shared=args.min_kmers)
         cand = candidate_pairs(sizes, pairs, args.k, args.min_kmers, args.min_ident)
-        # -- align: canonical task list, contiguous share per rank (couples stay together)
+        # -- align: canonical task list, contiguous share per rank, rows gathered over RCCL
         tasks = gs.align_tasks(cand)
-        n_couples = len(tasks) // 2
-        lo = (n_couples * rank // world) * 2
-        hi = (n_couples * (rank + 1) // world) * 2
-        stats = gs.lz_align(tasks[lo:hi])
-        stats = gather_rows(stats, api.STAT_DTYPE)
-        state.update(n_pairs=n_couples, stats=stats, tasks=tasks)
+        stats, _ = D.align_rows(gs, tasks, dist, dev, rank, world, None, False)
+        state.update(n_pairs=len(tasks) // 2, stats=stats, tasks=tasks)
 
     api.profile_enable(False)
     for _ in range(args.warmup):

@@ -1,0 +1,140 @@
+"""CPU-side tests of libvclust_gpu.so: the C-ABI loads and exports every declared symbol, the
+host-only entry points (ingest, writers, task lists) reproduce the reference's files from the
+golden integers, and compute calls fail loudly without a GPU (no CPU fallback)."""
+import collections
+import ctypes as C
+import filecmp
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+from vclust_amd import _lib, api
+
+
+def test_header_symbols_all_exported_and_bound():
+    header = (_lib.PKG_DIR.parent / 'include' / 'vclust_gpu.h').read_text()
+    declared = set(re.findall(r'\b(vg_[a-z_0-9]+)\s*\(', header))
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), f'{name} declared in vclust_gpu.h but not exported'
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+
+
+def test_no_gpu_means_loud_failure(golden_dir):
+    if api.device_count() > 0:
+        pytest.skip('a HIP device is visible')
+    gs = api.GenomeSet.load([golden_dir / 'multifasta.fna'], multisample=True)
+    with pytest.raises(_lib.VclustGpuError) as e:
+        gs.kmer_shared(k=25)
+    assert e.value.code == -3 and 'no CPU fallback' in str(e.value)
+    with pytest.raises(_lib.VclustGpuError):
+        gs.lz_align(np.zeros(2, dtype=api.TASK_DTYPE))
+    with pytest.raises(_lib.VclustGpuError):
+        api.set_device(0)
+
+
+@pytest.mark.parametrize('inp,multi', [('multifasta.fna', True), ('multifasta.fna.gz', True), ('fna', False)])
+def test_ingest(golden_dir, inp, multi):
+    codes, offsets, names = orc.read_fasta_codes(golden_dir / 'multifasta.fna')
+    paths = [golden_dir / inp] if multi else sorted((golden_dir / 'fna').iterdir())
+    gs = api.GenomeSet.load(paths, multisample=multi, n_threads=4)
+    assert len(gs) == 12
+    if multi:
+        assert gs.names() == names
+        assert list(gs.lengths()) == list(np.diff(offsets))
+    else:
+        assert sorted(n.replace('.fna', '') for n in gs.names()) == sorted(names)
+        assert sorted(gs.lengths()) == sorted(np.diff(offsets))
+    assert gs.total_len == int(offsets[-1])
+
+
+def test_ingest_errors(tmp_path):
+    with pytest.raises(_lib.VclustGpuError) as e:
+        api.GenomeSet.load([tmp_path / 'missing.fna'], multisample=True)
+    assert e.value.code == -2
+
+
+def test_write_fltr_from_oracle_counts_is_golden(tmp_path, golden_dir):
+    """K3 + K4 of the product's host writer; accepts concatenated per-shard partial counts."""
+    codes, offsets, names = orc.read_fasta_codes(golden_dir / 'multifasta.fna')
+    sizes, pairs = orc.shared_all(codes, offsets, k=25)
+    gs = api.GenomeSet.load([golden_dir / 'multifasta.fna'], multisample=True)
+    arr = np.array([(a, b, s) for (a, b), s in pairs.items()], dtype=api.PAIR_DTYPE)
+    gs.write_fltr(tmp_path / 'f.txt', sizes, arr)
+    assert filecmp.cmp(tmp_path / 'f.txt', golden_dir / 'output' / 'fltr.txt', shallow=False)
+    halves = np.concatenate([arr, arr]); halves['shared'] = np.concatenate([arr['shared'] // 2, arr['shared'] - arr['shared'] // 2])
+    gs.write_fltr(tmp_path / 'g.txt', sizes, halves[::-1])
+    assert filecmp.cmp(tmp_path / 'g.txt', golden_dir / 'output' / 'fltr.txt', shallow=False)
+
+
+def test_fltr_thresholds_and_max_seqs(tmp_path, golden_dir):
+    codes, offsets, names = orc.read_fasta_codes(golden_dir / 'multifasta.fna')
+    sizes, pairs = orc.shared_all(codes, offsets, k=25)
+    gs = api.GenomeSet.load([golden_dir / 'multifasta.fna'], multisample=True)
+    arr = np.array([(a, b, s) for (a, b), s in pairs.items()], dtype=api.PAIR_DTYPE)
+    gs.write_fltr(tmp_path / 'a.txt', sizes, arr, min_ident=0.99)
+    orc.run_cli('prefilter', '--min-ident', '0.99', '-o', tmp_path / 'b.txt', golden_dir / 'multifasta.fna')
+    assert filecmp.cmp(tmp_path / 'a.txt', tmp_path / 'b.txt', shallow=False)
+    gs.write_fltr(tmp_path / 'c.txt', sizes, arr, max_seqs=1)
+    orc.run_cli('prefilter', '--max-seqs', '1', '-o', tmp_path / 'd.txt', golden_dir / 'multifasta.fna')
+    assert filecmp.cmp(tmp_path / 'c.txt', tmp_path / 'd.txt', shallow=False)
+    assert sum(line.count(':') for line in open(tmp_path / 'c.txt')) - 1 <= 12
+
+
+def test_read_filter_and_tasks(golden_dir):
+    gs = api.GenomeSet.load([golden_dir / 'multifasta.fna'], multisample=True)
+    allp = gs.read_filter(None)
+    assert len(allp) == 66 and all(allp['a'] > allp['b'])
+    flt = gs.read_filter(golden_dir / 'output' / 'fltr.txt', 0.0)
+    assert len(flt) == 13
+    assert len(gs.read_filter(golden_dir / 'output' / 'fltr.txt', 0.99)) == 8
+    order = gs.align_order()
+    ids = [l.split('\t')[0] for l in open(golden_dir / 'output' / 'ani.ids.tsv').read().splitlines()[1:]]
+    assert [gs.names()[i] for i in order] == ids
+    tasks = gs.align_tasks(allp)
+    rank = {int(g): r for r, g in enumerate(order)}
+    rows = [l.split('\t')[:2] for l in open(golden_dir / 'output' / 'ani.tsv').read().splitlines()[1:]]
+    assert [[str(rank[int(t['q'])]), str(rank[int(t['r'])])] for t in tasks] == rows
+
+
+@pytest.mark.parametrize('fmt', ['standard', 'lite', 'complete'])
+def test_write_ani_from_golden_integers(tmp_path, golden_dir, fmt):
+    """L6-L8 of the product's host writer fed with the integers summed from the golden
+    alignment table: ani.tsv (all 792 numeric fields), ids file and the alignment table."""
+    gs = api.GenomeSet.load([golden_dir / 'multifasta.fna'], multisample=True)
+    names = gs.names(); idx = {n: i for i, n in enumerate(names)}
+    tasks = gs.align_tasks(gs.read_filter(None))
+    tpos = {(int(t['q']), int(t['r'])): i for i, t in enumerate(tasks)}
+    stats = np.zeros(len(tasks), dtype=api.STAT_DTYPE)
+    regions = []
+    lens = gs.lengths()
+    for line in open(golden_dir / 'output' / 'ani.aln.tsv').read().splitlines()[1:]:
+        c = line.split('\t')
+        t = tpos[(idx[c[0]], idx[c[1]])]
+        stats[t]['n_match'] += int(c[8]); stats[t]['aln_len'] += int(c[3]); stats[t]['n_regions'] += 1
+        L = int(lens[idx[c[1]]]); rs, re_ = int(c[6]), int(c[7])
+        to_rr = (lambda p: p - 1) if rs <= re_ else (lambda p: L + 1 + (L - p))
+        regions.append((t, int(c[4]) - 1, int(c[5]) - 1, to_rr(rs), to_rr(re_), int(c[8])))
+    regions = np.array(regions, dtype=api.REGION_DTYPE)
+    from vclust_amd.cli import ALIGN_OUTFMT
+    out = tmp_path / 'ani.tsv'; aln = tmp_path / 'ani.aln.tsv'
+    gs.write_ani(out, tasks, stats, regions=regions, columns=ALIGN_OUTFMT[fmt], out_aln=aln)
+    assert filecmp.cmp(tmp_path / 'ani.ids.tsv', golden_dir / 'output' / 'ani.ids.tsv', shallow=False)
+    if fmt == 'standard':
+        assert filecmp.cmp(out, golden_dir / 'output' / 'ani.tsv', shallow=False)
+        assert sorted(open(aln).read().splitlines()) == sorted(open(golden_dir / 'output' / 'ani.aln.tsv').read().splitlines())
+    else:
+        assert open(out).readline().split() == ALIGN_OUTFMT[fmt]
+        assert sum(1 for _ in open(out)) == 133
+
+
+def test_write_ani_output_filters(tmp_path, golden_dir):
+    gs = api.GenomeSet.load([golden_dir / 'multifasta.fna'], multisample=True)
+    tasks = gs.align_tasks(gs.read_filter(None))
+    stats = np.zeros(len(tasks), dtype=api.STAT_DTYPE)
+    stats['n_match'] = 30000; stats['aln_len'] = 35000; stats['n_regions'] = 5
+    stats[0] = (100, 200, 1)
+    gs.write_ani(tmp_path / 'o.tsv', tasks, stats, out_filters={'ani': 0.8})
+    assert sum(1 for _ in open(tmp_path / 'o.tsv')) == 132        # header + 131 rows, row 0 (ani 0.5) dropped

@@ -1,0 +1,125 @@
+"""The reference's black-box CLI tests for the hot path (test.py:336-588), run against the
+drop-in front-end on a real GPU."""
+import pathlib
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+VCLUST = ROOT / 'vclust.py'
+EX = ROOT / 'tests' / 'golden' / 'example'
+FASTA_DIR, FASTA_FILE, FASTAGZ_FILE = EX / 'fna', EX / 'multifasta.fna', EX / 'multifasta.fna.gz'
+
+
+def run(*args, capture=True):
+    return subprocess.run([sys.executable, str(VCLUST), *map(str, args)], stdout=subprocess.PIPE if capture else None,
+                          stderr=subprocess.PIPE if capture else None, text=True)
+
+
+def parse_fltr(path):
+    with open(path) as fh:
+        vids = fh.readline().strip().rstrip(',').split(',')[1:]
+        idx2vid = {i: v.rstrip('.fna') for i, v in enumerate(vids, start=1)}
+        res = {}
+        for line in fh:
+            cols = line.rstrip().rstrip(',').split(',')
+            v1 = cols[0].rstrip('.fna')
+            for f in cols[1:]:
+                i, ani = f.split(':')
+                res[(v1, idx2vid[int(i)])] = float(ani); res[(idx2vid[int(i)], v1)] = float(ani)
+    return res
+
+
+@pytest.mark.parametrize('inp,params', [(FASTA_DIR, []), (FASTA_FILE, []), (FASTA_FILE, ['--batch-size', '4']), (FASTAGZ_FILE, [])])
+def test_prefilter_default(tmp_path, inp, params):
+    out = tmp_path / 'filter.txt'
+    p = run('prefilter', '-i', inp, '-o', out, '-v', '0', *params)
+    assert p.returncode == 0 and not p.stderr
+    r = parse_fltr(out)
+    assert r[('NC_010807.alt1', 'NC_010807')] == 0.99848
+    assert r[('NC_010807.alt2', 'NC_010807.alt3')] == 0.992238
+    assert r[('NC_025457', 'NC_025457.alt1')] == 0.990832
+    assert r[('NC_010807.alt1', 'NC_010807.alt3')] == 0.996723
+    assert r[('NC_025457.alt2', 'NC_025457.alt1')] == 0.94527
+    assert r[('NC_002486', 'NC_002486.alt')] == 0.999979
+    assert len(r) == 26
+
+
+@pytest.mark.parametrize('params', [['--kmers-fraction', '0.2'], ['--max-seqs', '2'], ['-k', '20']])
+def test_prefilter_params(tmp_path, params):
+    out = tmp_path / 'filter.txt'
+    p = run('prefilter', '-i', FASTA_FILE, '-o', out, '-v', '0', *params)
+    assert p.returncode == 0 and not p.stderr and out.stat().st_size
+
+
+def test_prefilter_verbose(tmp_path):
+    p = run('prefilter', '-i', FASTA_FILE, '-o', tmp_path / 'f.txt')
+    assert p.returncode == 0 and all(w in p.stderr for w in ['Running', 'Completed', 'INFO'])
+
+
+@pytest.mark.parametrize('inp', [FASTA_DIR, FASTA_FILE, FASTAGZ_FILE])
+def test_align_default(tmp_path, inp):
+    out = tmp_path / 'ani.tsv'
+    p = run('align', '-i', inp, '-o', out, capture=False)
+    assert p.returncode == 0 and out.stat().st_size
+    truth = {('NC_010807', 'NC_010807.alt1'): 0.99753, ('NC_010807', 'NC_010807.alt2'): 0.98985,
+             ('NC_010807', 'NC_010807.alt3'): 0.98384, ('NC_005091', 'NC_005091.alt1'): 0.97161,
+             ('NC_005091', 'NC_005091.alt2'): 0.96707, ('NC_025457', 'NC_025457.alt1'): 0.80607,
+             ('NC_025457', 'NC_025457.alt2'): 0.75921, ('NC_002486', 'NC_002486.alt'): 1.00000}
+    pairs = {}
+    with open(out) as fh:
+        next(fh)
+        for line in fh:
+            c = line.split()
+            pairs[(c[2].rstrip('.fna'), c[3].rstrip('.fna'))] = float(c[4])
+    for k, t in truth.items():
+        assert abs(pairs[k] - t) < 0.007
+    assert (tmp_path / 'ani.ids.tsv').exists()
+
+
+@pytest.mark.parametrize('fmt', ['standard', 'lite', 'complete'])
+def test_align_outfmt(tmp_path, fmt):
+    sys.path.insert(0, str(ROOT))
+    import vclust
+    out = tmp_path / 'ani.tsv'
+    assert run('align', '-i', FASTA_FILE, '-o', out, '--outfmt', fmt).returncode == 0
+    assert open(out).readline().split() == vclust.ALIGN_OUTFMT[fmt]
+
+
+@pytest.mark.parametrize('inp', [FASTA_DIR, FASTA_FILE])
+def test_align_alignments(tmp_path, inp):
+    out, aln = tmp_path / 'ani.tsv', tmp_path / 'ani.aln.tsv'
+    assert run('align', '-i', inp, '-o', out, '--out-aln', aln).returncode == 0
+    with open(aln) as fh:
+        assert len(fh.readline().split()) == 10
+        assert fh.readlines()
+
+
+def test_align_verbose(tmp_path):
+    p = run('align', '-i', FASTA_FILE, '-o', tmp_path / 'ani.tsv')
+    assert p.returncode == 0 and all(w in p.stderr for w in ['Running', 'Completed', 'INFO'])
+
+
+@pytest.mark.parametrize('inp,params', [(FASTA_DIR, []), (FASTA_FILE, []), (FASTA_FILE, ['--batch-size', '4'])])
+def test_workflow_prefilter_align(tmp_path, inp, params):
+    flt, ani = tmp_path / 'filter.txt', tmp_path / 'ani.tsv'
+    assert run('prefilter', '-i', inp, '-o', flt, *params).returncode == 0 and flt.stat().st_size
+    assert run('align', '-i', inp, '-o', ani, '--filter', flt).returncode == 0
+    assert sum(1 for _ in open(ani)) == 27        # header + 13 pairs x 2 directions
+
+
+def test_workflow_equals_oracle_files(tmp_path):
+    """Whole-file identity with the CPU oracle through both CLIs (prefilter -> align --filter)."""
+    sys.path.insert(0, str(ROOT / 'tests'))
+    import filecmp
+    import oracle_lib as orc
+    flt, ani = tmp_path / 'f.txt', tmp_path / 'a.tsv'
+    assert run('prefilter', '-i', FASTA_FILE, '-o', flt, '-v', '0').returncode == 0
+    assert run('align', '-i', FASTA_FILE, '-o', ani, '--filter', flt, '--outfmt', 'complete', '-v', '0').returncode == 0
+    oflt, oani = tmp_path / 'of.txt', tmp_path / 'oa.tsv'
+    orc.run_cli('prefilter', '-o', oflt, FASTA_FILE)
+    orc.run_cli('align', '-o', oani, '--filter', oflt, '0', '--outfmt', 'complete', FASTA_FILE)
+    assert filecmp.cmp(flt, oflt, shallow=False) and filecmp.cmp(ani, oani, shallow=False)

@@ -1,0 +1,160 @@
+"""The CPU oracle against the reference's golden vectors (tests/golden/example/output/*).
+
+Pins the oracle: prefilter arithmetic and file layout exactly; number formatter
+exactly (792/792 fields of ani.tsv, 5693/5693 pident values); LZ parse region by region with
+regression floors for the fitted rules (the upstream source is absent).
+"""
+import collections
+import filecmp
+
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+
+KMER_COUNTS = {  # distinct canonical 25-mers, SURVEY §8c
+    'NC_010807': 38557, 'NC_010807.alt1': 38607, 'NC_010807.alt2': 38908, 'NC_010807.alt3': 39682,
+    'NC_005091': 57222, 'NC_005091.alt1': 57392, 'NC_005091.alt2': 58459, 'NC_025457': 42629,
+    'NC_025457.alt1': 39537, 'NC_025457.alt2': 61292, 'NC_002486': 45598, 'NC_002486.alt': 45598,
+}
+
+
+@pytest.fixture(scope='module')
+def example(golden_dir):
+    return orc.read_fasta_codes(golden_dir / 'multifasta.fna')
+
+
+def read_tsv(path):
+    with open(path) as fh:
+        return [line.rstrip('\n').split('\t') for line in fh]
+
+
+def test_kmer_set_sizes_and_shared_counts(example):
+    codes, offsets, names = example
+    sizes, pairs = orc.shared_all(codes, offsets, k=25)
+    assert dict(zip(names, sizes)) == KMER_COUNTS
+    idx = {n: i for i, n in enumerate(names)}
+    assert pairs[(idx['NC_010807.alt1'], idx['NC_010807'])] == 35785
+    assert pairs[(idx['NC_025457.alt2'], idx['NC_025457.alt1'])] == 5766
+    assert pairs[(idx['NC_002486.alt'], idx['NC_002486'])] == 45550
+    assert len(pairs) == 13                       # the 53 other pairs share no 25-mer at all
+
+
+@pytest.mark.parametrize('inp', ['multifasta.fna', 'multifasta.fna.gz'])
+def test_prefilter_file_is_golden(tmp_path, golden_dir, inp):
+    out = tmp_path / 'fltr.txt'
+    orc.run_cli('prefilter', '-o', out, golden_dir / inp)
+    assert filecmp.cmp(out, golden_dir / 'output' / 'fltr.txt', shallow=False)
+
+
+def test_prefilter_directory_mode_values(tmp_path, golden_dir):
+    """test.py:336-385: directory input gives the same 26 symmetric entries (names may keep .fna)."""
+    out = tmp_path / 'fltr.txt'
+    orc.run_cli('prefilter', '-o', out, *sorted((golden_dir / 'fna').iterdir()))
+    def values(p):
+        return sorted(v.split(':')[1] for line in open(p).read().splitlines()[1:] for v in line.split(',')[1:] if ':' in v)
+    assert values(out) == values(golden_dir / 'output' / 'fltr.txt')
+
+
+def test_number_format_reproduces_ani_tsv(golden_dir):
+    """L6 + L7: metrics from the golden integer sums, printed with the oracle's formatter."""
+    aln = read_tsv(golden_dir / 'output' / 'ani.aln.tsv')[1:]
+    ids = read_tsv(golden_dir / 'output' / 'ani.ids.tsv')[1:]
+    length = {r[0]: int(r[1]) for r in ids}
+    M = collections.Counter(); A = collections.Counter(); N = collections.Counter()
+    for r in aln:
+        key = (r[0], r[1]); M[key] += int(r[8]); A[key] += int(r[3]); N[key] += 1
+    rows = read_tsv(golden_dir / 'output' / 'ani.tsv')
+    cols = rows[0]
+    ok = total = 0
+    for r in rows[1:]:
+        q, ref = r[2], r[3]
+        lq, lr = length[q], length[ref]
+        want = {
+            'tani': (M[(q, ref)] + M[(ref, q)]) / (lq + lr), 'gani': M[(q, ref)] / lq, 'ani': M[(q, ref)] / A[(q, ref)],
+            'qcov': A[(q, ref)] / lq, 'rcov': A[(ref, q)] / lr,
+        }
+        for name, val in want.items():
+            total += 1
+            ok += orc.fmt_num(val) == r[cols.index(name)]
+        assert int(r[cols.index('num_alns')]) == N[(q, ref)]
+        total += 1
+        lo, hi = min(lq, lr), max(lq, lr)
+        ok += ('1' if lo == hi else f'{lo / hi:.4f}') == r[cols.index('len_ratio')]
+    assert (ok, total) == (792, 792)
+    pid_ok = sum(orc.fmt_num(100.0 * int(r[8]) / int(r[3])) == r[2] for r in aln)
+    assert pid_ok == len(aln) == 5693
+
+
+@pytest.fixture(scope='module')
+def oracle_align(tmp_path_factory, golden_dir):
+    d = tmp_path_factory.mktemp('oalign')
+    orc.run_cli('align', '-o', d / 'ani.tsv', '--out-aln', d / 'ani.aln.tsv', golden_dir / 'multifasta.fna')
+    return d
+
+
+def test_ids_file_is_golden(oracle_align, golden_dir):
+    assert filecmp.cmp(oracle_align / 'ani.ids.tsv', golden_dir / 'output' / 'ani.ids.tsv', shallow=False)
+
+
+def test_row_order_and_layout(oracle_align, golden_dir):
+    g = read_tsv(golden_dir / 'output' / 'ani.tsv'); m = read_tsv(oracle_align / 'ani.tsv')
+    assert g[0] == m[0] and len(g) == len(m) == 133
+    assert [r[:4] for r in g] == [r[:4] for r in m]
+    assert [r[10] for r in g] == [r[10] for r in m]          # len_ratio
+
+
+def test_lz_parse_against_golden_regions(oracle_align, golden_dir):
+    """Region-level score of the restated LZ parse.  The floors are the achieved fit:
+    boundaries 5575/5693, fully identical regions 2875/5693 — a drop means a rule regressed."""
+    def load(p):
+        d = collections.defaultdict(list)
+        for r in read_tsv(p)[1:]:
+            d[(r[0], r[1])].append(tuple(int(x) for x in r[3:10]))
+        return d
+    g = load(golden_dir / 'output' / 'ani.aln.tsv'); m = load(oracle_align / 'ani.aln.tsv')
+    exact = bounds = 0
+    for key, regs in g.items():
+        ms = set(m.get(key, [])); mb = {(x[1], x[2]) for x in m.get(key, [])}
+        exact += sum(1 for x in regs if x in ms)
+        bounds += sum(1 for x in regs if (x[1], x[2]) in mb)
+    total = sum(len(v) for v in g.values())
+    assert total == 5693
+    assert bounds >= 5575, bounds
+    assert exact >= 2875, exact
+    assert abs(sum(len(v) for v in m.values()) - total) <= 100
+
+
+def test_tani_within_reference_test_tolerance(oracle_align):
+    """test.py:456-477: tANI of the 8 simulated pairs within 0.007 of the simulated truth."""
+    truth = {('NC_010807', 'NC_010807.alt1'): 0.99753, ('NC_010807', 'NC_010807.alt2'): 0.98985,
+             ('NC_010807', 'NC_010807.alt3'): 0.98384, ('NC_005091', 'NC_005091.alt1'): 0.97161,
+             ('NC_005091', 'NC_005091.alt2'): 0.96707, ('NC_025457', 'NC_025457.alt1'): 0.80607,
+             ('NC_025457', 'NC_025457.alt2'): 0.75921, ('NC_002486', 'NC_002486.alt'): 1.00000}
+    rows = read_tsv(oracle_align / 'ani.tsv')[1:]
+    tani = {(r[2], r[3]): float(r[4]) for r in rows}
+    for pair, t in truth.items():
+        assert abs(tani[pair] - t) < 0.007
+
+
+def test_tani_close_to_golden(oracle_align, golden_dir):
+    g = read_tsv(golden_dir / 'output' / 'ani.tsv')[1:]; m = read_tsv(oracle_align / 'ani.tsv')[1:]
+    worst = max(abs(float(a[4]) - float(b[4])) for a, b in zip(g, m))
+    assert worst < 0.004, worst
+
+
+def test_identical_and_shuffled_genome(example):
+    codes, offsets, names = example
+    i, j = names.index('NC_002486'), names.index('NC_002486.alt')
+    a = codes[offsets[i]:offsets[i + 1]]; b = codes[offsets[j]:offsets[j + 1]]
+    assert orc.lz_pair_stat(a, a) == (len(a), len(a), 1)
+    assert orc.lz_pair_stat(b, a) == (45636, 45636, 3)       # example/output/ani.tsv:78-79
+
+
+def test_edge_inputs():
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 4, size=500, dtype=np.uint8)
+    assert orc.lz_pair_stat(a[:5], a) == (0, 0, 0)           # shorter than the anchor length
+    assert orc.lz_pair_stat(np.full(100, 4, np.uint8), a) == (0, 0, 0)   # all N
+    assert len(orc.kmer_set(a[:10], 25)) == 0
+    assert len(orc.kmer_set(np.full(100, 4, np.uint8), 25)) == 0
