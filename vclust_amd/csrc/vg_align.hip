@@ -282,14 +282,19 @@ __device__ __forceinline__ void rr_chunk(const uint32_t* __restrict__ gpk, const
 __device__ __forceinline__ uint64_t anchor_hash(uint64_t code) { return code * 0x9E3779B97F4A7C15ULL; }
 __device__ __forceinline__ uint32_t anchor_bucket(uint64_t h, int B) { return (uint32_t)(h >> (64 - B)); }
 __device__ __forceinline__ uint32_t anchor_tag(uint64_t h, int B, int pos_bits) {
-    return (uint32_t)((h << B) >> 32) >> pos_bits;          // the (32 - pos_bits) hash bits below the bucket bits
+    // up to 16 hash bits below the bucket bits, as many as fit above pos_bits in a 32-bit entry
+    const int tb = (32 - pos_bits) < 16 ? (32 - pos_bits) : 16;
+    return (uint32_t)((h << B) >> 48) & ((1u << tb) - 1u);
 }
 
-// ---- path A (references up to 2^18 RR symbols, msl <= 7): one 1024-thread workgroup per
-// reference builds RR and both bucket indexes by counting sort entirely in LDS (128 KiB table).
-constexpr int LDS_TAB = 32768;
+// ---- path A (references up to 2^18 RR symbols, msl <= 7): one 1024-thread workgroup builds RR
+// and both bucket indexes of a reference by counting sort in LDS.  Entries leave the LDS through a
+// staging window (buckets are filled range by range), so every global store of the index is a
+// coalesced copy: no 4-byte scatter to HBM (the first version wrote 10x the index size).
+constexpr int LDS_TAB = 16384;      // bucket table: anchors use B <= 14 bits, seeds 4^msl <= 16384
+constexpr int LDS_STAGE = 16384;    // staged entries per window
 __device__ __forceinline__ void lds_scan_exclusive(uint32_t* tab, int n, uint32_t* part) {
-    // n <= LDS_TAB, blockDim.x == 1024: each thread owns n/1024 consecutive entries
+    // blockDim.x == 1024: each thread owns ceil(n/1024) consecutive entries
     const int per = (n + 1023) / 1024;
     const int i0 = threadIdx.x * per;
     uint32_t s = 0;
@@ -308,54 +313,111 @@ __device__ __forceinline__ void lds_scan_exclusive(uint32_t* tab, int n, uint32_
 }
 
 __global__ void __launch_bounds__(1024)
-k_build_index_lds(const ref_desc* __restrict__ refs, const int* __restrict__ slot_list,
+k_build_index_lds(const ref_desc* __restrict__ refs, const int* __restrict__ slot_list, int n_list,
                   const uint32_t* __restrict__ packed, const uint32_t* __restrict__ nmask, const int64_t* __restrict__ base_off,
                   uint32_t* __restrict__ rr_pool, uint32_t* __restrict__ mask_pool, int mal, int msl,
                   uint32_t* __restrict__ atab_pool, uint32_t* __restrict__ aent_pool,
-                  uint32_t* __restrict__ stab_pool, uint32_t* __restrict__ sent_pool) {
+                  uint32_t* __restrict__ stab_pool, uint32_t* __restrict__ sent_pool,
+                  uint32_t* __restrict__ scratch_pool, int64_t scratch_stride) {
     __shared__ uint32_t tab[LDS_TAB];
+    __shared__ uint32_t stage[LDS_STAGE];
     __shared__ uint32_t part[1024];
-    const ref_desc rd = refs[slot_list[blockIdx.x]];
-    const int64_t g0 = base_off[rd.genome];
-    const uint32_t* gpk = packed + (g0 >> 4); const uint32_t* gmk = nmask + (g0 >> 5);
-    uint32_t* pk = rr_pool + rd.rr_w; uint32_t* mk = mask_pool + rd.mask_w;
-    const int64_t chunks = ((int64_t)rd.n_rr + RR_PAD + 31) / 32 + 2;
-    for (int64_t ch = threadIdx.x; ch < chunks; ch += blockDim.x) {
-        uint64_t bits; uint32_t m;
-        rr_chunk(gpk, gmk, rd.L, ch, &bits, &m);
-        pk[2 * ch] = (uint32_t)bits; pk[2 * ch + 1] = (uint32_t)(bits >> 32); mk[ch] = m;
-    }
-    __threadfence_block();
-    __syncthreads();
+    __shared__ int s_whi;
+    uint32_t* scratch = scratch_pool + (int64_t)blockIdx.x * scratch_stride;     // (bucket | tag << 16) per RR position
     const uint64_t amask = (mal >= 32) ? ~0ULL : ((1ULL << (2 * mal)) - 1);
     const uint64_t smask = (1ULL << (2 * msl)) - 1;
-    for (int phase = 0; phase < 2; ++phase) {
-        const int nb = phase == 0 ? (1 << rd.B) : (1 << (2 * msl));
-        const int w = phase == 0 ? mal : msl;
-        uint32_t* gtab = phase == 0 ? atab_pool + rd.atab : stab_pool + rd.stab;
-        uint32_t* gent = phase == 0 ? aent_pool + rd.aent : sent_pool + rd.sent;
-        for (int i = threadIdx.x; i < nb; i += blockDim.x) tab[i] = 0;
-        __syncthreads();
-        for (int pass = 0; pass < 2; ++pass) {
-            for (int p = threadIdx.x; p < rd.n_rr; p += blockDim.x) {
-                if (p + w > rd.n_rr) continue;
-                uint64_t m = (uint64_t)mk[p >> 5] | ((uint64_t)mk[(p >> 5) + 1] << 32);
-                m >>= (p & 31);
-                if (m & ((1ULL << w) - 1)) continue;
-                const uint64_t x = load32(pk, p);
-                uint32_t b, ent = (uint32_t)p;
-                if (phase == 0) {
-                    const uint64_t h = anchor_hash(x & amask);
-                    b = anchor_bucket(h, rd.B); ent |= anchor_tag(h, rd.B, rd.pos_bits) << rd.pos_bits;
-                } else b = (uint32_t)(x & smask);
-                const uint32_t slot = atomicAdd(&tab[b], 1u);
-                if (pass == 1) gent[slot] = ent;
-            }
-            __syncthreads();
-            if (pass == 0) lds_scan_exclusive(tab, nb, part);
+    for (int li = blockIdx.x; li < n_list; li += gridDim.x) {
+        const ref_desc rd = refs[slot_list[li]];
+        const int64_t g0 = base_off[rd.genome];
+        const uint32_t* gpk = packed + (g0 >> 4); const uint32_t* gmk = nmask + (g0 >> 5);
+        uint32_t* pk = rr_pool + rd.rr_w; uint32_t* mk = mask_pool + rd.mask_w;
+        const int64_t chunks = ((int64_t)rd.n_rr + RR_PAD + 31) / 32 + 2;
+        for (int64_t ch = threadIdx.x; ch < chunks; ch += blockDim.x) {
+            uint64_t bits; uint32_t m;
+            rr_chunk(gpk, gmk, rd.L, ch, &bits, &m);
+            pk[2 * ch] = (uint32_t)bits; pk[2 * ch + 1] = (uint32_t)(bits >> 32); mk[ch] = m;
         }
-        for (int i = threadIdx.x; i < nb; i += blockDim.x) gtab[i] = tab[i];     // END of every bucket
+        __threadfence_block();
         __syncthreads();
+        for (int phase = 0; phase < 2; ++phase) {
+            const int nb = phase == 0 ? (1 << rd.B) : (1 << (2 * msl));
+            const int w = phase == 0 ? mal : msl;
+            uint32_t* gtab = phase == 0 ? atab_pool + rd.atab : stab_pool + rd.stab;
+            uint32_t* gent = phase == 0 ? aent_pool + rd.aent : sent_pool + rd.sent;
+            for (int i = threadIdx.x; i < nb; i += blockDim.x) tab[i] = 0;
+            __syncthreads();
+            // pass 0: bucket (and tag) of every position -> scratch, bucket sizes -> tab.  Each thread
+            // takes 4 consecutive positions out of one 128-bit window of packed bases.
+            const int n4 = (rd.n_rr + 3) & ~3;
+            for (int p0 = 4 * threadIdx.x; p0 < n4; p0 += 4 * blockDim.x) {
+                const int wi = p0 >> 4; const int sh = 2 * (p0 & 15);
+                const uint64_t lo = (uint64_t)pk[wi] | ((uint64_t)pk[wi + 1] << 32);
+                const uint64_t hi = (uint64_t)pk[wi + 2] | ((uint64_t)pk[wi + 3] << 32);
+                const uint64_t ml = ((uint64_t)mk[p0 >> 5] | ((uint64_t)mk[(p0 >> 5) + 1] << 32)) >> (p0 & 31);
+                uint32_t out[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int p = p0 + j; const int s2 = sh + 2 * j;            // bit offset inside (hi:lo), <= 36
+                    uint32_t bt = 0xffffffffu;
+                    if (p + w <= rd.n_rr && ((ml >> j) & ((1ULL << w) - 1)) == 0) {
+                        const uint64_t x = s2 ? ((lo >> s2) | (hi << (64 - s2))) : lo;
+                        if (phase == 0) {
+                            const uint64_t h = anchor_hash(x & amask);
+                            bt = anchor_bucket(h, rd.B) | (anchor_tag(h, rd.B, rd.pos_bits) << 16);
+                        } else bt = (uint32_t)(x & smask);
+                        atomicAdd(&tab[bt & 0xffffu], 1u);
+                    }
+                    out[j] = bt;
+                }
+                *reinterpret_cast<uint4*>(&scratch[p0]) = make_uint4(out[0], out[1], out[2], out[3]);
+            }
+            __threadfence_block();
+            __syncthreads();
+            lds_scan_exclusive(tab, nb, part);                 // tab[b] = first slot of bucket b
+            const uint32_t total = part[1023];                 // inclusive sum of all thread partials
+            __syncthreads();
+            // fill, one window of whole buckets holding <= LDS_STAGE entries at a time.  Buckets at or
+            // beyond the window start are still untouched, so end(b) = tab[b + 1] (or the total).
+            int w_lo = 0;
+            while (w_lo < nb) {
+                const uint32_t base = tab[w_lo];
+                if (threadIdx.x == 0) s_whi = w_lo + 1;
+                __syncthreads();
+                int best = w_lo + 1;
+                for (int b2 = w_lo + threadIdx.x; b2 < nb; b2 += blockDim.x) {
+                    const uint32_t e2 = (b2 + 1 < nb) ? tab[b2 + 1] : total;
+                    if (e2 - base <= (uint32_t)LDS_STAGE) best = b2 + 1; else break;     // ends ascend
+                }
+                atomicMax(&s_whi, best);
+                __syncthreads();
+                const int w_hi = s_whi;
+                const uint32_t e_lo = (w_lo + 1 < nb) ? tab[w_lo + 1] : total;
+                const bool direct = (e_lo - base > (uint32_t)LDS_STAGE);   // one bucket larger than the stage
+                __syncthreads();
+                for (int p0 = 4 * threadIdx.x; p0 < n4; p0 += 4 * blockDim.x) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(&scratch[p0]);
+                    const uint32_t bts[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t bt = bts[j];
+                        const int b2 = (int)(bt & 0xffffu);
+                        if (bt == 0xffffffffu || b2 < w_lo || b2 >= w_hi) continue;
+                        const uint32_t ent = (uint32_t)(p0 + j) | (phase == 0 ? ((bt >> 16) << rd.pos_bits) : 0u);
+                        const uint32_t slot = atomicAdd(&tab[b2], 1u);
+                        if (direct) gent[slot] = ent; else stage[slot - base] = ent;
+                    }
+                }
+                __syncthreads();
+                if (!direct) {
+                    const uint32_t cnt = tab[w_hi - 1] - base;   // cursor of the last bucket == its end
+                    for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) gent[base + i] = stage[i];
+                }
+                __syncthreads();
+                w_lo = w_hi;
+            }
+            for (int i = threadIdx.x; i < nb; i += blockDim.x) gtab[i] = tab[i];     // END of every bucket
+            __syncthreads();
+        }
     }
 }
 
@@ -669,7 +731,7 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
             const uint32_t r = tasks[order[end]].r;
             const int64_t L = g->len[r]; const int64_t n_rr = 2 * L + 1;
             const bool small = n_rr <= (1 << 18) && p->msl <= 7;
-            int B = 8; while ((1LL << (B + 1)) <= n_rr && B + 1 <= 2 * p->mal && B < (small ? 15 : 26)) ++B;
+            int B = 8; while ((1LL << (B + 1)) <= n_rr && B + 1 <= 2 * p->mal && B < (small ? 14 : 26)) ++B;
             const int64_t chunks = (n_rr + RR_PAD + 31) / 32 + 2;
             const int64_t need = chunks * 12 + ((1LL << B) + n_rr + stab_n + n_rr) * 4;
             if (!refs.empty() && bytes + need > g_index_budget_bytes) break;
@@ -713,10 +775,15 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
         {
             vg_prof_scope ps("lz_build_index", (double)total_chunks * 32 * (0.375 + 0.375 + 8));
             if (!large_list.empty()) { atab_pool.zero(s); stab_pool.zero(s); }
-            if (!small_list.empty())
-                hipLaunchKernelGGL(k_build_index_lds, dim3((unsigned)small_list.size()), dim3(1024), 0, s, d_refs.p, d_small.p, g->d_packed.p,
-                                   g->d_nmask.p, g->d_base_off.p, rr_pool.p, mask_pool.p, p->mal, p->msl, atab_pool.p, aent_pool.p,
-                                   stab_pool.p, sent_pool.p);
+            if (!small_list.empty()) {
+                int64_t max_rr = 0; for (int i : small_list) max_rr = std::max<int64_t>(max_rr, refs[i].n_rr);
+                const int nblk = (int)std::min<size_t>(small_list.size(), 512);
+                const int64_t stride = (max_rr + 63) / 64 * 64;
+                dbuf<uint32_t> scratch((size_t)nblk * stride);
+                hipLaunchKernelGGL(k_build_index_lds, dim3(nblk), dim3(1024), 0, s, d_refs.p, d_small.p, (int)small_list.size(),
+                                   g->d_packed.p, g->d_nmask.p, g->d_base_off.p, rr_pool.p, mask_pool.p, p->mal, p->msl, atab_pool.p,
+                                   aent_pool.p, stab_pool.p, sent_pool.p, scratch.p, stride);
+            }
             if (!large_list.empty()) {
                 const int nl = (int)large_list.size(); const int64_t lc = large_chunks.back();
                 hipLaunchKernelGGL(k_build_rr, dim3(grid_for(lc)), dim3(256), 0, s, d_refs.p, d_large.p, nl, d_lchunk.p, g->d_packed.p,

@@ -66,9 +66,11 @@ bool vg_profile_on();
 // (base i of the padded stream sits in word i/16, bits 2*(i%16)..+1); N mask 1 bit per base,
 // 32 per word.  Every genome starts at a multiple of VG_ALIGN bases of the padded stream;
 // padding bases are A with mask bit 1.
-constexpr int64_t VG_ALIGN = 64;
+constexpr int64_t VG_ALIGN = 64;        // minimum alignment; the set's block size is 1 << align_shift
 struct vg_genomes {
     int n = 0;
+    int align_shift = 6;                 // genomes start at multiples of (1 << align_shift) bases
+    std::vector<uint32_t> blk2g;         // block (1 << align_shift bases) -> genome id
     std::vector<std::string> names;
     std::vector<int64_t> len;        // n
     std::vector<int32_t> n_parts;    // n
@@ -81,11 +83,14 @@ struct vg_genomes {
     dbuf<uint32_t> d_packed, d_nmask;
     dbuf<int64_t> d_base_off, d_len;
     dbuf<uint8_t> d_has_n;
+    dbuf<uint32_t> d_blk2g;
     int64_t padded_total() const { return base_off.empty() ? 0 : base_off.back(); }
 };
 // append one genome given codes (0..3, >3 = N); used by the FASTA reader and vg_genomes_from_codes
 void vg_genomes_append(vg_genomes* g, const std::string& name, const uint8_t* codes, int64_t len, int n_parts);
 void vg_genomes_finish(vg_genomes* g);
+// block size for a set of n genomes with total_len bases: ~mean/16, power of two in [64, 4096]
+int vg_choose_align_shift(int64_t total_len, int64_t n);
 
 // ---------------------------------------------------------------- host-side helpers shared by writers
 int  vg_fmt_num(double x, char* buf);                 // LZ-ANI number format

@@ -22,8 +22,9 @@ static inline uint8_t code_of(unsigned char ch) {
 void vg_genomes_append(vg_genomes* g, const std::string& name, const uint8_t* codes, int64_t len, int n_parts) {
     if (g->base_off.empty()) g->base_off.push_back(0);
     int64_t off = g->base_off.back();
-    int64_t padded = (len + VG_ALIGN - 1) / VG_ALIGN * VG_ALIGN;
-    if (padded == 0) padded = VG_ALIGN;
+    const int64_t al = 1LL << g->align_shift;
+    int64_t padded = (len + al - 1) / al * al;
+    if (padded == 0) padded = al;
     g->packed.resize((off + padded) / 16, 0u);
     g->nmask.resize((off + padded) / 32, 0u);
     uint32_t* pk = g->packed.data() + off / 16;
@@ -40,7 +41,15 @@ void vg_genomes_append(vg_genomes* g, const std::string& name, const uint8_t* co
     g->n_parts.push_back(n_parts);
     g->has_n.push_back(any_n ? 1 : 0);
     g->base_off.push_back(off + padded);
+    for (int64_t b = off >> g->align_shift; b < (off + padded) >> g->align_shift; ++b) g->blk2g.push_back((uint32_t)g->n);
     g->n++;
+}
+
+int vg_choose_align_shift(int64_t total_len, int64_t n) {
+    int64_t mean = n > 0 ? total_len / n : 0;
+    int sh = 6;
+    while (sh < 12 && (1LL << (sh + 1)) <= mean / 16) ++sh;
+    return sh;
 }
 
 void vg_genomes_finish(vg_genomes* g) {
@@ -48,6 +57,7 @@ void vg_genomes_finish(vg_genomes* g) {
     // slack so that kernels may read a few words past the last genome
     g->packed.resize(g->padded_total() / 16 + 16, 0u);
     g->nmask.resize(g->padded_total() / 32 + 16, 0xffffffffu);
+    g->blk2g.push_back(g->n > 0 ? (uint32_t)(g->n - 1) : 0u);
 }
 
 namespace {
@@ -112,6 +122,11 @@ extern "C" int vg_genomes_load(const char* const* paths, int n_paths, int multis
     for (auto& t : th) t.join();
     if (failed.load()) throw vg_error(VG_EIO, first_err);
     vg_genomes* g = new vg_genomes();
+    {
+        int64_t tot = 0, cnt = 0;
+        for (auto& v : per_file) for (auto& r : v) { tot += (int64_t)r.codes.size(); ++cnt; }
+        g->align_shift = vg_choose_align_shift(tot, cnt);
+    }
     for (auto& v : per_file)
         for (auto& r : v) vg_genomes_append(g, r.name, r.codes.data(), (int64_t)r.codes.size(), r.n_parts);
     vg_genomes_finish(g);
@@ -124,6 +139,7 @@ extern "C" int vg_genomes_from_codes(const uint8_t* codes, const int64_t* offset
     VG_API_BEGIN
     if (!codes || !offsets || n_genomes < 0 || !out) throw vg_error(VG_EINVAL, "vg_genomes_from_codes: bad arguments");
     vg_genomes* g = new vg_genomes();
+    g->align_shift = vg_choose_align_shift(n_genomes > 0 ? offsets[n_genomes] - offsets[0] : 0, n_genomes);
     for (int i = 0; i < n_genomes; ++i) {
         std::string nm = names && names[i] ? names[i] : ("g" + std::to_string(i));
         vg_genomes_append(g, nm, codes + offsets[i], offsets[i + 1] - offsets[i], 1);
@@ -160,6 +176,7 @@ extern "C" int vg_genomes_to_device(vg_genomes* g) {
     g->d_base_off.alloc(g->base_off.size()); g->d_base_off.upload(g->base_off.data(), g->base_off.size(), s);
     g->d_len.alloc(std::max<size_t>(1, g->len.size())); if (g->n) g->d_len.upload(g->len.data(), g->len.size(), s);
     g->d_has_n.alloc(std::max<size_t>(1, g->has_n.size())); if (g->n) g->d_has_n.upload(g->has_n.data(), g->has_n.size(), s);
+    g->d_blk2g.alloc(g->blk2g.size()); g->d_blk2g.upload(g->blk2g.data(), g->blk2g.size(), s);
     VG_HIP(hipStreamSynchronize(s));
     g->device = dev;
     VG_API_END

@@ -39,12 +39,13 @@ __global__ void __launch_bounds__(256)
 k_kmer_extract(const uint32_t* __restrict__ packed, const uint32_t* __restrict__ nmask,
                const uint32_t* __restrict__ blk2g, const int64_t* __restrict__ base_off,
                const int64_t* __restrict__ len, int64_t P, int k, int use_frac, uint64_t frac_thr,
-               uint32_t shard, uint32_t n_shards, uint64_t* __restrict__ keys,
-               unsigned long long* __restrict__ n_valid) {
+               uint32_t shard, uint32_t n_shards, int blk_shift, uint64_t* __restrict__ keys,
+               unsigned long long* __restrict__ n_valid, int* __restrict__ kept_per_genome) {
     const uint64_t kmask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
     unsigned long long local_valid = 0;
+    // P is a multiple of 64 and the stride a multiple of 64: whole waves stay in or out together
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (int64_t)gridDim.x * blockDim.x) {
-        uint32_t g = blk2g[p >> 6];
+        uint32_t g = blk2g[p >> blk_shift];
         int64_t local = p - base_off[g];
         uint64_t key = SENT;
         if (local + k <= len[g]) {
@@ -69,6 +70,13 @@ k_kmer_extract(const uint32_t* __restrict__ packed, const uint32_t* __restrict__
             }
         }
         keys[p] = key;
+        // k-mers kept per genome (|K_g| = kept - duplicates): one atomic per wave and genome
+        const bool kept = key != SENT;
+        const uint32_t g0 = __shfl(g, 0);
+        if (__all(g == g0)) {
+            const unsigned long long b = __ballot(kept);
+            if ((threadIdx.x & 63) == 0 && b) atomicAdd(&kept_per_genome[g0], __popcll(b));
+        } else if (kept) atomicAdd(&kept_per_genome[g], 1);
     }
     // one atomic per wave
     for (int o = 32; o > 0; o >>= 1) local_valid += __shfl_down(local_valid, o);
@@ -80,38 +88,51 @@ __global__ void k_iota(uint32_t* v, int64_t n) {
 }
 
 // ------------------------------------------------------------------ K2a: runs of the inverted index
-// sorted (key, pos): mark duplicates (same k-mer, same genome), run heads for the max-scan
+// One pass over the sorted (k-mer, position) list: every entry finds the boundaries of its run
+// of equal k-mers by galloping over its neighbours (runs are short; the neighbours are in
+// cache), flags duplicates (same k-mer, same genome), records its genome (the CSC side of the
+// SpGEMM) and, for k-mers shared by >= 2 entries, scatters one row descriptor
+// (run start, run length) to its base position (the CSR side).  Singletons write nothing.
+__device__ __forceinline__ int64_t run_lower(const uint64_t* __restrict__ keys, int64_t i, uint64_t key) {
+    int64_t lo = i;                                   // invariant: keys[lo] == key
+    int64_t step = 1;
+    while (lo - step >= 0 && keys[lo - step] == key) { lo -= step; step <<= 1; }
+    // first index in (lo - step, lo] holding key
+    int64_t a = lo - step < -1 ? -1 : lo - step;      // keys[a] != key (or a == -1)
+    while (lo - a > 1) { int64_t m = (a + lo) >> 1; if (keys[m] == key) lo = m; else a = m; }
+    return lo;
+}
+__device__ __forceinline__ int64_t run_upper(const uint64_t* __restrict__ keys, int64_t n, int64_t i, uint64_t key) {
+    int64_t hi = i; int64_t step = 1;
+    while (hi + step < n && keys[hi + step] == key) { hi += step; step <<= 1; }
+    int64_t b = hi + step > n ? n : hi + step;        // keys[b] != key (or b == n)
+    while (b - hi > 1) { int64_t m = (hi + b) >> 1; if (keys[m] == key) hi = m; else b = m; }
+    return hi + 1;                                    // exclusive end
+}
+
 __global__ void __launch_bounds__(256)
-k_mark(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos, const uint32_t* __restrict__ blk2g,
-       int64_t n, uint32_t* __restrict__ gen, uint32_t* __restrict__ head) {
+k_runs(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos, const uint32_t* __restrict__ blk2g, int blk_shift,
+       int64_t n, uint32_t* __restrict__ gen, uint64_t* __restrict__ rowinfo, int* __restrict__ dup_per_genome,
+       uint64_t* __restrict__ big_runs, unsigned int* __restrict__ n_big, unsigned int big_cap) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        uint64_t key = keys[i];
-        uint32_t g = blk2g[pos[i] >> 6];
-        bool is_head = true, dup = false;
-        if (i > 0 && keys[i - 1] == key) { is_head = false; dup = (blk2g[pos[i - 1] >> 6] == g); }
+        const uint64_t key = keys[i];
+        const uint32_t p = pos[i];
+        const uint32_t g = blk2g[p >> blk_shift];
+        const bool has_prev = i > 0 && keys[i - 1] == key;
+        const bool has_next = i + 1 < n && keys[i + 1] == key;
+        bool dup = false;
+        if (has_prev) dup = blk2g[pos[i - 1] >> blk_shift] == g;
         gen[i] = g | (dup ? DUP_BIT : 0u);
-        head[i] = is_head ? (uint32_t)i : 0u;
-    }
-}
-
-__global__ void __launch_bounds__(256)
-k_runlen(const uint32_t* __restrict__ run_start, int64_t n, uint32_t* __restrict__ run_len) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        uint32_t rs = run_start[i];
-        if (i == n - 1 || run_start[i + 1] != rs) run_len[rs] = (uint32_t)(i - rs + 1);
-    }
-}
-
-// CSR side of the SpGEMM: one descriptor per base position = (run start, run length) of its
-// k-mer in the inverted index; 0 = position holds no distinct k-mer of its genome
-__global__ void __launch_bounds__(256)
-k_rowinfo(const uint32_t* __restrict__ pos, const uint32_t* __restrict__ gen, const uint32_t* __restrict__ run_start,
-          const uint32_t* __restrict__ run_len, int64_t n, uint64_t* __restrict__ rowinfo) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        if (gen[i] & DUP_BIT) continue;
-        uint32_t rs = run_start[i];
-        uint64_t rl = run_len[rs]; if (rl > RUNLEN_MASK) rl = RUNLEN_MASK;
-        rowinfo[pos[i]] = ((uint64_t)rs << RUNLEN_BITS) | rl;
+        if (dup) { atomicAdd(&dup_per_genome[g], 1); continue; }
+        if (!has_prev && !has_next) continue;           // singleton k-mer: no partner possible
+        const int64_t rs = has_prev ? run_lower(keys, i, key) : i;
+        const int64_t re = has_next ? run_upper(keys, n, i, key) : i + 1;
+        uint64_t rl = (uint64_t)(re - rs);
+        if (rl >= RUNLEN_MASK) {
+            if (i == rs) { unsigned int o = atomicAdd(n_big, 1u); if (o < big_cap) { big_runs[2 * o] = (uint64_t)rs; big_runs[2 * o + 1] = rl; } }
+            rl = RUNLEN_MASK;
+        }
+        rowinfo[p] = ((uint64_t)rs << RUNLEN_BITS) | rl;
     }
 }
 
@@ -122,6 +143,11 @@ constexpr int HT_SIZE = 8192;          // LDS hash slots per workgroup (64 KiB)
 constexpr uint32_t HT_EMPTY = 0xffffffffu;
 constexpr int LONG_RUN = 48;           // runs longer than this are walked by the whole workgroup
 constexpr int LQ_CAP = 512;
+
+__device__ __forceinline__ uint32_t big_run_len(const uint64_t* __restrict__ big_runs, unsigned int n_big, uint32_t rs) {
+    for (unsigned int i = 0; i < n_big; ++i) if (big_runs[2 * i] == rs) return (uint32_t)big_runs[2 * i + 1];
+    return 0;
+}
 
 __device__ __forceinline__ bool ht_add(uint32_t* hk, uint32_t* hc, uint32_t b, uint32_t* n_used) {
     uint32_t h = (b * 2654435761u) >> (32 - 13);
@@ -139,28 +165,26 @@ __device__ __forceinline__ bool ht_add(uint32_t* hk, uint32_t* hc, uint32_t b, u
 }
 
 __global__ void __launch_bounds__(256)
-k_spgemm(const uint64_t* __restrict__ rowinfo, const uint32_t* __restrict__ gen, const uint32_t* __restrict__ run_len,
+k_spgemm(const uint64_t* __restrict__ rowinfo, const uint32_t* __restrict__ gen, const uint64_t* __restrict__ big_runs, unsigned int n_big,
          const int64_t* __restrict__ base_off, const int64_t* __restrict__ len, int n_genomes, uint32_t min_emit,
          const uint32_t* __restrict__ row_list, int n_rows,
-         int64_t* __restrict__ set_sizes, vg_pair_count* __restrict__ out, unsigned long long* __restrict__ out_cursor,
+         vg_pair_count* __restrict__ out, unsigned long long* __restrict__ out_cursor,
          unsigned long long out_cap, uint32_t* __restrict__ overflow_rows, uint32_t* __restrict__ n_overflow) {
     __shared__ uint32_t hk[HT_SIZE];
     __shared__ uint32_t hc[HT_SIZE];
     __shared__ uint64_t lq[LQ_CAP];
-    __shared__ uint32_t s_used, s_count, s_lq, s_fail;
+    __shared__ uint32_t s_used, s_lq, s_fail;
     const int row = blockIdx.x;
     if (row >= n_rows) return;
     const uint32_t a = row_list ? row_list[row] : (uint32_t)row;
     for (int i = threadIdx.x; i < HT_SIZE; i += blockDim.x) { hk[i] = HT_EMPTY; hc[i] = 0; }
-    if (threadIdx.x == 0) { s_used = 0; s_count = 0; s_lq = 0; s_fail = 0; }
+    if (threadIdx.x == 0) { s_used = 0; s_lq = 0; s_fail = 0; }
     __syncthreads();
     const int64_t p0 = base_off[a], L = len[a];
-    uint32_t my_count = 0;
     for (int64_t base = 0; base < L; base += blockDim.x) {
         int64_t i = base + threadIdx.x;
         uint64_t r = (i < L) ? rowinfo[p0 + i] : 0;
         if (r) {
-            ++my_count;
             uint32_t rl = (uint32_t)(r & RUNLEN_MASK); uint32_t rs = (uint32_t)(r >> RUNLEN_BITS);
             bool walk = false;
             if (rl >= 2) {
@@ -170,7 +194,7 @@ k_spgemm(const uint64_t* __restrict__ rowinfo, const uint32_t* __restrict__ gen,
                 } else walk = true;
             }
             if (walk) {
-                if (rl == RUNLEN_MASK) rl = run_len[rs];
+                if (rl == RUNLEN_MASK) rl = big_run_len(big_runs, n_big, rs);
                 for (uint32_t e = 0; e < rl; ++e) {
                     uint32_t g = gen[rs + e];
                     if (g & DUP_BIT) continue;
@@ -186,7 +210,7 @@ k_spgemm(const uint64_t* __restrict__ rowinfo, const uint32_t* __restrict__ gen,
             for (uint32_t qi = 0; qi < nq; ++qi) {
                 uint64_t rr = lq[qi];
                 uint32_t rl = (uint32_t)(rr & RUNLEN_MASK); uint32_t rs = (uint32_t)(rr >> RUNLEN_BITS);
-                if (rl == RUNLEN_MASK) rl = run_len[rs];
+                if (rl == RUNLEN_MASK) rl = big_run_len(big_runs, n_big, rs);
                 for (uint32_t e = threadIdx.x; e < rl; e += blockDim.x) {
                     uint32_t g = gen[rs + e];
                     if ((g & DUP_BIT) || g >= a) continue;
@@ -198,9 +222,7 @@ k_spgemm(const uint64_t* __restrict__ rowinfo, const uint32_t* __restrict__ gen,
             __syncthreads();
         }
     }
-    atomicAdd(&s_count, my_count);
     __syncthreads();
-    if (threadIdx.x == 0) set_sizes[a] = s_count;
     if (s_fail || s_used > HT_SIZE * 7 / 8) {
         // too many partners for the LDS table: hand the row to the dense fallback
         if (threadIdx.x == 0) { uint32_t o = atomicAdd(n_overflow, 1u); overflow_rows[o] = a; }
@@ -218,7 +240,7 @@ k_spgemm(const uint64_t* __restrict__ rowinfo, const uint32_t* __restrict__ gen,
 // dense fallback for rows whose partner set does not fit the LDS table: one workgroup per
 // overflowing row, counters in a private global array of n_genomes entries
 __global__ void __launch_bounds__(256)
-k_spgemm_dense(const uint64_t* __restrict__ rowinfo, const uint32_t* __restrict__ gen, const uint32_t* __restrict__ run_len,
+k_spgemm_dense(const uint64_t* __restrict__ rowinfo, const uint32_t* __restrict__ gen, const uint64_t* __restrict__ big_runs, unsigned int n_big,
                const int64_t* __restrict__ base_off, const int64_t* __restrict__ len, int n_genomes, uint32_t min_emit,
                const uint32_t* __restrict__ rows, uint32_t* __restrict__ dense /* gridDim.x * n_genomes, zeroed */,
                vg_pair_count* __restrict__ out, unsigned long long* __restrict__ out_cursor, unsigned long long out_cap) {
@@ -229,7 +251,7 @@ k_spgemm_dense(const uint64_t* __restrict__ rowinfo, const uint32_t* __restrict_
         uint64_t r = rowinfo[p0 + i];
         if (!r) continue;
         uint32_t rl = (uint32_t)(r & RUNLEN_MASK); uint32_t rs = (uint32_t)(r >> RUNLEN_BITS);
-        if (rl == RUNLEN_MASK) rl = run_len[rs];
+        if (rl == RUNLEN_MASK) rl = big_run_len(big_runs, n_big, rs);
         if (rl < 2) continue;
         for (uint32_t e = 0; e < rl; ++e) {
             uint32_t g = gen[rs + e];
@@ -258,44 +280,29 @@ struct max_op { __device__ __host__ uint32_t operator()(uint32_t a, uint32_t b) 
 
 }  // namespace
 
-// ------------------------------------------------------------------ device residency of the block->genome map
-struct vg_prefilter_dev {
-    dbuf<uint32_t> blk2g;
-};
-static void build_blk2g(const vg_genomes* g, dbuf<uint32_t>& out, hipStream_t s) {
-    std::vector<uint32_t> h((size_t)(g->padded_total() / 64) + 1, 0);
-    for (int i = 0; i < g->n; ++i)
-        for (int64_t b = g->base_off[i] / 64; b < g->base_off[i + 1] / 64; ++b) h[(size_t)b] = (uint32_t)i;
-    out.alloc(h.size());
-    out.upload(h.data(), h.size(), s);
-    VG_HIP(hipStreamSynchronize(s));
-}
-
-// shared pipeline: extract -> (compact) -> sort.  Returns sorted keys/pos of the n_valid real k-mers.
+// shared pipeline: extract -> sort.  Returns sorted keys/pos of the n_valid real k-mers and the
+// per-genome number of k-mers kept by extraction.
 struct sorted_index {
-    dbuf<uint64_t> keys; dbuf<uint32_t> pos; int64_t n_valid = 0;
+    dbuf<uint64_t> keys; dbuf<uint32_t> pos; dbuf<int> kept; int64_t n_valid = 0;
 };
 
-static void run_extract_sort(vg_genomes* g, const dbuf<uint32_t>& blk2g, int k, double fraction, int shard, int n_shards,
-                             sorted_index& out) {
+static void run_extract_sort(vg_genomes* g, int k, double fraction, int shard, int n_shards, sorted_index& out) {
     hipStream_t s = vg_stream();
     const int64_t P = g->padded_total();
     if (P >= (1LL << 32)) throw vg_error(VG_EOVERFLOW, "genome set exceeds 2^32 padded bases per call; use --batch-size");
     dbuf<uint64_t> keys_a((size_t)P), keys_b((size_t)P);
     dbuf<uint32_t> pos_a((size_t)P), pos_b((size_t)P);
     dbuf<unsigned long long> d_nvalid(1); d_nvalid.zero(s);
+    out.kept.alloc((size_t)std::max(1, g->n)); out.kept.zero(s);
     const int use_frac = fraction < 1.0;
     const uint64_t thr = use_frac ? (uint64_t)std::ldexp(fraction, 64) : ~0ULL;
     {
         vg_prof_scope ps("kmer_extract", (double)P * (3.0 / 8.0 + 8.0));
-        hipLaunchKernelGGL(k_kmer_extract, dim3(grid_for(P)), dim3(256), 0, s, g->d_packed.p, g->d_nmask.p, blk2g.p,
+        hipLaunchKernelGGL(k_kmer_extract, dim3(grid_for(P)), dim3(256), 0, s, g->d_packed.p, g->d_nmask.p, g->d_blk2g.p,
                            g->d_base_off.p, g->d_len.p, P, k, use_frac, thr, (uint32_t)shard, (uint32_t)n_shards,
-                           keys_a.p, d_nvalid.p);
+                           g->align_shift, keys_a.p, d_nvalid.p, out.kept.p);
     }
     hipLaunchKernelGGL(k_iota, dim3(grid_for(P)), dim3(256), 0, s, pos_a.p, P);
-    unsigned long long nv = 0;
-    d_nvalid.download(&nv, 1, s);
-    VG_HIP(hipStreamSynchronize(s));
     // stable LSD radix sort on the 2k key bits; sentinels (all ones) end up behind every real k-mer
     size_t tmp_bytes = 0;
     unsigned int end_bit = (unsigned)(2 * k);
@@ -306,6 +313,8 @@ static void run_extract_sort(vg_genomes* g, const dbuf<uint32_t>& blk2g, int k, 
         vg_prof_scope ps("radix_sort_pairs", (double)P * 12.0 * 2.0 * passes);
         VG_HIP(rocprim::radix_sort_pairs((void*)tmp.p, tmp_bytes, keys_a.p, keys_b.p, pos_a.p, pos_b.p, (size_t)P, 0u, end_bit, s));
     }
+    unsigned long long nv = 0;
+    d_nvalid.download(&nv, 1, s);
     VG_HIP(hipStreamSynchronize(s));
     out.keys = std::move(keys_b); out.pos = std::move(pos_b); out.n_valid = (int64_t)nv;
 }
@@ -323,35 +332,28 @@ extern "C" int vg_kmer_shared(vg_genomes* g, int k, double fraction, int shard, 
     *pairs = nullptr; *n_pairs = 0;
     const int n = g->n;
     if (n == 0) return VG_OK;
-    dbuf<uint32_t> blk2g; build_blk2g(g, blk2g, s);
     sorted_index si;
-    run_extract_sort(g, blk2g, k, fraction, shard, n_shards, si);
+    run_extract_sort(g, k, fraction, shard, n_shards, si);
     const int64_t nv = si.n_valid;
     const int64_t P = g->padded_total();
     dbuf<uint64_t> rowinfo((size_t)P); rowinfo.zero(s);
-    dbuf<uint32_t> gen((size_t)std::max<int64_t>(nv, 1)), head((size_t)std::max<int64_t>(nv, 1)),
-        run_start((size_t)std::max<int64_t>(nv, 1)), run_len((size_t)std::max<int64_t>(nv, 1));
+    dbuf<uint32_t> gen((size_t)std::max<int64_t>(nv, 1));
+    dbuf<int> d_dups((size_t)n); d_dups.zero(s);
+    constexpr unsigned int BIG_CAP = 4096;
+    dbuf<uint64_t> big_runs(2 * BIG_CAP); dbuf<unsigned int> d_nbig(1); d_nbig.zero(s);
     if (nv > 0) {
-        {
-            vg_prof_scope ps("mark_runs", (double)nv * (8 + 4 + 4 + 4));
-            hipLaunchKernelGGL(k_mark, dim3(grid_for(nv)), dim3(256), 0, s, si.keys.p, si.pos.p, blk2g.p, nv, gen.p, head.p);
-        }
-        size_t tb = 0;
-        VG_HIP(rocprim::inclusive_scan(nullptr, tb, head.p, run_start.p, (size_t)nv, max_op(), s));
-        dbuf<char> tmp(tb);
-        {
-            vg_prof_scope ps("run_start_scan", (double)nv * 8);
-            VG_HIP(rocprim::inclusive_scan((void*)tmp.p, tb, head.p, run_start.p, (size_t)nv, max_op(), s));
-        }
-        {
-            vg_prof_scope ps("run_len_rowinfo", (double)nv * (4 + 4 + 4 + 4 + 8));
-            hipLaunchKernelGGL(k_runlen, dim3(grid_for(nv)), dim3(256), 0, s, run_start.p, nv, run_len.p);
-            hipLaunchKernelGGL(k_rowinfo, dim3(grid_for(nv)), dim3(256), 0, s, si.pos.p, gen.p, run_start.p, run_len.p, nv, rowinfo.p);
-        }
+        vg_prof_scope ps("index_runs", (double)nv * (8 + 4 + 4 + 8));
+        hipLaunchKernelGGL(k_runs, dim3(grid_for(nv)), dim3(256), 0, s, si.keys.p, si.pos.p, g->d_blk2g.p, g->align_shift, nv,
+                           gen.p, rowinfo.p, d_dups.p, big_runs.p, d_nbig.p, BIG_CAP);
     }
+    unsigned int n_big = 0; d_nbig.download(&n_big, 1, s);
+    std::vector<int> kept((size_t)n), dups((size_t)n);
+    si.kept.download(kept.data(), (size_t)n, s); d_dups.download(dups.data(), (size_t)n, s);
+    VG_HIP(hipStreamSynchronize(s));
+    if (n_big > BIG_CAP) throw vg_error(VG_EOVERFLOW, "too many k-mers shared by >= 2^24 entries");
+    for (int i = 0; i < n; ++i) set_sizes[i] = (int64_t)kept[i] - dups[i];
     si.keys.release();
     // SpGEMM with a growing output buffer
-    dbuf<int64_t> d_sizes((size_t)n); d_sizes.zero(s);
     dbuf<unsigned long long> d_cursor(1);
     dbuf<uint32_t> d_over((size_t)n), d_nover(1);
     unsigned long long cap = std::max<unsigned long long>(1u << 20, (unsigned long long)n * 16);
@@ -361,8 +363,8 @@ extern "C" int vg_kmer_shared(vg_genomes* g, int k, double fraction, int shard, 
         d_cursor.zero(s); d_nover.zero(s);
         {
             vg_prof_scope ps("spgemm_rows", (double)P * 8.0);
-            hipLaunchKernelGGL(k_spgemm, dim3(n), dim3(256), 0, s, rowinfo.p, gen.p, run_len.p, g->d_base_off.p, g->d_len.p, n,
-                               min_shared, (const uint32_t*)nullptr, n, d_sizes.p, d_out.p, d_cursor.p, cap, d_over.p, d_nover.p);
+            hipLaunchKernelGGL(k_spgemm, dim3(n), dim3(256), 0, s, rowinfo.p, gen.p, big_runs.p, n_big, g->d_base_off.p, g->d_len.p, n,
+                               min_shared, (const uint32_t*)nullptr, n, d_out.p, d_cursor.p, cap, d_over.p, d_nover.p);
         }
         uint32_t nover = 0; d_nover.download(&nover, 1, s);
         VG_HIP(hipStreamSynchronize(s));
@@ -376,8 +378,8 @@ extern "C" int vg_kmer_shared(vg_genomes* g, int k, double fraction, int shard, 
                 dense.zero(s);
                 d_rows.upload(rows.data() + o, nb, s);
                 vg_prof_scope ps("spgemm_dense_rows", 0);
-                hipLaunchKernelGGL(k_spgemm_dense, dim3(nb), dim3(256), 0, s, rowinfo.p, gen.p, run_len.p, g->d_base_off.p, g->d_len.p,
-                                   n, min_shared, d_rows.p, dense.p, d_out.p, d_cursor.p, cap);
+                hipLaunchKernelGGL(k_spgemm_dense, dim3(nb), dim3(256), 0, s, rowinfo.p, gen.p, big_runs.p, n_big, g->d_base_off.p,
+                                   g->d_len.p, n, min_shared, d_rows.p, dense.p, d_out.p, d_cursor.p, cap);
                 VG_HIP(hipStreamSynchronize(s));
             }
         }
@@ -391,8 +393,6 @@ extern "C" int vg_kmer_shared(vg_genomes* g, int k, double fraction, int shard, 
         }
         cap = produced + produced / 8 + 1024;     // rerun with a buffer that fits
     }
-    d_sizes.download(set_sizes, (size_t)n, s);
-    VG_HIP(hipStreamSynchronize(s));
     vg_pair_count* outp = (vg_pair_count*)malloc(sizeof(vg_pair_count) * std::max<size_t>(1, host_pairs.size()));
     if (!outp) throw vg_error(VG_ENOMEM, "out of host memory");
     if (!host_pairs.empty()) memcpy(outp, host_pairs.data(), sizeof(vg_pair_count) * host_pairs.size());
@@ -407,9 +407,8 @@ extern "C" int vg_kmer_set(vg_genomes* g, int idx, int k, double fraction, uint6
     vg_require_device();
     int rc = vg_genomes_to_device(g); if (rc) return rc;
     hipStream_t s = vg_stream();
-    dbuf<uint32_t> blk2g; build_blk2g(g, blk2g, s);
     sorted_index si;
-    run_extract_sort(g, blk2g, k, fraction, 0, 1, si);
+    run_extract_sort(g, k, fraction, 0, 1, si);
     // host-side filter of one genome's keys out of the sorted index (test-only entry point)
     std::vector<uint64_t> keys((size_t)si.n_valid); std::vector<uint32_t> pos((size_t)si.n_valid);
     if (si.n_valid) { si.keys.download(keys.data(), keys.size(), s); si.pos.download(pos.data(), pos.size(), s); }
