@@ -1,0 +1,135 @@
+"""Randomised parity sweeps of the HIP path against the CPU oracle: ragged lengths, N runs,
+non-default parameters, duplicated/repetitive sequence, and size-independent properties on the
+bench-sized set (BASELINE.json configs[1])."""
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+from vclust_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_prefilter(codes, offsets, gs, k, fraction=1.0):
+    sizes, pairs = gs.kmer_shared(k=k, fraction=fraction)
+    osizes, opairs = orc.shared_all(codes, offsets, k=k, fraction=fraction)
+    assert list(sizes) == list(osizes)
+    assert {(int(p['a']), int(p['b'])): int(p['shared']) for p in pairs} == opairs
+    return pairs
+
+
+def _check_lz(codes, offsets, gs, tasks, lz=None):
+    stats = gs.lz_align(tasks, lz=lz)
+    bad = []
+    for t, s in zip(tasks, stats):
+        q, r = int(t['q']), int(t['r'])
+        ref = orc.lz_pair_stat(codes[offsets[q]:offsets[q + 1]], codes[offsets[r]:offsets[r + 1]], lz=lz)
+        if ref != (int(s['n_match']), int(s['aln_len']), int(s['n_regions'])):
+            bad.append((q, r, ref, tuple(int(x) for x in s)))
+    assert not bad, bad[:5]
+
+
+def _sprinkle_n(codes, rng, n_runs):
+    codes = codes.copy()
+    for _ in range(n_runs):
+        p = int(rng.integers(0, len(codes) - 60))
+        codes[p:p + int(rng.integers(1, 50))] = 4
+    return codes
+
+
+@pytest.mark.parametrize('seed', [1, 2, 3])
+def test_ragged_families_with_n(seed):
+    rng = np.random.default_rng(seed)
+    codes, offsets, names = synth.make_families(12, 4, seed=seed, length_range=(1500, 30000), p_hi=0.2)
+    codes = _sprinkle_n(codes, rng, 40)
+    gs = api.GenomeSet.from_codes(codes, offsets, names)
+    pairs = _check_prefilter(codes, offsets, gs, 25)
+    _check_prefilter(codes, offsets, gs, 17, fraction=0.3)
+    tasks = gs.align_tasks(pairs[pairs['shared'] >= 5])
+    assert len(tasks) > 40
+    _check_lz(codes, offsets, gs, tasks)
+
+
+@pytest.mark.parametrize('lz', [
+    dict(mal=9, msl=6, mrd=20, mqd=30, reg=20, aw=10, am=4, ar=2),
+    dict(mal=14, msl=7, mrd=60, mqd=70, reg=50, aw=25, am=12, ar=4),
+    dict(mal=11, msl=7, mrd=40, mqd=40, reg=35, aw=32, am=15, ar=1),
+    dict(mal=16, msl=5, mrd=10, mqd=5, reg=1, aw=3, am=0, ar=3),
+])
+def test_non_default_lz_parameters(lz):
+    codes, offsets, names = synth.make_families(5, 4, seed=11, length=8000, p_hi=0.25)
+    gs = api.GenomeSet.from_codes(codes, offsets, names)
+    tasks = gs.align_tasks(synth.family_pairs(5, 4))
+    _check_lz(codes, offsets, gs, tasks, lz=lz)
+
+
+def test_unrelated_and_repetitive_sequences():
+    """Probe-heavy pairs (unrelated genomes), tandem repeats and low-complexity runs."""
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 4, size=20000, dtype=np.uint8)
+    b = rng.integers(0, 4, size=15000, dtype=np.uint8)
+    unit = rng.integers(0, 4, size=37, dtype=np.uint8)
+    rep = np.tile(unit, 300)                                  # tandem repeat, 11 100 bp
+    rep2 = rep.copy(); rep2[rng.random(len(rep2)) < 0.03] = 1
+    poly = np.concatenate([a[:3000], np.zeros(4000, np.uint8), a[3000:6000]])   # poly-A block
+    dup = np.concatenate([a[:8000], a[2000:9000], a[:3000]])                   # duplicated segments
+    seqs = [a, b, rep, rep2, poly, dup]
+    offsets = np.zeros(len(seqs) + 1, dtype=np.int64); offsets[1:] = np.cumsum([len(s) for s in seqs])
+    codes = np.concatenate(seqs)
+    gs = api.GenomeSet.from_codes(codes, offsets)
+    _check_prefilter(codes, offsets, gs, 25)
+    _check_prefilter(codes, offsets, gs, 15)
+    _check_lz(codes, offsets, gs, gs.align_tasks(gs.read_filter(None)))
+
+
+def test_large_reference_global_index_path():
+    """References above 2^18 RR symbols use the global-memory index build."""
+    rng = np.random.default_rng(8)
+    a = rng.integers(0, 4, size=140000, dtype=np.uint8)
+    b = a.copy(); m = rng.random(len(b)) < 0.04; b[m] = (b[m] + 1) & 3
+    c = a[20000:60000].copy()
+    seqs = [a, b, c]
+    offsets = np.zeros(4, dtype=np.int64); offsets[1:] = np.cumsum([len(s) for s in seqs])
+    codes = np.concatenate(seqs)
+    gs = api.GenomeSet.from_codes(codes, offsets)
+    _check_lz(codes, offsets, gs, gs.align_tasks(gs.read_filter(None)))
+
+
+def test_full_size_properties():
+    """BASELINE configs[1] (1 000 x 40 kb): size-independent checks + oracle on a sample."""
+    nf, mem = 100, 10
+    codes, offsets, names = synth.make_families(nf, mem, length=40000, seed=1)
+    gs = api.GenomeSet.from_codes(codes, offsets, names)
+    sizes, pairs = gs.kmer_shared(k=25, min_shared=20)
+    lens = gs.lengths()
+    assert np.all(sizes <= lens - 24) and np.all(sizes > 0.9 * (lens - 24))
+    # random ancestors: exactly the within-family pairs survive, each counted once
+    got = {(int(p['a']), int(p['b'])) for p in pairs}
+    assert got == {(int(p['a']), int(p['b'])) for p in synth.family_pairs(nf, mem)}
+    assert np.all(pairs['shared'] <= np.minimum(sizes[pairs['a']], sizes[pairs['b']]))
+    # sharded runs add up to the unsharded one (checksum of checksums)
+    tot = np.zeros_like(sizes); acc = {}
+    for s in range(4):
+        sz, pr = gs.kmer_shared(k=25, shard=s, n_shards=4)
+        tot += sz
+        for p in pr:
+            acc[(int(p['a']), int(p['b']))] = acc.get((int(p['a']), int(p['b'])), 0) + int(p['shared'])
+    assert np.array_equal(tot, sizes)
+    assert {k: v for k, v in acc.items() if v >= 20} == {(int(p['a']), int(p['b'])): int(p['shared']) for p in pairs}
+    tasks = gs.align_tasks(pairs)
+    stats = gs.lz_align(tasks)
+    ql = lens[tasks['q']]
+    assert np.all(stats['n_match'] <= stats['aln_len']) and np.all(stats['aln_len'] <= ql)
+    assert np.all(stats['n_regions'] >= 1)
+    # a second run is bit-identical (no dependence on atomics / scheduling order)
+    assert np.array_equal(stats, gs.lz_align(tasks))
+    # self alignment: one region covering the genome
+    self_tasks = np.array([(i, i) for i in range(0, len(gs), 97)], dtype=api.TASK_DTYPE)
+    st = gs.lz_align(self_tasks)
+    assert np.array_equal(st['n_match'], lens[self_tasks['q']]) and np.all(st['n_regions'] == 1)
+    # oracle on a sample of the tasks
+    idx = np.random.default_rng(0).choice(len(tasks), 60, replace=False)
+    for i in idx:
+        q, r = int(tasks[i]['q']), int(tasks[i]['r'])
+        ref = orc.lz_pair_stat(codes[offsets[q]:offsets[q + 1]], codes[offsets[r]:offsets[r + 1]])
+        assert ref == tuple(int(x) for x in stats[i]), (q, r)

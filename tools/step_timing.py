@@ -5,7 +5,9 @@ sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
 import bench
 from vclust_amd import api, synth
 api.set_device(0)
-codes, offsets, names = synth.make_families(100, 10, 40000, seed=1)
+import os
+NF = int(os.environ.get('NF', '100'))
+codes, offsets, names = synth.make_families(NF, 10, 40000, seed=1)
 gs = api.GenomeSet.from_codes(codes, offsets, names); gs.to_device()
 for it in range(4):
     t = [time.perf_counter()]

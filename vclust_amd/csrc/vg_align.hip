@@ -708,10 +708,14 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
         if (tasks[t].q >= (uint32_t)g->n || tasks[t].r >= (uint32_t)g->n) throw vg_error(VG_EINVAL, "task id out of range");
     for (int i = 0; i < g->n; ++i) if (g->len[i] > (1 << 29)) throw vg_error(VG_EOVERFLOW, "genome longer than 2^29 bases");
 
-    // group tasks by reference
+    // group tasks by reference: counting sort on the reference id (stable, O(n))
     std::vector<int64_t> order((size_t)n_tasks);
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int64_t x, int64_t y) { return tasks[x].r < tasks[y].r; });
+    {
+        std::vector<int64_t> start((size_t)g->n + 1, 0);
+        for (int64_t t = 0; t < n_tasks; ++t) start[tasks[t].r + 1]++;
+        for (int i = 0; i < g->n; ++i) start[i + 1] += start[i];
+        for (int64_t t = 0; t < n_tasks; ++t) order[(size_t)start[tasks[t].r]++] = t;
+    }
     const lz_dev_params P{ p->mal, p->msl, p->mrd, p->mqd, p->reg, p->aw, p->am, p->ar };
     const int64_t stab_n = 1LL << (2 * p->msl);
 

@@ -180,7 +180,16 @@ extern "C" int vg_align_tasks(const vg_genomes* g, const vg_pair_count* pairs, i
         int32_t x = rank[pairs[i].a], y = rank[pairs[i].b];
         v[(size_t)i] = { std::min(x, y), std::max(x, y) };
     }
-    std::sort(v.begin(), v.end(), [](const rp& x, const rp& y) { return x.lo != y.lo ? x.lo < y.lo : x.hi < y.hi; });
+    {   // sort couples by (lo, hi): two stable counting passes over the ranks
+        std::vector<rp> tmp(v.size());
+        for (int pass = 0; pass < 2; ++pass) {
+            std::vector<size_t> start((size_t)g->n + 1, 0);
+            for (auto& e : v) start[(size_t)(pass == 0 ? e.hi : e.lo) + 1]++;
+            for (int i = 0; i < g->n; ++i) start[i + 1] += start[i];
+            for (auto& e : v) tmp[start[(size_t)(pass == 0 ? e.hi : e.lo)]++] = e;
+            v.swap(tmp);
+        }
+    }
     vg_task* o = (vg_task*)malloc(sizeof(vg_task) * std::max<size_t>(1, 2 * v.size()));
     if (!o) throw vg_error(VG_ENOMEM, "out of host memory");
     for (size_t i = 0; i < v.size(); ++i) {
