@@ -40,7 +40,7 @@ struct ref_desc {
     int32_t pos_bits;  // anchor entry = pos | tag << pos_bits (tag = next hash bits after the bucket)
 };
 
-struct lz_dev_params { int mal, msl, mrd, mqd, reg, aw, am, ar; };
+struct lz_dev_params { int mal, msl, mrd, mqd, reg, aw, am, ar; int ablate; };   // ablate: developer timing experiments only
 
 // ------------------------------------------------------------------ bit helpers
 // 32 bases (2-bit codes, first base in the low bits) starting at base position p (p >= 0)
@@ -144,38 +144,44 @@ __device__ __forceinline__ int match_len_wave(const pair_ctx& c, int qp, int rp,
     }
 }
 
-// Approximate extension (R4 / R5) in direction dir = +1 (right of (qp,rp), positions qp+e) or
-// -1 (left: positions qp-1-e), at most `bound` positions.  Returns accepted length; *n_match =
-// matching symbols inside it.  Bit-parallel restatement of the sequential window automaton:
-// stop at the first e whose trailing aw-window holds > am mismatches; accept up to the end of
-// the last run of >= ar matches before that.
-__device__ __forceinline__ int approx_ext(const pair_ctx& c, const lz_dev_params& P, int qp, int rp, int dir, int bound,
-                                           int lane, int* n_match) {
+// Exact + approximate extension in one pass (R2/R3 match length + R4, or R5 to the left).
+// dir = +1: positions qp+e (e = 0 is the first symbol of the match); dir = -1: positions qp-1-e.
+// At most `bound` positions.  Returns the accepted length; *n_match = matching symbols inside it.
+//
+// Sequentially the reference takes the maximal exact run and then walks on while the last aw
+// symbols hold <= am mismatches, cutting back to the end of the last run of >= ar matches.  The
+// symbol that ends the exact run is a mismatch, so window counts and match runs never straddle
+// the two phases, and the whole thing is the window automaton run over the mismatch mask from
+// e = 0, with the exact run as a lower bound of the result.  Bit-parallel: 32 bases per lane
+// (one XOR of 2-bit words), 2 048 per round; only mismatch positions can start a violation.
+__device__ __forceinline__ int extend(const pair_ctx& c, const lz_dev_params& P, int qp, int rp, int dir, int bound,
+                                      int lane, int* n_match) {
     int accepted = 0, matches_total = 0;
+    int first_mm = -1;            // position of the first mismatch (end of the exact run)
     uint64_t carry_mm = 0;        // mismatch bits of the previous 32 positions (0 before e = 0)
     uint64_t carry_ok = 0;        // match bits of the previous 32 positions (none before e = 0)
     int base = 0;                 // first position of this round
     int cum_before = 0;           // matches in [0, base)
-    int lanes_now = 64;
     const uint64_t awmask = (P.aw >= 32) ? ~0ULL : ((1ULL << (2 * P.aw)) - 1);
+    if (bound <= 0) { *n_match = 0; return 0; }
     for (;;) {
         uint64_t mm = EVEN;
-        const bool act = lane < lanes_now;
-        if (act) {
-            int e0 = base + 32 * lane;
-            if (e0 < bound) {
-                if (dir > 0) mm = mism32(c, qp + e0, rp + e0);
-                else mm = rev2(mism32(c, qp - e0 - 32, rp - e0 - 32));        // slot j <-> position e0 + j
-                mm &= EVEN;
-                int rem = bound - e0; if (rem < 32) mm |= EVEN & ~slots(0, rem);
-            }
+        const int e0 = base + 32 * lane;
+        if (e0 < bound) {
+            if (dir > 0) mm = mism32(c, qp + e0, rp + e0);
+            else mm = rev2(mism32(c, qp - e0 - 32, rp - e0 - 32)) & EVEN;        // slot j <-> position e0 + j
+            const int rem = bound - e0; if (rem < 32) mm |= EVEN & ~slots(0, rem);
         }
-        uint64_t prev_mm = __shfl_up(mm, 1); uint64_t okb = (~mm) & EVEN; uint64_t prev_ok = __shfl_up(okb, 1);
+        const unsigned long long anyb = __ballot(mm != 0);
+        if (first_mm < 0 && anyb) {
+            const int fl = __builtin_ctzll(anyb);
+            first_mm = base + 32 * fl + (__builtin_ctzll(__shfl(mm, fl)) >> 1);
+        }
+        uint64_t prev_mm = __shfl_up(mm, 1); const uint64_t okb = (~mm) & EVEN; uint64_t prev_ok = __shfl_up(okb, 1);
         if (lane == 0) { prev_mm = carry_mm; prev_ok = carry_ok; }
-        // first violation in this lane.  A window count can only newly exceed am at a mismatch
-        // position, and never if the chunk plus the aw-1 symbols before it hold <= am mismatches.
+        // first violation in this lane: never if the chunk plus the aw-1 symbols before it hold <= am
         int viol = 32;
-        if (act) {
+        {
             const uint64_t tail = (P.aw > 1) ? (prev_mm >> (64 - 2 * (P.aw - 1))) : 0ULL;
             if (__popcll(mm) + __popcll(tail) > P.am) {
                 uint64_t bits = mm;
@@ -191,38 +197,41 @@ __device__ __forceinline__ int approx_ext(const pair_ctx& c, const lz_dev_params
                 }
             }
         }
-        // positions ending a run of >= ar matches
-        uint64_t run = okb;
-        for (int t = 1; t < P.ar; ++t) run &= (okb << (2 * t)) | (prev_ok >> (64 - 2 * t));
-        unsigned long long vb = __ballot(viol < 32);
-        int fv = vb ? __builtin_ctzll(vb) : 64;            // first violating lane
-        int vj = __shfl(viol, fv & 63);
-        // candidate ends strictly before the violation
-        uint64_t cand = run;
-        if (lane > fv || !act) cand = 0;
-        else if (lane == fv) cand &= (vj == 0) ? 0ULL : ((1ULL << (2 * vj)) - 1);
-        unsigned long long cb = __ballot(cand != 0);
-        if (cb) {
-            int hl = 63 - __builtin_clzll(cb);
-            uint64_t ch = __shfl(cand, hl); uint64_t mh = __shfl(mm, hl);
-            int hj = (63 - __builtin_clzll(ch)) >> 1;
-            accepted = base + 32 * hl + hj + 1;
-            // matches inside [0, accepted): lanes below hl fully, lane hl up to hj
-            int part = (lane < hl && act) ? 32 - __popcll(mm) : 0;
-            int tot = wave_sum(part);
-            uint64_t upto = (hj == 31) ? ~0ULL : ((1ULL << (2 * hj + 2)) - 1);
-            tot += (hj + 1) - __popcll(mh & upto);
-            matches_total = cum_before + tot;
+        const unsigned long long vb = __ballot(viol < 32);
+        if (anyb) {
+            // positions ending a run of >= ar matches, strictly before the violation
+            uint64_t run = okb;
+            for (int t = 1; t < P.ar; ++t) run &= (okb << (2 * t)) | (prev_ok >> (64 - 2 * t));
+            const int fv = vb ? __builtin_ctzll(vb) : 64;
+            const int vj = __shfl(viol, fv & 63);
+            uint64_t cand = run;
+            if (lane > fv) cand = 0;
+            else if (lane == fv) cand &= (vj == 0) ? 0ULL : ((1ULL << (2 * vj)) - 1);
+            const unsigned long long cb = __ballot(cand != 0);
+            if (cb) {
+                const int hl = 63 - __builtin_clzll(cb);
+                const uint64_t ch = __shfl(cand, hl); const uint64_t mh = __shfl(mm, hl);
+                const int hj = (63 - __builtin_clzll(ch)) >> 1;
+                accepted = base + 32 * hl + hj + 1;
+                int tot = wave_sum(lane < hl ? 32 - __popcll(mm) : 0);
+                const uint64_t upto = (hj == 31) ? ~0ULL : ((1ULL << (2 * hj + 2)) - 1);
+                tot += (hj + 1) - __popcll(mh & upto);
+                matches_total = cum_before + tot;
+            }
+        } else {
+            // 2 048 matches in a row
+            accepted = base + 2048; matches_total = cum_before + 2048;
         }
         if (vb) break;
-        if (base + 32 * lanes_now >= bound) break;
-        // no violation yet: carry masks of the last active lane into the next round
-        int full = wave_sum(act ? 32 - __popcll(mm) : 0);
-        cum_before += full;
-        carry_mm = __shfl(mm, lanes_now - 1); carry_ok = __shfl(okb, lanes_now - 1);
-        base += 32 * lanes_now;
-        lanes_now = 64;
+        if (base + 2048 >= bound) break;
+        cum_before += anyb ? wave_sum(32 - __popcll(mm)) : 2048;
+        carry_mm = __shfl(mm, 63); carry_ok = __shfl(okb, 63);
+        base += 2048;
     }
+    if (first_mm < 0) first_mm = bound;                    // the whole range matched
+    if (first_mm > bound) first_mm = bound;
+    if (accepted < first_mm) { accepted = first_mm; matches_total = first_mm; }   // exact run is always taken
+    if (accepted > bound) { accepted = bound; }
     *n_match = matches_total;
     return accepted;
 }
@@ -575,29 +584,39 @@ k_lz_parse(const task_dev* __restrict__ tasks, int64_t n_tasks, const ref_desc* 
                 q_ok_a = (m & ((1ULL << P.mal) - 1)) == 0;
                 q_ok_s = q_ok_s && (m & ((1ULL << P.msl) - 1)) == 0;
             }
-            // R2: anchor = longest exact match >= mal over all occurrences, ties -> smallest position
-            if (q_ok_a) {
+            // candidate ranking shared by anchors and seeds: longest exact match, ties -> smallest position
+            int ncap = 0;
+            auto consider = [&](int rp, int min_len) {
+                int l = match_len_lane(c, qi, rp, 32);
+                if (l < min_len) return;
+                if (l >= 32) {
+                    // rare: several long candidates need their exact lengths to be ranked
+                    if (ncap++ > 0 || best_len >= 32) {
+                        l = match_len_lane(c, qi, rp, 1 << 30);
+                        if (best_len == 32) best_len = match_len_lane(c, qi, best_pos, 1 << 30);
+                    }
+                }
+                if (l > best_len || (l == best_len && rp < best_pos)) { best_len = l; best_pos = rp; }
+            };
+            // R2: anchor = longest exact match >= mal over all occurrences.  Bucket entries are read
+            // four at a time (independent loads: one memory round trip per group, not per entry).
+            if (q_ok_a && !(P.ablate & 16)) {
                 const uint64_t h = anchor_hash(xq & amask);
                 const uint32_t b = anchor_bucket(h, rd.B);
                 const uint32_t tag = anchor_tag(h, rd.B, rd.pos_bits);
                 const uint32_t posmask = (1u << rd.pos_bits) - 1u;
                 const uint32_t s = b ? atab[b - 1] : 0u, e = atab[b];
-                int ncap = 0;
-                for (uint32_t u = s; u < e; ++u) {
-                    const uint32_t ent = aent[u];
-                    if ((ent >> rd.pos_bits) != tag) continue;
-                    const int rp = (int)(ent & posmask);
-                    if ((load32(c.rpk, rp) ^ xq) & amask) continue;
-                    int l = match_len_lane(c, qi, rp, 32);
-                    if (l < P.mal) continue;
-                    if (l >= 32) {
-                        // rare: several long candidates need their exact lengths to be ranked
-                        if (ncap++ > 0 || best_len >= 32) {
-                            l = match_len_lane(c, qi, rp, 1 << 30);
-                            if (best_len == 32) best_len = match_len_lane(c, qi, best_pos, 1 << 30);
-                        }
+                for (uint32_t u = s; u < e; u += 4) {
+                    uint32_t ent[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ent[j] = aent[min(u + j, e - 1)];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (u + j >= e || (ent[j] >> rd.pos_bits) != tag) continue;
+                        const int rp = (int)(ent[j] & posmask);
+                        if ((load32(c.rpk, rp) ^ xq) & amask) continue;
+                        consider(rp, P.mal);
                     }
-                    if (l > best_len || (l == best_len && rp < best_pos)) { best_len = l; best_pos = rp; }
                 }
                 if (best_len > 0) {
                     const int d = best_pos - pred_l;
@@ -605,23 +624,20 @@ k_lz_parse(const task_dev* __restrict__ tasks, int64_t n_tasks, const ref_desc* 
                 }
             }
             // R3: seed near the prediction
-            if (best_len == 0 && alive_l && q_ok_s) {
+            if (best_len == 0 && alive_l && q_ok_s && !(P.ablate & 1)) {
                 const uint32_t b = (uint32_t)(xq & smask);
                 const uint32_t s = b ? stab[b - 1] : 0u, e = stab[b];
                 const int pred0 = pred - lit;                    // reference end of the previous match
-                int ncap = 0;
-                for (uint32_t u = s; u < e; ++u) {
-                    const int rp = (int)sent[u];
-                    if (rp < pred0 || rp - pred_l > P.mrd - 1) continue;
-                    int l = match_len_lane(c, qi, rp, 32);
-                    if (l < P.msl) continue;
-                    if (l >= 32) {
-                        if (ncap++ > 0 || best_len >= 32) {
-                            l = match_len_lane(c, qi, rp, 1 << 30);
-                            if (best_len == 32) best_len = match_len_lane(c, qi, best_pos, 1 << 30);
-                        }
+                ncap = 0;
+                for (uint32_t u = s; u < e; u += 4) {
+                    int rps[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) rps[j] = (int)sent[min(u + j, e - 1)];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (u + j >= e || rps[j] < pred0 || rps[j] - pred_l > P.mrd - 1) continue;
+                        consider(rps[j], P.msl);
                     }
-                    if (l > best_len || (l == best_len && rp < best_pos)) { best_len = l; best_pos = rp; }
                 }
                 if (best_len > 0) hit_close = true;
             }
@@ -638,42 +654,22 @@ k_lz_parse(const task_dev* __restrict__ tasks, int64_t n_tasks, const ref_desc* 
         const bool ev_close = __shfl((int)hit_close, f) != 0;
         // literals in front of the event
         i += f; lit += f; if (alive) { pred += f; if (lit > P.mqd) alive = false; }
-        // exact length of the chosen match, whole wave
-        const int ev_len = match_len_wave(c, i, ev_pos, lane);
         const int gap_end_ref = pred - 1;
         if (!ev_close) {
             // R5: new region, extended to the left (exact, then approximate), not into the last kept region
             close_region();
-            const int bound = i - kept_end;
-            int b = 0;
-            {   // maximal exact run to the left
-                int base = 0; bool done = false;
-                while (!done && base < bound) {
-                    int e0 = base + 32 * lane; uint64_t mm = EVEN;
-                    if (e0 < bound) {
-                        mm = rev2(mism32(c, i - e0 - 32, ev_pos - e0 - 32)) & EVEN;
-                        int rem = bound - e0; if (rem < 32) mm |= EVEN & ~slots(0, rem);
-                    }
-                    unsigned long long bb = __ballot(mm != 0);
-                    if (bb) { int fl = __builtin_ctzll(bb); uint64_t mf = __shfl(mm, fl); b = base + 32 * fl + (__builtin_ctzll(mf) >> 1); done = true; }
-                    else { base += 2048; b = min(base, bound); }
-                }
-                if (b > bound) b = bound;
-            }
-            int am_cnt = 0;
-            const int ab = approx_ext(c, P, i - b, ev_pos - b, -1, bound - b, lane, &am_cnt);
-            r_qstart = i - b - ab; r_rstart = ev_pos - b - ab; r_match = b + am_cnt; r_rend = -1;
+            int bm = 0;
+            const int b = (P.ablate & 2) ? 0 : extend(c, P, i, ev_pos, -1, i - kept_end, lane, &bm);
+            r_qstart = i - b; r_rstart = ev_pos - b; r_match = bm; r_rend = -1;
             in_region = true;
         } else if (lit > 0) {
             // R7: literal gap scored on the old diagonal
-            r_match += count_eq_wave(c, i - lit, pred - lit, lit, lane);
+            if (!(P.ablate & 8)) r_match += count_eq_wave(c, i - lit, pred - lit, lit, lane);
         }
-        r_match += ev_len;
-        i += ev_len; pred = ev_pos + ev_len; lit = 0; alive = true;
-        {   // R4
+        {   // the match itself and R4, one pass
             int fm = 0;
-            const int fe = approx_ext(c, P, i, pred, +1, 1 << 30, lane, &fm);
-            r_match += fm; i += fe; pred += fe;
+            const int fe = (P.ablate & 4) ? P.mal : extend(c, P, i, ev_pos, +1, 1 << 30, lane, &fm);
+            r_match += fm; i += fe; pred = ev_pos + fe; lit = 0; alive = true;
         }
         r_qend = i - 1;
         if (ev_close) { r_rend = max(r_rend, max(pred - 1, gap_end_ref)); }
@@ -716,7 +712,8 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
         for (int i = 0; i < g->n; ++i) start[i + 1] += start[i];
         for (int64_t t = 0; t < n_tasks; ++t) order[(size_t)start[tasks[t].r]++] = t;
     }
-    const lz_dev_params P{ p->mal, p->msl, p->mrd, p->mqd, p->reg, p->aw, p->am, p->ar };
+    const char* abl = getenv("VG_LZ_ABLATE");
+    const lz_dev_params P{ p->mal, p->msl, p->mrd, p->mqd, p->reg, p->aw, p->am, p->ar, abl ? atoi(abl) : 0 };
     const int64_t stab_n = 1LL << (2 * p->msl);
 
     dbuf<vg_pair_stat> d_stats((size_t)n_tasks);
