@@ -17,6 +17,9 @@
 namespace {
 
 constexpr uint64_t SENT = ~0ULL;
+// k-mers are stored scrambled: key = (canonical * SCRAMBLE) mod 4^k, a bijection that spreads any
+// composition bias over the HIGH key bits, so that sorting on a high-bit prefix gives tiny groups
+constexpr uint64_t SCRAMBLE = 0x9E3779B97F4A7C15ULL;      // odd
 constexpr uint32_t DUP_BIT = 0x80000000u;
 constexpr int RUNLEN_BITS = 24;
 constexpr uint64_t RUNLEN_MASK = (1ull << RUNLEN_BITS) - 1;
@@ -66,7 +69,7 @@ k_kmer_extract(const uint32_t* __restrict__ packed, const uint32_t* __restrict__
                     if (use_frac && !(h < frac_thr)) keep = false;
                     if (n_shards > 1 && (uint32_t)(((h & 0xffffffffULL) * n_shards) >> 32) != shard) keep = false;
                 }
-                if (keep) { key = cano; ++local_valid; }
+                if (keep) { key = (cano * SCRAMBLE) & kmask; ++local_valid; }      // bit 2k stays 0; SENT has it set
             }
         }
         keys[p] = key;
@@ -85,6 +88,33 @@ k_kmer_extract(const uint32_t* __restrict__ packed, const uint32_t* __restrict__
 
 __global__ void k_iota(uint32_t* v, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) v[i] = (uint32_t)i;
+}
+
+// ------------------------------------------------------------------ K1b: finish the partial sort
+// The device radix sort only orders the top `sort_bits` key bits (4-5 passes instead of 7).
+// Entries with equal prefix form tiny contiguous groups (the scramble makes prefixes uniform);
+// the first entry of each group orders its group by the full key with a stable insertion sort.
+__global__ void __launch_bounds__(256)
+k_group_sort(uint64_t* __restrict__ keys, uint32_t* __restrict__ pos, int64_t n, int low_bit) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t pre = keys[i] >> low_bit;
+        if (i > 0 && (keys[i - 1] >> low_bit) == pre) continue;        // not a group leader
+        int64_t e = i + 1;
+        bool sorted = true; uint64_t prev = keys[i];
+        while (e < n) {
+            const uint64_t kk = keys[e];
+            if ((kk >> low_bit) != pre) break;
+            if (kk < prev) sorted = false;
+            prev = kk; ++e;
+        }
+        if (sorted) continue;
+        for (int64_t a = i + 1; a < e; ++a) {
+            const uint64_t kk = keys[a]; const uint32_t pp = pos[a];
+            int64_t b = a - 1;
+            while (b >= i && keys[b] > kk) { keys[b + 1] = keys[b]; pos[b + 1] = pos[b]; --b; }
+            keys[b + 1] = kk; pos[b + 1] = pp;
+        }
+    }
 }
 
 // ------------------------------------------------------------------ K2a: runs of the inverted index
@@ -303,19 +333,27 @@ static void run_extract_sort(vg_genomes* g, int k, double fraction, int shard, i
                            g->align_shift, keys_a.p, d_nvalid.p, out.kept.p);
     }
     hipLaunchKernelGGL(k_iota, dim3(grid_for(P)), dim3(256), 0, s, pos_a.p, P);
-    // stable LSD radix sort on the 2k key bits; sentinels (all ones) end up behind every real k-mer
+    // Stable LSD radix sort on the top key bits only (bit 2k is the sentinel flag, so sentinels end
+    // up behind every real k-mer); k_group_sort then orders the small equal-prefix groups.
+    const unsigned int end_bit = (unsigned)(2 * k + 1);
+    unsigned int sort_bits = P <= (1LL << 29) ? 32u : 40u;
+    if (sort_bits > end_bit) sort_bits = end_bit;
+    const unsigned int begin_bit = end_bit - sort_bits;
     size_t tmp_bytes = 0;
-    unsigned int end_bit = (unsigned)(2 * k);
-    VG_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_a.p, keys_b.p, pos_a.p, pos_b.p, (size_t)P, 0u, end_bit, s));
+    VG_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_a.p, keys_b.p, pos_a.p, pos_b.p, (size_t)P, begin_bit, end_bit, s));
     dbuf<char> tmp(tmp_bytes);
     {
-        int passes = (2 * k + 7) / 8;
+        int passes = (int)(sort_bits + 7) / 8;
         vg_prof_scope ps("radix_sort_pairs", (double)P * 12.0 * 2.0 * passes);
-        VG_HIP(rocprim::radix_sort_pairs((void*)tmp.p, tmp_bytes, keys_a.p, keys_b.p, pos_a.p, pos_b.p, (size_t)P, 0u, end_bit, s));
+        VG_HIP(rocprim::radix_sort_pairs((void*)tmp.p, tmp_bytes, keys_a.p, keys_b.p, pos_a.p, pos_b.p, (size_t)P, begin_bit, end_bit, s));
     }
     unsigned long long nv = 0;
     d_nvalid.download(&nv, 1, s);
     VG_HIP(hipStreamSynchronize(s));
+    if (begin_bit > 0 && nv > 0) {
+        vg_prof_scope ps("group_sort", (double)nv * 12.0);
+        hipLaunchKernelGGL(k_group_sort, dim3(grid_for((int64_t)nv)), dim3(256), 0, s, keys_b.p, pos_b.p, (int64_t)nv, (int)begin_bit);
+    }
     out.keys = std::move(keys_b); out.pos = std::move(pos_b); out.n_valid = (int64_t)nv;
 }
 
@@ -415,8 +453,13 @@ extern "C" int vg_kmer_set(vg_genomes* g, int idx, int k, double fraction, uint6
     VG_HIP(hipStreamSynchronize(s));
     std::vector<uint64_t> mine;
     const int64_t lo = g->base_off[idx], hi = g->base_off[idx + 1];
+    uint64_t inv = SCRAMBLE;                                   // inverse of SCRAMBLE mod 2^64 (Newton)
+    for (int it = 0; it < 6; ++it) inv *= 2 - SCRAMBLE * inv;
+    const uint64_t kmask = (1ULL << (2 * k)) - 1;
     for (size_t i = 0; i < keys.size(); ++i)
-        if ((int64_t)pos[i] >= lo && (int64_t)pos[i] < hi && (mine.empty() || mine.back() != keys[i])) mine.push_back(keys[i]);
+        if ((int64_t)pos[i] >= lo && (int64_t)pos[i] < hi) mine.push_back((keys[i] * inv) & kmask);
+    std::sort(mine.begin(), mine.end());
+    mine.erase(std::unique(mine.begin(), mine.end()), mine.end());
     uint64_t* o = (uint64_t*)malloc(sizeof(uint64_t) * std::max<size_t>(1, mine.size()));
     if (!o) throw vg_error(VG_ENOMEM, "out of host memory");
     if (!mine.empty()) memcpy(o, mine.data(), sizeof(uint64_t) * mine.size());
