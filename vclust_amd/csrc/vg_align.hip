@@ -154,8 +154,21 @@ __device__ __forceinline__ int match_len_wave(const pair_ctx& c, int qp, int rp,
 // the two phases, and the whole thing is the window automaton run over the mismatch mask from
 // e = 0, with the exact run as a lower bound of the result.  Bit-parallel: 32 bases per lane
 // (one XOR of 2-bit words), 2 048 per round; only mismatch positions can start a violation.
+// mismatch mask of round 0 of extend(), split out so that a caller can issue the loads of several
+// extensions back to back (one memory round trip instead of one per extension)
+__device__ __forceinline__ uint64_t extend_mask0(const pair_ctx& c, int qp, int rp, int dir, int bound, int lane) {
+    uint64_t mm = EVEN;
+    const int e0 = 32 * lane;
+    if (e0 < bound) {
+        if (dir > 0) mm = mism32(c, qp + e0, rp + e0);
+        else mm = rev2(mism32(c, qp - e0 - 32, rp - e0 - 32)) & EVEN;        // slot j <-> position e0 + j
+        const int rem = bound - e0; if (rem < 32) mm |= EVEN & ~slots(0, rem);
+    }
+    return mm;
+}
+
 __device__ __forceinline__ int extend(const pair_ctx& c, const lz_dev_params& P, int qp, int rp, int dir, int bound,
-                                      int lane, int* n_match) {
+                                      int lane, int* n_match, uint64_t mm_first) {
     int accepted = 0, matches_total = 0;
     int first_mm = -1;            // position of the first mismatch (end of the exact run)
     uint64_t carry_mm = 0;        // mismatch bits of the previous 32 positions (0 before e = 0)
@@ -165,12 +178,15 @@ __device__ __forceinline__ int extend(const pair_ctx& c, const lz_dev_params& P,
     const uint64_t awmask = (P.aw >= 32) ? ~0ULL : ((1ULL << (2 * P.aw)) - 1);
     if (bound <= 0) { *n_match = 0; return 0; }
     for (;;) {
-        uint64_t mm = EVEN;
-        const int e0 = base + 32 * lane;
-        if (e0 < bound) {
-            if (dir > 0) mm = mism32(c, qp + e0, rp + e0);
-            else mm = rev2(mism32(c, qp - e0 - 32, rp - e0 - 32)) & EVEN;        // slot j <-> position e0 + j
-            const int rem = bound - e0; if (rem < 32) mm |= EVEN & ~slots(0, rem);
+        uint64_t mm = mm_first;
+        if (base > 0) {
+            mm = EVEN;
+            const int e0 = base + 32 * lane;
+            if (e0 < bound) {
+                if (dir > 0) mm = mism32(c, qp + e0, rp + e0);
+                else mm = rev2(mism32(c, qp - e0 - 32, rp - e0 - 32)) & EVEN;    // slot j <-> position e0 + j
+                const int rem = bound - e0; if (rem < 32) mm |= EVEN & ~slots(0, rem);
+            }
         }
         const unsigned long long anyb = __ballot(mm != 0);
         if (first_mm < 0 && anyb) {
@@ -613,9 +629,7 @@ k_lz_parse(const task_dev* __restrict__ tasks, int64_t n_tasks, const ref_desc* 
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         if (u + j >= e || (ent[j] >> rd.pos_bits) != tag) continue;
-                        const int rp = (int)(ent[j] & posmask);
-                        if ((load32(c.rpk, rp) ^ xq) & amask) continue;
-                        consider(rp, P.mal);
+                        consider((int)(ent[j] & posmask), P.mal);      // tag collisions fail the length test
                     }
                 }
                 if (best_len > 0) {
@@ -655,20 +669,26 @@ k_lz_parse(const task_dev* __restrict__ tasks, int64_t n_tasks, const ref_desc* 
         // literals in front of the event
         i += f; lit += f; if (alive) { pred += f; if (lit > P.mqd) alive = false; }
         const int gap_end_ref = pred - 1;
+        // first-round loads of the left extension / gap scoring and of the right extension are
+        // independent: issue them together, then run the window logic
+        // (closing the open region may move kept_end: use the value it will have)
+        const int kept_after = (in_region && r_qend - r_qstart + 1 >= P.reg) ? r_qend + 1 : kept_end;
+        const int bwd_bound = ev_close ? 0 : i - kept_after;
+        const uint64_t mm_b = (!ev_close && !(P.ablate & 2)) ? extend_mask0(c, i, ev_pos, -1, bwd_bound, lane) : EVEN;
+        const uint64_t mm_f = extend_mask0(c, i, ev_pos, +1, 1 << 30, lane);
+        int gap_m = 0;
+        if (ev_close && lit > 0 && !(P.ablate & 8)) gap_m = count_eq_wave(c, i - lit, pred - lit, lit, lane);   // R7: old diagonal
         if (!ev_close) {
             // R5: new region, extended to the left (exact, then approximate), not into the last kept region
             close_region();
             int bm = 0;
-            const int b = (P.ablate & 2) ? 0 : extend(c, P, i, ev_pos, -1, i - kept_end, lane, &bm);
+            const int b = (P.ablate & 2) ? 0 : extend(c, P, i, ev_pos, -1, bwd_bound, lane, &bm, mm_b);
             r_qstart = i - b; r_rstart = ev_pos - b; r_match = bm; r_rend = -1;
             in_region = true;
-        } else if (lit > 0) {
-            // R7: literal gap scored on the old diagonal
-            if (!(P.ablate & 8)) r_match += count_eq_wave(c, i - lit, pred - lit, lit, lane);
-        }
+        } else r_match += gap_m;
         {   // the match itself and R4, one pass
             int fm = 0;
-            const int fe = (P.ablate & 4) ? P.mal : extend(c, P, i, ev_pos, +1, 1 << 30, lane, &fm);
+            const int fe = (P.ablate & 4) ? P.mal : extend(c, P, i, ev_pos, +1, 1 << 30, lane, &fm, mm_f);
             r_match += fm; i += fe; pred = ev_pos + fe; lit = 0; alive = true;
         }
         r_qend = i - 1;
