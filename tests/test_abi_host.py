@@ -138,3 +138,30 @@ def test_write_ani_output_filters(tmp_path, golden_dir):
     stats[0] = (100, 200, 1)
     gs.write_ani(tmp_path / 'o.tsv', tasks, stats, out_filters={'ani': 0.8})
     assert sum(1 for _ in open(tmp_path / 'o.tsv')) == 132        # header + 131 rows, row 0 (ani 0.5) dropped
+
+
+def test_number_format_fast_path_equals_oracle(tmp_path, golden_dir):
+    """The product's fast formatter against the oracle's exact one on 40 000 random quotients
+    (plus the awkward cases: short decimals, exact ties, powers of ten)."""
+    rng = np.random.default_rng(12)
+    gs = api.GenomeSet.load([golden_dir / 'multifasta.fna'], multisample=True)
+    tasks = np.tile(gs.align_tasks(gs.read_filter(None)), 160)[:20000]
+    stats = np.zeros(len(tasks), dtype=api.STAT_DTYPE)
+    stats['aln_len'] = rng.integers(1, 60000, size=len(tasks))
+    stats['n_match'] = (stats['aln_len'] * rng.random(len(tasks))).astype(np.uint32)
+    special = [(1, 2), (5, 8), (73, 128), (125, 128), (117, 128), (1, 1), (0, 7), (1, 3), (999999, 1000000), (1, 1000000),
+               (9999995, 10000000), (64, 64000), (3, 64164), (12345, 100000)]
+    for i, (m, a) in enumerate(special):
+        stats[2 * i] = (m, a, 1); stats[2 * i + 1] = (m, a, 1)
+    gs.write_ani(tmp_path / 'o.tsv', tasks, stats, columns=['tani', 'gani', 'ani', 'qcov', 'rcov'])
+    lens = gs.lengths()
+    rows = [l.split('\t') for l in open(tmp_path / 'o.tsv').read().splitlines()[1:]]
+    assert len(rows) == len(tasks)
+    bad = 0
+    for t, (tk, s, row) in enumerate(zip(tasks, stats, rows)):
+        rev = stats[t ^ 1]
+        lq, lr = int(lens[tk['q']]), int(lens[tk['r']])
+        want = [(int(s['n_match']) + int(rev['n_match'])) / (lq + lr), int(s['n_match']) / lq,
+                int(s['n_match']) / int(s['aln_len']), int(s['aln_len']) / lq, int(rev['aln_len']) / lr]
+        bad += [orc.fmt_num(v) for v in want] != row
+    assert bad == 0

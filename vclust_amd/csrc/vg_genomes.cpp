@@ -8,6 +8,7 @@
 #include <thread>
 #include <atomic>
 #include <algorithm>
+#include <memory>
 
 static inline uint8_t code_of(unsigned char ch) {
     switch (ch) {
@@ -61,42 +62,117 @@ void vg_genomes_finish(vg_genomes* g) {
 }
 
 namespace {
-struct rec { std::string name; std::vector<uint8_t> codes; int n_parts = 0; };
+// ---- whole-file buffers ---------------------------------------------------------------------
+struct filebuf { std::vector<char> data; };
 
-// parse one file into records (multisample) or one record (one genome per file)
-void read_fasta(const std::string& path, bool multisample, std::vector<rec>& out) {
-    gzFile f = gzopen(path.c_str(), "rb");
+void slurp(const std::string& path, filebuf& fb) {
+    FILE* f = fopen(path.c_str(), "rb");
     if (!f) throw vg_error(VG_EIO, "cannot open " + path);
-    gzbuffer(f, 1 << 20);
-    std::vector<char> buf(1 << 20);
-    bool in_header = false; std::string hdr;
-    rec* cur = nullptr;
-    int n;
-    while ((n = gzread(f, buf.data(), (unsigned)buf.size())) > 0) {
-        for (int i = 0; i < n; ++i) {
-            char ch = buf[i];
-            if (in_header) {
-                if (ch == '\n') {
-                    in_header = false;
-                    size_t e = 0; while (e < hdr.size() && hdr[e] != ' ' && hdr[e] != '\t' && hdr[e] != '\r') ++e;
-                    hdr.resize(e);
-                    if (multisample || !cur) {
-                        out.emplace_back(); cur = &out.back();
-                        if (multisample) cur->name = hdr;
-                        else { size_t s = path.find_last_of('/'); cur->name = s == std::string::npos ? path : path.substr(s + 1); }
-                    } else cur->codes.push_back(4);      // contigs of one genome are separated by one N
-                    cur->n_parts++;
-                } else hdr.push_back(ch);
-                continue;
-            }
-            if (ch == '>') { in_header = true; hdr.clear(); continue; }
-            if (ch == '\n' || ch == '\r' || ch == ' ' || ch == '\t') continue;
-            if (cur) cur->codes.push_back(code_of((unsigned char)ch));
-        }
+    unsigned char magic[2] = { 0, 0 };
+    size_t got = fread(magic, 1, 2, f);
+    const bool gz = got == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+    if (!gz) {
+        fseek(f, 0, SEEK_END); long long sz = ftell(f); fseek(f, 0, SEEK_SET);
+        fb.data.resize((size_t)sz);
+        size_t off = 0;
+        while (off < (size_t)sz) { size_t r = fread(fb.data.data() + off, 1, (size_t)sz - off, f); if (!r) break; off += r; }
+        fclose(f);
+        if (off != (size_t)sz) throw vg_error(VG_EIO, "read error in " + path);
+        return;
     }
-    int zerr = 0; (void)gzerror(f, &zerr);
-    gzclose(f);
-    if (n < 0 || (zerr != Z_OK && zerr != Z_STREAM_END)) throw vg_error(VG_EIO, "read error in " + path);
+    fclose(f);
+    gzFile g = gzopen(path.c_str(), "rb");
+    if (!g) throw vg_error(VG_EIO, "cannot open " + path);
+    gzbuffer(g, 1 << 20);
+    size_t off = 0; fb.data.resize(1 << 22);
+    for (;;) {
+        if (fb.data.size() - off < (1 << 20)) fb.data.resize(fb.data.size() * 2);
+        int n = gzread(g, fb.data.data() + off, (unsigned)std::min<size_t>(fb.data.size() - off, 1u << 30));
+        if (n < 0) { gzclose(g); throw vg_error(VG_EIO, "read error in " + path); }
+        if (n == 0) break;
+        off += (size_t)n;
+    }
+    int zerr = 0; (void)gzerror(g, &zerr);
+    gzclose(g);
+    if (zerr != Z_OK && zerr != Z_STREAM_END) throw vg_error(VG_EIO, "read error in " + path);
+    fb.data.resize(off);
+}
+
+// one FASTA record inside a buffer: [hdr, hdr_end) header line without '>', [seq, end) sequence lines
+struct record { const char* hdr; const char* hdr_end; const char* seq; const char* end; int64_t len; };
+
+struct code_lut { uint8_t t[256]; code_lut() { for (int i = 0; i < 256; ++i) t[i] = code_of((unsigned char)i); } };
+const code_lut LUT;
+inline bool is_ws(char ch) { return ch == '\n' || ch == '\r' || ch == ' ' || ch == '\t'; }
+
+void find_records(const filebuf& fb, std::vector<record>& out, int n_threads) {
+    const char* p = fb.data.data(); const char* e = p + fb.data.size();
+    // record starts: '>' at the beginning of a line, found chunk-parallel with memchr
+    const int T = std::max(1, n_threads);
+    std::vector<std::vector<const char*>> starts(T);
+    auto scan = [&](int t) {
+        const char* lo = p + fb.data.size() * t / T; const char* hi = p + fb.data.size() * (t + 1) / T;
+        for (const char* q = lo; q < hi;) {
+            const char* g = (const char*)memchr(q, '>', (size_t)(hi - q));
+            if (!g) break;
+            if (g == p || g[-1] == '\n') starts[t].push_back(g);
+            q = g + 1;
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back(scan, t);
+    scan(0);
+    for (auto& x : th) x.join();
+    std::vector<const char*> all;
+    for (auto& v : starts) all.insert(all.end(), v.begin(), v.end());
+    out.resize(all.size());
+    for (size_t i = 0; i < all.size(); ++i) {
+        record& r = out[i];
+        r.hdr = all[i] + 1;
+        const char* rec_end = i + 1 < all.size() ? all[i + 1] : e;
+        const char* nl = (const char*)memchr(r.hdr, '\n', (size_t)(rec_end - r.hdr));
+        r.hdr_end = nl ? nl : rec_end; r.seq = nl ? nl + 1 : rec_end; r.end = rec_end; r.len = 0;
+    }
+}
+
+int64_t count_bases(const record& r) {
+    int64_t n = 0;
+    for (const char* q = r.seq; q < r.end; ++q) n += !is_ws(*q);
+    return n;
+}
+
+// pack the bases of one record into the set's arrays starting at padded base position `at`
+// (2-bit codes + N mask); returns true if an N was seen.  Callers own disjoint word ranges.
+bool pack_record(const record& r, vg_genomes* g, int64_t at) {
+    uint32_t* pk = g->packed.data(); uint32_t* mk = g->nmask.data();
+    bool any_n = false; int64_t i = at;
+    uint32_t w = pk[i >> 4], m = mk[i >> 5];
+    for (const char* q = r.seq; q < r.end; ++q) {
+        const char ch = *q;
+        if (is_ws(ch)) continue;
+        const uint8_t c = LUT.t[(unsigned char)ch];
+        if (c > 3) { m |= 1u << (i & 31); any_n = true; } else w |= (uint32_t)c << (2 * (i & 15));
+        ++i;
+        if ((i & 15) == 0) { pk[(i - 1) >> 4] = w; w = pk[i >> 4]; }
+        if ((i & 31) == 0) { mk[(i - 1) >> 5] = m; m = mk[i >> 5]; }
+    }
+    if (i & 15) pk[i >> 4] = w;
+    if (i & 31) mk[i >> 5] = m;
+    return any_n;
+}
+
+template <class F> void parallel_for(int64_t n, int n_threads, F fn) {
+    std::atomic<int64_t> next(0);
+    auto work = [&]() { for (;;) { int64_t i = next.fetch_add(1); if (i >= n) break; fn(i); } };
+    std::vector<std::thread> th;
+    for (int t = 1; t < std::min<int64_t>(n_threads, n); ++t) th.emplace_back(work);
+    work();
+    for (auto& x : th) x.join();
+}
+
+std::string first_token(const char* b, const char* e) {
+    const char* q = b; while (q < e && *q != ' ' && *q != '\t' && *q != '\r') ++q;
+    return std::string(b, q);
 }
 }  // namespace
 
@@ -104,33 +180,71 @@ extern "C" int vg_genomes_load(const char* const* paths, int n_paths, int multis
                                vg_genomes** out) {
     VG_API_BEGIN
     if (!paths || n_paths <= 0 || !out) throw vg_error(VG_EINVAL, "vg_genomes_load: bad arguments");
-    std::vector<std::vector<rec>> per_file(n_paths);
-    bool multi = multisample && n_paths == 1;
-    int nt = std::max(1, std::min(n_threads > 0 ? n_threads : 1, n_paths));
-    std::atomic<int> next(0); std::string first_err; std::atomic<bool> failed(false);
-    auto work = [&]() {
-        for (;;) {
-            int i = next.fetch_add(1);
-            if (i >= n_paths || failed.load()) break;
-            try { read_fasta(paths[i], multi, per_file[i]); }
-            catch (const std::exception& e) { if (!failed.exchange(true)) first_err = e.what(); }
-        }
-    };
-    std::vector<std::thread> th;
-    for (int t = 1; t < nt; ++t) th.emplace_back(work);
-    work();
-    for (auto& t : th) t.join();
-    if (failed.load()) throw vg_error(VG_EIO, first_err);
-    vg_genomes* g = new vg_genomes();
+    const int T = std::max(1, n_threads);
+    const bool multi = multisample && n_paths == 1;
+    // 1. whole files into memory (gz inflated), files in parallel
+    std::vector<filebuf> bufs((size_t)n_paths);
     {
-        int64_t tot = 0, cnt = 0;
-        for (auto& v : per_file) for (auto& r : v) { tot += (int64_t)r.codes.size(); ++cnt; }
-        g->align_shift = vg_choose_align_shift(tot, cnt);
+        std::string first_err; std::atomic<bool> failed(false);
+        parallel_for(n_paths, T, [&](int64_t i) {
+            if (failed.load()) return;
+            try { slurp(paths[i], bufs[(size_t)i]); }
+            catch (const std::exception& e) { if (!failed.exchange(true)) first_err = e.what(); }
+        });
+        if (failed.load()) throw vg_error(VG_EIO, first_err);
     }
-    for (auto& v : per_file)
-        for (auto& r : v) vg_genomes_append(g, r.name, r.codes.data(), (int64_t)r.codes.size(), r.n_parts);
+    // 2. records and their lengths
+    std::vector<std::vector<record>> recs((size_t)n_paths);
+    for (int i = 0; i < n_paths; ++i) find_records(bufs[(size_t)i], recs[(size_t)i], multi ? T : 1);
+    struct gdesc { int file; size_t r0, r1; int64_t len; };
+    std::vector<gdesc> gd;
+    for (int i = 0; i < n_paths; ++i) {
+        auto& v = recs[(size_t)i];
+        if (multi) for (size_t r = 0; r < v.size(); ++r) gd.push_back({ i, r, r + 1, 0 });
+        else if (!v.empty()) gd.push_back({ i, 0, v.size(), 0 });
+    }
+    {
+        std::vector<std::pair<int, size_t>> flat;
+        for (int i = 0; i < n_paths; ++i) for (size_t r = 0; r < recs[(size_t)i].size(); ++r) flat.push_back({ i, r });
+        parallel_for((int64_t)flat.size(), T, [&](int64_t j) { auto& r = recs[(size_t)flat[(size_t)j].first][flat[(size_t)j].second]; r.len = count_bases(r); });
+    }
+    int64_t total = 0;
+    for (auto& d : gd) {
+        for (size_t r = d.r0; r < d.r1; ++r) d.len += recs[(size_t)d.file][r].len;
+        d.len += (int64_t)(d.r1 - d.r0) - 1;                 // records of one genome are joined by one N
+        total += d.len;
+    }
+    // 3. layout, then parallel packing straight into the 2-bit arrays
+    vg_genomes* g = new vg_genomes();
+    std::unique_ptr<vg_genomes> guard(g);
+    g->align_shift = vg_choose_align_shift(total, (int64_t)gd.size());
+    const int64_t al = 1LL << g->align_shift;
+    g->base_off.push_back(0);
+    for (auto& d : gd) {
+        int64_t padded = (d.len + al - 1) / al * al; if (padded == 0) padded = al;
+        for (int64_t b = g->base_off.back() >> g->align_shift; b < (g->base_off.back() + padded) >> g->align_shift; ++b) g->blk2g.push_back((uint32_t)g->n);
+        g->base_off.push_back(g->base_off.back() + padded);
+        g->len.push_back(d.len); g->n_parts.push_back((int32_t)(d.r1 - d.r0)); g->has_n.push_back(0);
+        const record& r0 = recs[(size_t)d.file][d.r0];
+        if (multi) g->names.push_back(first_token(r0.hdr, r0.hdr_end));
+        else { std::string pth = paths[d.file]; size_t sl = pth.find_last_of('/'); g->names.push_back(sl == std::string::npos ? pth : pth.substr(sl + 1)); }
+        g->n++;
+    }
+    g->packed.assign((size_t)(g->padded_total() / 16), 0u);
+    g->nmask.assign((size_t)(g->padded_total() / 32), 0u);
+    parallel_for((int64_t)gd.size(), T, [&](int64_t gi) {
+        const gdesc& d = gd[(size_t)gi];
+        int64_t at = g->base_off[(size_t)gi]; bool any_n = false;
+        for (size_t r = d.r0; r < d.r1; ++r) {
+            if (r > d.r0) { g->nmask[(size_t)(at >> 5)] |= 1u << (at & 31); ++at; any_n = true; }   // joining N
+            any_n |= pack_record(recs[(size_t)d.file][r], g, at);
+            at += recs[(size_t)d.file][r].len;
+        }
+        for (int64_t i = at; i < g->base_off[(size_t)gi + 1]; ++i) g->nmask[(size_t)(i >> 5)] |= 1u << (i & 31);   // padding
+        g->has_n[(size_t)gi] = any_n ? 1 : 0;
+    });
     vg_genomes_finish(g);
-    *out = g;
+    *out = guard.release();
     VG_API_END
 }
 

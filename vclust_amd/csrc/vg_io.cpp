@@ -12,6 +12,8 @@
 #include <algorithm>
 #include <unordered_map>
 #include <numeric>
+#include <atomic>
+#include <thread>
 
 // ---------------------------------------------------------------- numbers
 double vg_ani_shorter(int64_t shared, int64_t na, int64_t nb, int k) {
@@ -23,7 +25,7 @@ double vg_ani_shorter(int64_t shared, int64_t na, int64_t nb, int k) {
 
 // LZ-ANI prints a double with the shortest "%.{1..6}g" that reproduces it exactly, else with six
 // significant digits in fixed notation (zeros kept), exact decimal ties rounded away from zero.
-int vg_fmt_num(double x, char* buf) {
+static int fmt_num_exact(double x, char* buf) {
     for (int prec = 1; prec <= 6; ++prec) {
         char t[64];
         snprintf(t, sizeof t, "%.*g", prec, x);
@@ -48,6 +50,35 @@ int vg_fmt_num(double x, char* buf) {
     else { out += digits.substr(0, int_len); out.push_back('.'); out += digits.substr(int_len); }
     strcpy(buf, out.c_str());
     return (int)out.size();
+}
+
+// Fast path for the overwhelmingly common case (a generic quotient that has no <= 6-digit decimal
+// representation and is not near a rounding tie): six significant digits by one multiplication.
+// Anything within 1e-6 of a short decimal or of a tie goes through the exact routine above.
+int vg_fmt_num(double x, char* buf) {
+    static const double P10[] = { 1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18 };
+    if (!(x > 1e-12 && x < 1e6)) return fmt_num_exact(x, buf);
+    int e = 0;                                                  // x in [10^e, 10^(e+1))
+    if (x >= 1.0) { while (e < 6 && x >= P10[e + 1]) ++e; }
+    else { e = -1; while (e > -13 && x < 1.0 / P10[-e]) --e; }
+    const int k = 5 - e;                                        // y = x * 10^k in [1e5, 1e6)
+    const double y = (k >= 0) ? x * P10[k] : x / P10[-k];
+    const double fl = floor(y); const double fr = y - fl;
+    if (!(y >= 1e5 && y < 999999.0)) return fmt_num_exact(x, buf);
+    if (fr < 1e-6 || fr > 1.0 - 1e-6 || (fr > 0.5 - 1e-6 && fr < 0.5 + 1e-6)) return fmt_num_exact(x, buf);
+    long d = (long)fl + (fr > 0.5 ? 1 : 0);                     // 6 significant digits
+    char dig[8]; for (int i = 5; i >= 0; --i) { dig[i] = (char)('0' + d % 10); d /= 10; }
+    int o = 0;
+    if (e >= 0) {                                               // e+1 integer digits (e <= 5)
+        for (int i = 0; i <= e; ++i) buf[o++] = dig[i];
+        if (e < 5) { buf[o++] = '.'; for (int i = e + 1; i < 6; ++i) buf[o++] = dig[i]; }
+    } else {
+        buf[o++] = '0'; buf[o++] = '.';
+        for (int i = 0; i < -e - 1; ++i) buf[o++] = '0';
+        for (int i = 0; i < 6; ++i) buf[o++] = dig[i];
+    }
+    buf[o] = 0;
+    return o;
 }
 
 int vg_fmt_len_ratio(int64_t a, int64_t b, char* buf) {
@@ -224,44 +255,67 @@ extern "C" int vg_write_ani(const vg_genomes* g, const vg_task* tasks, const vg_
     if (!f) throw vg_error(VG_EIO, std::string("cannot write ") + out_path);
     for (int c = 0; c < p->n_out_columns; ++c) fprintf(f, "%s%s", c ? "\t" : "", p->out_columns[c]);
     fputc('\n', f);
-    std::vector<char> line;
-    for (int64_t t = 0; t < n_tasks; ++t) {
-        const vg_task& tk = tasks[t]; const vg_pair_stat& x = stats[t]; const vg_pair_stat& rev = stats[t ^ 1];
-        if (tasks[t ^ 1].q != tk.r || tasks[t ^ 1].r != tk.q) { fclose(f); throw vg_error(VG_EINVAL, "vg_write_ani: task couple mismatch"); }
-        int64_t lq = g->len[tk.q], lr = g->len[tk.r];
-        double ani = x.aln_len ? (double)x.n_match / (double)x.aln_len : 0.0;
-        double gani = lq ? (double)x.n_match / (double)lq : 0.0;
-        double qcov = lq ? (double)x.aln_len / (double)lq : 0.0;
-        double rcov = lr ? (double)rev.aln_len / (double)lr : 0.0;
-        double tani = (lq + lr) ? (double)((uint64_t)x.n_match + rev.n_match) / (double)(lq + lr) : 0.0;
-        if (p->out_tani > 0 && tani < p->out_tani) continue;
-        if (p->out_gani > 0 && gani < p->out_gani) continue;
-        if (p->out_ani > 0 && ani < p->out_ani) continue;
-        if (p->out_qcov > 0 && qcov < p->out_qcov) continue;
-        if (p->out_rcov > 0 && rcov < p->out_rcov) continue;
-        char buf[64];
-        for (int c = 0; c < p->n_out_columns; ++c) {
-            const char* col = p->out_columns[c];
-            if (c) fputc('\t', f);
-            if (!strcmp(col, "qidx")) fprintf(f, "%d", rank[tk.q]);
-            else if (!strcmp(col, "ridx")) fprintf(f, "%d", rank[tk.r]);
-            else if (!strcmp(col, "query")) fputs(g->names[tk.q].c_str(), f);
-            else if (!strcmp(col, "reference")) fputs(g->names[tk.r].c_str(), f);
-            else if (!strcmp(col, "tani")) { vg_fmt_num(tani, buf); fputs(buf, f); }
-            else if (!strcmp(col, "gani")) { vg_fmt_num(gani, buf); fputs(buf, f); }
-            else if (!strcmp(col, "ani")) { vg_fmt_num(ani, buf); fputs(buf, f); }
-            else if (!strcmp(col, "qcov")) { vg_fmt_num(qcov, buf); fputs(buf, f); }
-            else if (!strcmp(col, "rcov")) { vg_fmt_num(rcov, buf); fputs(buf, f); }
-            else if (!strcmp(col, "num_alns")) fprintf(f, "%u", x.n_regions);
-            else if (!strcmp(col, "len_ratio")) { vg_fmt_len_ratio(lq, lr, buf); fputs(buf, f); }
-            else if (!strcmp(col, "qlen")) fprintf(f, "%lld", (long long)lq);
-            else if (!strcmp(col, "rlen")) fprintf(f, "%lld", (long long)lr);
-            else if (!strcmp(col, "nt_match")) fprintf(f, "%u", x.n_match);
-            else if (!strcmp(col, "nt_mismatch")) fprintf(f, "%u", x.aln_len - x.n_match);
-            else { fclose(f); throw vg_error(VG_EINVAL, std::string("unknown output column ") + col); }
-        }
-        fputc('\n', f);
+    // rows are formatted in parallel into per-chunk buffers and written in order
+    for (int c = 0; c < p->n_out_columns; ++c) {
+        static const char* known[] = { "qidx", "ridx", "query", "reference", "tani", "gani", "ani", "qcov", "rcov", "num_alns",
+                                       "len_ratio", "qlen", "rlen", "nt_match", "nt_mismatch" };
+        bool ok = false; for (const char* kn : known) ok |= !strcmp(kn, p->out_columns[c]);
+        if (!ok) { fclose(f); throw vg_error(VG_EINVAL, std::string("unknown output column ") + p->out_columns[c]); }
     }
+    for (int64_t t = 0; t < n_tasks; ++t)
+        if (tasks[t ^ 1].q != tasks[t].r || tasks[t ^ 1].r != tasks[t].q) { fclose(f); throw vg_error(VG_EINVAL, "vg_write_ani: task couple mismatch"); }
+    const int nthreads = std::max(1, std::min(p->num_threads > 0 ? p->num_threads : 8, 64));
+    const int64_t chunk = 1 << 14;
+    const int64_t n_chunks = (n_tasks + chunk - 1) / chunk;
+    std::vector<std::string> out_chunks((size_t)n_chunks);
+    auto format_chunk = [&](int64_t ci) {
+        std::string& o = out_chunks[(size_t)ci];
+        o.reserve((size_t)chunk * 96);
+        char buf[64];
+        for (int64_t t = ci * chunk; t < std::min(n_tasks, (ci + 1) * chunk); ++t) {
+            const vg_task& tk = tasks[t]; const vg_pair_stat& x = stats[t]; const vg_pair_stat& rev = stats[t ^ 1];
+            int64_t lq = g->len[tk.q], lr = g->len[tk.r];
+            double ani = x.aln_len ? (double)x.n_match / (double)x.aln_len : 0.0;
+            double gani = lq ? (double)x.n_match / (double)lq : 0.0;
+            double qcov = lq ? (double)x.aln_len / (double)lq : 0.0;
+            double rcov = lr ? (double)rev.aln_len / (double)lr : 0.0;
+            double tani = (lq + lr) ? (double)((uint64_t)x.n_match + rev.n_match) / (double)(lq + lr) : 0.0;
+            if (p->out_tani > 0 && tani < p->out_tani) continue;
+            if (p->out_gani > 0 && gani < p->out_gani) continue;
+            if (p->out_ani > 0 && ani < p->out_ani) continue;
+            if (p->out_qcov > 0 && qcov < p->out_qcov) continue;
+            if (p->out_rcov > 0 && rcov < p->out_rcov) continue;
+            for (int c = 0; c < p->n_out_columns; ++c) {
+                const char* col = p->out_columns[c];
+                if (c) o.push_back('\t');
+                if (!strcmp(col, "qidx")) o += std::to_string(rank[tk.q]);
+                else if (!strcmp(col, "ridx")) o += std::to_string(rank[tk.r]);
+                else if (!strcmp(col, "query")) o += g->names[tk.q];
+                else if (!strcmp(col, "reference")) o += g->names[tk.r];
+                else if (!strcmp(col, "tani")) { vg_fmt_num(tani, buf); o += buf; }
+                else if (!strcmp(col, "gani")) { vg_fmt_num(gani, buf); o += buf; }
+                else if (!strcmp(col, "ani")) { vg_fmt_num(ani, buf); o += buf; }
+                else if (!strcmp(col, "qcov")) { vg_fmt_num(qcov, buf); o += buf; }
+                else if (!strcmp(col, "rcov")) { vg_fmt_num(rcov, buf); o += buf; }
+                else if (!strcmp(col, "num_alns")) o += std::to_string(x.n_regions);
+                else if (!strcmp(col, "len_ratio")) { vg_fmt_len_ratio(lq, lr, buf); o += buf; }
+                else if (!strcmp(col, "qlen")) o += std::to_string(lq);
+                else if (!strcmp(col, "rlen")) o += std::to_string(lr);
+                else if (!strcmp(col, "nt_match")) o += std::to_string(x.n_match);
+                else if (!strcmp(col, "nt_mismatch")) o += std::to_string(x.aln_len - x.n_match);
+            }
+            o.push_back('\n');
+        }
+    };
+    {
+        std::atomic<int64_t> next(0);
+        auto work = [&]() { for (;;) { int64_t ci = next.fetch_add(1); if (ci >= n_chunks) break; format_chunk(ci); } };
+        std::vector<std::thread> th;
+        for (int t = 1; t < std::min<int64_t>(nthreads, n_chunks); ++t) th.emplace_back(work);
+        work();
+        for (auto& x : th) x.join();
+    }
+    for (auto& o : out_chunks) if (!o.empty() && fwrite(o.data(), 1, o.size(), f) != o.size()) { fclose(f); throw vg_error(VG_EIO, std::string("write error on ") + out_path); }
     if (fclose(f)) throw vg_error(VG_EIO, std::string("write error on ") + out_path);
 
     if (p->out_aln_path && regions) {
