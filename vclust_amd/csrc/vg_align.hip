@@ -419,17 +419,27 @@ k_build_index_lds(const ref_desc* __restrict__ refs, const int* __restrict__ slo
                 const uint32_t e_lo = (w_lo + 1 < nb) ? tab[w_lo + 1] : total;
                 const bool direct = (e_lo - base > (uint32_t)LDS_STAGE);   // one bucket larger than the stage
                 __syncthreads();
-                for (int p0 = 4 * threadIdx.x; p0 < n4; p0 += 4 * blockDim.x) {
-                    const uint4 v = *reinterpret_cast<const uint4*>(&scratch[p0]);
-                    const uint32_t bts[4] = { v.x, v.y, v.z, v.w };
+                // four independent 16-byte loads per thread and trip: the loop is latency bound
+                for (int pb = 4 * threadIdx.x; pb < n4; pb += 16 * blockDim.x) {
+                    uint4 v[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const uint32_t bt = bts[j];
-                        const int b2 = (int)(bt & 0xffffu);
-                        if (bt == 0xffffffffu || b2 < w_lo || b2 >= w_hi) continue;
-                        const uint32_t ent = (uint32_t)(p0 + j) | (phase == 0 ? ((bt >> 16) << rd.pos_bits) : 0u);
-                        const uint32_t slot = atomicAdd(&tab[b2], 1u);
-                        if (direct) gent[slot] = ent; else stage[slot - base] = ent;
+                    for (int u = 0; u < 4; ++u) {
+                        const int p0 = pb + u * 4 * (int)blockDim.x;
+                        v[u] = (p0 < n4) ? *reinterpret_cast<const uint4*>(&scratch[p0]) : make_uint4(~0u, ~0u, ~0u, ~0u);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int p0 = pb + u * 4 * (int)blockDim.x;
+                        const uint32_t bts[4] = { v[u].x, v[u].y, v[u].z, v[u].w };
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const uint32_t bt = bts[j];
+                            const int b2 = (int)(bt & 0xffffu);
+                            if (bt == 0xffffffffu || b2 < w_lo || b2 >= w_hi) continue;
+                            const uint32_t ent = (uint32_t)(p0 + j) | (phase == 0 ? ((bt >> 16) << rd.pos_bits) : 0u);
+                            const uint32_t slot = atomicAdd(&tab[b2], 1u);
+                            if (direct) gent[slot] = ent; else stage[slot - base] = ent;
+                        }
                     }
                 }
                 __syncthreads();

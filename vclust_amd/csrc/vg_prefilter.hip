@@ -36,54 +36,98 @@ __device__ __forceinline__ uint64_t rev2(uint64_t x) {
 }
 
 // ------------------------------------------------------------------ K1: canonical k-mers
-// One thread per padded base position.  64 consecutive lanes read the same 3-4 packed words
-// (served by one L1 line) and write 64 consecutive u64 keys (512 B, coalesced).
+struct kmer_args {
+    const uint32_t* packed; const uint32_t* nmask; const uint32_t* blk2g; const int64_t* base_off; const int64_t* len;
+    int64_t P; int k; int use_frac; uint64_t frac_thr; uint32_t shard, n_shards; int blk_shift;
+};
+
+// scrambled canonical k-mer starting at padded base position p, or SENT (window crosses the genome
+// end, contains N, or the k-mer is not kept by --kmers-fraction / belongs to another shard)
+__device__ __forceinline__ uint64_t kmer_at(const kmer_args& A, int64_t p, uint32_t* genome) {
+    const uint64_t kmask = (A.k == 32) ? ~0ULL : ((1ULL << (2 * A.k)) - 1);
+    const uint32_t g = A.blk2g[p >> A.blk_shift];
+    *genome = g;
+    const int64_t local = p - A.base_off[g];
+    if (local + A.k > A.len[g]) return SENT;
+    const int64_t mw = p >> 5; const int msh = (int)(p & 31);
+    const uint64_t m = (uint64_t)A.nmask[mw] | ((uint64_t)A.nmask[mw + 1] << 32);
+    if (((m >> msh) & ((1ULL << A.k) - 1)) != 0) return SENT;
+    const int64_t w = p >> 4; const int sh = 2 * (int)(p & 15);
+    const uint64_t lo = (uint64_t)A.packed[w] | ((uint64_t)A.packed[w + 1] << 32);
+    const uint64_t hi = (uint64_t)A.packed[w + 2] | ((uint64_t)A.packed[w + 3] << 32);
+    uint64_t x = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;   // first base in the low bits
+    x &= kmask;
+    const uint64_t fwd = rev2(x) >> (64 - 2 * A.k);             // first base most significant
+    const uint64_t rc = (~x) & kmask;                           // reverse complement, same convention
+    const uint64_t cano = fwd < rc ? fwd : rc;
+    if (A.use_frac || A.n_shards > 1) {
+        const uint64_t h = mix64(cano);
+        if (A.use_frac && !(h < A.frac_thr)) return SENT;
+        if (A.n_shards > 1 && (uint32_t)(((h & 0xffffffffULL) * A.n_shards) >> 32) != A.shard) return SENT;
+    }
+    return (cano * SCRAMBLE) & kmask;                           // bit 2k stays 0; SENT has it set
+}
+
+// k-mers kept per genome (|K_g| = kept - duplicates): one atomic per wave and genome
+__device__ __forceinline__ void count_kept(bool kept, uint32_t g, int* __restrict__ kept_per_genome) {
+    const uint32_t g0 = __shfl(g, 0);
+    if (__all(g == g0)) {
+        const unsigned long long b = __ballot(kept);
+        if ((threadIdx.x & 63) == 0 && b) atomicAdd(&kept_per_genome[g0], __popcll(b));
+    } else if (kept) atomicAdd(&kept_per_genome[g], 1);
+}
+
+// Dense form (all k-mers kept: one shard, fraction 1): one thread per padded base position, 64
+// consecutive lanes read the same 3-4 packed words and write 64 consecutive u64 keys (512 B).
 __global__ void __launch_bounds__(256)
-k_kmer_extract(const uint32_t* __restrict__ packed, const uint32_t* __restrict__ nmask,
-               const uint32_t* __restrict__ blk2g, const int64_t* __restrict__ base_off,
-               const int64_t* __restrict__ len, int64_t P, int k, int use_frac, uint64_t frac_thr,
-               uint32_t shard, uint32_t n_shards, int blk_shift, uint64_t* __restrict__ keys,
-               unsigned long long* __restrict__ n_valid, int* __restrict__ kept_per_genome) {
-    const uint64_t kmask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
+k_kmer_extract(kmer_args A, uint64_t* __restrict__ keys, unsigned long long* __restrict__ n_valid,
+               int* __restrict__ kept_per_genome) {
     unsigned long long local_valid = 0;
     // P is a multiple of 64 and the stride a multiple of 64: whole waves stay in or out together
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (int64_t)gridDim.x * blockDim.x) {
-        uint32_t g = blk2g[p >> blk_shift];
-        int64_t local = p - base_off[g];
-        uint64_t key = SENT;
-        if (local + k <= len[g]) {
-            int64_t mw = p >> 5; int msh = (int)(p & 31);
-            uint64_t m = (uint64_t)nmask[mw] | ((uint64_t)nmask[mw + 1] << 32);
-            if (((m >> msh) & ((1ULL << k) - 1)) == 0) {
-                int64_t w = p >> 4; int sh = 2 * (int)(p & 15);
-                uint64_t lo = (uint64_t)packed[w] | ((uint64_t)packed[w + 1] << 32);
-                uint64_t hi = (uint64_t)packed[w + 2] | ((uint64_t)packed[w + 3] << 32);
-                uint64_t x = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;   // first base in the low bits
-                x &= kmask;
-                uint64_t fwd = rev2(x) >> (64 - 2 * k);                     // first base most significant
-                uint64_t rc = (~x) & kmask;                                 // reverse complement, same convention
-                uint64_t cano = fwd < rc ? fwd : rc;
-                bool keep = true;
-                if (use_frac || n_shards > 1) {
-                    uint64_t h = mix64(cano);
-                    if (use_frac && !(h < frac_thr)) keep = false;
-                    if (n_shards > 1 && (uint32_t)(((h & 0xffffffffULL) * n_shards) >> 32) != shard) keep = false;
-                }
-                if (keep) { key = (cano * SCRAMBLE) & kmask; ++local_valid; }      // bit 2k stays 0; SENT has it set
-            }
-        }
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < A.P; p += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t g;
+        const uint64_t key = kmer_at(A, p, &g);
         keys[p] = key;
-        // k-mers kept per genome (|K_g| = kept - duplicates): one atomic per wave and genome
-        const bool kept = key != SENT;
-        const uint32_t g0 = __shfl(g, 0);
-        if (__all(g == g0)) {
-            const unsigned long long b = __ballot(kept);
-            if ((threadIdx.x & 63) == 0 && b) atomicAdd(&kept_per_genome[g0], __popcll(b));
-        } else if (kept) atomicAdd(&kept_per_genome[g], 1);
+        local_valid += key != SENT;
+        count_kept(key != SENT, g, kept_per_genome);
     }
-    // one atomic per wave
     for (int o = 32; o > 0; o >>= 1) local_valid += __shfl_down(local_valid, o);
     if ((threadIdx.x & 63) == 0 && local_valid) atomicAdd(n_valid, local_valid);
+}
+
+// Compact form (k-mer range shards, --kmers-fraction): only kept k-mers are written, in position
+// order.  Pass 1 records per 64-position wave the ballot of kept lanes and its popcount; after an
+// exclusive scan of the popcounts pass 2 recomputes the k-mers (cheaper than a dense key array) and
+// writes (key, position) at wave_base + rank.  c(p) = wave_base[p/64] + popc(mask[p/64] below p)
+// later maps a position to its compact index.
+__global__ void __launch_bounds__(256)
+k_kmer_count(kmer_args A, unsigned long long* __restrict__ wave_mask, uint32_t* __restrict__ wave_cnt,
+             int* __restrict__ kept_per_genome) {
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < A.P; p += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t g;
+        const bool kept = kmer_at(A, p, &g) != SENT;
+        const unsigned long long b = __ballot(kept);
+        if ((threadIdx.x & 63) == 0) { wave_mask[p >> 6] = b; wave_cnt[p >> 6] = (uint32_t)__popcll(b); }
+        count_kept(kept, g, kept_per_genome);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_kmer_emit(kmer_args A, const unsigned long long* __restrict__ wave_mask, const uint32_t* __restrict__ wave_base,
+            uint64_t* __restrict__ keys, uint32_t* __restrict__ pos) {
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < A.P; p += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned long long m = wave_mask[p >> 6];
+        if (!((m >> (p & 63)) & 1ULL)) continue;
+        uint32_t g;
+        const uint64_t key = kmer_at(A, p, &g);
+        const uint32_t c = wave_base[p >> 6] + (uint32_t)__popcll(m & ((1ULL << (p & 63)) - 1ULL));
+        keys[c] = key; pos[c] = (uint32_t)p;
+    }
+}
+
+__device__ __forceinline__ uint32_t compact_index(const unsigned long long* __restrict__ wave_mask,
+                                                  const uint32_t* __restrict__ wave_base, uint32_t p) {
+    return wave_base[p >> 6] + (uint32_t)__popcll(wave_mask[p >> 6] & ((1ULL << (p & 63)) - 1ULL));
 }
 
 __global__ void k_iota(uint32_t* v, int64_t n) {
@@ -142,7 +186,8 @@ __device__ __forceinline__ int64_t run_upper(const uint64_t* __restrict__ keys, 
 
 __global__ void __launch_bounds__(256)
 k_runs(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos, const uint32_t* __restrict__ blk2g, int blk_shift,
-       int64_t n, uint32_t* __restrict__ gen, uint64_t* __restrict__ rowinfo, int* __restrict__ dup_per_genome,
+       int64_t n, uint32_t* __restrict__ gen, uint64_t* __restrict__ rowinfo,
+       const unsigned long long* __restrict__ wave_mask, const uint32_t* __restrict__ wave_base, int* __restrict__ dup_per_genome,
        uint64_t* __restrict__ big_runs, unsigned int* __restrict__ n_big, unsigned int big_cap) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const uint64_t key = keys[i];
@@ -162,7 +207,7 @@ k_runs(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos, cons
             if (i == rs) { unsigned int o = atomicAdd(n_big, 1u); if (o < big_cap) { big_runs[2 * o] = (uint64_t)rs; big_runs[2 * o + 1] = rl; } }
             rl = RUNLEN_MASK;
         }
-        rowinfo[p] = ((uint64_t)rs << RUNLEN_BITS) | rl;
+        rowinfo[wave_base ? compact_index(wave_mask, wave_base, p) : p] = ((uint64_t)rs << RUNLEN_BITS) | rl;
     }
 }
 
@@ -196,8 +241,8 @@ __device__ __forceinline__ bool ht_add(uint32_t* hk, uint32_t* hc, uint32_t b, u
 
 __global__ void __launch_bounds__(256)
 k_spgemm(const uint64_t* __restrict__ rowinfo, const uint32_t* __restrict__ gen, const uint64_t* __restrict__ big_runs, unsigned int n_big,
-         const int64_t* __restrict__ base_off, const int64_t* __restrict__ len, int n_genomes, uint32_t min_emit,
-         const uint32_t* __restrict__ row_list, int n_rows,
+         const int64_t* __restrict__ base_off, const int64_t* __restrict__ len, const uint32_t* __restrict__ wave_base,
+         int n_genomes, uint32_t min_emit, const uint32_t* __restrict__ row_list, int n_rows,
          vg_pair_count* __restrict__ out, unsigned long long* __restrict__ out_cursor,
          unsigned long long out_cap, uint32_t* __restrict__ overflow_rows, uint32_t* __restrict__ n_overflow) {
     __shared__ uint32_t hk[HT_SIZE];
@@ -210,7 +255,9 @@ k_spgemm(const uint64_t* __restrict__ rowinfo, const uint32_t* __restrict__ gen,
     for (int i = threadIdx.x; i < HT_SIZE; i += blockDim.x) { hk[i] = HT_EMPTY; hc[i] = 0; }
     if (threadIdx.x == 0) { s_used = 0; s_lq = 0; s_fail = 0; }
     __syncthreads();
-    const int64_t p0 = base_off[a], L = len[a];
+    // row a = its base positions (dense) or its kept k-mers (compact index space)
+    const int64_t p0 = wave_base ? (int64_t)wave_base[base_off[a] >> 6] : base_off[a];
+    const int64_t L = wave_base ? (int64_t)wave_base[base_off[a + 1] >> 6] - p0 : len[a];
     for (int64_t base = 0; base < L; base += blockDim.x) {
         int64_t i = base + threadIdx.x;
         uint64_t r = (i < L) ? rowinfo[p0 + i] : 0;
@@ -271,12 +318,13 @@ k_spgemm(const uint64_t* __restrict__ rowinfo, const uint32_t* __restrict__ gen,
 // overflowing row, counters in a private global array of n_genomes entries
 __global__ void __launch_bounds__(256)
 k_spgemm_dense(const uint64_t* __restrict__ rowinfo, const uint32_t* __restrict__ gen, const uint64_t* __restrict__ big_runs, unsigned int n_big,
-               const int64_t* __restrict__ base_off, const int64_t* __restrict__ len, int n_genomes, uint32_t min_emit,
-               const uint32_t* __restrict__ rows, uint32_t* __restrict__ dense /* gridDim.x * n_genomes, zeroed */,
+               const int64_t* __restrict__ base_off, const int64_t* __restrict__ len, const uint32_t* __restrict__ wave_base,
+               int n_genomes, uint32_t min_emit, const uint32_t* __restrict__ rows, uint32_t* __restrict__ dense /* gridDim.x * n_genomes, zeroed */,
                vg_pair_count* __restrict__ out, unsigned long long* __restrict__ out_cursor, unsigned long long out_cap) {
     const uint32_t a = rows[blockIdx.x];
     uint32_t* cnt = dense + (size_t)blockIdx.x * n_genomes;
-    const int64_t p0 = base_off[a], L = len[a];
+    const int64_t p0 = wave_base ? (int64_t)wave_base[base_off[a] >> 6] : base_off[a];
+    const int64_t L = wave_base ? (int64_t)wave_base[base_off[a + 1] >> 6] - p0 : len[a];
     for (int64_t i = threadIdx.x; i < L; i += blockDim.x) {
         uint64_t r = rowinfo[p0 + i];
         if (!r) continue;
@@ -311,44 +359,70 @@ struct max_op { __device__ __host__ uint32_t operator()(uint32_t a, uint32_t b) 
 }  // namespace
 
 // shared pipeline: extract -> sort.  Returns sorted keys/pos of the n_valid real k-mers and the
-// per-genome number of k-mers kept by extraction.
+// per-genome number of k-mers kept by extraction.  compact = true: only kept k-mers were written
+// (wave_mask / wave_base map a position to its compact index).
 struct sorted_index {
     dbuf<uint64_t> keys; dbuf<uint32_t> pos; dbuf<int> kept; int64_t n_valid = 0;
+    bool compact = false; dbuf<unsigned long long> wave_mask; dbuf<uint32_t> wave_base;
 };
 
 static void run_extract_sort(vg_genomes* g, int k, double fraction, int shard, int n_shards, sorted_index& out) {
     hipStream_t s = vg_stream();
     const int64_t P = g->padded_total();
     if (P >= (1LL << 32)) throw vg_error(VG_EOVERFLOW, "genome set exceeds 2^32 padded bases per call; use --batch-size");
-    dbuf<uint64_t> keys_a((size_t)P), keys_b((size_t)P);
-    dbuf<uint32_t> pos_a((size_t)P), pos_b((size_t)P);
-    dbuf<unsigned long long> d_nvalid(1); d_nvalid.zero(s);
     out.kept.alloc((size_t)std::max(1, g->n)); out.kept.zero(s);
     const int use_frac = fraction < 1.0;
-    const uint64_t thr = use_frac ? (uint64_t)std::ldexp(fraction, 64) : ~0ULL;
-    {
-        vg_prof_scope ps("kmer_extract", (double)P * (3.0 / 8.0 + 8.0));
-        hipLaunchKernelGGL(k_kmer_extract, dim3(grid_for(P)), dim3(256), 0, s, g->d_packed.p, g->d_nmask.p, g->d_blk2g.p,
-                           g->d_base_off.p, g->d_len.p, P, k, use_frac, thr, (uint32_t)shard, (uint32_t)n_shards,
-                           g->align_shift, keys_a.p, d_nvalid.p, out.kept.p);
+    kmer_args A{ g->d_packed.p, g->d_nmask.p, g->d_blk2g.p, g->d_base_off.p, g->d_len.p, P, k, use_frac,
+                 use_frac ? (uint64_t)std::ldexp(fraction, 64) : ~0ULL, (uint32_t)shard, (uint32_t)n_shards, g->align_shift };
+    out.compact = use_frac || n_shards > 1;
+    dbuf<uint64_t> keys_a, keys_b; dbuf<uint32_t> pos_a, pos_b;
+    int64_t n_sort = P; unsigned long long nv = 0;
+    if (!out.compact) {
+        keys_a.alloc((size_t)P); keys_b.alloc((size_t)P); pos_a.alloc((size_t)P); pos_b.alloc((size_t)P);
+        dbuf<unsigned long long> d_nvalid(1); d_nvalid.zero(s);
+        {
+            vg_prof_scope ps("kmer_extract", (double)P * (3.0 / 8.0 + 8.0));
+            hipLaunchKernelGGL(k_kmer_extract, dim3(grid_for(P)), dim3(256), 0, s, A, keys_a.p, d_nvalid.p, out.kept.p);
+        }
+        hipLaunchKernelGGL(k_iota, dim3(grid_for(P)), dim3(256), 0, s, pos_a.p, P);
+        d_nvalid.download(&nv, 1, s);
+    } else {
+        const int64_t W = P / 64;
+        out.wave_mask.alloc((size_t)W + 1); dbuf<uint32_t> wave_cnt((size_t)W + 1); out.wave_base.alloc((size_t)W + 1);
+        VG_HIP(hipMemsetAsync(wave_cnt.p + W, 0, sizeof(uint32_t), s));
+        {
+            vg_prof_scope ps("kmer_count", (double)P * (3.0 / 8.0 + 12.0 / 64.0));
+            hipLaunchKernelGGL(k_kmer_count, dim3(grid_for(P)), dim3(256), 0, s, A, out.wave_mask.p, wave_cnt.p, out.kept.p);
+        }
+        size_t tb = 0;
+        VG_HIP(rocprim::exclusive_scan(nullptr, tb, wave_cnt.p, out.wave_base.p, 0u, (size_t)W + 1, rocprim::plus<uint32_t>(), s));
+        dbuf<char> tmp(tb);
+        VG_HIP(rocprim::exclusive_scan((void*)tmp.p, tb, wave_cnt.p, out.wave_base.p, 0u, (size_t)W + 1, rocprim::plus<uint32_t>(), s));
+        uint32_t total = 0;
+        VG_HIP(hipMemcpyAsync(&total, out.wave_base.p + W, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        VG_HIP(hipStreamSynchronize(s));
+        nv = total; n_sort = (int64_t)total;
+        const size_t na = (size_t)std::max<int64_t>(n_sort, 1);
+        keys_a.alloc(na); keys_b.alloc(na); pos_a.alloc(na); pos_b.alloc(na);
+        if (n_sort > 0) {
+            vg_prof_scope ps("kmer_emit", (double)P * 3.0 / 8.0 + (double)n_sort * 12.0);
+            hipLaunchKernelGGL(k_kmer_emit, dim3(grid_for(P)), dim3(256), 0, s, A, out.wave_mask.p, out.wave_base.p, keys_a.p, pos_a.p);
+        }
     }
-    hipLaunchKernelGGL(k_iota, dim3(grid_for(P)), dim3(256), 0, s, pos_a.p, P);
     // Stable LSD radix sort on the top key bits only (bit 2k is the sentinel flag, so sentinels end
     // up behind every real k-mer); k_group_sort then orders the small equal-prefix groups.
     const unsigned int end_bit = (unsigned)(2 * k + 1);
-    unsigned int sort_bits = P <= (1LL << 29) ? 32u : 40u;
+    unsigned int sort_bits = n_sort <= (1LL << 29) ? 32u : 40u;
     if (sort_bits > end_bit) sort_bits = end_bit;
     const unsigned int begin_bit = end_bit - sort_bits;
-    size_t tmp_bytes = 0;
-    VG_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_a.p, keys_b.p, pos_a.p, pos_b.p, (size_t)P, begin_bit, end_bit, s));
-    dbuf<char> tmp(tmp_bytes);
-    {
+    if (n_sort > 0) {
+        size_t tmp_bytes = 0;
+        VG_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_a.p, keys_b.p, pos_a.p, pos_b.p, (size_t)n_sort, begin_bit, end_bit, s));
+        dbuf<char> tmp(tmp_bytes);
         int passes = (int)(sort_bits + 7) / 8;
-        vg_prof_scope ps("radix_sort_pairs", (double)P * 12.0 * 2.0 * passes);
-        VG_HIP(rocprim::radix_sort_pairs((void*)tmp.p, tmp_bytes, keys_a.p, keys_b.p, pos_a.p, pos_b.p, (size_t)P, begin_bit, end_bit, s));
+        vg_prof_scope ps("radix_sort_pairs", (double)n_sort * 12.0 * 2.0 * passes);
+        VG_HIP(rocprim::radix_sort_pairs((void*)tmp.p, tmp_bytes, keys_a.p, keys_b.p, pos_a.p, pos_b.p, (size_t)n_sort, begin_bit, end_bit, s));
     }
-    unsigned long long nv = 0;
-    d_nvalid.download(&nv, 1, s);
     VG_HIP(hipStreamSynchronize(s));
     if (begin_bit > 0 && nv > 0) {
         vg_prof_scope ps("group_sort", (double)nv * 12.0);
@@ -374,7 +448,10 @@ extern "C" int vg_kmer_shared(vg_genomes* g, int k, double fraction, int shard, 
     run_extract_sort(g, k, fraction, shard, n_shards, si);
     const int64_t nv = si.n_valid;
     const int64_t P = g->padded_total();
-    dbuf<uint64_t> rowinfo((size_t)P); rowinfo.zero(s);
+    const int64_t n_rows_info = si.compact ? std::max<int64_t>(nv, 1) : P;      // row descriptors: per kept k-mer or per base
+    dbuf<uint64_t> rowinfo((size_t)n_rows_info); rowinfo.zero(s);
+    const unsigned long long* wmask = si.compact ? si.wave_mask.p : nullptr;
+    const uint32_t* wbase = si.compact ? si.wave_base.p : nullptr;
     dbuf<uint32_t> gen((size_t)std::max<int64_t>(nv, 1));
     dbuf<int> d_dups((size_t)n); d_dups.zero(s);
     constexpr unsigned int BIG_CAP = 4096;
@@ -382,7 +459,7 @@ extern "C" int vg_kmer_shared(vg_genomes* g, int k, double fraction, int shard, 
     if (nv > 0) {
         vg_prof_scope ps("index_runs", (double)nv * (8 + 4 + 4 + 8));
         hipLaunchKernelGGL(k_runs, dim3(grid_for(nv)), dim3(256), 0, s, si.keys.p, si.pos.p, g->d_blk2g.p, g->align_shift, nv,
-                           gen.p, rowinfo.p, d_dups.p, big_runs.p, d_nbig.p, BIG_CAP);
+                           gen.p, rowinfo.p, wmask, wbase, d_dups.p, big_runs.p, d_nbig.p, BIG_CAP);
     }
     unsigned int n_big = 0; d_nbig.download(&n_big, 1, s);
     std::vector<int> kept((size_t)n), dups((size_t)n);
@@ -400,8 +477,8 @@ extern "C" int vg_kmer_shared(vg_genomes* g, int k, double fraction, int shard, 
         dbuf<vg_pair_count> d_out((size_t)cap);
         d_cursor.zero(s); d_nover.zero(s);
         {
-            vg_prof_scope ps("spgemm_rows", (double)P * 8.0);
-            hipLaunchKernelGGL(k_spgemm, dim3(n), dim3(256), 0, s, rowinfo.p, gen.p, big_runs.p, n_big, g->d_base_off.p, g->d_len.p, n,
+            vg_prof_scope ps("spgemm_rows", (double)n_rows_info * 8.0);
+            hipLaunchKernelGGL(k_spgemm, dim3(n), dim3(256), 0, s, rowinfo.p, gen.p, big_runs.p, n_big, g->d_base_off.p, g->d_len.p, wbase, n,
                                min_shared, (const uint32_t*)nullptr, n, d_out.p, d_cursor.p, cap, d_over.p, d_nover.p);
         }
         uint32_t nover = 0; d_nover.download(&nover, 1, s);
@@ -417,7 +494,7 @@ extern "C" int vg_kmer_shared(vg_genomes* g, int k, double fraction, int shard, 
                 d_rows.upload(rows.data() + o, nb, s);
                 vg_prof_scope ps("spgemm_dense_rows", 0);
                 hipLaunchKernelGGL(k_spgemm_dense, dim3(nb), dim3(256), 0, s, rowinfo.p, gen.p, big_runs.p, n_big, g->d_base_off.p,
-                                   g->d_len.p, n, min_shared, d_rows.p, dense.p, d_out.p, d_cursor.p, cap);
+                                   g->d_len.p, wbase, n, min_shared, d_rows.p, dense.p, d_out.p, d_cursor.p, cap);
                 VG_HIP(hipStreamSynchronize(s));
             }
         }
