@@ -94,14 +94,13 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     dist = None
     import torch
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     if api.device_count() < 1:
         raise SystemExit('bench.py needs a HIP device: libvclust_gpu has no CPU fallback')
-    api.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        dist, dev = D.init_process_group()          # nccl (= RCCL) unless VCLUST_DIST_BACKEND says otherwise
+    else:
+        dev = torch.device('cuda', local_rank)
+    api.set_device(local_rank % api.device_count())
 
     n_fam = args.families * world
     codes, offsets, names = synth.make_families(n_fam, args.members, length=args.length, seed=1)

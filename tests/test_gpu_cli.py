@@ -123,3 +123,39 @@ def test_workflow_equals_oracle_files(tmp_path):
     orc.run_cli('prefilter', '-o', oflt, FASTA_FILE)
     orc.run_cli('align', '-o', oani, '--filter', oflt, '0', '--outfmt', 'complete', FASTA_FILE)
     assert filecmp.cmp(flt, oflt, shallow=False) and filecmp.cmp(ani, oani, shallow=False)
+
+
+def _torchrun(nproc, *cmd):
+    import os
+    import socket
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, VCLUST_DIST_BACKEND='gloo')      # two ranks share the one GPU of the test box
+    return subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={nproc}',
+                           '--master-addr', '127.0.0.1', '--master-port', str(port), *map(str, cmd)],
+                          env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+
+
+def test_two_ranks_write_the_same_files(tmp_path):
+    """One process per rank (here both on the single GPU, gathers over gloo): the sharded prefilter
+    and align produce byte-identical files to the single-process run."""
+    import filecmp
+    f1, a1, l1 = tmp_path / 'f1.txt', tmp_path / 'a1.tsv', tmp_path / 'l1.tsv'
+    assert run('prefilter', '-i', FASTA_FILE, '-o', f1, '-v', '0').returncode == 0
+    assert run('align', '-i', FASTA_FILE, '-o', a1, '--out-aln', l1, '-v', '0').returncode == 0
+    f2, a2, l2 = tmp_path / 'f2.txt', tmp_path / 'a2.tsv', tmp_path / 'l2.tsv'
+    p = _torchrun(2, VCLUST, 'prefilter', '-i', FASTA_FILE, '-o', f2, '-v', '0')
+    assert p.returncode == 0, p.stderr[-2000:]
+    p = _torchrun(2, VCLUST, 'align', '-i', FASTA_FILE, '-o', a2, '--out-aln', l2, '-v', '0')
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert filecmp.cmp(f1, f2, shallow=False)
+    assert filecmp.cmp(a1, a2, shallow=False)
+    assert sorted(open(l1).read().splitlines()) == sorted(open(l2).read().splitlines())
+
+
+def test_bench_two_ranks_smoke():
+    p = _torchrun(2, ROOT / 'bench.py', '--gpus', '2', '--steps', '1', '--warmup', '1', '--families', '6', '--no-cpu-baseline')
+    assert p.returncode == 0, p.stderr[-2000:]
+    import json
+    line = [l for l in p.stdout.splitlines() if l.startswith('{')][-1]
+    d = json.loads(line)
+    assert d['n_gpus'] == 2 and d['config']['pairs_per_step'] == 2 * 6 * 45 and d['value'] > 0

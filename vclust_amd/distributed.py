@@ -25,7 +25,8 @@ def init_process_group(backend=None):
     import torch.distributed as dist
     rank, world, local_rank = dist_env()
     if backend is None:
-        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        # VCLUST_DIST_BACKEND=gloo: host-side gathers (testing several ranks on one GPU box)
+        backend = os.environ.get('VCLUST_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
     if backend == 'nccl':
         torch.cuda.set_device(local_rank)
         device = torch.device('cuda', local_rank)
@@ -118,7 +119,7 @@ def prefilter(paths, out_path, is_multifasta, k=25, min_kmers=20, min_ident=0.7,
     from . import api
     dist, device = init_process_group()
     rank, world, local_rank = dist_env()
-    api.set_device(local_rank)
+    api.set_device(local_rank % max(api.device_count(), 1))
     gs = api.GenomeSet.load(paths, is_multifasta, n_threads=num_threads)
     sizes, pairs = prefilter_counts(gs, dist, device, rank, world, k, kmers_fraction)
     if rank == 0:
@@ -132,7 +133,7 @@ def align(paths, out_path, is_multifasta, columns, filter_path=None, filter_thre
     from . import api
     dist, device = init_process_group()
     rank, world, local_rank = dist_env()
-    api.set_device(local_rank)
+    api.set_device(local_rank % max(api.device_count(), 1))
     gs = api.GenomeSet.load(paths, is_multifasta, n_threads=num_threads)
     tasks = gs.align_tasks(gs.read_filter(filter_path, filter_threshold))
     stats, regions = align_rows(gs, tasks, dist, device, rank, world, lz, out_aln is not None)
