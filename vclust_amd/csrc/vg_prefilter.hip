@@ -140,23 +140,33 @@ __global__ void k_iota(uint32_t* v, int64_t n) {
 // the first entry of each group orders its group by the full key with a stable insertion sort.
 __global__ void __launch_bounds__(256)
 k_group_sort(uint64_t* __restrict__ keys, uint32_t* __restrict__ pos, int64_t n, int low_bit) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const uint64_t pre = keys[i] >> low_bit;
-        if (i > 0 && (keys[i - 1] >> low_bit) == pre) continue;        // not a group leader
-        int64_t e = i + 1;
-        bool sorted = true; uint64_t prev = keys[i];
-        while (e < n) {
-            const uint64_t kk = keys[e];
-            if ((kk >> low_bit) != pre) break;
-            if (kk < prev) sorted = false;
-            prev = kk; ++e;
-        }
-        if (sorted) continue;
-        for (int64_t a = i + 1; a < e; ++a) {
-            const uint64_t kk = keys[a]; const uint32_t pp = pos[a];
-            int64_t b = a - 1;
-            while (b >= i && keys[b] > kk) { keys[b + 1] = keys[b]; pos[b + 1] = pos[b]; --b; }
-            keys[b + 1] = kk; pos[b + 1] = pp;
+    const int64_t n4 = (n + 3) >> 2;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i0 = q << 2;
+        uint64_t kk[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) { const int64_t i = i0 - 1 + j; kk[j] = (i >= 0 && i < n) ? keys[i] : SENT; }
+#pragma unroll
+        for (int j = 1; j < 5; ++j) {
+            const int64_t i = i0 - 1 + j;
+            if (i >= n) continue;
+            const uint64_t pre = kk[j] >> low_bit;
+            if (i > 0 && (kk[j - 1] >> low_bit) == pre) continue;          // not a group leader
+            int64_t e = i + 1;
+            bool sorted = true; uint64_t prev = kk[j];
+            while (e < n) {
+                const uint64_t k2 = keys[e];
+                if ((k2 >> low_bit) != pre) break;
+                if (k2 < prev) sorted = false;
+                prev = k2; ++e;
+            }
+            if (sorted) continue;
+            for (int64_t a = i + 1; a < e; ++a) {
+                const uint64_t k2 = keys[a]; const uint32_t p2 = pos[a];
+                int64_t b = a - 1;
+                while (b >= i && keys[b] > k2) { keys[b + 1] = keys[b]; pos[b + 1] = pos[b]; --b; }
+                keys[b + 1] = k2; pos[b + 1] = p2;
+            }
         }
     }
 }
@@ -189,25 +199,38 @@ k_runs(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos, cons
        int64_t n, uint32_t* __restrict__ gen, uint64_t* __restrict__ rowinfo,
        const unsigned long long* __restrict__ wave_mask, const uint32_t* __restrict__ wave_base, int* __restrict__ dup_per_genome,
        uint64_t* __restrict__ big_runs, unsigned int* __restrict__ n_big, unsigned int big_cap) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const uint64_t key = keys[i];
-        const uint32_t p = pos[i];
-        const uint32_t g = blk2g[p >> blk_shift];
-        const bool has_prev = i > 0 && keys[i - 1] == key;
-        const bool has_next = i + 1 < n && keys[i + 1] == key;
-        bool dup = false;
-        if (has_prev) dup = blk2g[pos[i - 1] >> blk_shift] == g;
-        gen[i] = g | (dup ? DUP_BIT : 0u);
-        if (dup) { atomicAdd(&dup_per_genome[g], 1); continue; }
-        if (!has_prev && !has_next) continue;           // singleton k-mer: no partner possible
-        const int64_t rs = has_prev ? run_lower(keys, i, key) : i;
-        const int64_t re = has_next ? run_upper(keys, n, i, key) : i + 1;
-        uint64_t rl = (uint64_t)(re - rs);
-        if (rl >= RUNLEN_MASK) {
-            if (i == rs) { unsigned int o = atomicAdd(n_big, 1u); if (o < big_cap) { big_runs[2 * o] = (uint64_t)rs; big_runs[2 * o + 1] = rl; } }
-            rl = RUNLEN_MASK;
+    // four consecutive entries per thread: their keys, positions and genomes are fetched with
+    // independent loads first (the kernel is bound by load latency, not by bandwidth)
+    const int64_t n4 = (n + 3) >> 2;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i0 = q << 2;
+        uint64_t kk[6]; uint32_t pp[5]; uint32_t gg[5];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { const int64_t i = i0 - 1 + j; kk[j] = (i >= 0 && i < n) ? keys[i] : SENT; }
+#pragma unroll
+        for (int j = 0; j < 5; ++j) { const int64_t i = i0 - 1 + j; pp[j] = (i >= 0 && i < n) ? pos[i] : 0u; }
+#pragma unroll
+        for (int j = 0; j < 5; ++j) gg[j] = blk2g[pp[j] >> blk_shift];
+#pragma unroll
+        for (int j = 1; j < 5; ++j) {
+            const int64_t i = i0 - 1 + j;
+            if (i >= n) continue;
+            const uint64_t key = kk[j]; const uint32_t p = pp[j]; const uint32_t g = gg[j];
+            const bool has_prev = kk[j - 1] == key;             // SENT never equals a real key
+            const bool has_next = kk[j + 1] == key;
+            const bool dup = has_prev && gg[j - 1] == g;
+            gen[i] = g | (dup ? DUP_BIT : 0u);
+            if (dup) { atomicAdd(&dup_per_genome[g], 1); continue; }
+            if (!has_prev && !has_next) continue;               // singleton k-mer: no partner possible
+            const int64_t rs = has_prev ? run_lower(keys, i, key) : i;
+            const int64_t re = has_next ? run_upper(keys, n, i, key) : i + 1;
+            uint64_t rl = (uint64_t)(re - rs);
+            if (rl >= RUNLEN_MASK) {
+                if (i == rs) { unsigned int o = atomicAdd(n_big, 1u); if (o < big_cap) { big_runs[2 * o] = (uint64_t)rs; big_runs[2 * o + 1] = rl; } }
+                rl = RUNLEN_MASK;
+            }
+            rowinfo[wave_base ? compact_index(wave_mask, wave_base, p) : p] = ((uint64_t)rs << RUNLEN_BITS) | rl;
         }
-        rowinfo[wave_base ? compact_index(wave_mask, wave_base, p) : p] = ((uint64_t)rs << RUNLEN_BITS) | rl;
     }
 }
 
@@ -258,31 +281,45 @@ k_spgemm(const uint64_t* __restrict__ rowinfo, const uint32_t* __restrict__ gen,
     // row a = its base positions (dense) or its kept k-mers (compact index space)
     const int64_t p0 = wave_base ? (int64_t)wave_base[base_off[a] >> 6] : base_off[a];
     const int64_t L = wave_base ? (int64_t)wave_base[base_off[a + 1] >> 6] - p0 : len[a];
-    for (int64_t base = 0; base < L; base += blockDim.x) {
-        int64_t i = base + threadIdx.x;
-        uint64_t r = (i < L) ? rowinfo[p0 + i] : 0;
-        if (r) {
-            uint32_t rl = (uint32_t)(r & RUNLEN_MASK); uint32_t rs = (uint32_t)(r >> RUNLEN_BITS);
-            bool walk = false;
-            if (rl >= 2) {
-                if (rl > LONG_RUN) {
-                    uint32_t slot = atomicAdd(&s_lq, 1u);
-                    if (slot < LQ_CAP) lq[slot] = r; else walk = true;
-                } else walk = true;
+    constexpr int ROWS_PER_TRIP = 4;              // independent row-descriptor loads per thread and trip
+    for (int64_t base = 0; base < L; base += (int64_t)blockDim.x * ROWS_PER_TRIP) {
+        uint64_t rr4[ROWS_PER_TRIP];
+#pragma unroll
+        for (int u = 0; u < ROWS_PER_TRIP; ++u) {
+            const int64_t i = base + (int64_t)u * blockDim.x + threadIdx.x;
+            rr4[u] = (i < L) ? rowinfo[p0 + i] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < ROWS_PER_TRIP; ++u) {
+            const uint64_t r = rr4[u];
+            if (!r) continue;
+            uint32_t rl = (uint32_t)(r & RUNLEN_MASK); const uint32_t rs = (uint32_t)(r >> RUNLEN_BITS);
+            if (rl < 2) continue;
+            if (rl > LONG_RUN) {
+                const uint32_t slot = atomicAdd(&s_lq, 1u);
+                if (slot < LQ_CAP) { lq[slot] = r; continue; }
             }
-            if (walk) {
-                if (rl == RUNLEN_MASK) rl = big_run_len(big_runs, n_big, rs);
-                for (uint32_t e = 0; e < rl; ++e) {
-                    uint32_t g = gen[rs + e];
+            if (rl == RUNLEN_MASK) rl = big_run_len(big_runs, n_big, rs);
+            // the genome list of the run, four entries per memory round trip; ascending, so the
+            // first genome >= a ends the walk
+            bool done = false;
+            for (uint32_t e = 0; e < rl && !done; e += 4) {
+                uint32_t g4[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) g4[j] = gen[rs + min(e + j, rl - 1)];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (e + j >= rl || done) continue;
+                    const uint32_t g = g4[j];
                     if (g & DUP_BIT) continue;
-                    if (g >= a) break;
+                    if (g >= a) { done = true; continue; }
                     if (!ht_add(hk, hc, g, &s_used)) s_fail = 1;
                 }
             }
         }
         // drain the long-run queue cooperatively when it fills up
         __syncthreads();
-        if (s_lq >= LQ_CAP - 256 || base + blockDim.x >= L) {
+        if (s_lq >= LQ_CAP / 2 || base + (int64_t)blockDim.x * ROWS_PER_TRIP >= L) {
             uint32_t nq = s_lq < LQ_CAP ? s_lq : LQ_CAP;
             for (uint32_t qi = 0; qi < nq; ++qi) {
                 uint64_t rr = lq[qi];
@@ -426,7 +463,7 @@ static void run_extract_sort(vg_genomes* g, int k, double fraction, int shard, i
     VG_HIP(hipStreamSynchronize(s));
     if (begin_bit > 0 && nv > 0) {
         vg_prof_scope ps("group_sort", (double)nv * 12.0);
-        hipLaunchKernelGGL(k_group_sort, dim3(grid_for((int64_t)nv)), dim3(256), 0, s, keys_b.p, pos_b.p, (int64_t)nv, (int)begin_bit);
+        hipLaunchKernelGGL(k_group_sort, dim3(grid_for(((int64_t)nv + 3) / 4)), dim3(256), 0, s, keys_b.p, pos_b.p, (int64_t)nv, (int)begin_bit);
     }
     out.keys = std::move(keys_b); out.pos = std::move(pos_b); out.n_valid = (int64_t)nv;
 }
@@ -458,7 +495,7 @@ extern "C" int vg_kmer_shared(vg_genomes* g, int k, double fraction, int shard, 
     dbuf<uint64_t> big_runs(2 * BIG_CAP); dbuf<unsigned int> d_nbig(1); d_nbig.zero(s);
     if (nv > 0) {
         vg_prof_scope ps("index_runs", (double)nv * (8 + 4 + 4 + 8));
-        hipLaunchKernelGGL(k_runs, dim3(grid_for(nv)), dim3(256), 0, s, si.keys.p, si.pos.p, g->d_blk2g.p, g->align_shift, nv,
+        hipLaunchKernelGGL(k_runs, dim3(grid_for((nv + 3) / 4)), dim3(256), 0, s, si.keys.p, si.pos.p, g->d_blk2g.p, g->align_shift, nv,
                            gen.p, rowinfo.p, wmask, wbase, d_dups.p, big_runs.p, d_nbig.p, BIG_CAP);
     }
     unsigned int n_big = 0; d_nbig.download(&n_big, 1, s);
