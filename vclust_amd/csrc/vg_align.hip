@@ -571,6 +571,7 @@ k_lz_parse(const task_dev* __restrict__ tasks, int64_t n_tasks, const ref_desc* 
     const uint64_t amask = (P.mal >= 32) ? ~0ULL : ((1ULL << (2 * P.mal)) - 1);
     const uint64_t smask = (1ULL << (2 * P.msl)) - 1;
 
+    const long long t_start = (P.ablate & 32) ? (long long)wall_clock64() : 0;
     int i = 0, lit = 0, pred = 0; bool alive = false;
     bool in_region = false; int r_qstart = 0, r_rstart = 0, r_qend = 0, r_rend = -1, r_match = 0;
     int kept_end = 0;
@@ -706,6 +707,7 @@ k_lz_parse(const task_dev* __restrict__ tasks, int64_t n_tasks, const ref_desc* 
         else r_rend = pred - 1;
     }
     close_region();
+    if (P.ablate & 32) NR = (uint32_t)((long long)wall_clock64() - t_start);        // developer timing: 100 MHz ticks
     if (lane == 0) { vg_pair_stat st; st.n_match = M; st.aln_len = A; st.n_regions = NR; stats[tk.out_idx] = st; }
 }
 
