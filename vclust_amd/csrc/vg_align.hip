@@ -124,24 +124,25 @@ __device__ __forceinline__ int match_len_lane(const pair_ctx& c, int qp, int rp,
     return l;
 }
 
-__device__ __forceinline__ int wave_sum(int v) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+// ---- cross-lane helpers that stay off the LDS crossbar (ds_bpermute costs ~100 cycles of
+// latency each, and a wave that owns a pair runs these in a dependent chain) ----------------
+// value of a wave-uniform lane: v_readlane
+__device__ __forceinline__ uint32_t lane32(uint32_t v, int src_lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src_lane); }
+__device__ __forceinline__ uint64_t lane64(uint64_t v, int src_lane) {
+    return (uint64_t)lane32((uint32_t)v, src_lane) | ((uint64_t)lane32((uint32_t)(v >> 32), src_lane) << 32);
 }
-
-// exact match length from (qp, rp), whole wave (2048 bases per round); uniform result
-__device__ __forceinline__ int match_len_wave(const pair_ctx& c, int qp, int rp, int lane) {
-    int base = 0;
-    for (;;) {
-        uint64_t mm = mism32(c, qp + base + 32 * lane, rp + base + 32 * lane);
-        unsigned long long b = __ballot(mm != 0);
-        if (b) {
-            int f = __builtin_ctzll(b);
-            uint64_t mf = __shfl(mm, f);
-            return base + 32 * f + (__builtin_ctzll(mf) >> 1);
-        }
-        base += 2048;
-    }
+// lane l receives the value of lane l-1 (lane 0 receives 0): DPP wave_shr:1
+__device__ __forceinline__ uint64_t lane_prev64(uint64_t v) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, 0x138, 0xf, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), 0x138, 0xf, 0xf, false);
+    return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+// sum over the wave of a per-lane value in [0, 63]: six ballots + scalar popcounts
+__device__ __forceinline__ int wave_sum(int v) {
+    int t = 0;
+#pragma unroll
+    for (int b = 0; b < 6; ++b) t += __popcll(__ballot((v >> b) & 1)) << b;
+    return t;
 }
 
 // Exact + approximate extension in one pass (R2/R3 match length + R4, or R5 to the left).
@@ -191,9 +192,9 @@ __device__ __forceinline__ int extend(const pair_ctx& c, const lz_dev_params& P,
         const unsigned long long anyb = __ballot(mm != 0);
         if (first_mm < 0 && anyb) {
             const int fl = __builtin_ctzll(anyb);
-            first_mm = base + 32 * fl + (__builtin_ctzll(__shfl(mm, fl)) >> 1);
+            first_mm = base + 32 * fl + (__builtin_ctzll(lane64(mm, fl)) >> 1);
         }
-        uint64_t prev_mm = __shfl_up(mm, 1); const uint64_t okb = (~mm) & EVEN; uint64_t prev_ok = __shfl_up(okb, 1);
+        uint64_t prev_mm = lane_prev64(mm); const uint64_t okb = (~mm) & EVEN; uint64_t prev_ok = lane_prev64(okb);
         if (lane == 0) { prev_mm = carry_mm; prev_ok = carry_ok; }
         // first violation in this lane: never if the chunk plus the aw-1 symbols before it hold <= am
         int viol = 32;
@@ -219,14 +220,14 @@ __device__ __forceinline__ int extend(const pair_ctx& c, const lz_dev_params& P,
             uint64_t run = okb;
             for (int t = 1; t < P.ar; ++t) run &= (okb << (2 * t)) | (prev_ok >> (64 - 2 * t));
             const int fv = vb ? __builtin_ctzll(vb) : 64;
-            const int vj = __shfl(viol, fv & 63);
+            const int vj = (int)lane32((uint32_t)viol, fv & 63);
             uint64_t cand = run;
             if (lane > fv) cand = 0;
             else if (lane == fv) cand &= (vj == 0) ? 0ULL : ((1ULL << (2 * vj)) - 1);
             const unsigned long long cb = __ballot(cand != 0);
             if (cb) {
                 const int hl = 63 - __builtin_clzll(cb);
-                const uint64_t ch = __shfl(cand, hl); const uint64_t mh = __shfl(mm, hl);
+                const uint64_t ch = lane64(cand, hl); const uint64_t mh = lane64(mm, hl);
                 const int hj = (63 - __builtin_clzll(ch)) >> 1;
                 accepted = base + 32 * hl + hj + 1;
                 int tot = wave_sum(lane < hl ? 32 - __popcll(mm) : 0);
@@ -241,7 +242,7 @@ __device__ __forceinline__ int extend(const pair_ctx& c, const lz_dev_params& P,
         if (vb) break;
         if (base + 2048 >= bound) break;
         cum_before += anyb ? wave_sum(32 - __popcll(mm)) : 2048;
-        carry_mm = __shfl(mm, 63); carry_ok = __shfl(okb, 63);
+        carry_mm = lane64(mm, 63); carry_ok = lane64(okb, 63);
         base += 2048;
     }
     if (first_mm < 0) first_mm = bound;                    // the whole range matched
@@ -573,6 +574,10 @@ k_lz_parse(const task_dev* __restrict__ tasks, int64_t n_tasks, const ref_desc* 
 
     const long long t_start = (P.ablate & 32) ? (long long)wall_clock64() : 0;
     int i = 0, lit = 0, pred = 0; bool alive = false;
+    int n_events = 0;
+    const bool prof = (P.ablate & 128) != 0; const int psel = (P.ablate >> 8) & 7;
+    long long pc[6] = {0, 0, 0, 0, 0, 0}; long long tp = prof ? (long long)clock64() : 0;
+#define PROF_MARK(k) do { if (prof) { long long tn_ = (long long)clock64(); pc[k] += tn_ - tp; tp = tn_; } } while (0)
     bool in_region = false; int r_qstart = 0, r_rstart = 0, r_qend = 0, r_rend = -1, r_match = 0;
     int kept_end = 0;
     uint32_t M = 0, A = 0, NR = 0;
@@ -668,6 +673,7 @@ k_lz_parse(const task_dev* __restrict__ tasks, int64_t n_tasks, const ref_desc* 
             }
         }
         const unsigned long long hb = __ballot(best_len > 0);
+        PROF_MARK(0);
         if (!hb) {
             // 64 literals (or the tail)
             const int n = min(64, lim - i);
@@ -675,8 +681,16 @@ k_lz_parse(const task_dev* __restrict__ tasks, int64_t n_tasks, const ref_desc* 
             continue;
         }
         const int f = __builtin_ctzll(hb);
-        const int ev_pos = __shfl(best_pos, f);
-        const bool ev_close = __shfl((int)hit_close, f) != 0;
+        // Pairs that need many events are the tail of the launch: a wave raises its own issue priority
+        // as its event count grows, so the heavy pairs overtake the light ones sharing their SIMD.
+        if (!(P.ablate & 64)) {
+            ++n_events;
+            if (n_events == 24) __builtin_amdgcn_s_setprio(1);
+            else if (n_events == 64) __builtin_amdgcn_s_setprio(2);
+            else if (n_events == 160) __builtin_amdgcn_s_setprio(3);
+        }
+        const int ev_pos = (int)lane32((uint32_t)best_pos, f);
+        const bool ev_close = lane32((uint32_t)hit_close, f) != 0;
         // literals in front of the event
         i += f; lit += f; if (alive) { pred += f; if (lit > P.mqd) alive = false; }
         const int gap_end_ref = pred - 1;
@@ -689,6 +703,7 @@ k_lz_parse(const task_dev* __restrict__ tasks, int64_t n_tasks, const ref_desc* 
         const uint64_t mm_f = extend_mask0(c, i, ev_pos, +1, 1 << 30, lane);
         int gap_m = 0;
         if (ev_close && lit > 0 && !(P.ablate & 8)) gap_m = count_eq_wave(c, i - lit, pred - lit, lit, lane);   // R7: old diagonal
+        PROF_MARK(1);
         if (!ev_close) {
             // R5: new region, extended to the left (exact, then approximate), not into the last kept region
             close_region();
@@ -697,16 +712,19 @@ k_lz_parse(const task_dev* __restrict__ tasks, int64_t n_tasks, const ref_desc* 
             r_qstart = i - b; r_rstart = ev_pos - b; r_match = bm; r_rend = -1;
             in_region = true;
         } else r_match += gap_m;
+        PROF_MARK(2);
         {   // the match itself and R4, one pass
             int fm = 0;
             const int fe = (P.ablate & 4) ? P.mal : extend(c, P, i, ev_pos, +1, 1 << 30, lane, &fm, mm_f);
             r_match += fm; i += fe; pred = ev_pos + fe; lit = 0; alive = true;
         }
+        PROF_MARK(3);
         r_qend = i - 1;
         if (ev_close) { r_rend = max(r_rend, max(pred - 1, gap_end_ref)); }
         else r_rend = pred - 1;
     }
     close_region();
+    if (prof) { M = (uint32_t)(pc[psel] >> 4); A = (uint32_t)n_events; }
     if (P.ablate & 32) NR = (uint32_t)((long long)wall_clock64() - t_start);        // developer timing: 100 MHz ticks
     if (lane == 0) { vg_pair_stat st; st.n_match = M; st.aln_len = A; st.n_regions = NR; stats[tk.out_idx] = st; }
 }
