@@ -85,9 +85,9 @@ def test_unrelated_and_repetitive_sequences():
 def test_large_reference_global_index_path():
     """References above 2^18 RR symbols use the global-memory index build."""
     rng = np.random.default_rng(8)
-    a = rng.integers(0, 4, size=140000, dtype=np.uint8)
+    a = rng.integers(0, 4, size=1100000, dtype=np.uint8)
     b = a.copy(); m = rng.random(len(b)) < 0.04; b[m] = (b[m] + 1) & 3
-    c = a[20000:60000].copy()
+    c = a[200000:260000].copy()
     seqs = [a, b, c]
     offsets = np.zeros(4, dtype=np.int64); offsets[1:] = np.cumsum([len(s) for s in seqs])
     codes = np.concatenate(seqs)

@@ -313,7 +313,7 @@ __device__ __forceinline__ uint32_t anchor_tag(uint64_t h, int B, int pos_bits) 
     return (uint32_t)((h << B) >> 48) & ((1u << tb) - 1u);
 }
 
-// ---- path A (references up to 2^18 RR symbols, msl <= 7): one 1024-thread workgroup builds RR
+// ---- path A (references up to 2^21 RR symbols, msl <= 7): one 1024-thread workgroup builds RR
 // and both bucket indexes of a reference by counting sort in LDS.  Entries leave the LDS through a
 // staging window (buckets are filled range by range), so every global store of the index is a
 // coalesced copy: no 4-byte scatter to HBM (the first version wrote 10x the index size).
@@ -781,7 +781,7 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
         while (end < n_tasks) {
             const uint32_t r = tasks[order[end]].r;
             const int64_t L = g->len[r]; const int64_t n_rr = 2 * L + 1;
-            const bool small = n_rr <= (1 << 18) && p->msl <= 7;
+            const bool small = n_rr <= (1 << 21) && p->msl <= 7;
             int B = 8; while ((1LL << (B + 1)) <= n_rr && B + 1 <= 2 * p->mal && B < (small ? 14 : 26)) ++B;
             const int64_t chunks = (n_rr + RR_PAD + 31) / 32 + 2;
             const int64_t need = chunks * 12 + ((1LL << B) + n_rr + stab_n + n_rr) * 4;
@@ -814,7 +814,7 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
         // split the batch: LDS counting sort for ordinary references, global path for the rest
         std::vector<int> small_list, large_list; std::vector<int64_t> large_chunks{ 0 };
         for (int i = 0; i < n_refs; ++i) {
-            const bool small = refs[i].n_rr <= (1 << 18) && p->msl <= 7;
+            const bool small = refs[i].n_rr <= (1 << 21) && p->msl <= 7;
             if (small) small_list.push_back(i);
             else { large_list.push_back(i); large_chunks.push_back(large_chunks.back() + (chunk_off[i + 1] - chunk_off[i])); }
         }
