@@ -308,8 +308,8 @@ __device__ __forceinline__ void rr_chunk(const uint32_t* __restrict__ gpk, const
 __device__ __forceinline__ uint64_t anchor_hash(uint64_t code) { return code * 0x9E3779B97F4A7C15ULL; }
 __device__ __forceinline__ uint32_t anchor_bucket(uint64_t h, int B) { return (uint32_t)(h >> (64 - B)); }
 __device__ __forceinline__ uint32_t anchor_tag(uint64_t h, int B, int pos_bits) {
-    // up to 16 hash bits below the bucket bits, as many as fit above pos_bits in a 32-bit entry
-    const int tb = (32 - pos_bits) < 16 ? (32 - pos_bits) : 16;
+    // up to 14 hash bits below the bucket bits, as many as fit above pos_bits in a 32-bit entry
+    const int tb = (32 - pos_bits) < 14 ? (32 - pos_bits) : 14;
     return (uint32_t)((h << B) >> 48) & ((1u << tb) - 1u);
 }
 
@@ -366,14 +366,19 @@ k_build_index_lds(const ref_desc* __restrict__ refs, const int* __restrict__ slo
         __threadfence_block();
         __syncthreads();
         for (int phase = 0; phase < 2; ++phase) {
-            const int nb = phase == 0 ? (1 << rd.B) : (1 << (2 * msl));
+            // Bucket tables larger than the LDS table are built section by section (LDS_TAB buckets at a
+            // time); scratch keeps (bucket : 18 bits | tag : 14 bits) per position so that the k-mer
+            // is hashed once.
+            const int nbits = phase == 0 ? rd.B : 2 * msl;
+            const int n_sec = nbits > 14 ? (1 << (nbits - 14)) : 1;
+            const int nb = nbits > 14 ? LDS_TAB : (1 << nbits);
             const int w = phase == 0 ? mal : msl;
             uint32_t* gtab = phase == 0 ? atab_pool + rd.atab : stab_pool + rd.stab;
             uint32_t* gent = phase == 0 ? aent_pool + rd.aent : sent_pool + rd.sent;
-            for (int i = threadIdx.x; i < nb; i += blockDim.x) tab[i] = 0;
+            if (n_sec == 1) { for (int i = threadIdx.x; i < nb; i += blockDim.x) tab[i] = 0; }
             __syncthreads();
-            // pass 0: bucket (and tag) of every position -> scratch, bucket sizes -> tab.  Each thread
-            // takes 4 consecutive positions out of one 128-bit window of packed bases.
+            // pass 0: bucket (and tag) of every position -> scratch (and bucket sizes when there is one
+            // section).  Each thread takes 4 consecutive positions out of one 128-bit window.
             const int n4 = (rd.n_rr + 3) & ~3;
             for (int p0 = 4 * threadIdx.x; p0 < n4; p0 += 4 * blockDim.x) {
                 const int wi = p0 >> 4; const int sh = 2 * (p0 & 15);
@@ -389,9 +394,9 @@ k_build_index_lds(const ref_desc* __restrict__ refs, const int* __restrict__ slo
                         const uint64_t x = s2 ? ((lo >> s2) | (hi << (64 - s2))) : lo;
                         if (phase == 0) {
                             const uint64_t h = anchor_hash(x & amask);
-                            bt = anchor_bucket(h, rd.B) | (anchor_tag(h, rd.B, rd.pos_bits) << 16);
+                            bt = anchor_bucket(h, rd.B) | (anchor_tag(h, rd.B, rd.pos_bits) << 18);
                         } else bt = (uint32_t)(x & smask);
-                        atomicAdd(&tab[bt & 0xffffu], 1u);
+                        if (n_sec == 1) atomicAdd(&tab[bt & 0x3ffffu], 1u);
                     }
                     out[j] = bt;
                 }
@@ -399,60 +404,87 @@ k_build_index_lds(const ref_desc* __restrict__ refs, const int* __restrict__ slo
             }
             __threadfence_block();
             __syncthreads();
-            lds_scan_exclusive(tab, nb, part);                 // tab[b] = first slot of bucket b
-            const uint32_t total = part[1023];                 // inclusive sum of all thread partials
-            __syncthreads();
-            // fill, one window of whole buckets holding <= LDS_STAGE entries at a time.  Buckets at or
-            // beyond the window start are still untouched, so end(b) = tab[b + 1] (or the total).
-            int w_lo = 0;
-            while (w_lo < nb) {
-                const uint32_t base = tab[w_lo];
-                if (threadIdx.x == 0) s_whi = w_lo + 1;
-                __syncthreads();
-                int best = w_lo + 1;
-                for (int b2 = w_lo + threadIdx.x; b2 < nb; b2 += blockDim.x) {
-                    const uint32_t e2 = (b2 + 1 < nb) ? tab[b2 + 1] : total;
-                    if (e2 - base <= (uint32_t)LDS_STAGE) best = b2 + 1; else break;     // ends ascend
-                }
-                atomicMax(&s_whi, best);
-                __syncthreads();
-                const int w_hi = s_whi;
-                const uint32_t e_lo = (w_lo + 1 < nb) ? tab[w_lo + 1] : total;
-                const bool direct = (e_lo - base > (uint32_t)LDS_STAGE);   // one bucket larger than the stage
-                __syncthreads();
-                // four independent 16-byte loads per thread and trip: the loop is latency bound
-                for (int pb = 4 * threadIdx.x; pb < n4; pb += 16 * blockDim.x) {
-                    uint4 v[4];
+            uint32_t sbase = 0;                                    // entries of the sections done so far
+            for (int sec = 0; sec < n_sec; ++sec) {
+                if (n_sec > 1) {
+                    for (int i = threadIdx.x; i < nb; i += blockDim.x) tab[i] = 0;
+                    __syncthreads();
+                    for (int pb = 4 * threadIdx.x; pb < n4; pb += 16 * blockDim.x) {
+                        uint4 v[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int p0 = pb + u * 4 * (int)blockDim.x;
-                        v[u] = (p0 < n4) ? *reinterpret_cast<const uint4*>(&scratch[p0]) : make_uint4(~0u, ~0u, ~0u, ~0u);
-                    }
+                        for (int u = 0; u < 4; ++u) {
+                            const int p0 = pb + u * 4 * (int)blockDim.x;
+                            v[u] = (p0 < n4) ? *reinterpret_cast<const uint4*>(&scratch[p0]) : make_uint4(~0u, ~0u, ~0u, ~0u);
+                        }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int p0 = pb + u * 4 * (int)blockDim.x;
-                        const uint32_t bts[4] = { v[u].x, v[u].y, v[u].z, v[u].w };
+                        for (int u = 0; u < 4; ++u) {
+                            const uint32_t bts[4] = { v[u].x, v[u].y, v[u].z, v[u].w };
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const uint32_t bt = bts[j];
-                            const int b2 = (int)(bt & 0xffffu);
-                            if (bt == 0xffffffffu || b2 < w_lo || b2 >= w_hi) continue;
-                            const uint32_t ent = (uint32_t)(p0 + j) | (phase == 0 ? ((bt >> 16) << rd.pos_bits) : 0u);
-                            const uint32_t slot = atomicAdd(&tab[b2], 1u);
-                            if (direct) gent[slot] = ent; else stage[slot - base] = ent;
+                            for (int j = 0; j < 4; ++j) {
+                                const uint32_t b18 = bts[j] & 0x3ffffu;
+                                if (bts[j] != 0xffffffffu && (int)(b18 >> 14) == sec) atomicAdd(&tab[b18 & 0x3fffu], 1u);
+                            }
                         }
                     }
+                    __syncthreads();
                 }
+                lds_scan_exclusive(tab, nb, part);                 // tab[b] = first slot of bucket b inside the section
+                const uint32_t total = part[1023];                 // inclusive sum of all thread partials
                 __syncthreads();
-                if (!direct) {
-                    const uint32_t cnt = tab[w_hi - 1] - base;   // cursor of the last bucket == its end
-                    for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) gent[base + i] = stage[i];
+                // fill, one window of whole buckets holding <= LDS_STAGE entries at a time.  Buckets at or
+                // beyond the window start are still untouched, so end(b) = tab[b + 1] (or the total).
+                int w_lo = 0;
+                while (w_lo < nb) {
+                    const uint32_t base = tab[w_lo];
+                    if (threadIdx.x == 0) s_whi = w_lo + 1;
+                    __syncthreads();
+                    int best = w_lo + 1;
+                    for (int b2 = w_lo + threadIdx.x; b2 < nb; b2 += blockDim.x) {
+                        const uint32_t e2 = (b2 + 1 < nb) ? tab[b2 + 1] : total;
+                        if (e2 - base <= (uint32_t)LDS_STAGE) best = b2 + 1; else break;     // ends ascend
+                    }
+                    atomicMax(&s_whi, best);
+                    __syncthreads();
+                    const int w_hi = s_whi;
+                    const uint32_t e_lo = (w_lo + 1 < nb) ? tab[w_lo + 1] : total;
+                    const bool direct = (e_lo - base > (uint32_t)LDS_STAGE);   // one bucket larger than the stage
+                    __syncthreads();
+                    // four independent 16-byte loads per thread and trip: the loop is latency bound
+                    for (int pb = 4 * threadIdx.x; pb < n4; pb += 16 * blockDim.x) {
+                        uint4 v[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int p0 = pb + u * 4 * (int)blockDim.x;
+                            v[u] = (p0 < n4) ? *reinterpret_cast<const uint4*>(&scratch[p0]) : make_uint4(~0u, ~0u, ~0u, ~0u);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int p0 = pb + u * 4 * (int)blockDim.x;
+                            const uint32_t bts[4] = { v[u].x, v[u].y, v[u].z, v[u].w };
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const uint32_t bt = bts[j];
+                                const uint32_t b18 = bt & 0x3ffffu;
+                                const int b2 = (int)(b18 & 0x3fffu);
+                                if (bt == 0xffffffffu || (int)(b18 >> 14) != sec || b2 < w_lo || b2 >= w_hi) continue;
+                                const uint32_t ent = (uint32_t)(p0 + j) | (phase == 0 ? ((bt >> 18) << rd.pos_bits) : 0u);
+                                const uint32_t slot = atomicAdd(&tab[b2], 1u);
+                                if (direct) gent[sbase + slot] = ent; else stage[slot - base] = ent;
+                            }
+                        }
+                    }
+                    __syncthreads();
+                    if (!direct) {
+                        const uint32_t cnt = tab[w_hi - 1] - base;   // cursor of the last bucket == its end
+                        for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) gent[sbase + base + i] = stage[i];
+                    }
+                    __syncthreads();
+                    w_lo = w_hi;
                 }
+                for (int i = threadIdx.x; i < nb; i += blockDim.x) gtab[(size_t)sec * LDS_TAB + i] = sbase + tab[i];   // END of every bucket
+                sbase += total;
                 __syncthreads();
-                w_lo = w_hi;
             }
-            for (int i = threadIdx.x; i < nb; i += blockDim.x) gtab[i] = tab[i];     // END of every bucket
-            __syncthreads();
         }
     }
 }
@@ -782,7 +814,9 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
             const uint32_t r = tasks[order[end]].r;
             const int64_t L = g->len[r]; const int64_t n_rr = 2 * L + 1;
             const bool small = n_rr <= (1 << 21) && p->msl <= 7;
-            int B = 8; while ((1LL << (B + 1)) <= n_rr && B + 1 <= 2 * p->mal && B < (small ? 14 : 26)) ++B;
+            // anchor buckets: ~1 entry per bucket for short references, 4-8 per bucket above 2^16 symbols
+            int B = 8; while ((1LL << (B + 1)) <= n_rr && B + 1 <= 2 * p->mal && B < 26) ++B;
+            if (small && B > 14) B = std::min(18, std::max(14, B - 2));
             const int64_t chunks = (n_rr + RR_PAD + 31) / 32 + 2;
             const int64_t need = chunks * 12 + ((1LL << B) + n_rr + stab_n + n_rr) * 4;
             if (!refs.empty() && bytes + need > g_index_budget_bytes) break;
