@@ -578,6 +578,19 @@ k_scan_tables(const ref_desc* __restrict__ refs, const int* __restrict__ slot_li
 // ------------------------------------------------------------------ the parse
 struct task_dev { uint32_t q, r_slot, out_idx, pad; };
 
+// One wave parses one (query, reference) task (S == 1), or the S waves of a workgroup share it
+// (S > 1, "segments"): wave w starts a speculative parse at query position w * seg_len with an empty
+// state while wave w - 1 is still busy with its own segment.  Right after an event (a match placed
+// at query i, reference j) the scan state is a function of (i, j) alone, so every wave logs its
+// events together with its running sums; a wave that runs past the end of its segment stops as soon
+// as one of its own events equals a logged event of the wave that owns that stretch: from there on
+// the two parses are the same parse.  The chain of such hand-overs is followed from wave 0 and the
+// partial sums are added up; the result is identical to the single-wave parse, only the critical
+// path is ~S times shorter.
+constexpr int SEG_LOG_CAP = 256;
+struct seg_rec { int i_ev, ev_pos; uint32_t VM, VA, VN; };     // VN: bit 31 = open region already spans >= reg
+
+template <int S>
 __global__ void __launch_bounds__(256)
 k_lz_parse(const task_dev* __restrict__ tasks, int64_t n_tasks, const ref_desc* __restrict__ refs,
            const uint32_t* __restrict__ packed, const uint32_t* __restrict__ nmask, const int64_t* __restrict__ base_off,
@@ -587,12 +600,16 @@ k_lz_parse(const task_dev* __restrict__ tasks, int64_t n_tasks, const ref_desc* 
            const uint32_t* __restrict__ stab_pool, const uint32_t* __restrict__ sent_pool,
            lz_dev_params P, vg_pair_stat* __restrict__ stats,
            vg_region* __restrict__ regions, unsigned long long* __restrict__ region_cursor, unsigned long long region_cap) {
+    __shared__ seg_rec s_log[S > 1 ? S * SEG_LOG_CAP : 1];
+    __shared__ int s_cnt[4], s_sync_v[4], s_sync_idx[4];
+    __shared__ uint32_t s_end[4][3];
     const int lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
     // XCD-aware dealing: consecutive task groups of one reference stay on one XCD (block b runs on XCD b % 8)
     const int64_t per_xcd = gridDim.x / 8;           // grid is a multiple of 8 workgroups
     const int64_t vblk = (int64_t)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
-    const int64_t t = vblk * 4 + (threadIdx.x >> 6);
-    if (t >= n_tasks) return;
+    const int64_t t = (S == 1) ? vblk * 4 + w : vblk;
+    if (t >= n_tasks) return;                        // S > 1: the whole workgroup leaves together
     const task_dev tk = tasks[t];
     const ref_desc rd = refs[tk.r_slot];
     pair_ctx c;
@@ -604,16 +621,21 @@ k_lz_parse(const task_dev* __restrict__ tasks, int64_t n_tasks, const ref_desc* 
     const uint64_t amask = (P.mal >= 32) ? ~0ULL : ((1ULL << (2 * P.mal)) - 1);
     const uint64_t smask = (1ULL << (2 * P.msl)) - 1;
 
-    const long long t_start = (P.ablate & 32) ? (long long)wall_clock64() : 0;
-    int i = 0, lit = 0, pred = 0; bool alive = false;
-    int n_events = 0;
+    const long long t_start = (P.ablate & (32 | 512 | 1024)) ? (long long)wall_clock64() : 0;
+    const int lim = c.qlen - P.mal;
+    // segments: only worth it for queries of a few thousand bases
+    const int seg_len = (S > 1 && lim >= S * 2048) ? ((((lim + S - 1) / S) + 63) & ~63) : (lim > 0 ? lim : 1);
+    const int seg_start = (S > 1) ? min(w * seg_len, lim > 0 ? lim : 0) : 0;
+    int phase_end = (S > 1 && w < S - 1) ? min((w + 1) * seg_len, lim) : lim;
+    int i = seg_start, lit = 0, pred = 0; bool alive = false;
+    int n_events = 0, n_iter = 0;
+    bool synced = false; int sync_v = -1, sync_idx = 0, log_n = 0, look_v = -1, look_cur = 0;
     const bool prof = (P.ablate & 128) != 0; const int psel = (P.ablate >> 8) & 7;
     long long pc[6] = {0, 0, 0, 0, 0, 0}; long long tp = prof ? (long long)clock64() : 0;
 #define PROF_MARK(k) do { if (prof) { long long tn_ = (long long)clock64(); pc[k] += tn_ - tp; tp = tn_; } } while (0)
     bool in_region = false; int r_qstart = 0, r_rstart = 0, r_qend = 0, r_rend = -1, r_match = 0;
-    int kept_end = 0;
+    int kept_end = seg_start;
     uint32_t M = 0, A = 0, NR = 0;
-    const int lim = c.qlen - P.mal;
 
     auto close_region = [&]() {
         if (in_region) {
@@ -633,7 +655,8 @@ k_lz_parse(const task_dev* __restrict__ tasks, int64_t n_tasks, const ref_desc* 
         }
     };
 
-    while (i < lim) {
+    for (int phase = 0; phase < (S > 1 ? 2 : 1); ++phase) {
+    while (i < phase_end) {
         // ---- speculative probe of positions i .. i+63
         const int qi = i + lane;
         int best_len = 0, best_pos = 0; bool hit_close = false;
@@ -705,6 +728,7 @@ k_lz_parse(const task_dev* __restrict__ tasks, int64_t n_tasks, const ref_desc* 
             }
         }
         const unsigned long long hb = __ballot(best_len > 0);
+        ++n_iter;
         PROF_MARK(0);
         if (!hb) {
             // 64 literals (or the tail)
@@ -726,6 +750,7 @@ k_lz_parse(const task_dev* __restrict__ tasks, int64_t n_tasks, const ref_desc* 
         // literals in front of the event
         i += f; lit += f; if (alive) { pred += f; if (lit > P.mqd) alive = false; }
         const int gap_end_ref = pred - 1;
+        const int ev_i = i;
         // first-round loads of the left extension / gap scoring and of the right extension are
         // independent: issue them together, then run the window logic
         // (closing the open region may move kept_end: use the value it will have)
@@ -754,10 +779,68 @@ k_lz_parse(const task_dev* __restrict__ tasks, int64_t n_tasks, const ref_desc* 
         r_qend = i - 1;
         if (ev_close) { r_rend = max(r_rend, max(pred - 1, gap_end_ref)); }
         else r_rend = pred - 1;
+        if (S > 1) {
+            // After an event at (ev_i, ev_pos) the scan state is (i, pred, lit = 0, alive): a function of the
+            // event alone.  The open regions of two parses that meet in the same event may have started
+            // at different places, but once both already span >= reg they are kept by both, end at the same
+            // place and set the same kept_end; their sums then differ by a constant, which the
+            // "virtual" sums (open region counted up to here) carry across the hand-over.
+            const bool span_ok = i - r_qstart >= P.reg;
+            if (phase == 1) {
+                const int v = min(S - 1, ev_i / seg_len);
+                if (v != look_v) { look_v = v; look_cur = 0; }
+                const seg_rec* lg = s_log + v * SEG_LOG_CAP; const int nv = s_cnt[v];
+                while (look_cur < nv && lg[look_cur].i_ev < ev_i) ++look_cur;
+                if (span_ok && look_cur < nv && lg[look_cur].i_ev == ev_i && lg[look_cur].ev_pos == ev_pos && (lg[look_cur].VN >> 31)) {
+                    synced = true; sync_v = v; sync_idx = look_cur;
+                    M += (uint32_t)r_match; A -= (uint32_t)r_qstart;      // virtual sums; the region itself is the owner's now
+                    break;
+                }
+            } else if (log_n < SEG_LOG_CAP) {
+                if (lane == 0) {
+                    seg_rec rc; rc.i_ev = ev_i; rc.ev_pos = ev_pos;
+                    rc.VM = M + (uint32_t)r_match; rc.VA = A - (uint32_t)r_qstart; rc.VN = NR | (span_ok ? 0x80000000u : 0u);
+                    s_log[w * SEG_LOG_CAP + log_n] = rc;
+                }
+                ++log_n;
+            }
+        }
     }
-    close_region();
+    if (S > 1 && phase == 0) {
+        if (lane == 0) s_cnt[w] = log_n;
+        __syncthreads();                             // every segment's log is complete
+        phase_end = lim;
+    }
+    if (synced) break;
+    }
+    if (!synced) close_region();
+    if (S > 1) {
+        if (lane == 0) { s_end[w][0] = M; s_end[w][1] = A; s_end[w][2] = NR; s_sync_v[w] = sync_v; s_sync_idx[w] = sync_idx; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            // follow the hand-overs from wave 0: its sums up to the hand-over, then the next wave's from there
+            uint32_t tm = 0, ta = 0, tn = 0, bm = 0, ba = 0, bn = 0; int cur = 0;
+            for (;;) {
+                tm += s_end[cur][0] - bm; ta += s_end[cur][1] - ba; tn += s_end[cur][2] - bn;
+                const int v = s_sync_v[cur];
+                if (v < 0) break;
+                const seg_rec rc = s_log[v * SEG_LOG_CAP + s_sync_idx[cur]];
+                bm = rc.VM; ba = rc.VA; bn = rc.VN & 0x7fffffffu; cur = v;
+            }
+            vg_pair_stat st; st.n_match = tm; st.aln_len = ta; st.n_regions = tn;
+            if (P.ablate & 512) {                    // developer view of the hand-overs
+                int hops = 0, c2 = 0; while (s_sync_v[c2] >= 0) { c2 = s_sync_v[c2]; ++hops; }
+                st.n_match = (uint32_t)(s_sync_v[0] >= 0 ? s_log[s_sync_v[0] * SEG_LOG_CAP + s_sync_idx[0]].i_ev - seg_len : lim - seg_len);
+                st.aln_len = (uint32_t)hops | ((uint32_t)s_cnt[1] << 8);
+                st.n_regions = (uint32_t)((long long)wall_clock64() - t_start);
+            }
+            stats[tk.out_idx] = st;
+        }
+        return;
+    }
     if (prof) { M = (uint32_t)(pc[psel] >> 4); A = (uint32_t)n_events; }
-    if (P.ablate & 32) NR = (uint32_t)((long long)wall_clock64() - t_start);        // developer timing: 100 MHz ticks
+    if (P.ablate & 1024) { M = (uint32_t)n_iter; A = (uint32_t)n_events; }
+    if (P.ablate & (32 | 1024)) NR = (uint32_t)((long long)wall_clock64() - t_start);        // developer timing: 100 MHz ticks
     if (lane == 0) { vg_pair_stat st; st.n_match = M; st.aln_len = A; st.n_regions = NR; stats[tk.out_idx] = st; }
 }
 
@@ -769,6 +852,7 @@ inline int grid_for(int64_t n, int block = 256, int max_blocks = 256 * 16) {
 }  // namespace
 
 static int64_t g_index_budget_bytes = 24LL << 30;
+static int64_t g_segment_task_limit = 16384;
 
 extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks, const vg_lz_params* p,
                            vg_pair_stat* stats, vg_region** regions, int64_t* n_regions) {
@@ -885,10 +969,21 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
             double bytes_alg = 0;
             for (int64_t t = pos; t < end; ++t) bytes_alg += (double)(g->len[tasks[order[t]].q] + g->len[tasks[order[t]].r]) / 4.0 + 20.0;
             vg_prof_scope ps("lz_parse", bytes_alg);
-            const int64_t nblk = ((nt + 3) / 4 + 7) / 8 * 8;
-            hipLaunchKernelGGL(k_lz_parse, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p, nt, d_refs.p, g->d_packed.p, g->d_nmask.p,
-                               g->d_base_off.p, g->d_len.p, g->d_has_n.p, rr_pool.p, mask_pool.p, atab_pool.p, aent_pool.p, stab_pool.p,
-                               sent_pool.p, P, d_stats.p, want_regions ? d_regions.p : (vg_region*)nullptr, d_rcur.p, region_cap);
+            // few tasks: the launch lasts as long as its slowest pair, so four waves share each pair;
+            // many tasks: one wave per pair keeps every SIMD busy without the duplicated stretches
+            static const char* seg_env = getenv("VG_LZ_SEGMENTS");
+            const bool segments = seg_env ? atoi(seg_env) > 1 : (nt <= g_segment_task_limit);
+            if (segments && !want_regions && (P.ablate & ~512) == 0) {
+                const int64_t nblk = (nt + 7) / 8 * 8;
+                hipLaunchKernelGGL(k_lz_parse<4>, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p, nt, d_refs.p, g->d_packed.p, g->d_nmask.p,
+                                   g->d_base_off.p, g->d_len.p, g->d_has_n.p, rr_pool.p, mask_pool.p, atab_pool.p, aent_pool.p, stab_pool.p,
+                                   sent_pool.p, P, d_stats.p, (vg_region*)nullptr, d_rcur.p, region_cap);
+            } else {
+                const int64_t nblk = ((nt + 3) / 4 + 7) / 8 * 8;
+                hipLaunchKernelGGL(k_lz_parse<1>, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p, nt, d_refs.p, g->d_packed.p, g->d_nmask.p,
+                                   g->d_base_off.p, g->d_len.p, g->d_has_n.p, rr_pool.p, mask_pool.p, atab_pool.p, aent_pool.p, stab_pool.p,
+                                   sent_pool.p, P, d_stats.p, want_regions ? d_regions.p : (vg_region*)nullptr, d_rcur.p, region_cap);
+            }
         }
         VG_HIP(hipStreamSynchronize(s));
         VG_HIP(hipGetLastError());
