@@ -590,21 +590,26 @@ struct task_dev { uint32_t q, r_slot, out_idx, pad; };
 constexpr int SEG_LOG_CAP = 256;
 struct seg_rec { int i_ev, ev_pos; uint32_t VM, VA, VN; };     // VN: bit 31 = open region already spans >= reg
 
-template <int S>
-__global__ void __launch_bounds__(256)
-k_lz_parse(const task_dev* __restrict__ tasks, int64_t n_tasks, const ref_desc* __restrict__ refs,
-           const uint32_t* __restrict__ packed, const uint32_t* __restrict__ nmask, const int64_t* __restrict__ base_off,
-           const int64_t* __restrict__ glen, const uint8_t* __restrict__ g_has_n,
-           const uint32_t* __restrict__ rr_pool, const uint32_t* __restrict__ mask_pool,
-           const uint32_t* __restrict__ atab_pool, const uint32_t* __restrict__ aent_pool,
-           const uint32_t* __restrict__ stab_pool, const uint32_t* __restrict__ sent_pool,
-           lz_dev_params P, vg_pair_stat* __restrict__ stats,
-           vg_region* __restrict__ regions, unsigned long long* __restrict__ region_cursor, unsigned long long region_cap) {
+#define PARSE_ARGS \
+    const task_dev* __restrict__ tasks, int64_t n_tasks, const ref_desc* __restrict__ refs, \
+    const uint32_t* __restrict__ packed, const uint32_t* __restrict__ nmask, const int64_t* __restrict__ base_off, \
+    const int64_t* __restrict__ glen, const uint8_t* __restrict__ g_has_n, \
+    const uint32_t* __restrict__ rr_pool, const uint32_t* __restrict__ mask_pool, \
+    const uint32_t* __restrict__ atab_pool, const uint32_t* __restrict__ aent_pool, \
+    const uint32_t* __restrict__ stab_pool, const uint32_t* __restrict__ sent_pool, \
+    lz_dev_params P, vg_pair_stat* __restrict__ stats, \
+    vg_region* __restrict__ regions, unsigned long long* __restrict__ region_cursor, unsigned long long region_cap
+#define PARSE_ARG_NAMES tasks, n_tasks, refs, packed, nmask, base_off, glen, g_has_n, rr_pool, mask_pool, atab_pool, aent_pool, \
+    stab_pool, sent_pool, P, stats, regions, region_cursor, region_cap
+
+template <int S, bool DEV>
+__device__ __forceinline__ void lz_parse_body(PARSE_ARGS) {
+    const int ABL = DEV ? P.ablate : 0;           // developer timing knobs: compiled out of the production kernels
     __shared__ seg_rec s_log[S > 1 ? S * SEG_LOG_CAP : 1];
     __shared__ int s_cnt[4], s_sync_v[4], s_sync_idx[4];
     __shared__ uint32_t s_end[4][3];
     const int lane = threadIdx.x & 63;
-    const int w = threadIdx.x >> 6;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // wave-uniform: task data lives in SGPRs
     // XCD-aware dealing: consecutive task groups of one reference stay on one XCD (block b runs on XCD b % 8)
     const int64_t per_xcd = gridDim.x / 8;           // grid is a multiple of 8 workgroups
     const int64_t vblk = (int64_t)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
@@ -621,18 +626,18 @@ k_lz_parse(const task_dev* __restrict__ tasks, int64_t n_tasks, const ref_desc* 
     const uint64_t amask = (P.mal >= 32) ? ~0ULL : ((1ULL << (2 * P.mal)) - 1);
     const uint64_t smask = (1ULL << (2 * P.msl)) - 1;
 
-    const long long t_start = (P.ablate & (32 | 512 | 1024)) ? (long long)wall_clock64() : 0;
+    const long long t_start = (ABL & (32 | 512 | 1024)) ? (long long)wall_clock64() : 0;
     const int lim = c.qlen - P.mal;
     // segments: only worth it for queries of a few thousand bases
     const int seg_len = (S > 1 && lim >= S * 2048) ? ((((lim + S - 1) / S) + 63) & ~63) : (lim > 0 ? lim : 1);
     const int seg_start = (S > 1) ? min(w * seg_len, lim > 0 ? lim : 0) : 0;
     int phase_end = (S > 1 && w < S - 1) ? min((w + 1) * seg_len, lim) : lim;
     int i = seg_start, lit = 0, pred = 0; bool alive = false;
-    int n_events = 0, n_iter = 0;
+    int n_events = 0, n_iter = 0, n_ab = 0, n_sb = 0;
     bool synced = false; int sync_v = -1, sync_idx = 0, log_n = 0, look_v = -1, look_cur = 0;
-    const bool prof = (P.ablate & 128) != 0; const int psel = (P.ablate >> 8) & 7;
+    const bool prof = (ABL & 128) != 0; const int psel = (ABL >> 8) & 7;
     long long pc[6] = {0, 0, 0, 0, 0, 0}; long long tp = prof ? (long long)clock64() : 0;
-#define PROF_MARK(k) do { if (prof) { long long tn_ = (long long)clock64(); pc[k] += tn_ - tp; tp = tn_; } } while (0)
+#define PROF_MARK(k) do { if (DEV && prof) { long long tn_ = (long long)clock64(); pc[k] += tn_ - tp; tp = tn_; } } while (0)
     bool in_region = false; int r_qstart = 0, r_rstart = 0, r_qend = 0, r_rend = -1, r_match = 0;
     int kept_end = seg_start;
     uint32_t M = 0, A = 0, NR = 0;
@@ -687,13 +692,14 @@ k_lz_parse(const task_dev* __restrict__ tasks, int64_t n_tasks, const ref_desc* 
             };
             // R2: anchor = longest exact match >= mal over all occurrences.  Bucket entries are read
             // four at a time (independent loads: one memory round trip per group, not per entry).
-            if (q_ok_a && !(P.ablate & 16)) {
+            if (q_ok_a && !(ABL & 16)) {
                 const uint64_t h = anchor_hash(xq & amask);
                 const uint32_t b = anchor_bucket(h, rd.B);
                 const uint32_t tag = anchor_tag(h, rd.B, rd.pos_bits);
                 const uint32_t posmask = (1u << rd.pos_bits) - 1u;
                 const uint32_t s = b ? atab[b - 1] : 0u, e = atab[b];
                 for (uint32_t u = s; u < e; u += 4) {
+                    if (DEV) ++n_ab;
                     uint32_t ent[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) ent[j] = aent[min(u + j, e - 1)];
@@ -708,13 +714,15 @@ k_lz_parse(const task_dev* __restrict__ tasks, int64_t n_tasks, const ref_desc* 
                     hit_close = alive_l && d >= -P.mrd && d <= P.mrd;
                 }
             }
+            PROF_MARK(4);
             // R3: seed near the prediction
-            if (best_len == 0 && alive_l && q_ok_s && !(P.ablate & 1)) {
+            if (best_len == 0 && alive_l && q_ok_s && !(ABL & 1)) {
                 const uint32_t b = (uint32_t)(xq & smask);
                 const uint32_t s = b ? stab[b - 1] : 0u, e = stab[b];
                 const int pred0 = pred - lit;                    // reference end of the previous match
                 ncap = 0;
                 for (uint32_t u = s; u < e; u += 4) {
+                    if (DEV) ++n_sb;
                     int rps[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) rps[j] = (int)sent[min(u + j, e - 1)];
@@ -727,8 +735,9 @@ k_lz_parse(const task_dev* __restrict__ tasks, int64_t n_tasks, const ref_desc* 
                 if (best_len > 0) hit_close = true;
             }
         }
+        PROF_MARK(5);
         const unsigned long long hb = __ballot(best_len > 0);
-        ++n_iter;
+        if (DEV) ++n_iter;
         PROF_MARK(0);
         if (!hb) {
             // 64 literals (or the tail)
@@ -739,7 +748,7 @@ k_lz_parse(const task_dev* __restrict__ tasks, int64_t n_tasks, const ref_desc* 
         const int f = __builtin_ctzll(hb);
         // Pairs that need many events are the tail of the launch: a wave raises its own issue priority
         // as its event count grows, so the heavy pairs overtake the light ones sharing their SIMD.
-        if (!(P.ablate & 64)) {
+        if (!(ABL & 64)) {
             ++n_events;
             if (n_events == 24) __builtin_amdgcn_s_setprio(1);
             else if (n_events == 64) __builtin_amdgcn_s_setprio(2);
@@ -756,23 +765,23 @@ k_lz_parse(const task_dev* __restrict__ tasks, int64_t n_tasks, const ref_desc* 
         // (closing the open region may move kept_end: use the value it will have)
         const int kept_after = (in_region && r_qend - r_qstart + 1 >= P.reg) ? r_qend + 1 : kept_end;
         const int bwd_bound = ev_close ? 0 : i - kept_after;
-        const uint64_t mm_b = (!ev_close && !(P.ablate & 2)) ? extend_mask0(c, i, ev_pos, -1, bwd_bound, lane) : EVEN;
+        const uint64_t mm_b = (!ev_close && !(ABL & 2)) ? extend_mask0(c, i, ev_pos, -1, bwd_bound, lane) : EVEN;
         const uint64_t mm_f = extend_mask0(c, i, ev_pos, +1, 1 << 30, lane);
         int gap_m = 0;
-        if (ev_close && lit > 0 && !(P.ablate & 8)) gap_m = count_eq_wave(c, i - lit, pred - lit, lit, lane);   // R7: old diagonal
+        if (ev_close && lit > 0 && !(ABL & 8)) gap_m = count_eq_wave(c, i - lit, pred - lit, lit, lane);   // R7: old diagonal
         PROF_MARK(1);
         if (!ev_close) {
             // R5: new region, extended to the left (exact, then approximate), not into the last kept region
             close_region();
             int bm = 0;
-            const int b = (P.ablate & 2) ? 0 : extend(c, P, i, ev_pos, -1, bwd_bound, lane, &bm, mm_b);
+            const int b = (ABL & 2) ? 0 : extend(c, P, i, ev_pos, -1, bwd_bound, lane, &bm, mm_b);
             r_qstart = i - b; r_rstart = ev_pos - b; r_match = bm; r_rend = -1;
             in_region = true;
         } else r_match += gap_m;
         PROF_MARK(2);
         {   // the match itself and R4, one pass
             int fm = 0;
-            const int fe = (P.ablate & 4) ? P.mal : extend(c, P, i, ev_pos, +1, 1 << 30, lane, &fm, mm_f);
+            const int fe = (ABL & 4) ? P.mal : extend(c, P, i, ev_pos, +1, 1 << 30, lane, &fm, mm_f);
             r_match += fm; i += fe; pred = ev_pos + fe; lit = 0; alive = true;
         }
         PROF_MARK(3);
@@ -828,7 +837,7 @@ k_lz_parse(const task_dev* __restrict__ tasks, int64_t n_tasks, const ref_desc* 
                 bm = rc.VM; ba = rc.VA; bn = rc.VN & 0x7fffffffu; cur = v;
             }
             vg_pair_stat st; st.n_match = tm; st.aln_len = ta; st.n_regions = tn;
-            if (P.ablate & 512) {                    // developer view of the hand-overs
+            if (ABL & 512) {                    // developer view of the hand-overs
                 int hops = 0, c2 = 0; while (s_sync_v[c2] >= 0) { c2 = s_sync_v[c2]; ++hops; }
                 st.n_match = (uint32_t)(s_sync_v[0] >= 0 ? s_log[s_sync_v[0] * SEG_LOG_CAP + s_sync_idx[0]].i_ev - seg_len : lim - seg_len);
                 st.aln_len = (uint32_t)hops | ((uint32_t)s_cnt[1] << 8);
@@ -839,10 +848,24 @@ k_lz_parse(const task_dev* __restrict__ tasks, int64_t n_tasks, const ref_desc* 
         return;
     }
     if (prof) { M = (uint32_t)(pc[psel] >> 4); A = (uint32_t)n_events; }
-    if (P.ablate & 1024) { M = (uint32_t)n_iter; A = (uint32_t)n_events; }
-    if (P.ablate & (32 | 1024)) NR = (uint32_t)((long long)wall_clock64() - t_start);        // developer timing: 100 MHz ticks
+    if (ABL & 1024) {
+        // wave-level trip counts of the bucket loops = max over lanes
+        int mab = n_ab, msb = n_sb;
+        for (int o = 32; o; o >>= 1) { mab = max(mab, __shfl_xor(mab, o)); msb = max(msb, __shfl_xor(msb, o)); }
+        M = (uint32_t)n_iter; A = (uint32_t)n_events; if (ABL & 2048) { M = (uint32_t)mab; A = (uint32_t)msb; }
+    }
+    if (ABL & (32 | 1024)) NR = (uint32_t)((long long)wall_clock64() - t_start);        // developer timing: 100 MHz ticks
     if (lane == 0) { vg_pair_stat st; st.n_match = M; st.aln_len = A; st.n_regions = NR; stats[tk.out_idx] = st; }
 }
+
+// The parse is bound by dependent memory round trips, so resident waves are throughput: the
+// register budget is capped for the occupancy named in each kernel (waves per SIMD).
+#define PARSE_KERNEL(NAME, S, DEV, WAVES) \
+    __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) NAME(PARSE_ARGS) { \
+        lz_parse_body<S, DEV>(PARSE_ARG_NAMES); }
+PARSE_KERNEL(k_lz_parse, 1, false, 6)
+PARSE_KERNEL(k_lz_parse_seg, 4, false, 6)
+PARSE_KERNEL(k_lz_parse_dev, 1, true, 3)
 
 inline int grid_for(int64_t n, int block = 256, int max_blocks = 256 * 16) {
     int64_t b = (n + block - 1) / block; if (b < 1) b = 1;
@@ -973,16 +996,22 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
             // many tasks: one wave per pair keeps every SIMD busy without the duplicated stretches
             static const char* seg_env = getenv("VG_LZ_SEGMENTS");
             const bool segments = seg_env ? atoi(seg_env) > 1 : (nt <= g_segment_task_limit);
-            if (segments && !want_regions && (P.ablate & ~512) == 0) {
+            if (segments && !want_regions && (P.ablate & ~512) == 0 && P.ablate == 0) {
                 const int64_t nblk = (nt + 7) / 8 * 8;
-                hipLaunchKernelGGL(k_lz_parse<4>, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p, nt, d_refs.p, g->d_packed.p, g->d_nmask.p,
+                hipLaunchKernelGGL(k_lz_parse_seg, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p, nt, d_refs.p, g->d_packed.p, g->d_nmask.p,
                                    g->d_base_off.p, g->d_len.p, g->d_has_n.p, rr_pool.p, mask_pool.p, atab_pool.p, aent_pool.p, stab_pool.p,
                                    sent_pool.p, P, d_stats.p, (vg_region*)nullptr, d_rcur.p, region_cap);
             } else {
                 const int64_t nblk = ((nt + 3) / 4 + 7) / 8 * 8;
-                hipLaunchKernelGGL(k_lz_parse<1>, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p, nt, d_refs.p, g->d_packed.p, g->d_nmask.p,
+if (P.ablate) {
+                    hipLaunchKernelGGL(k_lz_parse_dev, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p, nt, d_refs.p, g->d_packed.p, g->d_nmask.p,
                                    g->d_base_off.p, g->d_len.p, g->d_has_n.p, rr_pool.p, mask_pool.p, atab_pool.p, aent_pool.p, stab_pool.p,
                                    sent_pool.p, P, d_stats.p, want_regions ? d_regions.p : (vg_region*)nullptr, d_rcur.p, region_cap);
+                } else {
+                    hipLaunchKernelGGL(k_lz_parse, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p, nt, d_refs.p, g->d_packed.p, g->d_nmask.p,
+                                   g->d_base_off.p, g->d_len.p, g->d_has_n.p, rr_pool.p, mask_pool.p, atab_pool.p, aent_pool.p, stab_pool.p,
+                                   sent_pool.p, P, d_stats.p, want_regions ? d_regions.p : (vg_region*)nullptr, d_rcur.p, region_cap);
+                }
             }
         }
         VG_HIP(hipStreamSynchronize(s));
