@@ -1,7 +1,7 @@
 """Developer tool: cycle split of one parse task (VG_LZ_ABLATE=128|sel<<8|32)."""
 import os, sys, pathlib, subprocess
 root = pathlib.Path(__file__).resolve().parent.parent
-names = ['probe rest', 'event loads (masks+gap)', 'bwd extend + region', 'fwd extend', 'probe: q loads + anchors', 'probe: seeds']
+names = ['probe', 'event loads (masks+gap)', 'bwd extend + region', 'fwd extend']
 for sel, nm in enumerate(names):
     env = dict(os.environ, VG_LZ_ABLATE=str(128 | 32 | (sel << 8)))
     out = subprocess.run([sys.executable, str(root / 'tools' / 'one_task.py')], env=env, capture_output=True, text=True).stdout.splitlines()[0]

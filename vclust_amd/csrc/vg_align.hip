@@ -676,66 +676,74 @@ __device__ __forceinline__ void lz_parse_body(PARSE_ARGS) {
                 q_ok_a = (m & ((1ULL << P.mal) - 1)) == 0;
                 q_ok_s = q_ok_s && (m & ((1ULL << P.msl) - 1)) == 0;
             }
-            // candidate ranking shared by anchors and seeds: longest exact match, ties -> smallest position
-            int ncap = 0;
-            auto consider = [&](int rp, int min_len) {
-                int l = match_len_lane(c, qi, rp, 32);
-                if (l < min_len) return;
-                if (l >= 32) {
-                    // rare: several long candidates need their exact lengths to be ranked
-                    if (ncap++ > 0 || best_len >= 32) {
-                        l = match_len_lane(c, qi, rp, 1 << 30);
-                        if (best_len == 32) best_len = match_len_lane(c, qi, best_pos, 1 << 30);
-                    }
-                }
-                if (l > best_len || (l == best_len && rp < best_pos)) { best_len = l; best_pos = rp; }
-            };
-            // R2: anchor = longest exact match >= mal over all occurrences.  Bucket entries are read
-            // four at a time (independent loads: one memory round trip per group, not per entry).
-            if (q_ok_a && !(ABL & 16)) {
+            // R2 (anchor = longest exact match >= mal over all occurrences of the mal-mer) and R3 (seed
+            // >= msl near the prediction, only for positions without an anchor) walk their buckets
+            // together, four entries of each per trip, so that a trip costs one memory round for the
+            // entries and one per verified candidate.  Both rank candidates the same way: longest
+            // exact match, ties -> smallest reference position.
+            const bool do_a = q_ok_a && !(ABL & 16);
+            const bool do_s = alive_l && q_ok_s && !(ABL & 1);
+            uint32_t a_u = 0, a_e = 0, s_u = 0, s_e = 0, tag = 0;
+            const uint32_t posmask = (1u << rd.pos_bits) - 1u;
+            if (do_a) {
                 const uint64_t h = anchor_hash(xq & amask);
                 const uint32_t b = anchor_bucket(h, rd.B);
-                const uint32_t tag = anchor_tag(h, rd.B, rd.pos_bits);
-                const uint32_t posmask = (1u << rd.pos_bits) - 1u;
-                const uint32_t s = b ? atab[b - 1] : 0u, e = atab[b];
-                for (uint32_t u = s; u < e; u += 4) {
-                    if (DEV) ++n_ab;
-                    uint32_t ent[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) ent[j] = aent[min(u + j, e - 1)];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (u + j >= e || (ent[j] >> rd.pos_bits) != tag) continue;
-                        consider((int)(ent[j] & posmask), P.mal);      // tag collisions fail the length test
-                    }
-                }
-                if (best_len > 0) {
-                    const int d = best_pos - pred_l;
-                    hit_close = alive_l && d >= -P.mrd && d <= P.mrd;
-                }
+                tag = anchor_tag(h, rd.B, rd.pos_bits);
+                a_u = b ? atab[b - 1] : 0u; a_e = atab[b];
             }
-            PROF_MARK(4);
-            // R3: seed near the prediction
-            if (best_len == 0 && alive_l && q_ok_s && !(ABL & 1)) {
+            if (do_s) {
                 const uint32_t b = (uint32_t)(xq & smask);
-                const uint32_t s = b ? stab[b - 1] : 0u, e = stab[b];
-                const int pred0 = pred - lit;                    // reference end of the previous match
-                ncap = 0;
-                for (uint32_t u = s; u < e; u += 4) {
-                    if (DEV) ++n_sb;
-                    int rps[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) rps[j] = (int)sent[min(u + j, e - 1)];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (u + j >= e || rps[j] < pred0 || rps[j] - pred_l > P.mrd - 1) continue;
-                        consider(rps[j], P.msl);
-                    }
-                }
-                if (best_len > 0) hit_close = true;
+                s_u = b ? stab[b - 1] : 0u; s_e = stab[b];
             }
+            const int pred0 = pred - lit;                        // reference end of the previous match
+            int sbest_len = 0, sbest_pos = 0, ncap_a = 0, ncap_s = 0;
+            while (a_u < a_e || s_u < s_e) {
+                if (DEV) { ++n_ab; }
+                uint32_t ea0 = 0, ea1 = 0, ea2 = 0, ea3 = 0; int es0 = 0, es1 = 0, es2 = 0, es3 = 0;
+                const bool la = a_u < a_e, ls = s_u < s_e;
+                if (la) { ea0 = aent[a_u]; ea1 = aent[min(a_u + 1, a_e - 1)]; ea2 = aent[min(a_u + 2, a_e - 1)]; ea3 = aent[min(a_u + 3, a_e - 1)]; }
+                if (ls) { es0 = (int)sent[s_u]; es1 = (int)sent[min(s_u + 1, s_e - 1)]; es2 = (int)sent[min(s_u + 2, s_e - 1)]; es3 = (int)sent[min(s_u + 3, s_e - 1)]; }
+                // candidate slots: bits 0..3 anchors (tag collisions fail the length test), 4..7 seeds
+                unsigned cm = 0;
+                if (la) {
+                    cm |= ((ea0 >> rd.pos_bits) == tag) ? 1u : 0u;
+                    cm |= (a_u + 1 < a_e && (ea1 >> rd.pos_bits) == tag) ? 2u : 0u;
+                    cm |= (a_u + 2 < a_e && (ea2 >> rd.pos_bits) == tag) ? 4u : 0u;
+                    cm |= (a_u + 3 < a_e && (ea3 >> rd.pos_bits) == tag) ? 8u : 0u;
+                }
+                if (ls) {
+                    const int hi = pred_l + P.mrd - 1;
+                    cm |= (es0 >= pred0 && es0 <= hi) ? 16u : 0u;
+                    cm |= (s_u + 1 < s_e && es1 >= pred0 && es1 <= hi) ? 32u : 0u;
+                    cm |= (s_u + 2 < s_e && es2 >= pred0 && es2 <= hi) ? 64u : 0u;
+                    cm |= (s_u + 3 < s_e && es3 >= pred0 && es3 <= hi) ? 128u : 0u;
+                }
+                while (cm) {
+                    const int j = __builtin_ctz(cm); cm &= cm - 1;
+                    const bool seed = j >= 4;
+                    const int ja = j & 3;
+                    const uint32_t eas = ja == 0 ? ea0 : ja == 1 ? ea1 : ja == 2 ? ea2 : ea3;
+                    const int ess = ja == 0 ? es0 : ja == 1 ? es1 : ja == 2 ? es2 : es3;
+                    const int rp = seed ? ess : (int)(eas & posmask);
+                    int l = match_len_lane(c, qi, rp, 32);
+                    int& bl = seed ? sbest_len : best_len; int& bp = seed ? sbest_pos : best_pos; int& nc = seed ? ncap_s : ncap_a;
+                    if (l < (seed ? P.msl : P.mal)) continue;
+                    if (l >= 32) {
+                        // rare: several long candidates need their exact lengths to be ranked
+                        if (nc++ > 0 || bl >= 32) {
+                            l = match_len_lane(c, qi, rp, 1 << 30);
+                            if (bl == 32) bl = match_len_lane(c, qi, bp, 1 << 30);
+                        }
+                    }
+                    if (l > bl || (l == bl && rp < bp)) { bl = l; bp = rp; }
+                }
+                a_u += 4; s_u += 4;
+            }
+            if (best_len > 0) {
+                const int d = best_pos - pred_l;
+                hit_close = alive_l && d >= -P.mrd && d <= P.mrd;
+            } else if (sbest_len > 0) { best_len = sbest_len; best_pos = sbest_pos; hit_close = true; }
         }
-        PROF_MARK(5);
         const unsigned long long hb = __ballot(best_len > 0);
         if (DEV) ++n_iter;
         PROF_MARK(0);
