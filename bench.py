@@ -33,6 +33,25 @@ from vclust_amd import distributed as D  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
+# profile-scope name -> kernel name in the rocprofv3 summaries under profiles/
+KERNEL_OF_SCOPE = {'lz_parse': ('k_lz_parse_seg', 'k_lz_parse'), 'lz_build_index': ('k_build_index_lds',),
+                   'radix_sort_pairs': ('rocprim::onesweep_iteration',), 'index_runs': ('k_runs',),
+                   'spgemm_rows': ('k_spgemm',), 'kmer_extract': ('k_kmer_extract',), 'group_sort': ('k_group_sort',)}
+
+
+def pmc_traffic(scope):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (separate rocprofv3
+    --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, tools/collect_profiles.sh): counters cannot
+    be read inside the timed run.  Raw FETCH_SIZE + WRITE_SIZE; see the file for the gfx950 x2 bound."""
+    files = sorted((ROOT / 'profiles').glob('*_pmc_hbm_traffic.json'))
+    if not files:
+        return None, None
+    doc = json.loads(files[-1].read_text())
+    for k in KERNEL_OF_SCOPE.get(scope, ()):
+        if k in doc.get('kernels', {}):
+            return doc['kernels'][k]['hbm_bytes_per_launch_raw'], f'profiles/{files[-1].name}:{k}'
+    return None, None
+
 
 def candidate_pairs(sizes, pairs, k, min_kmers, min_ident):
     """K3 thresholds on the summed shared counts (same arithmetic as vg_write_fltr)."""
@@ -155,8 +174,9 @@ def main():
             avg_ms = dom['total_ms'] / dom['launches']
             alg_bytes = dom['bytes'] / dom['launches']
             achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+            traffic, traffic_src = pmc_traffic(dom['name']) if world == 1 and args.families == 100 else (None, None)
             roofline = dict(bound='hbm', kernel=dom['name'], achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit='GB/s',
-                            frac=round(achieved / HBM_PEAK_GBS, 6), traffic=None,
+                            frac=round(achieved / HBM_PEAK_GBS, 6), traffic=traffic, traffic_source=traffic_src,
                             avg_launch_ms=round(avg_ms, 4), algorithmic_bytes_per_launch=round(alg_bytes),
                             kernels={e['name']: round(e['total_ms'] / max(e['launches'], 1), 4) for e in prof})
         cpu = None

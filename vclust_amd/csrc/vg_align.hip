@@ -626,7 +626,7 @@ __device__ __forceinline__ void lz_parse_body(PARSE_ARGS) {
     const uint64_t amask = (P.mal >= 32) ? ~0ULL : ((1ULL << (2 * P.mal)) - 1);
     const uint64_t smask = (1ULL << (2 * P.msl)) - 1;
 
-    const long long t_start = (ABL & (32 | 512 | 1024)) ? (long long)wall_clock64() : 0;
+    const long long t_start = (ABL & (32 | 1024)) ? (long long)wall_clock64() : 0;
     const int lim = c.qlen - P.mal;
     // segments: only worth it for queries of a few thousand bases
     const int seg_len = (S > 1 && lim >= S * 2048) ? ((((lim + S - 1) / S) + 63) & ~63) : (lim > 0 ? lim : 1);
@@ -845,12 +845,6 @@ __device__ __forceinline__ void lz_parse_body(PARSE_ARGS) {
                 bm = rc.VM; ba = rc.VA; bn = rc.VN & 0x7fffffffu; cur = v;
             }
             vg_pair_stat st; st.n_match = tm; st.aln_len = ta; st.n_regions = tn;
-            if (ABL & 512) {                    // developer view of the hand-overs
-                int hops = 0, c2 = 0; while (s_sync_v[c2] >= 0) { c2 = s_sync_v[c2]; ++hops; }
-                st.n_match = (uint32_t)(s_sync_v[0] >= 0 ? s_log[s_sync_v[0] * SEG_LOG_CAP + s_sync_idx[0]].i_ev - seg_len : lim - seg_len);
-                st.aln_len = (uint32_t)hops | ((uint32_t)s_cnt[1] << 8);
-                st.n_regions = (uint32_t)((long long)wall_clock64() - t_start);
-            }
             stats[tk.out_idx] = st;
         }
         return;
@@ -1004,7 +998,7 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
             // many tasks: one wave per pair keeps every SIMD busy without the duplicated stretches
             static const char* seg_env = getenv("VG_LZ_SEGMENTS");
             const bool segments = seg_env ? atoi(seg_env) > 1 : (nt <= g_segment_task_limit);
-            if (segments && !want_regions && (P.ablate & ~512) == 0 && P.ablate == 0) {
+            if (segments && !want_regions && P.ablate == 0) {
                 const int64_t nblk = (nt + 7) / 8 * 8;
                 hipLaunchKernelGGL(k_lz_parse_seg, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p, nt, d_refs.p, g->d_packed.p, g->d_nmask.p,
                                    g->d_base_off.p, g->d_len.p, g->d_has_n.p, rr_pool.p, mask_pool.p, atab_pool.p, aent_pool.p, stab_pool.p,
