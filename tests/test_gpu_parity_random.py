@@ -82,6 +82,26 @@ def test_unrelated_and_repetitive_sequences():
     _check_lz(codes, offsets, gs, gs.align_tasks(gs.read_filter(None)))
 
 
+def test_kmers_shared_by_many_genomes():
+    """A conserved block in 700 genomes: k-mer runs longer than one staged tile of the run kernel
+    (general path), next to ordinary short runs."""
+    rng = np.random.default_rng(8)
+    core = rng.integers(0, 4, size=60, dtype=np.uint8)
+    seqs = []
+    for i in range(700):
+        flank = rng.integers(0, 4, size=int(rng.integers(150, 400)), dtype=np.uint8)
+        cut = int(rng.integers(0, len(flank)))
+        seqs.append(np.concatenate([flank[:cut], core, flank[cut:]]))
+    for i in range(0, 40, 2):                                   # a few close relatives on top
+        seqs[i + 1] = seqs[i].copy(); seqs[i + 1][::37] = (seqs[i + 1][::37] + 1) % 4
+    offsets = np.zeros(len(seqs) + 1, dtype=np.int64); offsets[1:] = np.cumsum([len(s) for s in seqs])
+    codes = np.concatenate(seqs)
+    gs = api.GenomeSet.from_codes(codes, offsets)
+    pairs = _check_prefilter(codes, offsets, gs, 25)
+    assert len(pairs) >= 600 * 599 // 2
+    _check_prefilter(codes, offsets, gs, 18, fraction=0.5)
+
+
 def test_large_reference_global_index_path():
     """References above 2^18 RR symbols use the global-memory index build."""
     rng = np.random.default_rng(8)

@@ -135,38 +135,68 @@ __global__ void k_iota(uint32_t* v, int64_t n) {
 }
 
 // ------------------------------------------------------------------ K1b: finish the partial sort
-// The device radix sort only orders the top `sort_bits` key bits (4-5 passes instead of 7).
-// Entries with equal prefix form tiny contiguous groups (the scramble makes prefixes uniform);
-// the first entry of each group orders its group by the full key with a stable insertion sort.
+// The device radix sort only orders the top `sort_bits` key bits (3-4 passes instead of 7).
+// Entries with equal prefix form small contiguous groups (the scramble makes prefixes uniform:
+// about n / 2^sort_bits entries each, plus the repeats of a k-mer).  A workgroup stages a tile of
+// the list (+ a halo, so that every group that starts inside the tile is complete) in the LDS;
+// every entry then ranks itself inside its group by the full key (stable) and is written to its
+// final place only if it moves.  Groups longer than the halo (a k-mer that occurs thousands of
+// times) are ordered in place in global memory by their first entry.
+constexpr int GS_TILE = 2048;
+constexpr int GS_HALO = 512;
+
+__device__ void group_sort_global(uint64_t* __restrict__ keys, uint32_t* __restrict__ pos, int64_t n, int64_t i, int low_bit) {
+    const uint64_t pre = keys[i] >> low_bit;
+    int64_t e = i + 1;
+    bool sorted = true; uint64_t prev = keys[i];
+    while (e < n) {
+        const uint64_t k2 = keys[e];
+        if ((k2 >> low_bit) != pre) break;
+        if (k2 < prev) sorted = false;
+        prev = k2; ++e;
+    }
+    if (sorted) return;
+    for (int64_t a = i + 1; a < e; ++a) {
+        const uint64_t k2 = keys[a]; const uint32_t p2 = pos[a];
+        int64_t b = a - 1;
+        while (b >= i && keys[b] > k2) { keys[b + 1] = keys[b]; pos[b + 1] = pos[b]; --b; }
+        keys[b + 1] = k2; pos[b + 1] = p2;
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k_group_sort(uint64_t* __restrict__ keys, uint32_t* __restrict__ pos, int64_t n, int low_bit) {
-    const int64_t n4 = (n + 3) >> 2;
-    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t i0 = q << 2;
-        uint64_t kk[5];
-#pragma unroll
-        for (int j = 0; j < 5; ++j) { const int64_t i = i0 - 1 + j; kk[j] = (i >= 0 && i < n) ? keys[i] : SENT; }
-#pragma unroll
-        for (int j = 1; j < 5; ++j) {
-            const int64_t i = i0 - 1 + j;
-            if (i >= n) continue;
-            const uint64_t pre = kk[j] >> low_bit;
-            if (i > 0 && (kk[j - 1] >> low_bit) == pre) continue;          // not a group leader
-            int64_t e = i + 1;
-            bool sorted = true; uint64_t prev = kk[j];
-            while (e < n) {
-                const uint64_t k2 = keys[e];
-                if ((k2 >> low_bit) != pre) break;
-                if (k2 < prev) sorted = false;
-                prev = k2; ++e;
+    __shared__ uint64_t sk[GS_TILE + GS_HALO + 1];
+    __shared__ uint32_t sp[GS_TILE + GS_HALO + 1];
+    const int64_t n_tiles = (n + GS_TILE - 1) / GS_TILE;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t t0 = tile * GS_TILE;
+        // LDS slot j holds list entry t0 - 1 + j
+        const int m = (int)min<int64_t>((int64_t)GS_TILE + GS_HALO + 1, n - t0 + 1);
+        __syncthreads();
+        for (int j = threadIdx.x; j < m; j += blockDim.x) {
+            const int64_t g = t0 - 1 + j;
+            sk[j] = g >= 0 ? keys[g] : ~0ULL;           // no real key shares the all-ones prefix
+            sp[j] = g >= 0 ? pos[g] : 0u;
+        }
+        __syncthreads();
+        const int own = (int)min<int64_t>(GS_TILE, n - t0);
+        // every staged entry ranks itself inside its group (stable): entries in front of it with a larger
+        // key move behind it, entries behind it with a smaller key move in front of it
+        for (int j = 1 + threadIdx.x; j < m; j += blockDim.x) {
+            const uint64_t key = sk[j]; const uint64_t pre = key >> low_bit;
+            int b = j - 1, before_gt = 0;
+            while (b >= 0 && (sk[b] >> low_bit) == pre) { before_gt += sk[b] > key; --b; }
+            const int gs = b + 1;                                        // slot of the group's first entry
+            if (gs < 1 || gs > own) continue;                            // the group starts in another tile
+            int f = j + 1, after_lt = 0;
+            while (f < m && (sk[f] >> low_bit) == pre) { after_lt += sk[f] < key; ++f; }
+            if (f == m && t0 - 1 + m < n) {                              // runs past the halo
+                if (j == gs) group_sort_global(keys, pos, n, t0 - 1 + j, low_bit);
+                continue;
             }
-            if (sorted) continue;
-            for (int64_t a = i + 1; a < e; ++a) {
-                const uint64_t k2 = keys[a]; const uint32_t p2 = pos[a];
-                int64_t b = a - 1;
-                while (b >= i && keys[b] > k2) { keys[b + 1] = keys[b]; pos[b + 1] = pos[b]; --b; }
-                keys[b + 1] = k2; pos[b + 1] = p2;
-            }
+            const int to = j - before_gt + after_lt;
+            if (to != j) { keys[t0 - 1 + to] = key; pos[t0 - 1 + to] = sp[j]; }
         }
     }
 }
@@ -229,6 +259,62 @@ k_runs(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos, cons
                 if (i == rs) { unsigned int o = atomicAdd(n_big, 1u); if (o < big_cap) { big_runs[2 * o] = (uint64_t)rs; big_runs[2 * o + 1] = rl; } }
                 rl = RUNLEN_MASK;
             }
+            rowinfo[wave_base ? compact_index(wave_mask, wave_base, p) : p] = ((uint64_t)rs << RUNLEN_BITS) | rl;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ K1b + K2a fused
+// The common case: every equal-prefix group fits a staged tile.  Each entry ranks itself inside
+// its group (as k_group_sort does) and, from the same two scans, knows the run of its own k-mer:
+// where it starts in the fully sorted list, how long it is, and whether the entry in front of it
+// in that order belongs to the same genome (duplicate).  It writes its genome to its final place
+// and scatters the row descriptor; the sorted keys themselves are never written.  A group that
+// does not fit raises *too_long and the host falls back to k_group_sort + k_runs.
+__global__ void __launch_bounds__(256)
+k_group_runs(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos, const uint32_t* __restrict__ blk2g, int blk_shift,
+             int64_t n, int low_bit, uint32_t* __restrict__ gen, uint64_t* __restrict__ rowinfo,
+             const unsigned long long* __restrict__ wave_mask, const uint32_t* __restrict__ wave_base, int* __restrict__ dup_per_genome,
+             unsigned int* __restrict__ too_long) {
+    __shared__ uint64_t sk[GS_TILE + GS_HALO + 1];
+    __shared__ uint32_t sp[GS_TILE + GS_HALO + 1];
+    __shared__ uint32_t sg[GS_TILE + GS_HALO + 1];
+    const int64_t n_tiles = (n + GS_TILE - 1) / GS_TILE;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t t0 = tile * GS_TILE;
+        const int m = (int)min<int64_t>((int64_t)GS_TILE + GS_HALO + 1, n - t0 + 1);
+        __syncthreads();
+        for (int j = threadIdx.x; j < m; j += blockDim.x) {
+            const int64_t g = t0 - 1 + j;
+            const uint32_t p = g >= 0 ? pos[g] : 0u;
+            sk[j] = g >= 0 ? keys[g] : ~0ULL;
+            sp[j] = p;
+            sg[j] = blk2g[p >> blk_shift];
+        }
+        __syncthreads();
+        const int own = (int)min<int64_t>(GS_TILE, n - t0);
+        for (int j = 1 + threadIdx.x; j < m; j += blockDim.x) {
+            const uint64_t key = sk[j]; const uint64_t pre = key >> low_bit;
+            int b = j - 1, lt = 0, eq_before = 0, prev_eq = -1;
+            while (b >= 0 && (sk[b] >> low_bit) == pre) {
+                const uint64_t kb = sk[b];
+                lt += kb < key;
+                if (kb == key) { if (prev_eq < 0) prev_eq = b; ++eq_before; }
+                --b;
+            }
+            const int gs = b + 1;
+            if (gs < 1 || gs > own) continue;                            // the group starts in another tile
+            int f = j + 1, eq_after = 0;
+            while (f < m && (sk[f] >> low_bit) == pre) { const uint64_t kf = sk[f]; lt += kf < key; eq_after += kf == key; ++f; }
+            if (f == m && t0 - 1 + m < n) { if (j == gs) atomicOr(too_long, 1u); continue; }
+            const int64_t rs = t0 - 1 + gs + lt;                         // first entry of this k-mer's run, sorted order
+            const uint32_t g = sg[j];
+            const bool dup = prev_eq >= 0 && sg[prev_eq] == g;
+            gen[rs + eq_before] = g | (dup ? DUP_BIT : 0u);
+            if (dup) { atomicAdd(&dup_per_genome[g], 1); continue; }
+            const uint32_t rl = (uint32_t)(eq_before + eq_after + 1);
+            if (rl < 2) continue;                                        // singleton k-mer: no partner possible
+            const uint32_t p = sp[j];
             rowinfo[wave_base ? compact_index(wave_mask, wave_base, p) : p] = ((uint64_t)rs << RUNLEN_BITS) | rl;
         }
     }
@@ -401,9 +487,18 @@ struct max_op { __device__ __host__ uint32_t operator()(uint32_t a, uint32_t b) 
 struct sorted_index {
     dbuf<uint64_t> keys; dbuf<uint32_t> pos; dbuf<int> kept; int64_t n_valid = 0;
     bool compact = false; dbuf<unsigned long long> wave_mask; dbuf<uint32_t> wave_base;
+    int low_bit = 0;            // keys are ordered on bits >= low_bit only (finish = false)
 };
 
-static void run_extract_sort(vg_genomes* g, int k, double fraction, int shard, int n_shards, sorted_index& out) {
+static void finish_sort(sorted_index& si) {
+    if (si.low_bit > 0 && si.n_valid > 0) {
+        vg_prof_scope ps("group_sort", (double)si.n_valid * 12.0);
+        hipLaunchKernelGGL(k_group_sort, dim3(grid_for(si.n_valid, GS_TILE)), dim3(256), 0, vg_stream(), si.keys.p, si.pos.p, si.n_valid, si.low_bit);
+    }
+    si.low_bit = 0;
+}
+
+static void run_extract_sort(vg_genomes* g, int k, double fraction, int shard, int n_shards, sorted_index& out, bool finish = true) {
     hipStream_t s = vg_stream();
     const int64_t P = g->padded_total();
     if (P >= (1LL << 32)) throw vg_error(VG_EOVERFLOW, "genome set exceeds 2^32 padded bases per call; use --batch-size");
@@ -449,7 +544,9 @@ static void run_extract_sort(vg_genomes* g, int k, double fraction, int shard, i
     // Stable LSD radix sort on the top key bits only (bit 2k is the sentinel flag, so sentinels end
     // up behind every real k-mer); k_group_sort then orders the small equal-prefix groups.
     const unsigned int end_bit = (unsigned)(2 * k + 1);
-    unsigned int sort_bits = n_sort <= (1LL << 29) ? 32u : 40u;
+    // a few entries per equal-prefix group on average: the run kernel finishes the order in the LDS,
+    // at a cost that grows with the group size (measured break-even: ~2.5 entries per prefix)
+    unsigned int sort_bits = n_sort <= (5LL << 23) ? 24u : (n_sort <= (5LL << 31) ? 32u : 40u);
     if (sort_bits > end_bit) sort_bits = end_bit;
     const unsigned int begin_bit = end_bit - sort_bits;
     if (n_sort > 0) {
@@ -461,11 +558,8 @@ static void run_extract_sort(vg_genomes* g, int k, double fraction, int shard, i
         VG_HIP(rocprim::radix_sort_pairs((void*)tmp.p, tmp_bytes, keys_a.p, keys_b.p, pos_a.p, pos_b.p, (size_t)n_sort, begin_bit, end_bit, s));
     }
     VG_HIP(hipStreamSynchronize(s));
-    if (begin_bit > 0 && nv > 0) {
-        vg_prof_scope ps("group_sort", (double)nv * 12.0);
-        hipLaunchKernelGGL(k_group_sort, dim3(grid_for(((int64_t)nv + 3) / 4)), dim3(256), 0, s, keys_b.p, pos_b.p, (int64_t)nv, (int)begin_bit);
-    }
-    out.keys = std::move(keys_b); out.pos = std::move(pos_b); out.n_valid = (int64_t)nv;
+    out.keys = std::move(keys_b); out.pos = std::move(pos_b); out.n_valid = (int64_t)nv; out.low_bit = (int)begin_bit;
+    if (finish) finish_sort(out);
 }
 
 extern "C" int vg_kmer_shared(vg_genomes* g, int k, double fraction, int shard, int n_shards, uint32_t min_shared,
@@ -482,7 +576,7 @@ extern "C" int vg_kmer_shared(vg_genomes* g, int k, double fraction, int shard, 
     const int n = g->n;
     if (n == 0) return VG_OK;
     sorted_index si;
-    run_extract_sort(g, k, fraction, shard, n_shards, si);
+    run_extract_sort(g, k, fraction, shard, n_shards, si, false);
     const int64_t nv = si.n_valid;
     const int64_t P = g->padded_total();
     const int64_t n_rows_info = si.compact ? std::max<int64_t>(nv, 1) : P;      // row descriptors: per kept k-mer or per base
@@ -493,8 +587,19 @@ extern "C" int vg_kmer_shared(vg_genomes* g, int k, double fraction, int shard, 
     dbuf<int> d_dups((size_t)n); d_dups.zero(s);
     constexpr unsigned int BIG_CAP = 4096;
     dbuf<uint64_t> big_runs(2 * BIG_CAP); dbuf<unsigned int> d_nbig(1); d_nbig.zero(s);
+    dbuf<unsigned int> d_long(1); d_long.zero(s);
     if (nv > 0) {
         vg_prof_scope ps("index_runs", (double)nv * (8 + 4 + 4 + 8));
+        hipLaunchKernelGGL(k_group_runs, dim3(grid_for(nv, GS_TILE)), dim3(256), 0, s, si.keys.p, si.pos.p, g->d_blk2g.p, g->align_shift, nv,
+                           si.low_bit, gen.p, rowinfo.p, wmask, wbase, d_dups.p, d_long.p);
+    }
+    unsigned int too_long = 0; d_long.download(&too_long, 1, s);
+    VG_HIP(hipStreamSynchronize(s));
+    if (too_long) {
+        // some k-mer prefix group is longer than a staged tile: finish the sort in place, then the general run pass
+        rowinfo.zero(s); d_dups.zero(s);
+        finish_sort(si);
+        vg_prof_scope ps("index_runs_general", (double)nv * (8 + 4 + 4 + 8));
         hipLaunchKernelGGL(k_runs, dim3(grid_for((nv + 3) / 4)), dim3(256), 0, s, si.keys.p, si.pos.p, g->d_blk2g.p, g->align_shift, nv,
                            gen.p, rowinfo.p, wmask, wbase, d_dups.p, big_runs.p, d_nbig.p, BIG_CAP);
     }
