@@ -593,20 +593,22 @@ extern "C" int vg_kmer_shared(vg_genomes* g, int k, double fraction, int shard, 
         hipLaunchKernelGGL(k_group_runs, dim3(grid_for(nv, GS_TILE)), dim3(256), 0, s, si.keys.p, si.pos.p, g->d_blk2g.p, g->align_shift, nv,
                            si.low_bit, gen.p, rowinfo.p, wmask, wbase, d_dups.p, d_long.p);
     }
-    unsigned int too_long = 0; d_long.download(&too_long, 1, s);
+    unsigned int too_long = 0, n_big = 0;
+    std::vector<int> kept((size_t)n), dups((size_t)n);
+    d_long.download(&too_long, 1, s); si.kept.download(kept.data(), (size_t)n, s); d_dups.download(dups.data(), (size_t)n, s);
     VG_HIP(hipStreamSynchronize(s));
     if (too_long) {
         // some k-mer prefix group is longer than a staged tile: finish the sort in place, then the general run pass
         rowinfo.zero(s); d_dups.zero(s);
         finish_sort(si);
-        vg_prof_scope ps("index_runs_general", (double)nv * (8 + 4 + 4 + 8));
-        hipLaunchKernelGGL(k_runs, dim3(grid_for((nv + 3) / 4)), dim3(256), 0, s, si.keys.p, si.pos.p, g->d_blk2g.p, g->align_shift, nv,
-                           gen.p, rowinfo.p, wmask, wbase, d_dups.p, big_runs.p, d_nbig.p, BIG_CAP);
+        {
+            vg_prof_scope ps("index_runs_general", (double)nv * (8 + 4 + 4 + 8));
+            hipLaunchKernelGGL(k_runs, dim3(grid_for((nv + 3) / 4)), dim3(256), 0, s, si.keys.p, si.pos.p, g->d_blk2g.p, g->align_shift, nv,
+                               gen.p, rowinfo.p, wmask, wbase, d_dups.p, big_runs.p, d_nbig.p, BIG_CAP);
+        }
+        d_nbig.download(&n_big, 1, s); d_dups.download(dups.data(), (size_t)n, s);
+        VG_HIP(hipStreamSynchronize(s));
     }
-    unsigned int n_big = 0; d_nbig.download(&n_big, 1, s);
-    std::vector<int> kept((size_t)n), dups((size_t)n);
-    si.kept.download(kept.data(), (size_t)n, s); d_dups.download(dups.data(), (size_t)n, s);
-    VG_HIP(hipStreamSynchronize(s));
     if (n_big > BIG_CAP) throw vg_error(VG_EOVERFLOW, "too many k-mers shared by >= 2^24 entries");
     for (int i = 0; i < n; ++i) set_sizes[i] = (int64_t)kept[i] - dups[i];
     si.keys.release();
@@ -623,8 +625,13 @@ extern "C" int vg_kmer_shared(vg_genomes* g, int k, double fraction, int shard, 
             hipLaunchKernelGGL(k_spgemm, dim3(n), dim3(256), 0, s, rowinfo.p, gen.p, big_runs.p, n_big, g->d_base_off.p, g->d_len.p, wbase, n,
                                min_shared, (const uint32_t*)nullptr, n, d_out.p, d_cursor.p, cap, d_over.p, d_nover.p);
         }
-        uint32_t nover = 0; d_nover.download(&nover, 1, s);
+        // one round trip in the common case: overflow count, pair count and the first pairs together
+        constexpr size_t EAGER = 1 << 16;
+        uint32_t nover = 0; unsigned long long produced = 0;
+        host_pairs.resize(std::min<size_t>(EAGER, (size_t)cap));
+        d_nover.download(&nover, 1, s); d_cursor.download(&produced, 1, s); d_out.download(host_pairs.data(), host_pairs.size(), s);
         VG_HIP(hipStreamSynchronize(s));
+        if (nover == 0 && produced <= host_pairs.size()) { host_pairs.resize((size_t)produced); break; }
         if (nover > 0) {
             // dense fallback, a few rows at a time
             std::vector<uint32_t> rows(nover); d_over.download(rows.data(), nover, s); VG_HIP(hipStreamSynchronize(s));
@@ -640,7 +647,7 @@ extern "C" int vg_kmer_shared(vg_genomes* g, int k, double fraction, int shard, 
                 VG_HIP(hipStreamSynchronize(s));
             }
         }
-        unsigned long long produced = 0; d_cursor.download(&produced, 1, s);
+        d_cursor.download(&produced, 1, s);
         VG_HIP(hipStreamSynchronize(s));
         if (produced <= cap) {
             host_pairs.resize((size_t)produced);
