@@ -11,8 +11,8 @@ directions.  value = unordered pairs aligned per second (whole job, all ranks).
 
 N = 1 workload: configs[1] of BASELINE.json, "phage-1k" = 100 families x 10 members x 40 kb.
 N > 1: weak scaling, N x 100 families; the prefilter is sharded by k-mer hash range (partial
-counts all-gathered over RCCL and summed), the align tasks are dealt in contiguous reference
-groups, and the per-pair integer rows are gathered to rank 0.
+counts all-gathered over RCCL and summed on the device), the align tasks are dealt by reference
+range (each rank indexes 1/N of the genomes), and the per-pair integer rows are all-gathered.
 """
 import argparse
 import json
@@ -54,22 +54,15 @@ def pmc_traffic(scope):
 
 
 def candidate_pairs(sizes, pairs, k, min_kmers, min_ident):
-    """K3 thresholds on the summed shared counts (same arithmetic as vg_write_fltr)."""
+    """K3 thresholds on the shared counts (same arithmetic as vg_write_fltr); one entry per pair."""
     if len(pairs) == 0:
         return pairs
-    key = pairs['a'].astype(np.uint64) << np.uint64(32) | pairs['b'].astype(np.uint64)
-    uk, inv = np.unique(key, return_inverse=True)
-    shared = np.zeros(len(uk), dtype=np.int64)
-    np.add.at(shared, inv, pairs['shared'].astype(np.int64))
-    a = (uk >> np.uint64(32)).astype(np.int64)
-    b = (uk & np.uint64(0xffffffff)).astype(np.int64)
+    a, b = pairs['a'].astype(np.int64), pairs['b'].astype(np.int64)
+    shared = pairs['shared'].astype(np.int64)
     mn = np.minimum(sizes[a], sizes[b]).astype(np.float64)
     j = shared / np.maximum(mn, 1.0)
     ani = 1.0 + np.log(2.0 * j / (1.0 + j)) / k
-    keep = (shared >= min_kmers) & (ani >= min_ident)
-    out = np.zeros(int(keep.sum()), dtype=api.PAIR_DTYPE)
-    out['a'], out['b'], out['shared'] = a[keep], b[keep], shared[keep]
-    return out
+    return pairs[(shared >= min_kmers) & (ani >= min_ident)]
 
 
 def cpu_baseline(sample_families, members, length, seed, threads):
@@ -200,7 +193,7 @@ def main():
                 'workload': f'phage-1k x{world}: {n_fam} families x {args.members} members x {args.length} bp, '
                             f'k={args.k}, min-kmers={args.min_kmers}, min-ident={args.min_ident}, lz defaults',
                 'genomes': int(len(gs)), 'pairs_per_step': int(n_pairs), 'total_bases': int(lens.sum()),
-                'parallelism': f'kmer-range x{world} prefilter, task-range x{world} align',
+                'parallelism': f'kmer-range x{world} prefilter, reference-range x{world} align',
             },
             'roofline': roofline,
             'cpu_baseline': cpu,

@@ -111,3 +111,21 @@ def test_merge_pair_counts():
     p = np.array([(3, 1, 5), (2, 0, 1), (3, 1, 7), (2, 0, 2), (4, 3, 9)], dtype=api.PAIR_DTYPE)
     m = D.merge_pair_counts(p)
     assert {(int(x['a']), int(x['b'])): int(x['shared']) for x in m} == {(3, 1): 12, (2, 0): 3, (4, 3): 9}
+
+
+def test_ref_owner_partitions_by_reference():
+    sys.path.insert(0, str(ROOT))
+    from vclust_amd import api, distributed as D
+    rng = np.random.default_rng(3)
+    tasks = np.zeros(5000, dtype=api.TASK_DTYPE)
+    tasks['q'] = rng.integers(0, 300, 5000); tasks['r'] = rng.integers(0, 300, 5000) ** 2 // 300     # skewed
+    for world in (1, 2, 3, 8):
+        owner = D.ref_owner(tasks, world)
+        assert owner.min() >= 0 and owner.max() <= world - 1
+        for g in np.unique(tasks['r']):                          # a reference lives on exactly one rank
+            assert len(np.unique(owner[tasks['r'] == g])) == 1
+        refs_of = [set(tasks['r'][owner == r].tolist()) for r in range(world)]
+        assert all(max(refs_of[i], default=-1) < min(refs_of[i + 1], default=1 << 30) for i in range(world - 1))
+        counts = np.bincount(owner, minlength=world)
+        assert counts.max() <= len(tasks) / world + np.bincount(tasks['r']).max()
+    assert len(D.ref_owner(tasks[:0], 4)) == 0
