@@ -47,13 +47,14 @@ def test_kmer_shared_example(example, k):
     assert _pairs_dict(pairs) == opairs
 
 
-def test_kmer_shared_shards_add_up(example):
+@pytest.mark.parametrize('n_shards', [3, 8])       # 8: the sparse emit pass (few k-mers kept per wave)
+def test_kmer_shared_shards_add_up(example, n_shards):
     codes, offsets, names, gs = example
     osizes, opairs = orc.shared_all(codes, offsets, k=25)
     tot_sizes = np.zeros(len(gs), dtype=np.int64)
     tot = {}
-    for s in range(3):
-        sizes, pairs = gs.kmer_shared(k=25, shard=s, n_shards=3)
+    for s in range(n_shards):
+        sizes, pairs = gs.kmer_shared(k=25, shard=s, n_shards=n_shards)
         tot_sizes += sizes
         for key, v in _pairs_dict(pairs).items():
             tot[key] = tot.get(key, 0) + v

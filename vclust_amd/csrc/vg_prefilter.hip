@@ -60,12 +60,15 @@ __device__ __forceinline__ uint64_t kmer_at(const kmer_args& A, int64_t p, uint3
     const uint64_t fwd = rev2(x) >> (64 - 2 * A.k);             // first base most significant
     const uint64_t rc = (~x) & kmask;                           // reverse complement, same convention
     const uint64_t cano = fwd < rc ? fwd : rc;
-    if (A.use_frac || A.n_shards > 1) {
-        const uint64_t h = mix64(cano);
-        if (A.use_frac && !(h < A.frac_thr)) return SENT;
-        if (A.n_shards > 1 && (uint32_t)(((h & 0xffffffffULL) * A.n_shards) >> 32) != A.shard) return SENT;
+    if (A.use_frac && !(mix64(cano) < A.frac_thr)) return SENT;
+    const uint64_t key = (cano * SCRAMBLE) & kmask;             // bit 2k stays 0; SENT has it set
+    if (A.n_shards > 1) {
+        // shard = a cheap second multiplicative hash of the key's LOW half (one 32-bit multiply): it
+        // must not be a function of the high bits, which the radix sort relies on being uniform
+        const uint32_t h2 = (uint32_t)key * 0x85ebca6bu;
+        if ((uint32_t)(((uint64_t)h2 * A.n_shards) >> 32) != A.shard) return SENT;
     }
-    return (cano * SCRAMBLE) & kmask;                           // bit 2k stays 0; SENT has it set
+    return key;
 }
 
 // k-mers kept per genome (|K_g| = kept - duplicates): one atomic per wave and genome
@@ -122,6 +125,56 @@ k_kmer_emit(kmer_args A, const unsigned long long* __restrict__ wave_mask, const
         const uint64_t key = kmer_at(A, p, &g);
         const uint32_t c = wave_base[p >> 6] + (uint32_t)__popcll(m & ((1ULL << (p & 63)) - 1ULL));
         keys[c] = key; pos[c] = (uint32_t)p;
+    }
+}
+
+// Sparse form of the emit pass (few k-mers kept: many shards / small fractions): a wave takes
+// eight 64-position masks, lists their set bits and gives every lane one KEPT position, so the
+// k-mer is recomputed only where it is written.
+__device__ __forceinline__ int nth_set_bit(unsigned long long m, int r) {
+    int pos = 0;
+#pragma unroll
+    for (int w = 32; w >= 1; w >>= 1) {
+        const int c = __popcll(m & ((1ULL << w) - 1ULL));
+        if (r >= c) { r -= c; m >>= w; pos += w; }
+    }
+    return pos;
+}
+
+__global__ void __launch_bounds__(256)
+k_kmer_emit_sparse(kmer_args A, const unsigned long long* __restrict__ wave_mask, const uint32_t* __restrict__ wave_base,
+                   uint64_t* __restrict__ keys, uint32_t* __restrict__ pos) {
+    const int lane = threadIdx.x & 63;
+    const int64_t W = A.P >> 6;
+    const int64_t n_chunks = (W + 7) >> 3;
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t ch = wave0; ch < n_chunks; ch += n_waves) {
+        const int64_t w0 = ch << 3;
+        unsigned long long mine = 0; uint32_t base = 0;
+        if (lane < 8 && w0 + lane < W) { mine = wave_mask[w0 + lane]; base = wave_base[w0 + lane]; }
+        unsigned long long m[8]; int pre[9]; uint32_t bs[8]; pre[0] = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            bs[j] = (uint32_t)__builtin_amdgcn_readlane((int)base, j);
+            m[j] = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, j)
+                 | ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), j) << 32);
+            pre[j + 1] = pre[j] + __popcll(m[j]);
+        }
+        for (int t = lane; t < pre[8]; t += 64) {
+            int j = 0;
+#pragma unroll
+            for (int q = 1; q < 8; ++q) j += t >= pre[q];
+            unsigned long long mj = m[0]; int pj = pre[0]; uint32_t bj = bs[0];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) if (j == q) { mj = m[q]; pj = pre[q]; bj = bs[q]; }
+            const int r = t - pj;
+            const int64_t p = ((w0 + j) << 6) + nth_set_bit(mj, r);
+            uint32_t g;
+            const uint64_t key = kmer_at(A, p, &g);
+            const uint32_t c = bj + (uint32_t)r;
+            keys[c] = key; pos[c] = (uint32_t)p;
+        }
     }
 }
 
@@ -538,7 +591,8 @@ static void run_extract_sort(vg_genomes* g, int k, double fraction, int shard, i
         keys_a.alloc(na); keys_b.alloc(na); pos_a.alloc(na); pos_b.alloc(na);
         if (n_sort > 0) {
             vg_prof_scope ps("kmer_emit", (double)P * 3.0 / 8.0 + (double)n_sort * 12.0);
-            hipLaunchKernelGGL(k_kmer_emit, dim3(grid_for(P)), dim3(256), 0, s, A, out.wave_mask.p, out.wave_base.p, keys_a.p, pos_a.p);
+            if (n_sort * 4 <= P) hipLaunchKernelGGL(k_kmer_emit_sparse, dim3(grid_for(P / 8)), dim3(256), 0, s, A, out.wave_mask.p, out.wave_base.p, keys_a.p, pos_a.p);
+            else hipLaunchKernelGGL(k_kmer_emit, dim3(grid_for(P)), dim3(256), 0, s, A, out.wave_mask.p, out.wave_base.p, keys_a.p, pos_a.p);
         }
     }
     // Stable LSD radix sort on the top key bits only (bit 2k is the sentinel flag, so sentinels end

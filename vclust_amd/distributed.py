@@ -1,7 +1,7 @@
 """One process per GPU: sharding of the integer work and the RCCL gather of result rows.
 
 The hot path shards without any data-path collective inside the kernels:
-  * prefilter: rank r handles the k-mers whose hash falls into range r of `world` (set sizes
+  * prefilter: rank r handles the k-mers whose (second) hash falls into range r of `world` (set sizes
     and shared counts of the shards add up); one variable-length all-gather of
     (a, b, shared) records (set sizes ride along as diagonal records), summed on the device;
   * align: tasks are dealt by reference range (every rank indexes 1/world of the genomes; the
