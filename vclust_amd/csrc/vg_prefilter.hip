@@ -71,6 +71,41 @@ __device__ __forceinline__ uint64_t kmer_at(const kmer_args& A, int64_t p, uint3
     return key;
 }
 
+// the four k-mers starting at padded positions p0 .. p0+3 (p0 a multiple of 4): one genome lookup,
+// one 128-bit sequence window and one 64-bit N window serve all four
+__device__ __forceinline__ void kmers4(const kmer_args& A, int64_t p0, uint64_t out[4], uint32_t* genome) {
+    const uint64_t kmask = (A.k == 32) ? ~0ULL : ((1ULL << (2 * A.k)) - 1);
+    const uint32_t g = A.blk2g[p0 >> A.blk_shift];
+    *genome = g;
+    const int64_t room = A.len[g] - (p0 - A.base_off[g]) - A.k;      // position p0 + j is valid iff j <= room
+    const int64_t mw = p0 >> 5; const int msh = (int)(p0 & 31);
+    const uint64_t m = ((uint64_t)A.nmask[mw] | ((uint64_t)A.nmask[mw + 1] << 32)) >> msh;   // msh <= 28: 36+ bits left
+    const int64_t w = p0 >> 4; const int sh = 2 * (int)(p0 & 15);    // 0, 8, 16 or 24
+    const uint64_t lo = (uint64_t)A.packed[w] | ((uint64_t)A.packed[w + 1] << 32);
+    const uint64_t hi = (uint64_t)A.packed[w + 2] | ((uint64_t)A.packed[w + 3] << 32);
+    const uint64_t nk = (1ULL << A.k) - 1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        uint64_t key = SENT;
+        if (j <= room && ((m >> j) & nk) == 0) {
+            const int s2 = sh + 2 * j;
+            uint64_t x = s2 ? ((lo >> s2) | (hi << (64 - s2))) : lo;
+            x &= kmask;
+            const uint64_t fwd = rev2(x) >> (64 - 2 * A.k);
+            const uint64_t rc = (~x) & kmask;
+            const uint64_t cano = fwd < rc ? fwd : rc;
+            if (!(A.use_frac && !(mix64(cano) < A.frac_thr))) {
+                key = (cano * SCRAMBLE) & kmask;
+                if (A.n_shards > 1) {
+                    const uint32_t h2 = (uint32_t)key * 0x85ebca6bu;
+                    if ((uint32_t)(((uint64_t)h2 * A.n_shards) >> 32) != A.shard) key = SENT;
+                }
+            }
+        }
+        out[j] = key;
+    }
+}
+
 // k-mers kept per genome (|K_g| = kept - duplicates): one atomic per wave and genome
 __device__ __forceinline__ void count_kept(bool kept, uint32_t g, int* __restrict__ kept_per_genome) {
     const uint32_t g0 = __shfl(g, 0);
@@ -80,22 +115,33 @@ __device__ __forceinline__ void count_kept(bool kept, uint32_t g, int* __restric
     } else if (kept) atomicAdd(&kept_per_genome[g], 1);
 }
 
-// Dense form (all k-mers kept: one shard, fraction 1): one thread per padded base position, 64
-// consecutive lanes read the same 3-4 packed words and write 64 consecutive u64 keys (512 B).
+// Dense form (all k-mers kept: one shard, fraction 1): four consecutive padded base positions per
+// thread (one sequence window for the four), 32 contiguous bytes of keys per thread.
 __global__ void __launch_bounds__(256)
 k_kmer_extract(kmer_args A, uint64_t* __restrict__ keys, unsigned long long* __restrict__ n_valid,
                int* __restrict__ kept_per_genome) {
+    const int lane = threadIdx.x & 63;
     unsigned long long local_valid = 0;
-    // P is a multiple of 64 and the stride a multiple of 64: whole waves stay in or out together
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < A.P; p += (int64_t)gridDim.x * blockDim.x) {
-        uint32_t g;
-        const uint64_t key = kmer_at(A, p, &g);
-        keys[p] = key;
-        local_valid += key != SENT;
-        count_kept(key != SENT, g, kept_per_genome);
+    for (int64_t p0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; p0 < A.P + 252; p0 += (int64_t)gridDim.x * blockDim.x * 4) {
+        uint64_t kk[4] = {SENT, SENT, SENT, SENT}; uint32_t g = 0;
+        const bool in = p0 < A.P;                                   // P is a multiple of 64 (so of 4)
+        if (in) {
+            kmers4(A, p0, kk, &g);
+            uint4* o = reinterpret_cast<uint4*>(keys + p0);
+            o[0] = make_uint4((uint32_t)kk[0], (uint32_t)(kk[0] >> 32), (uint32_t)kk[1], (uint32_t)(kk[1] >> 32));
+            o[1] = make_uint4((uint32_t)kk[2], (uint32_t)(kk[2] >> 32), (uint32_t)kk[3], (uint32_t)(kk[3] >> 32));
+        }
+        const int mine = (kk[0] != SENT) + (kk[1] != SENT) + (kk[2] != SENT) + (kk[3] != SENT);
+        local_valid += mine;
+        const uint32_t g0 = __shfl(g, 0);
+        if (__all(g == g0 || !in)) {
+            int tot = mine;
+            for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+            if (lane == 0 && tot) atomicAdd(&kept_per_genome[g0], tot);
+        } else if (mine) atomicAdd(&kept_per_genome[g], mine);
     }
     for (int o = 32; o > 0; o >>= 1) local_valid += __shfl_down(local_valid, o);
-    if ((threadIdx.x & 63) == 0 && local_valid) atomicAdd(n_valid, local_valid);
+    if (lane == 0 && local_valid) atomicAdd(n_valid, local_valid);
 }
 
 // Compact form (k-mer range shards, --kmers-fraction): only kept k-mers are written, in position
@@ -103,15 +149,39 @@ k_kmer_extract(kmer_args A, uint64_t* __restrict__ keys, unsigned long long* __r
 // exclusive scan of the popcounts pass 2 recomputes the k-mers (cheaper than a dense key array) and
 // writes (key, position) at wave_base + rank.  c(p) = wave_base[p/64] + popc(mask[p/64] below p)
 // later maps a position to its compact index.
+// bit i of x (i < 16) -> bit 4 i
+__device__ __forceinline__ unsigned long long spread16x4(unsigned long long x) {
+    x = (x | (x << 24)) & 0x000000ff000000ffULL;
+    x = (x | (x << 12)) & 0x000f000f000f000fULL;
+    x = (x | (x << 6)) & 0x0303030303030303ULL;
+    x = (x | (x << 3)) & 0x1111111111111111ULL;
+    return x;
+}
+
+// four positions per thread: a wave covers 256 consecutive positions = four 64-position masks
 __global__ void __launch_bounds__(256)
 k_kmer_count(kmer_args A, unsigned long long* __restrict__ wave_mask, uint32_t* __restrict__ wave_cnt,
              int* __restrict__ kept_per_genome) {
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < A.P; p += (int64_t)gridDim.x * blockDim.x) {
-        uint32_t g;
-        const bool kept = kmer_at(A, p, &g) != SENT;
-        const unsigned long long b = __ballot(kept);
-        if ((threadIdx.x & 63) == 0) { wave_mask[p >> 6] = b; wave_cnt[p >> 6] = (uint32_t)__popcll(b); }
-        count_kept(kept, g, kept_per_genome);
+    const int lane = threadIdx.x & 63;
+    for (int64_t p0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; p0 < A.P + 252; p0 += (int64_t)gridDim.x * blockDim.x * 4) {
+        // P is a multiple of 64, not of 256: the last wave may be partly outside
+        uint64_t kk[4] = {SENT, SENT, SENT, SENT}; uint32_t g = 0;
+        if (p0 < A.P) kmers4(A, p0, kk, &g);
+        const unsigned long long b0 = __ballot(kk[0] != SENT), b1 = __ballot(kk[1] != SENT);
+        const unsigned long long b2 = __ballot(kk[2] != SENT), b3 = __ballot(kk[3] != SENT);
+        const int64_t wbase = (p0 - 4 * lane) >> 6;                    // first of the wave's four masks
+        if (lane < 4 && ((wbase + lane) << 6) < A.P) {
+            const int q = 16 * lane;
+            const unsigned long long mk = spread16x4((b0 >> q) & 0xffffULL) | (spread16x4((b1 >> q) & 0xffffULL) << 1)
+                                        | (spread16x4((b2 >> q) & 0xffffULL) << 2) | (spread16x4((b3 >> q) & 0xffffULL) << 3);
+            wave_mask[wbase + lane] = mk; wave_cnt[wbase + lane] = (uint32_t)__popcll(mk);
+        }
+        const int mine = (kk[0] != SENT) + (kk[1] != SENT) + (kk[2] != SENT) + (kk[3] != SENT);
+        const uint32_t g0 = __shfl(g, 0);
+        if (__all(g == g0 || p0 >= A.P)) {
+            const int tot = __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
+            if (lane == 0 && tot) atomicAdd(&kept_per_genome[g0], tot);
+        } else if (mine) atomicAdd(&kept_per_genome[g], mine);
     }
 }
 
@@ -567,7 +637,7 @@ static void run_extract_sort(vg_genomes* g, int k, double fraction, int shard, i
         dbuf<unsigned long long> d_nvalid(1); d_nvalid.zero(s);
         {
             vg_prof_scope ps("kmer_extract", (double)P * (3.0 / 8.0 + 8.0));
-            hipLaunchKernelGGL(k_kmer_extract, dim3(grid_for(P)), dim3(256), 0, s, A, keys_a.p, d_nvalid.p, out.kept.p);
+            hipLaunchKernelGGL(k_kmer_extract, dim3(grid_for((P + 255) / 4)), dim3(256), 0, s, A, keys_a.p, d_nvalid.p, out.kept.p);
         }
         hipLaunchKernelGGL(k_iota, dim3(grid_for(P)), dim3(256), 0, s, pos_a.p, P);
         d_nvalid.download(&nv, 1, s);
@@ -577,7 +647,7 @@ static void run_extract_sort(vg_genomes* g, int k, double fraction, int shard, i
         VG_HIP(hipMemsetAsync(wave_cnt.p + W, 0, sizeof(uint32_t), s));
         {
             vg_prof_scope ps("kmer_count", (double)P * (3.0 / 8.0 + 12.0 / 64.0));
-            hipLaunchKernelGGL(k_kmer_count, dim3(grid_for(P)), dim3(256), 0, s, A, out.wave_mask.p, wave_cnt.p, out.kept.p);
+            hipLaunchKernelGGL(k_kmer_count, dim3(grid_for((P + 255) / 4)), dim3(256), 0, s, A, out.wave_mask.p, wave_cnt.p, out.kept.p);
         }
         size_t tb = 0;
         VG_HIP(rocprim::exclusive_scan(nullptr, tb, wave_cnt.p, out.wave_base.p, 0u, (size_t)W + 1, rocprim::plus<uint32_t>(), s));
