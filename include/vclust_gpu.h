@@ -128,6 +128,10 @@ int vg_align_tasks(const vg_genomes* g, const vg_pair_count* pairs, int64_t n_pa
                    vg_task** tasks, int64_t* n_tasks);
 /* HBM budget (bytes) for the per-reference indexes of one vg_lz_align batch (default 24 GiB) */
 void vg_set_index_budget(int64_t bytes);
+/* vg_kmer_shared cuts sets that exceed the 32-bit row numbering of one pass (2^32 padded bases)
+ * into sub-shards of the k-mer range automatically -- the role of `--batch-size` in the
+ * reference (vclust.py:229-239, 1403-1442); n > 0 forces that many sub-shards (tests), 0 = automatic. */
+void vg_set_subshards(int n);
 
 typedef struct {            /* mirrors the align sub-parser and cmd_lzani, vclust.py:290-421, 1142-1181 */
     vg_lz_params lz;

@@ -62,6 +62,29 @@ def test_kmer_shared_shards_add_up(example, n_shards):
     assert tot == opairs
 
 
+def test_kmer_shared_subshard_loop(example):
+    """Sets too large for one pass are processed as sub-shards of the k-mer range inside one call:
+    forced here on the small example (sizes and counts must not change), alone and under an outer shard."""
+    from vclust_amd import _lib
+    lib = _lib.load()
+    codes, offsets, names, gs = example
+    osizes, opairs = orc.shared_all(codes, offsets, k=25)
+    lib.vg_set_subshards(3)
+    try:
+        sizes, pairs = gs.kmer_shared(k=25, min_shared=20)
+        assert list(sizes) == list(osizes)
+        assert _pairs_dict(pairs) == {k: v for k, v in opairs.items() if v >= 20}
+        tot_sizes = np.zeros(len(gs), dtype=np.int64); tot = {}
+        for s in range(2):
+            sz, pr = gs.kmer_shared(k=25, shard=s, n_shards=2)
+            tot_sizes += sz
+            for key, v in _pairs_dict(pr).items():
+                tot[key] = tot.get(key, 0) + v
+        assert list(tot_sizes) == list(osizes) and tot == opairs
+    finally:
+        lib.vg_set_subshards(0)
+
+
 def test_kmer_fraction(example):
     codes, offsets, names, gs = example
     sizes, pairs = gs.kmer_shared(k=25, fraction=0.2)

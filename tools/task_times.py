@@ -1,7 +1,7 @@
 """Developer tool: per-task duration distribution of the parse kernel (VG_LZ_ABLATE=32)."""
 import os, sys, pathlib
 import numpy as np
-os.environ['VG_LZ_ABLATE'] = '32'
+os.environ['VG_LZ_ABLATE'] = os.environ.get('VG_LZ_ABLATE', '32')
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
 from vclust_amd import api, synth
 api.set_device(0)

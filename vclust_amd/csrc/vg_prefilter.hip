@@ -147,8 +147,8 @@ k_kmer_extract(kmer_args A, uint64_t* __restrict__ keys, unsigned long long* __r
 // Compact form (k-mer range shards, --kmers-fraction): only kept k-mers are written, in position
 // order.  Pass 1 records per 64-position wave the ballot of kept lanes and its popcount; after an
 // exclusive scan of the popcounts pass 2 recomputes the k-mers (cheaper than a dense key array) and
-// writes (key, position) at wave_base + rank.  c(p) = wave_base[p/64] + popc(mask[p/64] below p)
-// later maps a position to its compact index.
+// writes (key, c) at c = wave_base + rank: the compact index c is the k-mer's row number, so positions
+// never need more than the 32 bits of c (P itself may exceed 2^32).
 // bit i of x (i < 16) -> bit 4 i
 __device__ __forceinline__ unsigned long long spread16x4(unsigned long long x) {
     x = (x | (x << 24)) & 0x000000ff000000ffULL;
@@ -194,7 +194,7 @@ k_kmer_emit(kmer_args A, const unsigned long long* __restrict__ wave_mask, const
         uint32_t g;
         const uint64_t key = kmer_at(A, p, &g);
         const uint32_t c = wave_base[p >> 6] + (uint32_t)__popcll(m & ((1ULL << (p & 63)) - 1ULL));
-        keys[c] = key; pos[c] = (uint32_t)p;
+        keys[c] = key; pos[c] = c;                               // payload = compact index (row number)
     }
 }
 
@@ -243,14 +243,27 @@ k_kmer_emit_sparse(kmer_args A, const unsigned long long* __restrict__ wave_mask
             uint32_t g;
             const uint64_t key = kmer_at(A, p, &g);
             const uint32_t c = bj + (uint32_t)r;
-            keys[c] = key; pos[c] = (uint32_t)p;
+            keys[c] = key; pos[c] = c;
         }
     }
 }
 
-__device__ __forceinline__ uint32_t compact_index(const unsigned long long* __restrict__ wave_mask,
-                                                  const uint32_t* __restrict__ wave_base, uint32_t p) {
-    return wave_base[p >> 6] + (uint32_t)__popcll(wave_mask[p >> 6] & ((1ULL << (p & 63)) - 1ULL));
+// compact space: genome of compact index c.  cblk[c >> CBLK_SHIFT] is the genome holding the first
+// index of that block; a genome's range is [wave_base[base_off[g]/64], wave_base[base_off[g+1]/64]).
+constexpr int CBLK_SHIFT = 10;
+struct compact_map { const uint32_t* goff; const uint32_t* cblk; };     // goff[g] = first compact index of genome g (n + 1 entries)
+__device__ __forceinline__ uint32_t genome_of_compact(const compact_map& M, uint32_t c) {
+    uint32_t g = M.cblk[c >> CBLK_SHIFT];
+    while (c >= M.goff[g + 1]) ++g;
+    return g;
+}
+__global__ void k_cblk(const uint32_t* __restrict__ wave_base, const int64_t* __restrict__ base_off, int n, uint32_t* __restrict__ cblk,
+                       uint32_t* __restrict__ goff) {
+    for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < n; g += gridDim.x * blockDim.x) {
+        const uint32_t c0 = wave_base[base_off[g] >> 6], c1 = wave_base[base_off[g + 1] >> 6];
+        goff[g] = c0; if (g == n - 1) goff[n] = c1;
+        for (uint64_t b = ((uint64_t)c0 + (1u << CBLK_SHIFT) - 1) >> CBLK_SHIFT; (b << CBLK_SHIFT) < c1; ++b) cblk[b] = (uint32_t)g;
+    }
 }
 
 __global__ void k_iota(uint32_t* v, int64_t n) {
@@ -350,7 +363,7 @@ __device__ __forceinline__ int64_t run_upper(const uint64_t* __restrict__ keys, 
 __global__ void __launch_bounds__(256)
 k_runs(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos, const uint32_t* __restrict__ blk2g, int blk_shift,
        int64_t n, uint32_t* __restrict__ gen, uint64_t* __restrict__ rowinfo,
-       const unsigned long long* __restrict__ wave_mask, const uint32_t* __restrict__ wave_base, int* __restrict__ dup_per_genome,
+       compact_map M, int* __restrict__ dup_per_genome,
        uint64_t* __restrict__ big_runs, unsigned int* __restrict__ n_big, unsigned int big_cap) {
     // four consecutive entries per thread: their keys, positions and genomes are fetched with
     // independent loads first (the kernel is bound by load latency, not by bandwidth)
@@ -363,7 +376,7 @@ k_runs(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos, cons
 #pragma unroll
         for (int j = 0; j < 5; ++j) { const int64_t i = i0 - 1 + j; pp[j] = (i >= 0 && i < n) ? pos[i] : 0u; }
 #pragma unroll
-        for (int j = 0; j < 5; ++j) gg[j] = blk2g[pp[j] >> blk_shift];
+        for (int j = 0; j < 5; ++j) gg[j] = M.cblk ? genome_of_compact(M, pp[j]) : blk2g[pp[j] >> blk_shift];
 #pragma unroll
         for (int j = 1; j < 5; ++j) {
             const int64_t i = i0 - 1 + j;
@@ -382,7 +395,7 @@ k_runs(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos, cons
                 if (i == rs) { unsigned int o = atomicAdd(n_big, 1u); if (o < big_cap) { big_runs[2 * o] = (uint64_t)rs; big_runs[2 * o + 1] = rl; } }
                 rl = RUNLEN_MASK;
             }
-            rowinfo[wave_base ? compact_index(wave_mask, wave_base, p) : p] = ((uint64_t)rs << RUNLEN_BITS) | rl;
+            rowinfo[p] = ((uint64_t)rs << RUNLEN_BITS) | rl;            // p = base position (dense) or compact index
         }
     }
 }
@@ -397,8 +410,7 @@ k_runs(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos, cons
 __global__ void __launch_bounds__(256)
 k_group_runs(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos, const uint32_t* __restrict__ blk2g, int blk_shift,
              int64_t n, int low_bit, uint32_t* __restrict__ gen, uint64_t* __restrict__ rowinfo,
-             const unsigned long long* __restrict__ wave_mask, const uint32_t* __restrict__ wave_base, int* __restrict__ dup_per_genome,
-             unsigned int* __restrict__ too_long) {
+             compact_map M, int* __restrict__ dup_per_genome, unsigned int* __restrict__ too_long) {
     __shared__ uint64_t sk[GS_TILE + GS_HALO + 1];
     __shared__ uint32_t sp[GS_TILE + GS_HALO + 1];
     __shared__ uint32_t sg[GS_TILE + GS_HALO + 1];
@@ -412,7 +424,7 @@ k_group_runs(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos
             const uint32_t p = g >= 0 ? pos[g] : 0u;
             sk[j] = g >= 0 ? keys[g] : ~0ULL;
             sp[j] = p;
-            sg[j] = blk2g[p >> blk_shift];
+            sg[j] = g < 0 ? 0u : (M.cblk ? genome_of_compact(M, p) : blk2g[p >> blk_shift]);
         }
         __syncthreads();
         const int own = (int)min<int64_t>(GS_TILE, n - t0);
@@ -438,7 +450,7 @@ k_group_runs(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos
             const uint32_t rl = (uint32_t)(eq_before + eq_after + 1);
             if (rl < 2) continue;                                        // singleton k-mer: no partner possible
             const uint32_t p = sp[j];
-            rowinfo[wave_base ? compact_index(wave_mask, wave_base, p) : p] = ((uint64_t)rs << RUNLEN_BITS) | rl;
+            rowinfo[p] = ((uint64_t)rs << RUNLEN_BITS) | rl;            // p = base position (dense) or compact index
         }
     }
 }
@@ -604,12 +616,14 @@ struct max_op { __device__ __host__ uint32_t operator()(uint32_t a, uint32_t b) 
 
 }  // namespace
 
+static int g_force_subshards = 0;
+
 // shared pipeline: extract -> sort.  Returns sorted keys/pos of the n_valid real k-mers and the
 // per-genome number of k-mers kept by extraction.  compact = true: only kept k-mers were written
-// (wave_mask / wave_base map a position to its compact index).
+// and the sort payload is the compact index itself (wave_base / cblk map it back to its genome).
 struct sorted_index {
     dbuf<uint64_t> keys; dbuf<uint32_t> pos; dbuf<int> kept; int64_t n_valid = 0;
-    bool compact = false; dbuf<unsigned long long> wave_mask; dbuf<uint32_t> wave_base;
+    bool compact = false; dbuf<unsigned long long> wave_mask; dbuf<uint32_t> wave_base; dbuf<uint32_t> cblk, goff;
     int low_bit = 0;            // keys are ordered on bits >= low_bit only (finish = false)
 };
 
@@ -624,12 +638,13 @@ static void finish_sort(sorted_index& si) {
 static void run_extract_sort(vg_genomes* g, int k, double fraction, int shard, int n_shards, sorted_index& out, bool finish = true) {
     hipStream_t s = vg_stream();
     const int64_t P = g->padded_total();
-    if (P >= (1LL << 32)) throw vg_error(VG_EOVERFLOW, "genome set exceeds 2^32 padded bases per call; use --batch-size");
     out.kept.alloc((size_t)std::max(1, g->n)); out.kept.zero(s);
     const int use_frac = fraction < 1.0;
     kmer_args A{ g->d_packed.p, g->d_nmask.p, g->d_blk2g.p, g->d_base_off.p, g->d_len.p, P, k, use_frac,
                  use_frac ? (uint64_t)std::ldexp(fraction, 64) : ~0ULL, (uint32_t)shard, (uint32_t)n_shards, g->align_shift };
     out.compact = use_frac || n_shards > 1;
+    if (!out.compact && P >= (1LL << 32)) throw vg_error(VG_EOVERFLOW, "dense k-mer pass needs < 2^32 padded bases");
+    if (P >= (1LL << 37)) throw vg_error(VG_EOVERFLOW, "genome set exceeds 2^37 padded bases");
     dbuf<uint64_t> keys_a, keys_b; dbuf<uint32_t> pos_a, pos_b;
     int64_t n_sort = P; unsigned long long nv = 0;
     if (!out.compact) {
@@ -654,8 +669,12 @@ static void run_extract_sort(vg_genomes* g, int k, double fraction, int shard, i
         dbuf<char> tmp(tb);
         VG_HIP(rocprim::exclusive_scan((void*)tmp.p, tb, wave_cnt.p, out.wave_base.p, 0u, (size_t)W + 1, rocprim::plus<uint32_t>(), s));
         uint32_t total = 0;
+        std::vector<int> kept_h((size_t)std::max(1, g->n));
         VG_HIP(hipMemcpyAsync(&total, out.wave_base.p + W, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        out.kept.download(kept_h.data(), (size_t)g->n, s);
         VG_HIP(hipStreamSynchronize(s));
+        int64_t total64 = 0; for (int i = 0; i < g->n; ++i) total64 += kept_h[i];
+        if (total64 >= (1LL << 32) - 1) throw vg_error(VG_EOVERFLOW, "more than 2^32 k-mers in one shard: use more shards");
         nv = total; n_sort = (int64_t)total;
         const size_t na = (size_t)std::max<int64_t>(n_sort, 1);
         keys_a.alloc(na); keys_b.alloc(na); pos_a.alloc(na); pos_b.alloc(na);
@@ -664,6 +683,9 @@ static void run_extract_sort(vg_genomes* g, int k, double fraction, int shard, i
             if (n_sort * 4 <= P) hipLaunchKernelGGL(k_kmer_emit_sparse, dim3(grid_for(P / 8)), dim3(256), 0, s, A, out.wave_mask.p, out.wave_base.p, keys_a.p, pos_a.p);
             else hipLaunchKernelGGL(k_kmer_emit, dim3(grid_for(P)), dim3(256), 0, s, A, out.wave_mask.p, out.wave_base.p, keys_a.p, pos_a.p);
         }
+        out.cblk.alloc((size_t)(n_sort >> CBLK_SHIFT) + 2); out.cblk.zero(s);
+        out.goff.alloc((size_t)g->n + 1);
+        hipLaunchKernelGGL(k_cblk, dim3(grid_for(g->n)), dim3(256), 0, s, out.wave_base.p, g->d_base_off.p, g->n, out.cblk.p, out.goff.p);
     }
     // Stable LSD radix sort on the top key bits only (bit 2k is the sentinel flag, so sentinels end
     // up behind every real k-mer); k_group_sort then orders the small equal-prefix groups.
@@ -686,26 +708,18 @@ static void run_extract_sort(vg_genomes* g, int k, double fraction, int shard, i
     if (finish) finish_sort(out);
 }
 
-extern "C" int vg_kmer_shared(vg_genomes* g, int k, double fraction, int shard, int n_shards, uint32_t min_shared,
-                              int64_t* set_sizes, vg_pair_count** pairs, int64_t* n_pairs) {
-    VG_API_BEGIN
-    if (!g || !set_sizes || !pairs || !n_pairs) throw vg_error(VG_EINVAL, "vg_kmer_shared: null argument");
-    if (k < 8 || k > 31) throw vg_error(VG_EINVAL, "k out of range (8..31)");
-    if (n_shards < 1 || shard < 0 || shard >= n_shards) throw vg_error(VG_EINVAL, "bad shard");
-    if (!(fraction > 0.0) || fraction > 1.0) throw vg_error(VG_EINVAL, "fraction must be in (0,1]");
-    vg_require_device();
-    int rc = vg_genomes_to_device(g); if (rc) return rc;
+// one pass over the k-mers of one shard: per-genome set sizes and (a, b, shared) of every pair
+static void kmer_shared_pass(vg_genomes* g, int k, double fraction, int shard, int n_shards, uint32_t min_shared,
+                             int64_t* set_sizes, std::vector<vg_pair_count>& host_pairs) {
     hipStream_t s = vg_stream();
-    *pairs = nullptr; *n_pairs = 0;
     const int n = g->n;
-    if (n == 0) return VG_OK;
     sorted_index si;
     run_extract_sort(g, k, fraction, shard, n_shards, si, false);
     const int64_t nv = si.n_valid;
     const int64_t P = g->padded_total();
     const int64_t n_rows_info = si.compact ? std::max<int64_t>(nv, 1) : P;      // row descriptors: per kept k-mer or per base
     dbuf<uint64_t> rowinfo((size_t)n_rows_info); rowinfo.zero(s);
-    const unsigned long long* wmask = si.compact ? si.wave_mask.p : nullptr;
+    const compact_map cmap{ si.compact ? si.goff.p : nullptr, si.compact ? si.cblk.p : nullptr };
     const uint32_t* wbase = si.compact ? si.wave_base.p : nullptr;
     dbuf<uint32_t> gen((size_t)std::max<int64_t>(nv, 1));
     dbuf<int> d_dups((size_t)n); d_dups.zero(s);
@@ -715,7 +729,7 @@ extern "C" int vg_kmer_shared(vg_genomes* g, int k, double fraction, int shard, 
     if (nv > 0) {
         vg_prof_scope ps("index_runs", (double)nv * (8 + 4 + 4 + 8));
         hipLaunchKernelGGL(k_group_runs, dim3(grid_for(nv, GS_TILE)), dim3(256), 0, s, si.keys.p, si.pos.p, g->d_blk2g.p, g->align_shift, nv,
-                           si.low_bit, gen.p, rowinfo.p, wmask, wbase, d_dups.p, d_long.p);
+                           si.low_bit, gen.p, rowinfo.p, cmap, d_dups.p, d_long.p);
     }
     unsigned int too_long = 0, n_big = 0;
     std::vector<int> kept((size_t)n), dups((size_t)n);
@@ -728,7 +742,7 @@ extern "C" int vg_kmer_shared(vg_genomes* g, int k, double fraction, int shard, 
         {
             vg_prof_scope ps("index_runs_general", (double)nv * (8 + 4 + 4 + 8));
             hipLaunchKernelGGL(k_runs, dim3(grid_for((nv + 3) / 4)), dim3(256), 0, s, si.keys.p, si.pos.p, g->d_blk2g.p, g->align_shift, nv,
-                               gen.p, rowinfo.p, wmask, wbase, d_dups.p, big_runs.p, d_nbig.p, BIG_CAP);
+                               gen.p, rowinfo.p, cmap, d_dups.p, big_runs.p, d_nbig.p, BIG_CAP);
         }
         d_nbig.download(&n_big, 1, s); d_dups.download(dups.data(), (size_t)n, s);
         VG_HIP(hipStreamSynchronize(s));
@@ -740,7 +754,6 @@ extern "C" int vg_kmer_shared(vg_genomes* g, int k, double fraction, int shard, 
     dbuf<unsigned long long> d_cursor(1);
     dbuf<uint32_t> d_over((size_t)n), d_nover(1);
     unsigned long long cap = std::max<unsigned long long>(1u << 20, (unsigned long long)n * 16);
-    std::vector<vg_pair_count> host_pairs;
     for (;;) {
         dbuf<vg_pair_count> d_out((size_t)cap);
         d_cursor.zero(s); d_nover.zero(s);
@@ -781,12 +794,59 @@ extern "C" int vg_kmer_shared(vg_genomes* g, int k, double fraction, int shard, 
         }
         cap = produced + produced / 8 + 1024;     // rerun with a buffer that fits
     }
-    vg_pair_count* outp = (vg_pair_count*)malloc(sizeof(vg_pair_count) * std::max<size_t>(1, host_pairs.size()));
+}
+
+extern "C" int vg_kmer_shared(vg_genomes* g, int k, double fraction, int shard, int n_shards, uint32_t min_shared,
+                              int64_t* set_sizes, vg_pair_count** pairs, int64_t* n_pairs) {
+    VG_API_BEGIN
+    if (!g || !set_sizes || !pairs || !n_pairs) throw vg_error(VG_EINVAL, "vg_kmer_shared: null argument");
+    if (k < 8 || k > 31) throw vg_error(VG_EINVAL, "k out of range (8..31)");
+    if (n_shards < 1 || shard < 0 || shard >= n_shards) throw vg_error(VG_EINVAL, "bad shard");
+    if (!(fraction > 0.0) || fraction > 1.0) throw vg_error(VG_EINVAL, "fraction must be in (0,1]");
+    vg_require_device();
+    int rc = vg_genomes_to_device(g); if (rc) return rc;
+    *pairs = nullptr; *n_pairs = 0;
+    const int n = g->n;
+    if (n == 0) return VG_OK;
+    // Sets beyond the 32-bit row numbering of one pass (2^32 padded bases dense, ~2^31 kept k-mers per
+    // shard) are cut into sub-shards of this shard's k-mer range; partial counts of a pair add up.
+    const int64_t P = g->padded_total();
+    const double expect = (double)P * fraction / n_shards;
+    int sub = g_force_subshards > 0 ? g_force_subshards : (int)std::ceil(expect / (double)(1LL << 31));
+    if (sub < 1) sub = 1;
+    std::vector<vg_pair_count> acc;
+    if (sub == 1) {
+        kmer_shared_pass(g, k, fraction, shard, n_shards, min_shared, set_sizes, acc);
+    } else {
+        std::vector<int64_t> part((size_t)n);
+        for (int i = 0; i < n; ++i) set_sizes[i] = 0;
+        auto key_less = [](const vg_pair_count& x, const vg_pair_count& y) { return x.a != y.a ? x.a < y.a : x.b < y.b; };
+        for (int t = 0; t < sub; ++t) {
+            std::vector<vg_pair_count> cur;
+            kmer_shared_pass(g, k, fraction, shard * sub + t, n_shards * sub, 1u, part.data(), cur);
+            for (int i = 0; i < n; ++i) set_sizes[i] += part[i];
+            std::sort(cur.begin(), cur.end(), key_less);
+            std::vector<vg_pair_count> merged; merged.reserve(acc.size() + cur.size());
+            size_t i = 0, j = 0;
+            while (i < acc.size() || j < cur.size()) {
+                if (j == cur.size() || (i < acc.size() && key_less(acc[i], cur[j]))) merged.push_back(acc[i++]);
+                else if (i == acc.size() || key_less(cur[j], acc[i])) merged.push_back(cur[j++]);
+                else { vg_pair_count m = acc[i++]; m.shared += cur[j++].shared; merged.push_back(m); }
+            }
+            acc.swap(merged);
+        }
+        if (min_shared > 1) acc.erase(std::remove_if(acc.begin(), acc.end(), [&](const vg_pair_count& x) { return x.shared < min_shared; }), acc.end());
+    }
+    vg_pair_count* outp = (vg_pair_count*)malloc(sizeof(vg_pair_count) * std::max<size_t>(1, acc.size()));
     if (!outp) throw vg_error(VG_ENOMEM, "out of host memory");
-    if (!host_pairs.empty()) memcpy(outp, host_pairs.data(), sizeof(vg_pair_count) * host_pairs.size());
-    *pairs = outp; *n_pairs = (int64_t)host_pairs.size();
+    if (!acc.empty()) memcpy(outp, acc.data(), sizeof(vg_pair_count) * acc.size());
+    *pairs = outp; *n_pairs = (int64_t)acc.size();
     VG_API_END
 }
+
+// developer/test knob: force the sub-shard loop on small inputs (0 = automatic)
+static_assert(sizeof(vg_pair_count) == 12, "pair record layout");
+extern "C" void vg_set_subshards(int n) { g_force_subshards = n; }
 
 extern "C" int vg_kmer_set(vg_genomes* g, int idx, int k, double fraction, uint64_t** out, int64_t* n_out) {
     VG_API_BEGIN
@@ -802,7 +862,14 @@ extern "C" int vg_kmer_set(vg_genomes* g, int idx, int k, double fraction, uint6
     if (si.n_valid) { si.keys.download(keys.data(), keys.size(), s); si.pos.download(pos.data(), pos.size(), s); }
     VG_HIP(hipStreamSynchronize(s));
     std::vector<uint64_t> mine;
-    const int64_t lo = g->base_off[idx], hi = g->base_off[idx + 1];
+    int64_t lo = g->base_off[idx], hi = g->base_off[idx + 1];
+    if (si.compact) {                                          // payload = compact index: the genome's row range
+        uint32_t c[2];
+        VG_HIP(hipMemcpyAsync(&c[0], si.wave_base.p + (lo >> 6), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        VG_HIP(hipMemcpyAsync(&c[1], si.wave_base.p + (hi >> 6), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        VG_HIP(hipStreamSynchronize(s));
+        lo = c[0]; hi = c[1];
+    }
     uint64_t inv = SCRAMBLE;                                   // inverse of SCRAMBLE mod 2^64 (Newton)
     for (int it = 0; it < 6; ++it) inv *= 2 - SCRAMBLE * inv;
     const uint64_t kmask = (1ULL << (2 * k)) - 1;
