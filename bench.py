@@ -97,6 +97,9 @@ def main():
     ap.add_argument('--k', type=int, default=25)
     ap.add_argument('--min-kmers', type=int, default=20)
     ap.add_argument('--min-ident', type=float, default=0.7)
+    ap.add_argument('--workload', choices=['phage', 'imgvr'], default='phage',
+                    help='phage: families x members x length (configs[1]/[3]); imgvr: --contigs mixed 5-200 kb contigs (configs[2])')
+    ap.add_argument('--contigs', type=int, default=10000, help='contigs per GPU for --workload imgvr')
     ap.add_argument('--cpu-sample-families', type=int, default=100)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
@@ -115,7 +118,12 @@ def main():
     api.set_device(local_rank % api.device_count())
 
     n_fam = args.families * world
-    codes, offsets, names = synth.make_families(n_fam, args.members, length=args.length, seed=1)
+    if args.workload == 'imgvr':
+        codes, offsets, names, _ = synth.make_contigs(args.contigs * world, seed=2)
+        wl = f'imgvr-like x{world}: {len(names)} contigs log-uniform 5-200 kb, families geometric(0.2) <= 20'
+    else:
+        codes, offsets, names = synth.make_families(n_fam, args.members, length=args.length, seed=1)
+        wl = f'phage-1k x{world}: {n_fam} families x {args.members} members x {args.length} bp'
     gs = api.GenomeSet.from_codes(codes, offsets, names)
     gs.to_device()
     lens = gs.lengths()
@@ -167,13 +175,13 @@ def main():
             avg_ms = dom['total_ms'] / dom['launches']
             alg_bytes = dom['bytes'] / dom['launches']
             achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-            traffic, traffic_src = pmc_traffic(dom['name']) if world == 1 and args.families == 100 else (None, None)
+            traffic, traffic_src = pmc_traffic(dom['name']) if world == 1 and args.families == 100 and args.workload == 'phage' else (None, None)
             roofline = dict(bound='hbm', kernel=dom['name'], achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit='GB/s',
                             frac=round(achieved / HBM_PEAK_GBS, 6), traffic=traffic, traffic_source=traffic_src,
                             avg_launch_ms=round(avg_ms, 4), algorithmic_bytes_per_launch=round(alg_bytes),
                             kernels={e['name']: round(e['total_ms'] / max(e['launches'], 1), 4) for e in prof})
         cpu = None
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == 'phage':
             cpu = cpu_baseline(min(args.cpu_sample_families, args.families), args.members, args.length, 1,
                                os.cpu_count() or 1)
         out = {
@@ -190,8 +198,7 @@ def main():
             'dtype': 'u64',
             'data': 'synthetic',
             'config': {
-                'workload': f'phage-1k x{world}: {n_fam} families x {args.members} members x {args.length} bp, '
-                            f'k={args.k}, min-kmers={args.min_kmers}, min-ident={args.min_ident}, lz defaults',
+                'workload': f'{wl}, k={args.k}, min-kmers={args.min_kmers}, min-ident={args.min_ident}, lz defaults',
                 'genomes': int(len(gs)), 'pairs_per_step': int(n_pairs), 'total_bases': int(lens.sum()),
                 'parallelism': f'kmer-range x{world} prefilter, reference-range x{world} align',
             },

@@ -153,3 +153,27 @@ def test_full_size_properties():
         q, r = int(tasks[i]['q']), int(tasks[i]['r'])
         ref = orc.lz_pair_stat(codes[offsets[q]:offsets[q + 1]], codes[offsets[r]:offsets[r + 1]])
         assert ref == tuple(int(x) for x in stats[i]), (q, r)
+
+
+def test_imgvr_like_properties():
+    """BASELINE configs[2] shape (mixed 5-200 kb contigs, families of 1-20), reduced to 600 contigs:
+    the prefilter passes exactly the within-family pairs, alignment rows obey the size-independent
+    invariants, and a sample of tasks (long and short references: LDS sections / plain) equals the oracle."""
+    codes, offsets, names, fam = synth.make_contigs(600, seed=2)
+    gs = api.GenomeSet.from_codes(codes, offsets, names)
+    sizes, pairs = gs.kmer_shared(k=25, min_shared=20)
+    assert np.all(fam[pairs['a']] == fam[pairs['b']])
+    n_expected = sum(c * (c - 1) // 2 for c in np.bincount(fam))
+    # (a few pairs of short, strongly diverged contigs keep < 20 shared 25-mers)
+    assert 0.98 * n_expected <= len(pairs) <= n_expected
+    tasks = gs.align_tasks(pairs)
+    stats = gs.lz_align(tasks)
+    lens = gs.lengths()
+    assert np.all(stats['n_match'] <= stats['aln_len']) and np.all(stats['aln_len'] <= lens[tasks['q']])
+    assert np.array_equal(stats, gs.lz_align(tasks))
+    order = np.argsort(lens[tasks['r']])
+    idx = np.concatenate([order[:10], order[-10:], np.random.default_rng(1).choice(len(tasks), 20, replace=False)])
+    for i in idx:
+        q, r = int(tasks[i]['q']), int(tasks[i]['r'])
+        ref = orc.lz_pair_stat(codes[offsets[q]:offsets[q + 1]], codes[offsets[r]:offsets[r + 1]])
+        assert ref == tuple(int(x) for x in stats[i]), (q, r)

@@ -56,6 +56,26 @@ def make_families(n_families, members, length=40000, seed=1, p_lo=0.005, p_hi=0.
     return codes, offsets, names
 
 
+def make_contigs(n_contigs, len_lo=5000, len_hi=200000, max_family=20, seed=2, p_lo=0.005, p_hi=0.12, n_indels=5):
+    """IMG/VR-like set (BASELINE configs[2] / [4]): ancestor lengths log-uniform in [len_lo, len_hi],
+    family sizes geometric(0.2) capped at max_family, same mutation model as make_families.
+    -> (codes, offsets, names, family id per contig)."""
+    rng = np.random.default_rng(seed)
+    seqs, names, fam_of = [], [], []
+    fam = 0
+    while len(seqs) < n_contigs:
+        members = min(int(rng.geometric(0.2)), max_family, n_contigs - len(seqs))
+        ln = int(np.exp(rng.uniform(np.log(len_lo), np.log(len_hi))))
+        anc = rng.integers(0, 4, size=ln, dtype=np.uint8)
+        for m in range(members):
+            seqs.append(_mutate(rng, anc, p_lo, p_hi, n_indels))
+            names.append(f'ctg{fam:06d}_{m:02d}'); fam_of.append(fam)
+        fam += 1
+    offsets = np.zeros(len(seqs) + 1, dtype=np.int64)
+    offsets[1:] = np.cumsum([len(s) for s in seqs])
+    return np.concatenate(seqs), offsets, names, np.array(fam_of, dtype=np.int64)
+
+
 def family_pairs(n_families, members):
     """All within-family pairs as a structured (a > b) array: what the prefilter is expected
     to pass on random-ancestor data."""
