@@ -177,3 +177,46 @@ def test_imgvr_like_properties():
         q, r = int(tasks[i]['q']), int(tasks[i]['r'])
         ref = orc.lz_pair_stat(codes[offsets[q]:offsets[q + 1]], codes[offsets[r]:offsets[r + 1]])
         assert ref == tuple(int(x) for x in stats[i]), (q, r)
+
+
+def _scrambled_key(kmer_codes, k):
+    """The product's sort key of a k-mer (vg_prefilter.hip: canonical, first base most significant,
+    times an odd constant mod 4^k) -- only used to BUILD an adversarial input, not to check results."""
+    fwd = 0
+    for c in kmer_codes:
+        fwd = (fwd << 2) | int(c)
+    rc = 0
+    for c in kmer_codes[::-1]:
+        rc = (rc << 2) | (3 - int(c))
+    return (min(fwd, rc) * 0x9E3779B97F4A7C15) & ((1 << (2 * k)) - 1)
+
+
+def test_two_frequent_kmers_in_one_prefix_group():
+    """Two k-mers that each occur 1 400 times AND share the 24-bit radix prefix: their group is longer
+    than a staged window and mixed, so the call must take the general path (full-bit sort + galloping
+    run search)."""
+    k = 25
+    rng = np.random.default_rng(21)
+    seen = {}
+    pair = None
+    while pair is None:
+        km = rng.integers(0, 4, size=k, dtype=np.uint8)
+        pre = _scrambled_key(km, k) >> (2 * k + 1 - 24)
+        if pre in seen and not np.array_equal(seen[pre], km):
+            pair = (seen[pre], km)
+        seen[pre] = km
+    seqs = []
+    for i in range(1400):
+        fl = [rng.integers(0, 4, size=int(rng.integers(40, 90)), dtype=np.uint8) for _ in range(3)]
+        seqs.append(np.concatenate([fl[0], pair[0], fl[1], pair[1], fl[2]]))
+    offsets = np.zeros(len(seqs) + 1, dtype=np.int64); offsets[1:] = np.cumsum([len(s) for s in seqs])
+    codes = np.concatenate(seqs)
+    gs = api.GenomeSet.from_codes(codes, offsets)
+    api.profile_enable(True); api.profile_reset()
+    try:
+        pairs = _check_prefilter(codes, offsets, gs, k)
+        scopes = {e['name'] for e in api.profile_get()}
+    finally:
+        api.profile_enable(False)
+    assert len(pairs) == 1400 * 1399 // 2 and int(pairs['shared'].min()) >= 2
+    assert 'index_long_runs' in scopes and 'index_runs_general' in scopes, scopes

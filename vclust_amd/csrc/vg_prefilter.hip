@@ -270,72 +270,13 @@ __global__ void k_iota(uint32_t* v, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) v[i] = (uint32_t)i;
 }
 
-// ------------------------------------------------------------------ K1b: finish the partial sort
+// ------------------------------------------------------------------ partial sort
 // The device radix sort only orders the top `sort_bits` key bits (3-4 passes instead of 7).
 // Entries with equal prefix form small contiguous groups (the scramble makes prefixes uniform:
-// about n / 2^sort_bits entries each, plus the repeats of a k-mer).  A workgroup stages a tile of
-// the list (+ a halo, so that every group that starts inside the tile is complete) in the LDS;
-// every entry then ranks itself inside its group by the full key (stable) and is written to its
-// final place only if it moves.  Groups longer than the halo (a k-mer that occurs thousands of
-// times) are ordered in place in global memory by their first entry.
-constexpr int GS_TILE = 2048;
-constexpr int GS_HALO = 512;
-
-__device__ void group_sort_global(uint64_t* __restrict__ keys, uint32_t* __restrict__ pos, int64_t n, int64_t i, int low_bit) {
-    const uint64_t pre = keys[i] >> low_bit;
-    int64_t e = i + 1;
-    bool sorted = true; uint64_t prev = keys[i];
-    while (e < n) {
-        const uint64_t k2 = keys[e];
-        if ((k2 >> low_bit) != pre) break;
-        if (k2 < prev) sorted = false;
-        prev = k2; ++e;
-    }
-    if (sorted) return;
-    for (int64_t a = i + 1; a < e; ++a) {
-        const uint64_t k2 = keys[a]; const uint32_t p2 = pos[a];
-        int64_t b = a - 1;
-        while (b >= i && keys[b] > k2) { keys[b + 1] = keys[b]; pos[b + 1] = pos[b]; --b; }
-        keys[b + 1] = k2; pos[b + 1] = p2;
-    }
-}
-
-__global__ void __launch_bounds__(256)
-k_group_sort(uint64_t* __restrict__ keys, uint32_t* __restrict__ pos, int64_t n, int low_bit) {
-    __shared__ uint64_t sk[GS_TILE + GS_HALO + 1];
-    __shared__ uint32_t sp[GS_TILE + GS_HALO + 1];
-    const int64_t n_tiles = (n + GS_TILE - 1) / GS_TILE;
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int64_t t0 = tile * GS_TILE;
-        // LDS slot j holds list entry t0 - 1 + j
-        const int m = (int)min<int64_t>((int64_t)GS_TILE + GS_HALO + 1, n - t0 + 1);
-        __syncthreads();
-        for (int j = threadIdx.x; j < m; j += blockDim.x) {
-            const int64_t g = t0 - 1 + j;
-            sk[j] = g >= 0 ? keys[g] : ~0ULL;           // no real key shares the all-ones prefix
-            sp[j] = g >= 0 ? pos[g] : 0u;
-        }
-        __syncthreads();
-        const int own = (int)min<int64_t>(GS_TILE, n - t0);
-        // every staged entry ranks itself inside its group (stable): entries in front of it with a larger
-        // key move behind it, entries behind it with a smaller key move in front of it
-        for (int j = 1 + threadIdx.x; j < m; j += blockDim.x) {
-            const uint64_t key = sk[j]; const uint64_t pre = key >> low_bit;
-            int b = j - 1, before_gt = 0;
-            while (b >= 0 && (sk[b] >> low_bit) == pre) { before_gt += sk[b] > key; --b; }
-            const int gs = b + 1;                                        // slot of the group's first entry
-            if (gs < 1 || gs > own) continue;                            // the group starts in another tile
-            int f = j + 1, after_lt = 0;
-            while (f < m && (sk[f] >> low_bit) == pre) { after_lt += sk[f] < key; ++f; }
-            if (f == m && t0 - 1 + m < n) {                              // runs past the halo
-                if (j == gs) group_sort_global(keys, pos, n, t0 - 1 + j, low_bit);
-                continue;
-            }
-            const int to = j - before_gt + after_lt;
-            if (to != j) { keys[t0 - 1 + to] = key; pos[t0 - 1 + to] = sp[j]; }
-        }
-    }
-}
+// about n / 2^sort_bits entries each, plus the repeats of a k-mer); k_group_runs below finishes
+// the order inside the groups on the fly.
+constexpr int GS_TILE = 2048;       // list entries owned by a workgroup per trip
+constexpr int GS_HALO = 512;        // staged beyond the tile so that groups starting inside it are complete
 
 // ------------------------------------------------------------------ K2a: runs of the inverted index
 // One pass over the sorted (k-mer, position) list: every entry finds the boundaries of its run
@@ -402,15 +343,17 @@ k_runs(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos, cons
 
 // ------------------------------------------------------------------ K1b + K2a fused
 // The common case: every equal-prefix group fits a staged tile.  Each entry ranks itself inside
-// its group (as k_group_sort does) and, from the same two scans, knows the run of its own k-mer:
+// its group by the full key (stable) and, from the same two scans, knows the run of its own k-mer:
 // where it starts in the fully sorted list, how long it is, and whether the entry in front of it
 // in that order belongs to the same genome (duplicate).  It writes its genome to its final place
 // and scatters the row descriptor; the sorted keys themselves are never written.  A group that
-// does not fit raises *too_long and the host falls back to k_group_sort + k_runs.
+// does not fit the staged window (a k-mer that occurs hundreds of times: low-complexity sequence,
+// conserved genes) is queued for k_long_groups.
 __global__ void __launch_bounds__(256)
 k_group_runs(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos, const uint32_t* __restrict__ blk2g, int blk_shift,
              int64_t n, int low_bit, uint32_t* __restrict__ gen, uint64_t* __restrict__ rowinfo,
-             compact_map M, int* __restrict__ dup_per_genome, unsigned int* __restrict__ too_long) {
+             compact_map M, int* __restrict__ dup_per_genome, int64_t* __restrict__ long_list, unsigned int* __restrict__ n_long,
+             unsigned int long_cap) {
     __shared__ uint64_t sk[GS_TILE + GS_HALO + 1];
     __shared__ uint32_t sp[GS_TILE + GS_HALO + 1];
     __shared__ uint32_t sg[GS_TILE + GS_HALO + 1];
@@ -441,7 +384,10 @@ k_group_runs(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos
             if (gs < 1 || gs > own) continue;                            // the group starts in another tile
             int f = j + 1, eq_after = 0;
             while (f < m && (sk[f] >> low_bit) == pre) { const uint64_t kf = sk[f]; lt += kf < key; eq_after += kf == key; ++f; }
-            if (f == m && t0 - 1 + m < n) { if (j == gs) atomicOr(too_long, 1u); continue; }
+            if (f == m && t0 - 1 + m < n) {                               // runs past the halo: one entry queues the group
+                if (j == gs) { const unsigned int o = atomicAdd(n_long, 1u); if (o < long_cap) long_list[o] = t0 - 1 + gs; }
+                continue;
+            }
             const int64_t rs = t0 - 1 + gs + lt;                         // first entry of this k-mer's run, sorted order
             const uint32_t g = sg[j];
             const bool dup = prev_eq >= 0 && sg[prev_eq] == g;
@@ -452,6 +398,49 @@ k_group_runs(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos
             const uint32_t p = sp[j];
             rowinfo[p] = ((uint64_t)rs << RUNLEN_BITS) | rl;            // p = base position (dense) or compact index
         }
+    }
+}
+
+// A queued group: one workgroup walks it.  If it is a single k-mer (the usual case: one long run),
+// start and length of the run are the group's, the order is already final, and every entry gets
+// its genome / duplicate flag / row descriptor in parallel.  Several k-mers sharing the prefix of
+// a long group need a real sort: *need_full_sort sends the call to the general path.
+__global__ void __launch_bounds__(256)
+k_long_groups(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos, const uint32_t* __restrict__ blk2g, int blk_shift,
+              int64_t n, int low_bit, const int64_t* __restrict__ long_list, uint32_t* __restrict__ gen, uint64_t* __restrict__ rowinfo,
+              compact_map M, int* __restrict__ dup_per_genome, uint64_t* __restrict__ big_runs, unsigned int* __restrict__ n_big,
+              unsigned int big_cap, unsigned int* __restrict__ need_full_sort) {
+    __shared__ int64_t s_end;
+    const int64_t gs = long_list[blockIdx.x];
+    const uint64_t key0 = keys[gs]; const uint64_t pre = key0 >> low_bit;
+    if (threadIdx.x == 0) s_end = n;
+    __syncthreads();
+    bool same = true;
+    for (int64_t base = gs; base < n; base += blockDim.x) {
+        const int64_t i = base + threadIdx.x;
+        bool inside = false;
+        if (i < n) {
+            const uint64_t kx = keys[i];
+            inside = (kx >> low_bit) == pre;
+            if (inside) same = same && kx == key0; else atomicMin((unsigned long long*)&s_end, (unsigned long long)i);
+        }
+        if (!__syncthreads_and(inside)) break;                     // the group ends inside this chunk (or at n)
+    }
+    if (!__syncthreads_and(same)) { if (threadIdx.x == 0) atomicOr(need_full_sort, 1u); return; }
+    const int64_t ge = s_end;
+    uint64_t rl = (uint64_t)(ge - gs);
+    if (rl >= RUNLEN_MASK) {
+        if (threadIdx.x == 0) { const unsigned int o = atomicAdd(n_big, 1u); if (o < big_cap) { big_runs[2 * o] = (uint64_t)gs; big_runs[2 * o + 1] = rl; } }
+        rl = RUNLEN_MASK;
+    }
+    for (int64_t i = gs + threadIdx.x; i < ge; i += blockDim.x) {
+        const uint32_t p = pos[i];
+        const uint32_t g = M.cblk ? genome_of_compact(M, p) : blk2g[p >> blk_shift];
+        bool dup = false;
+        if (i > gs) { const uint32_t pp = pos[i - 1]; dup = (M.cblk ? genome_of_compact(M, pp) : blk2g[pp >> blk_shift]) == g; }
+        gen[i] = g | (dup ? DUP_BIT : 0u);
+        if (dup) { atomicAdd(&dup_per_genome[g], 1); continue; }
+        rowinfo[p] = ((uint64_t)gs << RUNLEN_BITS) | rl;
     }
 }
 
@@ -627,10 +616,20 @@ struct sorted_index {
     int low_bit = 0;            // keys are ordered on bits >= low_bit only (finish = false)
 };
 
-static void finish_sort(sorted_index& si) {
+// general path: order the list on ALL key bits (the prefix order is thrown away: a stable LSD sort
+// from bit 0 keeps equal k-mers in position order) -- O(n) whatever the data looks like
+static void finish_sort(sorted_index& si, int k) {
     if (si.low_bit > 0 && si.n_valid > 0) {
-        vg_prof_scope ps("group_sort", (double)si.n_valid * 12.0);
-        hipLaunchKernelGGL(k_group_sort, dim3(grid_for(si.n_valid, GS_TILE)), dim3(256), 0, vg_stream(), si.keys.p, si.pos.p, si.n_valid, si.low_bit);
+        hipStream_t s = vg_stream();
+        const size_t n = (size_t)si.n_valid;
+        dbuf<uint64_t> k2(n); dbuf<uint32_t> p2(n);
+        size_t tmp_bytes = 0;
+        VG_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, si.keys.p, k2.p, si.pos.p, p2.p, n, 0u, (unsigned)(2 * k), s));
+        dbuf<char> tmp(tmp_bytes);
+        vg_prof_scope ps("radix_sort_full", (double)n * 12.0 * 2.0 * ((2 * k + 7) / 8));
+        VG_HIP(rocprim::radix_sort_pairs((void*)tmp.p, tmp_bytes, si.keys.p, k2.p, si.pos.p, p2.p, n, 0u, (unsigned)(2 * k), s));
+        VG_HIP(hipStreamSynchronize(s));
+        si.keys = std::move(k2); si.pos = std::move(p2);
     }
     si.low_bit = 0;
 }
@@ -688,7 +687,7 @@ static void run_extract_sort(vg_genomes* g, int k, double fraction, int shard, i
         hipLaunchKernelGGL(k_cblk, dim3(grid_for(g->n)), dim3(256), 0, s, out.wave_base.p, g->d_base_off.p, g->n, out.cblk.p, out.goff.p);
     }
     // Stable LSD radix sort on the top key bits only (bit 2k is the sentinel flag, so sentinels end
-    // up behind every real k-mer); k_group_sort then orders the small equal-prefix groups.
+    // up behind every real k-mer); k_group_runs then orders the small equal-prefix groups.
     const unsigned int end_bit = (unsigned)(2 * k + 1);
     // a few entries per equal-prefix group on average: the run kernel finishes the order in the LDS,
     // at a cost that grows with the group size (measured break-even: ~2.5 entries per prefix)
@@ -705,7 +704,7 @@ static void run_extract_sort(vg_genomes* g, int k, double fraction, int shard, i
     }
     VG_HIP(hipStreamSynchronize(s));
     out.keys = std::move(keys_b); out.pos = std::move(pos_b); out.n_valid = (int64_t)nv; out.low_bit = (int)begin_bit;
-    if (finish) finish_sort(out);
+    if (finish) finish_sort(out, k);
 }
 
 // one pass over the k-mers of one shard: per-genome set sizes and (a, b, shared) of every pair
@@ -725,20 +724,30 @@ static void kmer_shared_pass(vg_genomes* g, int k, double fraction, int shard, i
     dbuf<int> d_dups((size_t)n); d_dups.zero(s);
     constexpr unsigned int BIG_CAP = 4096;
     dbuf<uint64_t> big_runs(2 * BIG_CAP); dbuf<unsigned int> d_nbig(1); d_nbig.zero(s);
-    dbuf<unsigned int> d_long(1); d_long.zero(s);
+    constexpr unsigned int LONG_CAP = 1u << 16;
+    dbuf<int64_t> long_list(LONG_CAP); dbuf<unsigned int> d_nlong(1), d_full(1); d_nlong.zero(s); d_full.zero(s);
     if (nv > 0) {
         vg_prof_scope ps("index_runs", (double)nv * (8 + 4 + 4 + 8));
         hipLaunchKernelGGL(k_group_runs, dim3(grid_for(nv, GS_TILE)), dim3(256), 0, s, si.keys.p, si.pos.p, g->d_blk2g.p, g->align_shift, nv,
-                           si.low_bit, gen.p, rowinfo.p, cmap, d_dups.p, d_long.p);
+                           si.low_bit, gen.p, rowinfo.p, cmap, d_dups.p, long_list.p, d_nlong.p, LONG_CAP);
     }
-    unsigned int too_long = 0, n_big = 0;
+    unsigned int n_long = 0, need_full = 0, n_big = 0;
     std::vector<int> kept((size_t)n), dups((size_t)n);
-    d_long.download(&too_long, 1, s); si.kept.download(kept.data(), (size_t)n, s); d_dups.download(dups.data(), (size_t)n, s);
+    d_nlong.download(&n_long, 1, s); si.kept.download(kept.data(), (size_t)n, s); d_dups.download(dups.data(), (size_t)n, s);
     VG_HIP(hipStreamSynchronize(s));
-    if (too_long) {
-        // some k-mer prefix group is longer than a staged tile: finish the sort in place, then the general run pass
-        rowinfo.zero(s); d_dups.zero(s);
-        finish_sort(si);
+    if (n_long > 0 && n_long <= LONG_CAP) {
+        {
+            vg_prof_scope ps("index_long_runs", 0);
+            hipLaunchKernelGGL(k_long_groups, dim3(n_long), dim3(256), 0, s, si.keys.p, si.pos.p, g->d_blk2g.p, g->align_shift, nv, si.low_bit,
+                               long_list.p, gen.p, rowinfo.p, cmap, d_dups.p, big_runs.p, d_nbig.p, BIG_CAP, d_full.p);
+        }
+        d_full.download(&need_full, 1, s); d_nbig.download(&n_big, 1, s); d_dups.download(dups.data(), (size_t)n, s);
+        VG_HIP(hipStreamSynchronize(s));
+    }
+    if (need_full || n_long > LONG_CAP) {
+        // several frequent k-mers share a prefix group (or too many long groups): sort on all bits, general run pass
+        rowinfo.zero(s); d_dups.zero(s); d_nbig.zero(s);
+        finish_sort(si, k);
         {
             vg_prof_scope ps("index_runs_general", (double)nv * (8 + 4 + 4 + 8));
             hipLaunchKernelGGL(k_runs, dim3(grid_for((nv + 3) / 4)), dim3(256), 0, s, si.keys.p, si.pos.p, g->d_blk2g.p, g->align_shift, nv,
