@@ -319,6 +319,8 @@ __device__ __forceinline__ uint32_t anchor_tag(uint64_t h, int B, int pos_bits) 
 // coalesced copy: no 4-byte scatter to HBM (the first version wrote 10x the index size).
 constexpr int LDS_TAB = 16384;      // bucket table: anchors use B <= 14 bits, seeds 4^msl <= 16384
 constexpr int LDS_STAGE = 16384;    // staged entries per window
+constexpr int TOP_BITS = 9;         // big references: entries are first dealt into 2^TOP_BITS bins
+constexpr int BIG_RR = 131072;      // RR symbols from which the linear (binned) build is used
 __device__ __forceinline__ void lds_scan_exclusive(uint32_t* tab, int n, uint32_t* part) {
     // blockDim.x == 1024: each thread owns ceil(n/1024) consecutive entries
     const int per = (n + 1023) / 1024;
@@ -348,8 +350,11 @@ k_build_index_lds(const ref_desc* __restrict__ refs, const int* __restrict__ slo
     __shared__ uint32_t tab[LDS_TAB];
     __shared__ uint32_t stage[LDS_STAGE];
     __shared__ uint32_t part[1024];
+    __shared__ uint32_t s_bstart[(1 << TOP_BITS) + 1];
     __shared__ int s_whi;
-    uint32_t* scratch = scratch_pool + (int64_t)blockIdx.x * scratch_stride;     // (bucket | tag << 16) per RR position
+    // per workgroup: (bucket | tag << 18) per RR position, then the (bucket|tag, position) list by top-level bin
+    uint32_t* scratch = scratch_pool + (int64_t)blockIdx.x * scratch_stride * 3;
+    uint2* binned = reinterpret_cast<uint2*>(scratch + scratch_stride);
     const uint64_t amask = (mal >= 32) ? ~0ULL : ((1ULL << (2 * mal)) - 1);
     const uint64_t smask = (1ULL << (2 * msl)) - 1;
     for (int li = blockIdx.x; li < n_list; li += gridDim.x) {
@@ -366,19 +371,17 @@ k_build_index_lds(const ref_desc* __restrict__ refs, const int* __restrict__ slo
         __threadfence_block();
         __syncthreads();
         for (int phase = 0; phase < 2; ++phase) {
-            // Bucket tables larger than the LDS table are built section by section (LDS_TAB buckets at a
-            // time); scratch keeps (bucket : 18 bits | tag : 14 bits) per position so that the k-mer
-            // is hashed once.
             const int nbits = phase == 0 ? rd.B : 2 * msl;
-            const int n_sec = nbits > 14 ? (1 << (nbits - 14)) : 1;
-            const int nb = nbits > 14 ? LDS_TAB : (1 << nbits);
             const int w = phase == 0 ? mal : msl;
             uint32_t* gtab = phase == 0 ? atab_pool + rd.atab : stab_pool + rd.stab;
             uint32_t* gent = phase == 0 ? aent_pool + rd.aent : sent_pool + rd.sent;
-            if (n_sec == 1) { for (int i = threadIdx.x; i < nb; i += blockDim.x) tab[i] = 0; }
+            const bool big = rd.n_rr >= BIG_RR || nbits > 14;
+            // pass 0: bucket (and tag) of every position -> scratch; sizes of the buckets (plain path) or
+            // of the 512 top-level bins (big path).  4 consecutive positions out of one 128-bit window.
+            const int tsh = nbits > TOP_BITS ? nbits - TOP_BITS : 0;             // bucket -> top-level bin
+            const int n_cnt = big ? (1 << (nbits - tsh)) : (1 << nbits);
+            for (int i = threadIdx.x; i < n_cnt; i += blockDim.x) tab[i] = 0;
             __syncthreads();
-            // pass 0: bucket (and tag) of every position -> scratch (and bucket sizes when there is one
-            // section).  Each thread takes 4 consecutive positions out of one 128-bit window.
             const int n4 = (rd.n_rr + 3) & ~3;
             for (int p0 = 4 * threadIdx.x; p0 < n4; p0 += 4 * blockDim.x) {
                 const int wi = p0 >> 4; const int sh = 2 * (p0 & 15);
@@ -396,7 +399,7 @@ k_build_index_lds(const ref_desc* __restrict__ refs, const int* __restrict__ slo
                             const uint64_t h = anchor_hash(x & amask);
                             bt = anchor_bucket(h, rd.B) | (anchor_tag(h, rd.B, rd.pos_bits) << 18);
                         } else bt = (uint32_t)(x & smask);
-                        if (n_sec == 1) atomicAdd(&tab[bt & 0x3ffffu], 1u);
+                        atomicAdd(&tab[(bt & 0x3ffffu) >> (big ? tsh : 0)], 1u);
                     }
                     out[j] = bt;
                 }
@@ -404,35 +407,14 @@ k_build_index_lds(const ref_desc* __restrict__ refs, const int* __restrict__ slo
             }
             __threadfence_block();
             __syncthreads();
-            uint32_t sbase = 0;                                    // entries of the sections done so far
-            for (int sec = 0; sec < n_sec; ++sec) {
-                if (n_sec > 1) {
-                    for (int i = threadIdx.x; i < nb; i += blockDim.x) tab[i] = 0;
-                    __syncthreads();
-                    for (int pb = 4 * threadIdx.x; pb < n4; pb += 16 * blockDim.x) {
-                        uint4 v[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int p0 = pb + u * 4 * (int)blockDim.x;
-                            v[u] = (p0 < n4) ? *reinterpret_cast<const uint4*>(&scratch[p0]) : make_uint4(~0u, ~0u, ~0u, ~0u);
-                        }
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const uint32_t bts[4] = { v[u].x, v[u].y, v[u].z, v[u].w };
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const uint32_t b18 = bts[j] & 0x3ffffu;
-                                if (bts[j] != 0xffffffffu && (int)(b18 >> 14) == sec) atomicAdd(&tab[b18 & 0x3fffu], 1u);
-                            }
-                        }
-                    }
-                    __syncthreads();
-                }
-                lds_scan_exclusive(tab, nb, part);                 // tab[b] = first slot of bucket b inside the section
+            if (!big) {
+                lds_scan_exclusive(tab, n_cnt, part);              // tab[b] = first slot of bucket b
                 const uint32_t total = part[1023];                 // inclusive sum of all thread partials
                 __syncthreads();
                 // fill, one window of whole buckets holding <= LDS_STAGE entries at a time.  Buckets at or
                 // beyond the window start are still untouched, so end(b) = tab[b + 1] (or the total).
+                // Every window re-reads the scratch: fine for a handful of windows (< BIG_RR symbols).
+                const int nb = n_cnt;
                 int w_lo = 0;
                 while (w_lo < nb) {
                     const uint32_t base = tab[w_lo];
@@ -464,26 +446,86 @@ k_build_index_lds(const ref_desc* __restrict__ refs, const int* __restrict__ slo
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
                                 const uint32_t bt = bts[j];
-                                const uint32_t b18 = bt & 0x3ffffu;
-                                const int b2 = (int)(b18 & 0x3fffu);
-                                if (bt == 0xffffffffu || (int)(b18 >> 14) != sec || b2 < w_lo || b2 >= w_hi) continue;
+                                const int b2 = (int)(bt & 0x3ffffu);
+                                if (bt == 0xffffffffu || b2 < w_lo || b2 >= w_hi) continue;
                                 const uint32_t ent = (uint32_t)(p0 + j) | (phase == 0 ? ((bt >> 18) << rd.pos_bits) : 0u);
                                 const uint32_t slot = atomicAdd(&tab[b2], 1u);
-                                if (direct) gent[sbase + slot] = ent; else stage[slot - base] = ent;
+                                if (direct) gent[slot] = ent; else stage[slot - base] = ent;
                             }
                         }
                     }
                     __syncthreads();
                     if (!direct) {
                         const uint32_t cnt = tab[w_hi - 1] - base;   // cursor of the last bucket == its end
-                        for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) gent[sbase + base + i] = stage[i];
+                        for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) gent[base + i] = stage[i];
                     }
                     __syncthreads();
                     w_lo = w_hi;
                 }
-                for (int i = threadIdx.x; i < nb; i += blockDim.x) gtab[(size_t)sec * LDS_TAB + i] = sbase + tab[i];   // END of every bucket
-                sbase += total;
+                for (int i = threadIdx.x; i < nb; i += blockDim.x) gtab[i] = tab[i];   // END of every bucket
                 __syncthreads();
+                continue;
+            }
+            // ---- big references: a scratch re-read per window would be quadratic, so the entries are first
+            // dealt into 512 top-level bins (contiguous bucket ranges) in a second scratch; a window is then
+            // a contiguous slice of that list and every pass is linear in the reference.
+            const int n_bins = n_cnt;
+            lds_scan_exclusive(tab, n_bins, part);
+            const uint32_t total = part[1023];
+            __syncthreads();
+            for (int i = threadIdx.x; i <= n_bins; i += blockDim.x) { s_bstart[i] = i < n_bins ? tab[i] : total; }
+            __syncthreads();
+            for (int pb = 4 * threadIdx.x; pb < n4; pb += 16 * blockDim.x) {
+                uint4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int p0 = pb + u * 4 * (int)blockDim.x;
+                    v[u] = (p0 < n4) ? *reinterpret_cast<const uint4*>(&scratch[p0]) : make_uint4(~0u, ~0u, ~0u, ~0u);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int p0 = pb + u * 4 * (int)blockDim.x;
+                    const uint32_t bts[4] = { v[u].x, v[u].y, v[u].z, v[u].w };
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (bts[j] == 0xffffffffu) continue;
+                        const uint32_t slot = atomicAdd(&tab[(bts[j] & 0x3ffffu) >> tsh], 1u);
+                        binned[slot] = make_uint2(bts[j], (uint32_t)(p0 + j));
+                    }
+                }
+            }
+            __threadfence_block();
+            __syncthreads();
+            const int per_bin = 1 << tsh;                          // buckets per top-level bin
+            int w_lo = 0;
+            while (w_lo < n_bins) {
+                // window = as many whole bins as fit the stage (entries) and the table (buckets)
+                if (threadIdx.x == 0) {
+                    int hi = w_lo + 1;
+                    while (hi < n_bins && s_bstart[hi + 1] - s_bstart[w_lo] <= (uint32_t)LDS_STAGE && (hi + 1 - w_lo) * per_bin <= LDS_TAB) ++hi;
+                    s_whi = hi;
+                }
+                __syncthreads();
+                const int w_hi = s_whi;
+                const uint32_t base = s_bstart[w_lo], cnt = s_bstart[w_hi] - base;
+                const int nbw = (w_hi - w_lo) * per_bin; const uint32_t b_lo = (uint32_t)w_lo << tsh;
+                const bool direct = cnt > (uint32_t)LDS_STAGE;     // a single bin larger than the stage
+                for (int i = threadIdx.x; i < nbw; i += blockDim.x) tab[i] = 0;
+                __syncthreads();
+                for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) atomicAdd(&tab[(binned[base + i].x & 0x3ffffu) - b_lo], 1u);
+                __syncthreads();
+                lds_scan_exclusive(tab, nbw, part);
+                for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
+                    const uint2 e = binned[base + i];
+                    const uint32_t ent = e.y | (phase == 0 ? ((e.x >> 18) << rd.pos_bits) : 0u);
+                    const uint32_t slot = atomicAdd(&tab[(e.x & 0x3ffffu) - b_lo], 1u);
+                    if (direct) gent[base + slot] = ent; else stage[slot] = ent;
+                }
+                __syncthreads();
+                if (!direct) for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) gent[base + i] = stage[i];
+                for (int i = threadIdx.x; i < nbw; i += blockDim.x) gtab[b_lo + i] = base + tab[i];       // END of every bucket
+                __syncthreads();
+                w_lo = w_hi;
             }
         }
     }
@@ -878,6 +920,7 @@ inline int grid_for(int64_t n, int block = 256, int max_blocks = 256 * 16) {
 
 static int64_t g_index_budget_bytes = 24LL << 30;
 static int64_t g_segment_task_limit = 16384;
+static int g_bucket_shift = 2;
 
 extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks, const vg_lz_params* p,
                            vg_pair_stat* stats, vg_region** regions, int64_t* n_regions) {
@@ -925,7 +968,7 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
             const bool small = n_rr <= (1 << 21) && p->msl <= 7;
             // anchor buckets: ~1 entry per bucket for short references, 4-8 per bucket above 2^16 symbols
             int B = 8; while ((1LL << (B + 1)) <= n_rr && B + 1 <= 2 * p->mal && B < 26) ++B;
-            if (small && B > 14) B = std::min(18, std::max(14, B - 2));
+            if (small && B > 14) B = std::min(18, std::max(14, B - g_bucket_shift));
             const int64_t chunks = (n_rr + RR_PAD + 31) / 32 + 2;
             const int64_t need = chunks * 12 + ((1LL << B) + n_rr + stab_n + n_rr) * 4;
             if (!refs.empty() && bytes + need > g_index_budget_bytes) break;
@@ -961,6 +1004,8 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
             if (small) small_list.push_back(i);
             else { large_list.push_back(i); large_chunks.push_back(large_chunks.back() + (chunk_off[i + 1] - chunk_off[i])); }
         }
+        // longest references first: the persistent workgroups take them round-robin, so their loads even out
+        std::stable_sort(small_list.begin(), small_list.end(), [&](int x, int y) { return refs[x].n_rr > refs[y].n_rr; });
         dbuf<int> d_small(std::max<size_t>(1, small_list.size())), d_large(std::max<size_t>(1, large_list.size()));
         dbuf<int64_t> d_lchunk(large_chunks.size());
         if (!small_list.empty()) d_small.upload(small_list.data(), small_list.size(), s);
@@ -973,7 +1018,7 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
                 int64_t max_rr = 0; for (int i : small_list) max_rr = std::max<int64_t>(max_rr, refs[i].n_rr);
                 const int nblk = (int)std::min<size_t>(small_list.size(), 512);
                 const int64_t stride = (max_rr + 63) / 64 * 64;
-                dbuf<uint32_t> scratch((size_t)nblk * stride);
+                dbuf<uint32_t> scratch((size_t)nblk * stride * 3);
                 hipLaunchKernelGGL(k_build_index_lds, dim3(nblk), dim3(1024), 0, s, d_refs.p, d_small.p, (int)small_list.size(),
                                    g->d_packed.p, g->d_nmask.p, g->d_base_off.p, rr_pool.p, mask_pool.p, p->mal, p->msl, atab_pool.p,
                                    aent_pool.p, stab_pool.p, sent_pool.p, scratch.p, stride);
