@@ -129,7 +129,8 @@ def read_fasta_codes(path, multisample=True):
         raise IOError(path)
     seqs, names = [], []
     for i in range(gs.n):
-        seqs.append(np.ctypeslib.as_array(gs.g[i].seq, shape=(gs.g[i].len,)).copy())
+        n = gs.g[i].len
+        seqs.append(np.ctypeslib.as_array(gs.g[i].seq, shape=(n,)).copy() if n else np.zeros(0, dtype=np.uint8))
         names.append(gs.g[i].name.decode())
     lib().vo_free_genomes(C.byref(gs))
     offsets = np.zeros(len(seqs) + 1, dtype=np.int64)

@@ -165,3 +165,20 @@ def test_number_format_fast_path_equals_oracle(tmp_path, golden_dir):
                 int(s['n_match']) / int(s['aln_len']), int(s['aln_len']) / lq, int(rev['aln_len']) / lr]
         bad += [orc.fmt_num(v) for v in want] != row
     assert bad == 0
+
+
+MESSY = (b">g1 first genome\tdescription\r\nACGTacgtNNnnRYKM\r\n\r\nacgtACGT\r\n"
+         b">g2\nAC\nGT\n\n>empty_record\n>g4|pipes and spaces  \nTTTTGGGGCCCCAAAA-*.\nacgu")
+
+
+def test_ingest_messy_fasta(tmp_path):
+    """Lower case, IUPAC and other symbols (all non-ACGT -> N), CRLF, blank lines, an empty record, no
+    final newline: names and lengths equal the oracle reader's (GPU test compares the bases too)."""
+    import gzip
+    p = tmp_path / 'messy.fna'; p.write_bytes(MESSY)
+    pz = tmp_path / 'messy.fna.gz'; pz.write_bytes(gzip.compress(MESSY))
+    codes, offsets, names = orc.read_fasta_codes(p)
+    for path in (p, pz):
+        gs = api.GenomeSet.load([path], multisample=True, n_threads=3)
+        assert gs.names() == names
+        assert list(gs.lengths()) == list(np.diff(offsets))

@@ -174,3 +174,43 @@ def test_lz_with_n_and_edges():
         q, r = int(t['q']), int(t['r'])
         ref = orc.lz_pair_stat(seqs[q], seqs[r])
         assert ref == (int(s['n_match']), int(s['aln_len']), int(s['n_regions'])), (q, r)
+
+
+def test_messy_fasta_bases_equal_oracle_reader(tmp_path):
+    """Same file as tests/test_abi_host.py::test_ingest_messy_fasta: the packed bases (seen through the
+    k-mer sets at a small k) equal the oracle reader's, plain and gzip."""
+    import gzip
+    from test_abi_host import MESSY
+    p = tmp_path / 'messy.fna'; p.write_bytes(MESSY)
+    pz = tmp_path / 'messy.fna.gz'; pz.write_bytes(gzip.compress(MESSY))
+    codes, offsets, names = orc.read_fasta_codes(p)
+    for path in (p, pz):
+        gs = api.GenomeSet.load([path], multisample=True)
+        for i in range(len(gs)):
+            assert list(gs.kmer_set(i, 8)) == list(orc.kmer_set(codes[offsets[i]:offsets[i + 1]], 8)), names[i]
+
+
+def test_degenerate_genome_sets():
+    """One genome; genomes shorter than k / mal; an all-N genome; an empty genome; identical genomes."""
+    rng = np.random.default_rng(12)
+    a = rng.integers(0, 4, size=3000, dtype=np.uint8)
+    one = api.GenomeSet.from_codes(a, np.array([0, 3000], dtype=np.int64))
+    sizes, pairs = one.kmer_shared(k=25)
+    assert list(sizes) == list(orc.shared_all(a, np.array([0, 3000]), k=25)[0]) and len(pairs) == 0
+    assert len(one.align_tasks(pairs)) == 0 and len(one.lz_align(one.align_tasks(pairs))) == 0
+    seqs = [a, a.copy(), a[:20].copy(), np.full(100, 4, dtype=np.uint8), np.zeros(0, dtype=np.uint8),
+            rng.integers(0, 4, size=2500, dtype=np.uint8), a[::-1].copy()]
+    offsets = np.zeros(len(seqs) + 1, dtype=np.int64); offsets[1:] = np.cumsum([len(s) for s in seqs])
+    codes = np.concatenate(seqs)
+    gs = api.GenomeSet.from_codes(codes, offsets)
+    for k in (25, 12):
+        sizes, pairs = gs.kmer_shared(k=k)
+        osizes, opairs = orc.shared_all(codes, offsets, k=k)
+        assert list(sizes) == list(osizes) and _pairs_dict(pairs) == opairs
+    tasks = gs.align_tasks(gs.read_filter(None))           # all-vs-all, including the empty and the N genome
+    stats = gs.lz_align(tasks)
+    for t, s in zip(tasks, stats):
+        q, r = int(t['q']), int(t['r'])
+        assert orc.lz_pair_stat(seqs[q], seqs[r]) == (int(s['n_match']), int(s['aln_len']), int(s['n_regions'])), (q, r)
+    ident = [s for t, s in zip(tasks, stats) if {int(t['q']), int(t['r'])} == {0, 1}]
+    assert all(int(s['n_match']) == 3000 and int(s['aln_len']) == 3000 and int(s['n_regions']) == 1 for s in ident)
