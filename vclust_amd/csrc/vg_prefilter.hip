@@ -820,8 +820,11 @@ extern "C" int vg_kmer_shared(vg_genomes* g, int k, double fraction, int shard, 
     // Sets beyond the 32-bit row numbering of one pass (2^32 padded bases dense, ~2^31 kept k-mers per
     // shard) are cut into sub-shards of this shard's k-mer range; partial counts of a pair add up.
     const int64_t P = g->padded_total();
-    const double expect = (double)P * fraction / n_shards;
-    int sub = g_force_subshards > 0 ? g_force_subshards : (int)std::ceil(expect / (double)(1LL << 31));
+    const double expect = (double)P * fraction / n_shards;                 // k-mers kept by this shard, at most
+    const bool dense = fraction >= 1.0 && n_shards == 1;
+    int sub = 1;
+    if (g_force_subshards > 0) sub = g_force_subshards;
+    else if (dense ? P >= (1LL << 32) : expect >= 3.0e9) sub = (int)std::ceil(expect / 2.0e9);
     if (sub < 1) sub = 1;
     std::vector<vg_pair_count> acc;
     if (sub == 1) {
