@@ -220,3 +220,62 @@ def test_two_frequent_kmers_in_one_prefix_group():
         api.profile_enable(False)
     assert len(pairs) == 1400 * 1399 // 2 and int(pairs['shared'].min()) >= 2
     assert 'index_long_runs' in scopes and 'index_runs_general' in scopes, scopes
+
+
+def _core_set(n, rng, core_len=40, flank=(30, 60)):
+    """n genomes = random flank + shared core + random flank; also the 16 flank bases next to the core."""
+    core = rng.integers(0, 4, size=core_len, dtype=np.uint8)
+    seqs, left, right = [], [], []
+    for i in range(n):
+        f1 = rng.integers(0, 4, size=int(rng.integers(*flank)), dtype=np.uint8)
+        f2 = rng.integers(0, 4, size=int(rng.integers(*flank)), dtype=np.uint8)
+        seqs.append(np.concatenate([f1, core, f2])); left.append(f1[-16:][::-1]); right.append(f2[:16])
+    offsets = np.zeros(n + 1, dtype=np.int64); offsets[1:] = np.cumsum([len(s) for s in seqs])
+    return np.concatenate(seqs), offsets, np.array(left), np.array(right)
+
+
+def _common_prefix_len(m):
+    """m: n x d bases; -> n x n matrix of common-prefix lengths of the rows."""
+    n, d = m.shape
+    run = np.ones((n, n), dtype=bool); out = np.zeros((n, n), dtype=np.int32)
+    for j in range(d):
+        run &= m[:, j][:, None] == m[:, j][None, :]
+        out += run
+    return out
+
+
+def test_genome_with_thousands_of_partners():
+    """Rows of the SpGEMM whose partner set overflows the 2^11-slot LDS table (second try, 2^13 slots)
+    and the 2^13-slot one (dense counters): 2 100 genomes against the oracle, 7 500 by a closed form."""
+    rng = np.random.default_rng(31)
+    codes, offsets, _, _ = _core_set(2100, rng)
+    gs = api.GenomeSet.from_codes(codes, offsets)
+    api.profile_enable(True); api.profile_reset()
+    try:
+        sizes, pairs = gs.kmer_shared(k=25)
+        scopes = {e['name'] for e in api.profile_get()}
+    finally:
+        api.profile_enable(False)
+    assert 'spgemm_rows_wide' in scopes
+    osizes, opairs = orc.shared_all(codes, offsets, k=25)
+    assert list(sizes) == list(osizes)
+    key = (pairs['a'].astype(np.int64) << 32) | pairs['b']
+    okey = np.array([(a << 32) | b for a, b in opairs], dtype=np.int64); oval = np.array(list(opairs.values()), dtype=np.int64)
+    o1, o2 = np.argsort(key), np.argsort(okey)
+    assert np.array_equal(key[o1], okey[o2]) and np.array_equal(pairs['shared'][o1].astype(np.int64), oval[o2])
+    # 7 500 genomes sharing a 40-base core: a pair shares the 25-mers of core + the flank bases that happen to
+    # agree next to it: 16 + common suffix of the left flanks + common prefix of the right flanks
+    n = 7500
+    codes, offsets, left, right = _core_set(n, rng)
+    gs = api.GenomeSet.from_codes(codes, offsets)
+    api.profile_enable(True); api.profile_reset()
+    try:
+        sizes, pairs = gs.kmer_shared(k=25)
+        scopes = {e['name'] for e in api.profile_get()}
+    finally:
+        api.profile_enable(False)
+    assert 'spgemm_dense_rows' in scopes
+    assert len(pairs) == n * (n - 1) // 2 and np.all(pairs['a'] > pairs['b'])
+    assert len(np.unique((pairs['a'].astype(np.int64) << 32) | pairs['b'])) == len(pairs)
+    expect = 16 + _common_prefix_len(left) + _common_prefix_len(right)
+    assert np.array_equal(pairs['shared'].astype(np.int64), expect[pairs['a'], pairs['b']])

@@ -447,7 +447,8 @@ k_long_groups(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ po
 // ------------------------------------------------------------------ K2b: row-wise SpGEMM
 // One workgroup per genome a: for every distinct k-mer of a, walk the (ascending) genome list
 // of that k-mer and count partners b < a in an LDS hash table; emit (a, b, shared).
-constexpr int HT_SIZE = 8192;          // LDS hash slots per workgroup (64 KiB)
+// LDS hash slots per workgroup: 2^11 (16 KiB: five workgroups per CU hide the latency of the list
+// gathers) for the first try, 2^13 (64 KiB) for the rows whose partners did not fit, dense after that
 constexpr uint32_t HT_EMPTY = 0xffffffffu;
 constexpr int LONG_RUN = 48;           // runs longer than this are walked by the whole workgroup
 constexpr int LQ_CAP = 512;
@@ -457,8 +458,10 @@ __device__ __forceinline__ uint32_t big_run_len(const uint64_t* __restrict__ big
     return 0;
 }
 
+template <int HT_BITS>
 __device__ __forceinline__ bool ht_add(uint32_t* hk, uint32_t* hc, uint32_t b, uint32_t* n_used) {
-    uint32_t h = (b * 2654435761u) >> (32 - 13);
+    constexpr int HT_SIZE = 1 << HT_BITS;
+    uint32_t h = (b * 2654435761u) >> (32 - HT_BITS);
     for (int probe = 0; probe < HT_SIZE; ++probe) {
         uint32_t cur = hk[h];
         if (cur == b) { atomicAdd(&hc[h], 1u); return true; }
@@ -472,12 +475,14 @@ __device__ __forceinline__ bool ht_add(uint32_t* hk, uint32_t* hc, uint32_t b, u
     return false;
 }
 
+template <int HT_BITS>
 __global__ void __launch_bounds__(256)
 k_spgemm(const uint64_t* __restrict__ rowinfo, const uint32_t* __restrict__ gen, const uint64_t* __restrict__ big_runs, unsigned int n_big,
          const int64_t* __restrict__ base_off, const int64_t* __restrict__ len, const uint32_t* __restrict__ wave_base,
          int n_genomes, uint32_t min_emit, const uint32_t* __restrict__ row_list, int n_rows,
          vg_pair_count* __restrict__ out, unsigned long long* __restrict__ out_cursor,
          unsigned long long out_cap, uint32_t* __restrict__ overflow_rows, uint32_t* __restrict__ n_overflow) {
+    constexpr int HT_SIZE = 1 << HT_BITS;
     __shared__ uint32_t hk[HT_SIZE];
     __shared__ uint32_t hc[HT_SIZE];
     __shared__ uint64_t lq[LQ_CAP];
@@ -523,7 +528,7 @@ k_spgemm(const uint64_t* __restrict__ rowinfo, const uint32_t* __restrict__ gen,
                     const uint32_t g = g4[j];
                     if (g & DUP_BIT) continue;
                     if (g >= a) { done = true; continue; }
-                    if (!ht_add(hk, hc, g, &s_used)) s_fail = 1;
+                    if (!ht_add<HT_BITS>(hk, hc, g, &s_used)) s_fail = 1;
                 }
             }
         }
@@ -538,7 +543,7 @@ k_spgemm(const uint64_t* __restrict__ rowinfo, const uint32_t* __restrict__ gen,
                 for (uint32_t e = threadIdx.x; e < rl; e += blockDim.x) {
                     uint32_t g = gen[rs + e];
                     if ((g & DUP_BIT) || g >= a) continue;
-                    if (!ht_add(hk, hc, g, &s_used)) s_fail = 1;
+                    if (!ht_add<HT_BITS>(hk, hc, g, &s_used)) s_fail = 1;
                 }
             }
             __syncthreads();
@@ -768,7 +773,7 @@ static void kmer_shared_pass(vg_genomes* g, int k, double fraction, int shard, i
         d_cursor.zero(s); d_nover.zero(s);
         {
             vg_prof_scope ps("spgemm_rows", (double)n_rows_info * 8.0);
-            hipLaunchKernelGGL(k_spgemm, dim3(n), dim3(256), 0, s, rowinfo.p, gen.p, big_runs.p, n_big, g->d_base_off.p, g->d_len.p, wbase, n,
+            hipLaunchKernelGGL(k_spgemm<11>, dim3(n), dim3(256), 0, s, rowinfo.p, gen.p, big_runs.p, n_big, g->d_base_off.p, g->d_len.p, wbase, n,
                                min_shared, (const uint32_t*)nullptr, n, d_out.p, d_cursor.p, cap, d_over.p, d_nover.p);
         }
         // one round trip in the common case: overflow count, pair count and the first pairs together
@@ -778,6 +783,20 @@ static void kmer_shared_pass(vg_genomes* g, int k, double fraction, int shard, i
         d_nover.download(&nover, 1, s); d_cursor.download(&produced, 1, s); d_out.download(host_pairs.data(), host_pairs.size(), s);
         VG_HIP(hipStreamSynchronize(s));
         if (nover == 0 && produced <= host_pairs.size()) { host_pairs.resize((size_t)produced); break; }
+        if (nover > 0) {
+            // second try with the 64 KiB table for the rows that overflowed the small one
+            dbuf<uint32_t> d_rows2(nover), d_over2(nover);
+            VG_HIP(hipMemcpyAsync(d_rows2.p, d_over.p, sizeof(uint32_t) * nover, hipMemcpyDeviceToDevice, s));
+            d_nover.zero(s);
+            {
+                vg_prof_scope ps("spgemm_rows_wide", 0);
+                hipLaunchKernelGGL(k_spgemm<13>, dim3(nover), dim3(256), 0, s, rowinfo.p, gen.p, big_runs.p, n_big, g->d_base_off.p, g->d_len.p, wbase, n,
+                                   min_shared, (const uint32_t*)d_rows2.p, (int)nover, d_out.p, d_cursor.p, cap, d_over2.p, d_nover.p);
+            }
+            VG_HIP(hipMemcpyAsync(d_over.p, d_over2.p, sizeof(uint32_t) * nover, hipMemcpyDeviceToDevice, s));
+            d_nover.download(&nover, 1, s);
+            VG_HIP(hipStreamSynchronize(s));
+        }
         if (nover > 0) {
             // dense fallback, a few rows at a time
             std::vector<uint32_t> rows(nover); d_over.download(rows.data(), nover, s); VG_HIP(hipStreamSynchronize(s));
