@@ -356,7 +356,6 @@ k_group_runs(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos
              unsigned int long_cap) {
     __shared__ uint64_t sk[GS_TILE + GS_HALO + 1];
     __shared__ uint32_t sp[GS_TILE + GS_HALO + 1];
-    __shared__ uint32_t sg[GS_TILE + GS_HALO + 1];
     const int64_t n_tiles = (n + GS_TILE - 1) / GS_TILE;
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t t0 = tile * GS_TILE;
@@ -367,7 +366,6 @@ k_group_runs(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos
             const uint32_t p = g >= 0 ? pos[g] : 0u;
             sk[j] = g >= 0 ? keys[g] : ~0ULL;
             sp[j] = p;
-            sg[j] = g < 0 ? 0u : (M.cblk ? genome_of_compact(M, p) : blk2g[p >> blk_shift]);
         }
         __syncthreads();
         const int own = (int)min<int64_t>(GS_TILE, n - t0);
@@ -389,8 +387,11 @@ k_group_runs(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos
                 continue;
             }
             const int64_t rs = t0 - 1 + gs + lt;                         // first entry of this k-mer's run, sorted order
-            const uint32_t g = sg[j];
-            const bool dup = prev_eq >= 0 && sg[prev_eq] == g;
+            // genomes are looked up here, not staged: 12 bytes of LDS per entry keep five workgroups on a CU
+            const uint32_t pj = sp[j];
+            const uint32_t g = M.cblk ? genome_of_compact(M, pj) : blk2g[pj >> blk_shift];
+            bool dup = false;
+            if (prev_eq >= 0) { const uint32_t pq = sp[prev_eq]; dup = (M.cblk ? genome_of_compact(M, pq) : blk2g[pq >> blk_shift]) == g; }
             gen[rs + eq_before] = g | (dup ? DUP_BIT : 0u);
             if (dup) { atomicAdd(&dup_per_genome[g], 1); continue; }
             const uint32_t rl = (uint32_t)(eq_before + eq_after + 1);
