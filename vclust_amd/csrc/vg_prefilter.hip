@@ -275,8 +275,8 @@ __global__ void k_iota(uint32_t* v, int64_t n) {
 // Entries with equal prefix form small contiguous groups (the scramble makes prefixes uniform:
 // about n / 2^sort_bits entries each, plus the repeats of a k-mer); k_group_runs below finishes
 // the order inside the groups on the fly.
-constexpr int GS_TILE = 2048;       // list entries owned by a workgroup per trip
-constexpr int GS_HALO = 512;        // staged beyond the tile so that groups starting inside it are complete
+constexpr int GS_TILE = 1024;       // list entries owned by a workgroup per trip
+constexpr int GS_HALO = 256;        // staged beyond the tile so that groups starting inside it are complete
 
 // ------------------------------------------------------------------ K2a: runs of the inverted index
 // One pass over the sorted (k-mer, position) list: every entry finds the boundaries of its run
