@@ -53,18 +53,6 @@ def pmc_traffic(scope):
     return None, None
 
 
-def candidate_pairs(sizes, pairs, k, min_kmers, min_ident):
-    """K3 thresholds on the shared counts (same arithmetic as vg_write_fltr); one entry per pair."""
-    if len(pairs) == 0:
-        return pairs
-    a, b = pairs['a'].astype(np.int64), pairs['b'].astype(np.int64)
-    shared = pairs['shared'].astype(np.int64)
-    mn = np.minimum(sizes[a], sizes[b]).astype(np.float64)
-    j = shared / np.maximum(mn, 1.0)
-    ani = 1.0 + np.log(2.0 * j / (1.0 + j)) / k
-    return pairs[(shared >= min_kmers) & (ani >= min_ident)]
-
-
 def cpu_baseline(sample_families, members, length, seed, threads):
     """Time the CPU oracle (own restatement, not upstream) on a bounded sample of the workload."""
     cli = ROOT / 'oracle' / '_build' / 'oracle_cli'
@@ -142,7 +130,7 @@ def main():
             sizes, pairs = D.prefilter_counts(gs, dist, dev, rank, world, args.k, 1.0)
         else:
             sizes, pairs = gs.kmer_shared(k=args.k, min_shared=args.min_kmers)
-        cand = candidate_pairs(sizes, pairs, args.k, args.min_kmers, args.min_ident)
+        cand = gs.filter_pairs(sizes, pairs, k=args.k, min_kmers=args.min_kmers, min_ident=args.min_ident)
         # -- align: canonical task list, contiguous share per rank, rows gathered over RCCL
         tasks = gs.align_tasks(cand)
         stats, _ = D.align_rows(gs, tasks, dist, dev, rank, world, None, False)

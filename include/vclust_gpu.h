@@ -88,6 +88,12 @@ int vg_write_fltr(const vg_genomes* g, int k, double fraction, int min_kmers, do
                   int max_seqs, const int64_t* set_sizes, const vg_pair_count* pairs,
                   int64_t n_pairs, const char* out_path);
 
+/* K3 without the file: the pairs that vg_write_fltr would print (shared >= min_kmers and
+ * ani-shorter >= min_ident, same arithmetic), for a prefilter -> align hand-over in memory.
+ * One entry per pair expected (vg_kmer_shared output, or merged shard outputs); *out is malloc'ed. */
+int vg_filter_pairs(int k, int min_kmers, double min_ident, const int64_t* set_sizes, int64_t n_genomes,
+                    const vg_pair_count* pairs, int64_t n_pairs, vg_pair_count** out, int64_t* n_out);
+
 typedef struct {            /* mirrors the prefilter sub-parser, vclust.py:208-262 */
     int    k;               /* -k, 15..30 */
     int    min_kmers;       /* --min-kmers */

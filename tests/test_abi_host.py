@@ -182,3 +182,21 @@ def test_ingest_messy_fasta(tmp_path):
         gs = api.GenomeSet.load([path], multisample=True, n_threads=3)
         assert gs.names() == names
         assert list(gs.lengths()) == list(np.diff(offsets))
+
+
+def test_filter_pairs_equals_fltr_file(tmp_path, golden_dir):
+    """vg_filter_pairs keeps exactly the pairs vg_write_fltr prints (golden fltr.txt: 13 entries)."""
+    codes, offsets, names = orc.read_fasta_codes(golden_dir / 'multifasta.fna')
+    sizes, pairs = orc.shared_all(codes, offsets, k=25)
+    arr = np.array([(a, b, s) for (a, b), s in pairs.items()], dtype=api.PAIR_DTYPE)
+    gs = api.GenomeSet.load([golden_dir / 'multifasta.fna'], multisample=True)
+    kept = gs.filter_pairs(sizes, arr, k=25, min_kmers=20, min_ident=0.7)
+    out = tmp_path / 'f.txt'
+    gs.write_fltr(out, sizes, arr, k=25, min_kmers=20, min_ident=0.7)
+    printed = set()
+    for row, line in enumerate(open(out).read().splitlines()[1:]):
+        for ent in line.split(',')[1:]:
+            if ent:
+                printed.add((row, int(ent.split(':')[0]) - 1))
+    assert {(int(p['a']), int(p['b'])) for p in kept} == printed and len(printed) == 13
+    assert len(gs.filter_pairs(sizes, arr, k=25, min_kmers=20, min_ident=0.999)) < 13

@@ -24,7 +24,7 @@ for it in range(3):
     api.profile_enable(True); api.profile_reset()
     t0 = time.perf_counter()
     sizes, pairs = gs.kmer_shared(k=25, min_shared=20)
-    cand = bench.candidate_pairs(sizes, pairs, 25, 20, 0.7)
+    cand = gs.filter_pairs(sizes, pairs, k=25, min_kmers=20, min_ident=0.7)
     tasks = gs.align_tasks(cand)
     stats = gs.lz_align(tasks)
     dt = time.perf_counter() - t0

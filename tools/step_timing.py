@@ -12,7 +12,7 @@ gs = api.GenomeSet.from_codes(codes, offsets, names); gs.to_device()
 for it in range(4):
     t = [time.perf_counter()]
     sizes, pairs = gs.kmer_shared(k=25, min_shared=20); t.append(time.perf_counter())
-    cand = bench.candidate_pairs(sizes, pairs, 25, 20, 0.7); t.append(time.perf_counter())
+    cand = gs.filter_pairs(sizes, pairs, k=25, min_kmers=20, min_ident=0.7); t.append(time.perf_counter())
     tasks = gs.align_tasks(cand); t.append(time.perf_counter())
     stats = gs.lz_align(tasks); t.append(time.perf_counter())
     d = np.diff(t) * 1e3

@@ -13,7 +13,7 @@ for N in (1, 2, 4, 8):
     gs = api.GenomeSet.from_codes(codes, offsets, names); gs.to_device()
     # global candidate list (what every rank holds after the gather)
     sizes, pairs = gs.kmer_shared(k=25, min_shared=20)
-    cand = bench.candidate_pairs(sizes, pairs, 25, 20, 0.7)
+    cand = gs.filter_pairs(sizes, pairs, k=25, min_kmers=20, min_ident=0.7)
     tasks = gs.align_tasks(cand)
     mine = tasks[D.ref_owner(tasks, N) == 0]
     for it in range(3):

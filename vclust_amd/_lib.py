@@ -77,6 +77,8 @@ SYMBOLS = {
     'vg_kmer_shared': (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_uint32,
                                  P(C.c_int64), P(P(PairCount)), P(C.c_int64)]),
     'vg_kmer_set': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, P(P(C.c_uint64)), P(C.c_int64)]),
+    'vg_filter_pairs': (C.c_int, [C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int64), C.c_int64, C.POINTER(PairCount), C.c_int64,
+                                  C.POINTER(C.POINTER(PairCount)), C.POINTER(C.c_int64)]),
     'vg_write_fltr': (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int,
                                 P(C.c_int64), P(PairCount), C.c_int64, C.c_char_p]),
     'vg_prefilter': (C.c_int, [P(C.c_char_p), C.c_int, C.c_char_p, P(PrefilterParams)]),

@@ -126,6 +126,15 @@ class GenomeSet:
         check(self._lib.vg_kmer_set(self._h, idx, k, float(fraction), C.byref(p), C.byref(n)))
         return _take(p, n.value, np.dtype('<u8'))
 
+    def filter_pairs(self, set_sizes, pairs, k=25, min_kmers=20, min_ident=0.7):
+        """The pairs write_fltr would print (thresholds on shared count and ani-shorter), in memory."""
+        sizes = np.ascontiguousarray(set_sizes, dtype=np.int64)
+        pairs = np.ascontiguousarray(pairs, dtype=PAIR_DTYPE)
+        out = C.POINTER(PairCount)(); n = C.c_int64()
+        check(self._lib.vg_filter_pairs(int(k), int(min_kmers), float(min_ident), sizes.ctypes.data_as(C.POINTER(C.c_int64)), len(sizes),
+                                        pairs.ctypes.data_as(C.POINTER(PairCount)), len(pairs), C.byref(out), C.byref(n)))
+        return _take(out, n.value, PAIR_DTYPE)
+
     def write_fltr(self, out_path, set_sizes, pairs, k=25, fraction=1.0, min_kmers=20, min_ident=0.7, max_seqs=0):
         sizes = np.ascontiguousarray(set_sizes, dtype=np.int64)
         pairs = np.ascontiguousarray(pairs, dtype=PAIR_DTYPE)

@@ -87,6 +87,25 @@ int vg_fmt_len_ratio(int64_t a, int64_t b, char* buf) {
 }
 
 // ---------------------------------------------------------------- fltr.txt
+extern "C" int vg_filter_pairs(int k, int min_kmers, double min_ident, const int64_t* set_sizes, int64_t n_genomes,
+                               const vg_pair_count* pairs, int64_t n_pairs, vg_pair_count** out, int64_t* n_out) {
+    VG_API_BEGIN
+    if (!set_sizes || (!pairs && n_pairs) || !out || !n_out) throw vg_error(VG_EINVAL, "vg_filter_pairs: null argument");
+    std::vector<vg_pair_count> keep;
+    keep.reserve((size_t)n_pairs);
+    for (int64_t i = 0; i < n_pairs; ++i) {
+        const vg_pair_count& p = pairs[i];
+        if ((int64_t)p.a >= n_genomes || (int64_t)p.b >= n_genomes) throw vg_error(VG_EINVAL, "pair id out of range");
+        if ((int64_t)p.shared < min_kmers) continue;
+        if (vg_ani_shorter(p.shared, set_sizes[p.a], set_sizes[p.b], k) >= min_ident) keep.push_back(p);
+    }
+    vg_pair_count* o = (vg_pair_count*)malloc(sizeof(vg_pair_count) * std::max<size_t>(1, keep.size()));
+    if (!o) throw vg_error(VG_ENOMEM, "out of host memory");
+    if (!keep.empty()) memcpy(o, keep.data(), sizeof(vg_pair_count) * keep.size());
+    *out = o; *n_out = (int64_t)keep.size();
+    VG_API_END
+}
+
 extern "C" int vg_write_fltr(const vg_genomes* g, int k, double fraction, int min_kmers, double min_ident,
                              int max_seqs, const int64_t* set_sizes, const vg_pair_count* pairs,
                              int64_t n_pairs, const char* out_path) {
