@@ -159,3 +159,11 @@ def test_bench_two_ranks_smoke():
     line = [l for l in p.stdout.splitlines() if l.startswith('{')][-1]
     d = json.loads(line)
     assert d['n_gpus'] == 2 and d['config']['pairs_per_step'] == 2 * 6 * 45 and d['value'] > 0
+
+
+def test_rccl_collectives_one_rank():
+    """The gathers / device-side merge of vclust_amd/distributed.py on the real nccl (= RCCL) backend with
+    world size 1 (the test box has one GPU): results equal the plain single-process calls."""
+    p = subprocess.run([sys.executable, str(ROOT / 'tools' / 'rccl_one_rank.py')], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=600)
+    assert p.returncode == 0 and 'rccl one-rank ok' in p.stdout, (p.stdout[-500:], p.stderr[-1500:])

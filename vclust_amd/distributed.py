@@ -15,6 +15,10 @@ import os
 import numpy as np
 
 
+# test hook: run the collectives even with a single rank (RCCL smoke test on a one-GPU box)
+FORCE_COLLECTIVES = bool(int(os.environ.get('VCLUST_DIST_FORCE', '0')))
+
+
 def dist_env():
     return int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('LOCAL_RANK', '0'))
 
@@ -74,7 +78,7 @@ def gather_known(arr, sizes, dist, device, world):
 def gather_rows(arr, dtype, dist, device, world):
     """Variable-length all-gather of a structured numpy array (lengths exchanged first); rank order."""
     import torch
-    if world == 1 or dist is None:
+    if dist is None or (world == 1 and not FORCE_COLLECTIVES):
         return arr
     raw = np.ascontiguousarray(arr).view(np.uint8).reshape(-1)
     cnt = torch.tensor([raw.size], device=device, dtype=torch.int64)
@@ -131,7 +135,7 @@ def prefilter_counts(gs, dist, device, rank, world, k, fraction):
     import torch
     from . import api
     sizes, pairs = gs.kmer_shared(k=k, fraction=fraction, shard=rank, n_shards=world, min_shared=1)
-    if world == 1 or dist is None:
+    if dist is None or (world == 1 and not FORCE_COLLECTIVES):
         return sizes, pairs
     n = len(sizes)
     rec = np.empty((len(pairs) + n, 2), dtype=np.int64)
@@ -163,7 +167,7 @@ def prefilter_counts(gs, dist, device, rank, world, k, fraction):
 def align_rows(gs, tasks, dist, device, rank, world, lz, want_regions):
     """Every rank parses the tasks of its reference range; all ranks receive all rows in task order."""
     from . import api
-    if world == 1 or dist is None:
+    if dist is None or (world == 1 and not FORCE_COLLECTIVES):
         if want_regions:
             stats, regions = gs.lz_align(tasks, lz=lz, want_regions=True)
             return stats, regions
