@@ -620,6 +620,7 @@ struct sorted_index {
     dbuf<uint64_t> keys; dbuf<uint32_t> pos; dbuf<int> kept; int64_t n_valid = 0;
     bool compact = false; dbuf<unsigned long long> wave_mask; dbuf<uint32_t> wave_base; dbuf<uint32_t> cblk, goff;
     int low_bit = 0;            // keys are ordered on bits >= low_bit only (finish = false)
+    dbuf<uint64_t> spare64; dbuf<uint32_t> spare32;     // buffers the sort no longer needs (reused by the caller)
 };
 
 // general path: order the list on ALL key bits (the prefix order is thrown away: a stable LSD sort
@@ -710,6 +711,7 @@ static void run_extract_sort(vg_genomes* g, int k, double fraction, int shard, i
     }
     VG_HIP(hipStreamSynchronize(s));
     out.keys = std::move(keys_b); out.pos = std::move(pos_b); out.n_valid = (int64_t)nv; out.low_bit = (int)begin_bit;
+    out.spare64 = std::move(keys_a); out.spare32 = std::move(pos_a);      // the sort's input: free again, same sizes as rowinfo / gen
     if (finish) finish_sort(out, k);
 }
 
@@ -723,10 +725,12 @@ static void kmer_shared_pass(vg_genomes* g, int k, double fraction, int shard, i
     const int64_t nv = si.n_valid;
     const int64_t P = g->padded_total();
     const int64_t n_rows_info = si.compact ? std::max<int64_t>(nv, 1) : P;      // row descriptors: per kept k-mer or per base
-    dbuf<uint64_t> rowinfo((size_t)n_rows_info); rowinfo.zero(s);
+    // row descriptors and genome list live in the sort's input buffers (32 + 16 GB less at 100 k genomes)
+    dbuf<uint64_t> rowinfo = si.spare64.n >= (size_t)n_rows_info ? std::move(si.spare64) : dbuf<uint64_t>((size_t)n_rows_info);
+    VG_HIP(hipMemsetAsync(rowinfo.p, 0, (size_t)n_rows_info * sizeof(uint64_t), s));
     const compact_map cmap{ si.compact ? si.goff.p : nullptr, si.compact ? si.cblk.p : nullptr };
     const uint32_t* wbase = si.compact ? si.wave_base.p : nullptr;
-    dbuf<uint32_t> gen((size_t)std::max<int64_t>(nv, 1));
+    dbuf<uint32_t> gen = si.spare32.n >= (size_t)std::max<int64_t>(nv, 1) ? std::move(si.spare32) : dbuf<uint32_t>((size_t)std::max<int64_t>(nv, 1));
     dbuf<int> d_dups((size_t)n); d_dups.zero(s);
     constexpr unsigned int BIG_CAP = 4096;
     dbuf<uint64_t> big_runs(2 * BIG_CAP); dbuf<unsigned int> d_nbig(1); d_nbig.zero(s);
