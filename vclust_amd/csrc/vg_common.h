@@ -67,6 +67,14 @@ bool vg_profile_on();
 // 32 per word.  Every genome starts at a multiple of VG_ALIGN bases of the padded stream;
 // padding bases are A with mask bit 1.
 constexpr int64_t VG_ALIGN = 64;        // minimum alignment; the set's block size is 1 << align_shift
+// std::vector storage without the value-initialising fill (resize() leaves new elements untouched):
+// the 2-bit arrays of a big set are zeroed / written by many threads, not by one
+template <class T> struct no_init_alloc : std::allocator<T> {
+    template <class U> struct rebind { using other = no_init_alloc<U>; };
+    template <class U> void construct(U* p) noexcept { ::new ((void*)p) U; }
+    template <class U, class... A> void construct(U* p, A&&... a) { ::new ((void*)p) U(std::forward<A>(a)...); }
+};
+
 struct vg_genomes {
     int n = 0;
     int align_shift = 6;                 // genomes start at multiples of (1 << align_shift) bases
@@ -76,8 +84,8 @@ struct vg_genomes {
     std::vector<int32_t> n_parts;    // n
     std::vector<int64_t> base_off;   // n+1, padded base offsets
     std::vector<uint8_t> has_n;      // n
-    std::vector<uint32_t> packed;    // base_off[n]/16 words (+ slack)
-    std::vector<uint32_t> nmask;     // base_off[n]/32 words (+ slack)
+    std::vector<uint32_t, no_init_alloc<uint32_t>> packed;    // base_off[n]/16 words (+ slack)
+    std::vector<uint32_t, no_init_alloc<uint32_t>> nmask;     // base_off[n]/32 words (+ slack)
     // device residency
     int device = -1;
     dbuf<uint32_t> d_packed, d_nmask;

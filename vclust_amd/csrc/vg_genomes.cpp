@@ -2,6 +2,7 @@
 // Input conventions follow the reference front-end (vclust.py:687-702, 962-963, 1159-1160):
 // a single (multi-)FASTA file = one genome per record, a directory = one genome per file.
 #include "vg_common.h"
+#include <sys/mman.h>
 #include <zlib.h>
 #include <string.h>
 #include <stdlib.h>
@@ -63,7 +64,14 @@ void vg_genomes_finish(vg_genomes* g) {
 
 namespace {
 // ---- whole-file buffers ---------------------------------------------------------------------
-struct filebuf { std::vector<char> data; };
+struct filebuf {            // plain files are mapped (no copy), gzip files are inflated into `own`
+    std::vector<char> own; const char* ptr = nullptr; size_t len = 0; void* map = nullptr; size_t map_len = 0;
+    filebuf() {}
+    filebuf(const filebuf&) = delete; filebuf& operator=(const filebuf&) = delete;
+    ~filebuf() { if (map) munmap(map, map_len); }
+    const char* data() const { return ptr; }
+    size_t size() const { return len; }
+};
 
 void slurp(const std::string& path, filebuf& fb) {
     FILE* f = fopen(path.c_str(), "rb");
@@ -72,22 +80,33 @@ void slurp(const std::string& path, filebuf& fb) {
     size_t got = fread(magic, 1, 2, f);
     const bool gz = got == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
     if (!gz) {
-        fseek(f, 0, SEEK_END); long long sz = ftell(f); fseek(f, 0, SEEK_SET);
-        fb.data.resize((size_t)sz);
+        fseek(f, 0, SEEK_END); const long long sz = ftell(f);
+        if (sz > 0) {
+            void* m = mmap(nullptr, (size_t)sz, PROT_READ, MAP_PRIVATE, fileno(f), 0);
+            if (m != MAP_FAILED) {
+                (void)madvise(m, (size_t)sz, MADV_WILLNEED);
+                fb.map = m; fb.map_len = (size_t)sz; fb.ptr = (const char*)m; fb.len = (size_t)sz;
+                fclose(f);
+                return;
+            }
+        }
+        fseek(f, 0, SEEK_SET);                           // not mappable (pipe, special file): read it
+        fb.own.resize((size_t)std::max<long long>(sz, 0));
         size_t off = 0;
-        while (off < (size_t)sz) { size_t r = fread(fb.data.data() + off, 1, (size_t)sz - off, f); if (!r) break; off += r; }
+        while (off < fb.own.size()) { size_t r = fread(fb.own.data() + off, 1, fb.own.size() - off, f); if (!r) break; off += r; }
         fclose(f);
-        if (off != (size_t)sz) throw vg_error(VG_EIO, "read error in " + path);
+        if (off != fb.own.size()) throw vg_error(VG_EIO, "read error in " + path);
+        fb.ptr = fb.own.data(); fb.len = fb.own.size();
         return;
     }
     fclose(f);
     gzFile g = gzopen(path.c_str(), "rb");
     if (!g) throw vg_error(VG_EIO, "cannot open " + path);
     gzbuffer(g, 1 << 20);
-    size_t off = 0; fb.data.resize(1 << 22);
+    size_t off = 0; fb.own.resize(1 << 22);
     for (;;) {
-        if (fb.data.size() - off < (1 << 20)) fb.data.resize(fb.data.size() * 2);
-        int n = gzread(g, fb.data.data() + off, (unsigned)std::min<size_t>(fb.data.size() - off, 1u << 30));
+        if (fb.own.size() - off < (1 << 20)) fb.own.resize(fb.own.size() * 2);
+        int n = gzread(g, fb.own.data() + off, (unsigned)std::min<size_t>(fb.own.size() - off, 1u << 30));
         if (n < 0) { gzclose(g); throw vg_error(VG_EIO, "read error in " + path); }
         if (n == 0) break;
         off += (size_t)n;
@@ -95,7 +114,8 @@ void slurp(const std::string& path, filebuf& fb) {
     int zerr = 0; (void)gzerror(g, &zerr);
     gzclose(g);
     if (zerr != Z_OK && zerr != Z_STREAM_END) throw vg_error(VG_EIO, "read error in " + path);
-    fb.data.resize(off);
+    fb.own.resize(off);
+    fb.ptr = fb.own.data(); fb.len = off;
 }
 
 // one FASTA record inside a buffer: [hdr, hdr_end) header line without '>', [seq, end) sequence lines
@@ -106,12 +126,12 @@ const code_lut LUT;
 inline bool is_ws(char ch) { return ch == '\n' || ch == '\r' || ch == ' ' || ch == '\t'; }
 
 void find_records(const filebuf& fb, std::vector<record>& out, int n_threads) {
-    const char* p = fb.data.data(); const char* e = p + fb.data.size();
+    const char* p = fb.data(); const char* e = p + fb.size();
     // record starts: '>' at the beginning of a line, found chunk-parallel with memchr
     const int T = std::max(1, n_threads);
     std::vector<std::vector<const char*>> starts(T);
     auto scan = [&](int t) {
-        const char* lo = p + fb.data.size() * t / T; const char* hi = p + fb.data.size() * (t + 1) / T;
+        const char* lo = p + fb.size() * t / T; const char* hi = p + fb.size() * (t + 1) / T;
         for (const char* q = lo; q < hi;) {
             const char* g = (const char*)memchr(q, '>', (size_t)(hi - q));
             if (!g) break;
@@ -230,8 +250,17 @@ extern "C" int vg_genomes_load(const char* const* paths, int n_paths, int multis
         else { std::string pth = paths[d.file]; size_t sl = pth.find_last_of('/'); g->names.push_back(sl == std::string::npos ? pth : pth.substr(sl + 1)); }
         g->n++;
     }
-    g->packed.assign((size_t)(g->padded_total() / 16), 0u);
-    g->nmask.assign((size_t)(g->padded_total() / 32), 0u);
+    // first touch in parallel: the arrays are written by the packing threads right below
+    g->packed.reserve((size_t)(g->padded_total() / 16) + 16); g->nmask.reserve((size_t)(g->padded_total() / 32) + 16);   // + the slack vg_genomes_finish adds
+    g->packed.resize((size_t)(g->padded_total() / 16)); g->nmask.resize((size_t)(g->padded_total() / 32));
+    {
+        const int64_t chunk = 1 << 20, np = ((int64_t)g->packed.size() + chunk - 1) / chunk, nm = ((int64_t)g->nmask.size() + chunk - 1) / chunk;
+        parallel_for(np + nm, T, [&](int64_t c) {
+            std::vector<uint32_t, no_init_alloc<uint32_t>>& v = c < np ? g->packed : g->nmask;
+            const int64_t lo = (c < np ? c : c - np) * chunk, hi = std::min<int64_t>(lo + chunk, (int64_t)v.size());
+            memset(v.data() + lo, 0, (size_t)(hi - lo) * sizeof(uint32_t));
+        });
+    }
     parallel_for((int64_t)gd.size(), T, [&](int64_t gi) {
         const gdesc& d = gd[(size_t)gi];
         int64_t at = g->base_off[(size_t)gi]; bool any_n = false;
