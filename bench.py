@@ -168,6 +168,13 @@ def main():
                             frac=round(achieved / HBM_PEAK_GBS, 6), traffic=traffic, traffic_source=traffic_src,
                             avg_launch_ms=round(avg_ms, 4), algorithmic_bytes_per_launch=round(alg_bytes),
                             kernels={e['name']: round(e['total_ms'] / max(e['launches'], 1), 4) for e in prof})
+            # whole path: B_pre = sum(L/4 + 16 (L-k+1)) + 16 P, B_aln = sum over ordered pairs ((Lq+Lr)/4 + 20)
+            b_pre = float(np.sum(lens / 4.0 + 16.0 * np.maximum(lens - args.k + 1, 0))) + 16.0 * n_pairs
+            tk = state['tasks']
+            b_aln = float(np.sum((lens[tk['q']] + lens[tk['r']]) / 4.0 + 20.0))
+            step_s = dt / args.steps
+            roofline['path'] = dict(algorithmic_bytes_per_step=round(b_pre + b_aln), achieved=round((b_pre + b_aln) / step_s / 1e9, 3),
+                                    frac=round((b_pre + b_aln) / step_s / 1e9 / HBM_PEAK_GBS, 6), note='whole step incl. host time, all ranks' if world > 1 else 'whole step incl. host time')
         cpu = None
         if world == 1 and not args.no_cpu_baseline and args.workload == 'phage':
             cpu = cpu_baseline(min(args.cpu_sample_families, args.families), args.members, args.length, 1,
