@@ -200,7 +200,7 @@ __device__ __forceinline__ int extend(const pair_ctx& c, const lz_dev_params& P,
         int viol = 32;
         {
             const uint64_t tail = (P.aw > 1) ? (prev_mm >> (64 - 2 * (P.aw - 1))) : 0ULL;
-            if (__popcll(mm) + __popcll(tail) > P.am) {
+            if ((int)(__popcll(mm) + __popcll(tail)) > P.am) {
                 uint64_t bits = mm;
                 while (bits) {
                     const int j = __builtin_ctzll(bits) >> 1;
@@ -993,7 +993,6 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
             }
         }
         dbuf<ref_desc> d_refs((size_t)n_refs); d_refs.upload(refs.data(), refs.size(), s);
-        dbuf<int64_t> d_chunk(chunk_off.size()); d_chunk.upload(chunk_off.data(), chunk_off.size(), s);
         dbuf<uint32_t> rr_pool((size_t)rr_words + 8), mask_pool((size_t)mask_words + 8), atab_pool((size_t)atab_n), aent_pool((size_t)aent_n),
             stab_pool((size_t)stab_tot), sent_pool((size_t)sent_n);
         dbuf<task_dev> d_tasks(td.size()); d_tasks.upload(td.data(), td.size(), s);

@@ -106,15 +106,6 @@ __device__ __forceinline__ void kmers4(const kmer_args& A, int64_t p0, uint64_t 
     }
 }
 
-// k-mers kept per genome (|K_g| = kept - duplicates): one atomic per wave and genome
-__device__ __forceinline__ void count_kept(bool kept, uint32_t g, int* __restrict__ kept_per_genome) {
-    const uint32_t g0 = __shfl(g, 0);
-    if (__all(g == g0)) {
-        const unsigned long long b = __ballot(kept);
-        if ((threadIdx.x & 63) == 0 && b) atomicAdd(&kept_per_genome[g0], __popcll(b));
-    } else if (kept) atomicAdd(&kept_per_genome[g], 1);
-}
-
 // Dense form (all k-mers kept: one shard, fraction 1): four consecutive padded base positions per
 // thread (one sequence window for the four), 32 contiguous bytes of keys per thread.
 __global__ void __launch_bounds__(256)
