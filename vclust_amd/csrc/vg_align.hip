@@ -919,7 +919,7 @@ inline int grid_for(int64_t n, int block = 256, int max_blocks = 256 * 16) {
 }  // namespace
 
 static int64_t g_index_budget_bytes = 24LL << 30;
-static int64_t g_segment_task_limit = 16384;
+static int64_t g_segment_task_limit = 32768;
 static int g_bucket_shift = 2;
 
 extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks, const vg_lz_params* p,
@@ -1035,13 +1035,20 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
         }
         {
             const int64_t nt = end - pos;
-            double bytes_alg = 0;
-            for (int64_t t = pos; t < end; ++t) bytes_alg += (double)(g->len[tasks[order[t]].q] + g->len[tasks[order[t]].r]) / 4.0 + 20.0;
+            double bytes_alg = 0; int64_t q_max = 0, q_sum = 0;
+            for (int64_t t = pos; t < end; ++t) {
+                const int64_t ql = g->len[tasks[order[t]].q];
+                bytes_alg += (double)(ql + g->len[tasks[order[t]].r]) / 4.0 + 20.0;
+                q_max = std::max(q_max, ql); q_sum += ql;
+            }
             vg_prof_scope ps("lz_parse", bytes_alg);
-            // few tasks: the launch lasts as long as its slowest pair, so four waves share each pair;
-            // many tasks: one wave per pair keeps every SIMD busy without the duplicated stretches
+            // Four waves per pair (segments) shorten the critical path: worth it when the launch would
+            // otherwise last as long as its slowest pair -- few tasks, or queries several times longer than
+            // the average one (mixed contig sets).  With many uniform tasks one wave per pair keeps every
+            // SIMD busy without the duplicated stretches.
             static const char* seg_env = getenv("VG_LZ_SEGMENTS");
-            const bool segments = seg_env ? atoi(seg_env) > 1 : (nt <= g_segment_task_limit);
+            const bool uneven = q_max * nt > 3 * q_sum;
+            const bool segments = seg_env ? atoi(seg_env) > 1 : (nt <= g_segment_task_limit || uneven);
             if (segments && !want_regions && P.ablate == 0) {
                 const int64_t nblk = (nt + 7) / 8 * 8;
                 hipLaunchKernelGGL(k_lz_parse_seg, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p, nt, d_refs.p, g->d_packed.p, g->d_nmask.p,
