@@ -630,6 +630,7 @@ struct task_dev { uint32_t q, r_slot, out_idx, pad; };
 // partial sums are added up; the result is identical to the single-wave parse, only the critical
 // path is ~S times shorter.
 constexpr int SEG_LOG_CAP = 256;
+constexpr int PW_AFTER_EVENT = 32;
 struct seg_rec { int i_ev, ev_pos; uint32_t VM, VA, VN; };     // VN: bit 31 = open region already spans >= reg
 
 #define PARSE_ARGS \
@@ -676,6 +677,7 @@ __device__ __forceinline__ void lz_parse_body(PARSE_ARGS) {
     int phase_end = (S > 1 && w < S - 1) ? min((w + 1) * seg_len, lim) : lim;
     int i = seg_start, lit = 0, pred = 0; bool alive = false;
     int n_events = 0, n_iter = 0, n_ab = 0, n_sb = 0;
+    int pw = 64;                 // lanes (query positions) probed per trip
     bool synced = false; int sync_v = -1, sync_idx = 0, log_n = 0, look_v = -1, look_cur = 0;
     const bool prof = (ABL & 128) != 0; const int psel = (ABL >> 8) & 7;
     long long pc[6] = {0, 0, 0, 0, 0, 0}; long long tp = prof ? (long long)clock64() : 0;
@@ -707,7 +709,7 @@ __device__ __forceinline__ void lz_parse_body(PARSE_ARGS) {
         // ---- speculative probe of positions i .. i+63
         const int qi = i + lane;
         int best_len = 0, best_pos = 0; bool hit_close = false;
-        if (qi < lim) {
+        if (qi < lim && lane < pw) {
             const bool alive_l = alive && (lit + lane <= P.mqd);
             const int pred_l = pred + lane;
             uint64_t xq = load32(c.qpk, qi);
@@ -790,12 +792,14 @@ __device__ __forceinline__ void lz_parse_body(PARSE_ARGS) {
         if (DEV) ++n_iter;
         PROF_MARK(0);
         if (!hb) {
-            // 64 literals (or the tail)
-            const int n = min(64, lim - i);
+            // pw literals (or the tail); widen the next probe: a stretch without matches is scanned 64 at a time
+            const int n = min(pw, lim - i);
             i += n; lit += n; if (alive) { pred += n; if (lit > P.mqd) alive = false; }
+            pw = 64;
             continue;
         }
         const int f = __builtin_ctzll(hb);
+        pw = PW_AFTER_EVENT;        // the next match usually starts within a few positions of the end of this one
         // Pairs that need many events are the tail of the launch: a wave raises its own issue priority
         // as its event count grows, so the heavy pairs overtake the light ones sharing their SIMD.
         if (!(ABL & 64)) {
