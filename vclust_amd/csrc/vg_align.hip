@@ -124,6 +124,17 @@ __device__ __forceinline__ int match_len_lane(const pair_ctx& c, int qp, int rp,
     return l;
 }
 
+// exact match length (<= 32) of the query chunk already held in registers (xq, qbad = even-bit mask of
+// its unusable slots: beyond the query end or N) against rr[rp ..]: only the reference side is loaded
+__device__ __forceinline__ int match_len32_q(const pair_ctx& c, uint64_t xq, uint64_t qbad, int rp) {
+    const uint64_t d = xq ^ load32(c.rpk, rp);
+    uint64_t mm = ((d | (d >> 1)) & EVEN) | qbad;
+    if (c.r_has_n) mm |= spread(loadm32(c.rmk, rp));
+    const int hi = c.n_rr - rp; if (hi < 32) mm |= EVEN & ~slots(0, hi);
+    const int sj = c.L - rp; if ((unsigned)sj < 32u) mm |= 1ULL << (2 * sj);
+    return mm ? (__builtin_ctzll(mm) >> 1) : 32;
+}
+
 // ---- cross-lane helpers that stay off the LDS crossbar (ds_bpermute costs ~100 cycles of
 // latency each, and a wave that owns a pair runs these in a dependent chain) ----------------
 // value of a wave-uniform lane: v_readlane
@@ -714,11 +725,13 @@ __device__ __forceinline__ void lz_parse_body(PARSE_ARGS) {
             const int pred_l = pred + lane;
             uint64_t xq = load32(c.qpk, qi);
             bool q_ok_a = true, q_ok_s = (qi + P.msl <= c.qlen);
+            uint64_t qbad = (c.qlen - qi < 32) ? (EVEN & ~slots(0, c.qlen - qi)) : 0ULL;     // slots past the query end
             if (c.q_has_n) {
                 uint64_t m = (uint64_t)c.qmk[qi >> 5] | ((uint64_t)c.qmk[(qi >> 5) + 1] << 32);
                 m >>= (qi & 31);
                 q_ok_a = (m & ((1ULL << P.mal) - 1)) == 0;
                 q_ok_s = q_ok_s && (m & ((1ULL << P.msl) - 1)) == 0;
+                qbad |= spread((uint32_t)m);
             }
             // R2 (anchor = longest exact match >= mal over all occurrences of the mal-mer) and R3 (seed
             // >= msl near the prediction, only for positions without an anchor) walk their buckets
@@ -769,7 +782,7 @@ __device__ __forceinline__ void lz_parse_body(PARSE_ARGS) {
                     const uint32_t eas = ja == 0 ? ea0 : ja == 1 ? ea1 : ja == 2 ? ea2 : ea3;
                     const int ess = ja == 0 ? es0 : ja == 1 ? es1 : ja == 2 ? es2 : es3;
                     const int rp = seed ? ess : (int)(eas & posmask);
-                    int l = match_len_lane(c, qi, rp, 32);
+                    int l = match_len32_q(c, xq, qbad, rp);
                     int& bl = seed ? sbest_len : best_len; int& bp = seed ? sbest_pos : best_pos; int& nc = seed ? ncap_s : ncap_a;
                     if (l < (seed ? P.msl : P.mal)) continue;
                     if (l >= 32) {
