@@ -45,10 +45,12 @@ struct lz_dev_params { int mal, msl, mrd, mqd, reg, aw, am, ar; int ablate; };  
 // ------------------------------------------------------------------ bit helpers
 // 32 bases (2-bit codes, first base in the low bits) starting at base position p (p >= 0)
 __device__ __forceinline__ uint64_t load32(const uint32_t* __restrict__ pk, int64_t p) {
-    int64_t w = p >> 4; int sh = 2 * (int)(p & 15);
-    uint64_t lo = (uint64_t)pk[w] | ((uint64_t)pk[w + 1] << 32);
+    const int64_t w = p >> 4; const int sh = 2 * (int)(p & 15);
+    uint4 v; __builtin_memcpy(&v, pk + w, 16);          // one 16-byte load (4-byte aligned); every packed array has slack words
+    asm volatile("" :: "v"(v.w));                      // keep it one instruction (the narrowed form is two loads)
+    const uint64_t lo = (uint64_t)v.x | ((uint64_t)v.y << 32);
     if (sh == 0) return lo;
-    return (lo >> sh) | ((uint64_t)pk[w + 2] << (64 - sh));
+    return (lo >> sh) | ((uint64_t)v.z << (64 - sh));
 }
 // 32 mask bits starting at base position p
 __device__ __forceinline__ uint32_t loadm32(const uint32_t* __restrict__ mk, int64_t p) {
@@ -758,8 +760,10 @@ __device__ __forceinline__ void lz_parse_body(PARSE_ARGS) {
                 if (DEV) { ++n_ab; }
                 uint32_t ea0 = 0, ea1 = 0, ea2 = 0, ea3 = 0; int es0 = 0, es1 = 0, es2 = 0, es3 = 0;
                 const bool la = a_u < a_e, ls = s_u < s_e;
-                if (la) { ea0 = aent[a_u]; ea1 = aent[min(a_u + 1, a_e - 1)]; ea2 = aent[min(a_u + 2, a_e - 1)]; ea3 = aent[min(a_u + 3, a_e - 1)]; }
-                if (ls) { es0 = (int)sent[s_u]; es1 = (int)sent[min(s_u + 1, s_e - 1)]; es2 = (int)sent[min(s_u + 2, s_e - 1)]; es3 = (int)sent[min(s_u + 3, s_e - 1)]; }
+                // four consecutive entries = one 16-byte load (the pools carry four entries of slack; entries past
+                // the bucket end are ignored below)
+                if (la) { uint4 v; __builtin_memcpy(&v, aent + a_u, 16); ea0 = v.x; ea1 = v.y; ea2 = v.z; ea3 = v.w; }
+                if (ls) { uint4 v; __builtin_memcpy(&v, sent + s_u, 16); es0 = (int)v.x; es1 = (int)v.y; es2 = (int)v.z; es3 = (int)v.w; }
                 // candidate slots: bits 0..3 anchors (tag collisions fail the length test), 4..7 seeds
                 unsigned cm = 0;
                 if (la) {
@@ -1010,8 +1014,8 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
             }
         }
         dbuf<ref_desc> d_refs((size_t)n_refs); d_refs.upload(refs.data(), refs.size(), s);
-        dbuf<uint32_t> rr_pool((size_t)rr_words + 8), mask_pool((size_t)mask_words + 8), atab_pool((size_t)atab_n), aent_pool((size_t)aent_n),
-            stab_pool((size_t)stab_tot), sent_pool((size_t)sent_n);
+        dbuf<uint32_t> rr_pool((size_t)rr_words + 8), mask_pool((size_t)mask_words + 8), atab_pool((size_t)atab_n), aent_pool((size_t)aent_n + 4),
+            stab_pool((size_t)stab_tot), sent_pool((size_t)sent_n + 4);
         dbuf<task_dev> d_tasks(td.size()); d_tasks.upload(td.data(), td.size(), s);
         // split the batch: LDS counting sort for ordinary references, global path for the rest
         std::vector<int> small_list, large_list; std::vector<int64_t> large_chunks{ 0 };
