@@ -512,8 +512,7 @@ k_spgemm(const uint64_t* __restrict__ rowinfo, const uint32_t* __restrict__ gen,
             bool done = false;
             for (uint32_t e = 0; e < rl && !done; e += 4) {
                 uint32_t g4[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) g4[j] = gen[rs + min(e + j, rl - 1)];
+                __builtin_memcpy(g4, gen + (size_t)rs + e, 16);            // one 16-byte load; entries past the run are ignored (4 slack entries)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (e + j >= rl || done) continue;
@@ -645,7 +644,7 @@ static void run_extract_sort(vg_genomes* g, int k, double fraction, int shard, i
     dbuf<uint64_t> keys_a, keys_b; dbuf<uint32_t> pos_a, pos_b;
     int64_t n_sort = P; unsigned long long nv = 0;
     if (!out.compact) {
-        keys_a.alloc((size_t)P); keys_b.alloc((size_t)P); pos_a.alloc((size_t)P); pos_b.alloc((size_t)P);
+        keys_a.alloc((size_t)P); keys_b.alloc((size_t)P); pos_a.alloc((size_t)P + 4); pos_b.alloc((size_t)P);
         dbuf<unsigned long long> d_nvalid(1); d_nvalid.zero(s);
         {
             vg_prof_scope ps("kmer_extract", (double)P * (3.0 / 8.0 + 8.0));
@@ -674,7 +673,7 @@ static void run_extract_sort(vg_genomes* g, int k, double fraction, int shard, i
         if (total64 >= (1LL << 32) - 1) throw vg_error(VG_EOVERFLOW, "more than 2^32 k-mers in one shard: use more shards");
         nv = total; n_sort = (int64_t)total;
         const size_t na = (size_t)std::max<int64_t>(n_sort, 1);
-        keys_a.alloc(na); keys_b.alloc(na); pos_a.alloc(na); pos_b.alloc(na);
+        keys_a.alloc(na); keys_b.alloc(na); pos_a.alloc(na + 4); pos_b.alloc(na);
         if (n_sort > 0) {
             vg_prof_scope ps("kmer_emit", (double)P * 3.0 / 8.0 + (double)n_sort * 12.0);
             if (n_sort * 4 <= P) hipLaunchKernelGGL(k_kmer_emit_sparse, dim3(grid_for(P / 8)), dim3(256), 0, s, A, out.wave_mask.p, out.wave_base.p, keys_a.p, pos_a.p);
@@ -721,7 +720,7 @@ static void kmer_shared_pass(vg_genomes* g, int k, double fraction, int shard, i
     VG_HIP(hipMemsetAsync(rowinfo.p, 0, (size_t)n_rows_info * sizeof(uint64_t), s));
     const compact_map cmap{ si.compact ? si.goff.p : nullptr, si.compact ? si.cblk.p : nullptr };
     const uint32_t* wbase = si.compact ? si.wave_base.p : nullptr;
-    dbuf<uint32_t> gen = si.spare32.n >= (size_t)std::max<int64_t>(nv, 1) ? std::move(si.spare32) : dbuf<uint32_t>((size_t)std::max<int64_t>(nv, 1));
+    dbuf<uint32_t> gen = si.spare32.n >= (size_t)std::max<int64_t>(nv, 1) + 4 ? std::move(si.spare32) : dbuf<uint32_t>((size_t)std::max<int64_t>(nv, 1) + 4);
     dbuf<int> d_dups((size_t)n); d_dups.zero(s);
     constexpr unsigned int BIG_CAP = 4096;
     dbuf<uint64_t> big_runs(2 * BIG_CAP); dbuf<unsigned int> d_nbig(1); d_nbig.zero(s);
