@@ -331,7 +331,7 @@ __device__ __forceinline__ uint32_t anchor_tag(uint64_t h, int B, int pos_bits) 
 // staging window (buckets are filled range by range), so every global store of the index is a
 // coalesced copy: no 4-byte scatter to HBM (the first version wrote 10x the index size).
 constexpr int LDS_TAB = 16384;      // bucket table: anchors use B <= 14 bits, seeds 4^msl <= 16384
-constexpr int LDS_STAGE = 16384;    // staged entries per window
+constexpr int LDS_STAGE = 22016;    // staged entries per window (tab + stage + scan scratch fill the 160 KiB of a CU)
 constexpr int TOP_BITS = 9;         // big references: entries are first dealt into 2^TOP_BITS bins
 constexpr int BIG_RR = 131072;      // RR symbols from which the linear (binned) build is used
 __device__ __forceinline__ void lds_scan_exclusive(uint32_t* tab, int n, uint32_t* part) {
