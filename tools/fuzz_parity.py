@@ -1,0 +1,48 @@
+"""Randomised parity fuzzing of the HIP path against the CPU oracle (longer than the test suite).
+usage: fuzz_parity.py [n_cases] [seed]"""
+import sys, pathlib, time
+import numpy as np
+root = pathlib.Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(root)); sys.path.insert(0, str(root / 'tests'))
+import oracle_lib as orc
+from vclust_amd import api, synth
+api.set_device(0)
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+bad = 0
+t0 = time.time()
+for case in range(n_cases):
+    rng = np.random.default_rng(seed0 + case)
+    nf = int(rng.integers(1, 5)); mem = int(rng.integers(2, 6))
+    lo = int(rng.choice([300, 2000, 9000, 30000])); hi = lo * int(rng.integers(1, 5))
+    p_hi = float(rng.choice([0.02, 0.12, 0.25, 0.4]))
+    codes, offsets, names = synth.make_families(nf, mem, seed=seed0 + case, length_range=(lo, hi), p_hi=p_hi)
+    codes = codes.copy()
+    for _ in range(int(rng.integers(0, 6))):                       # N runs
+        p = int(rng.integers(0, max(1, len(codes) - 80))); codes[p:p + int(rng.integers(1, 70))] = 4
+    gs = api.GenomeSet.from_codes(codes, offsets, names)
+    k = int(rng.choice([15, 21, 25, 30])); frac = float(rng.choice([1.0, 1.0, 0.5, 0.1]))
+    sizes, pairs = gs.kmer_shared(k=k, fraction=frac)
+    osizes, opairs = orc.shared_all(codes, offsets, k=k, fraction=frac)
+    if list(sizes) != list(osizes) or {(int(p['a']), int(p['b'])): int(p['shared']) for p in pairs} != opairs:
+        bad += 1; print('PREFILTER MISMATCH case', case, 'seed', seed0 + case, flush=True)
+    ns = int(rng.choice([2, 3, 8])); tot = np.zeros_like(sizes); acc = {}
+    for s in range(ns):
+        sz, pr = gs.kmer_shared(k=k, fraction=frac, shard=s, n_shards=ns); tot += sz
+        for p in pr: acc[(int(p['a']), int(p['b']))] = acc.get((int(p['a']), int(p['b'])), 0) + int(p['shared'])
+    if list(tot) != list(osizes) or acc != opairs:
+        bad += 1; print('SHARD MISMATCH case', case, 'seed', seed0 + case, flush=True)
+    lz = None
+    if rng.random() < 0.5:
+        mal = int(rng.integers(9, 17)); msl = int(rng.integers(5, min(mal, 9) + 1))
+        lz = dict(mal=mal, msl=msl, mrd=int(rng.integers(10, 80)), mqd=int(rng.integers(10, 80)), reg=int(rng.integers(20, 80)),
+                  aw=int(rng.integers(8, 24)), am=int(rng.integers(2, 10)), ar=int(rng.integers(2, 6)))
+        lz['am'] = min(lz['am'], lz['aw'] - 1)
+    tasks = gs.align_tasks(gs.read_filter(None)) if len(gs) <= 8 else gs.align_tasks(synth.family_pairs(nf, mem))
+    stats = gs.lz_align(tasks, lz=lz)
+    for t, s in zip(tasks, stats):
+        q, r = int(t['q']), int(t['r'])
+        ref = orc.lz_pair_stat(codes[offsets[q]:offsets[q + 1]], codes[offsets[r]:offsets[r + 1]], lz=lz)
+        if ref != (int(s['n_match']), int(s['aln_len']), int(s['n_regions'])):
+            bad += 1; print('LZ MISMATCH case', case, 'seed', seed0 + case, (q, r), ref, tuple(int(x) for x in s), lz, flush=True); break
+print(f'{n_cases} cases, {bad} mismatches, {time.time() - t0:.0f} s')
