@@ -347,6 +347,8 @@ k_group_runs(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos
              unsigned int long_cap) {
     __shared__ uint64_t sk[GS_TILE + GS_HALO + 1];
     __shared__ uint32_t sp[GS_TILE + GS_HALO + 1];
+    __shared__ unsigned long long sh[(GS_TILE + GS_HALO + 1) / 64 + 2];      // bit j: entry j starts an equal-prefix group
+    constexpr int SLOTS = (GS_TILE + GS_HALO + 1 + 255) / 256 * 256;
     const int64_t n_tiles = (n + GS_TILE - 1) / GS_TILE;
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t t0 = tile * GS_TILE;
@@ -359,23 +361,37 @@ k_group_runs(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos
             sp[j] = p;
         }
         __syncthreads();
+        // group heads as a bit map (slot 0 and everything from slot m on count as heads), so that an entry
+        // finds the bounds of its group with two bit scans instead of walking to them
+        for (int j = threadIdx.x; j < SLOTS; j += blockDim.x) {
+            const bool head = j == 0 || j >= m || (sk[j] >> low_bit) != (sk[j - 1] >> low_bit);
+            const unsigned long long hb = __ballot(head);
+            if ((threadIdx.x & 63) == 0 && (j >> 6) < (int)(sizeof(sh) / sizeof(sh[0]))) sh[j >> 6] = hb;
+        }
+        if (threadIdx.x == 0) sh[sizeof(sh) / sizeof(sh[0]) - 1] = ~0ULL;
+        __syncthreads();
         const int own = (int)min<int64_t>(GS_TILE, n - t0);
         for (int j = 1 + threadIdx.x; j < m; j += blockDim.x) {
-            const uint64_t key = sk[j]; const uint64_t pre = key >> low_bit;
-            int b = j - 1, lt = 0, eq_before = 0, prev_eq = -1;
-            while (b >= 0 && (sk[b] >> low_bit) == pre) {
-                const uint64_t kb = sk[b];
-                lt += kb < key;
-                if (kb == key) { if (prev_eq < 0) prev_eq = b; ++eq_before; }
-                --b;
-            }
-            const int gs = b + 1;
+            int w = j >> 6;
+            unsigned long long x = sh[w] & (~0ULL >> (63 - (j & 63)));
+            while (x == 0) x = sh[--w];
+            const int gs = (w << 6) + 63 - __builtin_clzll(x);
             if (gs < 1 || gs > own) continue;                            // the group starts in another tile
-            int f = j + 1, eq_after = 0;
-            while (f < m && (sk[f] >> low_bit) == pre) { const uint64_t kf = sk[f]; lt += kf < key; eq_after += kf == key; ++f; }
-            if (f == m && t0 - 1 + m < n) {                               // runs past the halo: one entry queues the group
+            w = j >> 6;
+            x = (j & 63) == 63 ? 0ULL : sh[w] & (~0ULL << ((j & 63) + 1));
+            while (x == 0) x = sh[++w];
+            const int ge = min(m, (w << 6) + __builtin_ctzll(x));
+            if (ge == m && t0 - 1 + m < n) {                              // runs past the halo: one entry queues the group
                 if (j == gs) { const unsigned int o = atomicAdd(n_long, 1u); if (o < long_cap) long_list[o] = t0 - 1 + gs; }
                 continue;
+            }
+            // rank inside the group by the full key (stable), and the run of the entry's own k-mer
+            const uint64_t key = sk[j];
+            int lt = 0, eq_before = 0, eq_after = 0, prev_eq = -1;
+            for (int t = gs; t < ge; ++t) {
+                const uint64_t kt = sk[t];
+                lt += kt < key;
+                if (kt == key) { if (t < j) { ++eq_before; prev_eq = t; } else if (t > j) ++eq_after; }
             }
             const int64_t rs = t0 - 1 + gs + lt;                         // first entry of this k-mer's run, sorted order
             // genomes are looked up here, not staged: 12 bytes of LDS per entry keep five workgroups on a CU
