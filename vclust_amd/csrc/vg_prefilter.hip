@@ -327,6 +327,7 @@ k_runs(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos, cons
                 if (i == rs) { unsigned int o = atomicAdd(n_big, 1u); if (o < big_cap) { big_runs[2 * o] = (uint64_t)rs; big_runs[2 * o + 1] = rl; } }
                 rl = RUNLEN_MASK;
             }
+            if (!has_prev) continue;                            // the run's smallest genome: no partner b < a
             rowinfo[p] = ((uint64_t)rs << RUNLEN_BITS) | rl;            // p = base position (dense) or compact index
         }
     }
@@ -402,7 +403,7 @@ k_group_runs(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos
             gen[rs + eq_before] = g | (dup ? DUP_BIT : 0u);
             if (dup) { atomicAdd(&dup_per_genome[g], 1); continue; }
             const uint32_t rl = (uint32_t)(eq_before + eq_after + 1);
-            if (rl < 2) continue;                                        // singleton k-mer: no partner possible
+            if (rl < 2 || eq_before == 0) continue;                      // singleton k-mer, or the run's smallest genome: no partner b < a
             const uint32_t p = sp[j];
             rowinfo[p] = ((uint64_t)rs << RUNLEN_BITS) | rl;            // p = base position (dense) or compact index
         }
@@ -447,7 +448,7 @@ k_long_groups(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ po
         bool dup = false;
         if (i > gs) { const uint32_t pp = pos[i - 1]; dup = (M.cblk ? genome_of_compact(M, pp) : blk2g[pp >> blk_shift]) == g; }
         gen[i] = g | (dup ? DUP_BIT : 0u);
-        if (dup) { atomicAdd(&dup_per_genome[g], 1); continue; }
+        if (dup || i == gs) { if (dup) atomicAdd(&dup_per_genome[g], 1); continue; }   // (the run's smallest genome has no partner b < a)
         rowinfo[p] = ((uint64_t)gs << RUNLEN_BITS) | rl;
     }
 }
