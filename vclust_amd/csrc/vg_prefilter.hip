@@ -394,6 +394,8 @@ k_group_runs(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos
                 lt += kt < key;
                 if (kt == key) { if (t < j) { ++eq_before; prev_eq = t; } else if (t > j) ++eq_after; }
             }
+            const uint32_t rl = (uint32_t)(eq_before + eq_after + 1);
+            if (rl < 2) continue;                                        // singleton k-mer: no partner, and nobody reads its gen[] slot
             const int64_t rs = t0 - 1 + gs + lt;                         // first entry of this k-mer's run, sorted order
             // genomes are looked up here, not staged: 12 bytes of LDS per entry keep five workgroups on a CU
             const uint32_t pj = sp[j];
@@ -402,8 +404,7 @@ k_group_runs(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos
             if (prev_eq >= 0) { const uint32_t pq = sp[prev_eq]; dup = (M.cblk ? genome_of_compact(M, pq) : blk2g[pq >> blk_shift]) == g; }
             gen[rs + eq_before] = g | (dup ? DUP_BIT : 0u);
             if (dup) { atomicAdd(&dup_per_genome[g], 1); continue; }
-            const uint32_t rl = (uint32_t)(eq_before + eq_after + 1);
-            if (rl < 2 || eq_before == 0) continue;                      // singleton k-mer, or the run's smallest genome: no partner b < a
+            if (eq_before == 0) continue;                                // the run's smallest genome: no partner b < a
             const uint32_t p = sp[j];
             rowinfo[p] = ((uint64_t)rs << RUNLEN_BITS) | rl;            // p = base position (dense) or compact index
         }
