@@ -215,6 +215,9 @@ __device__ __forceinline__ int extend(const pair_ctx& c, const lz_dev_params& P,
             const uint64_t tail = (P.aw > 1) ? (prev_mm >> (64 - 2 * (P.aw - 1))) : 0ULL;
             if ((int)(__popcll(mm) + __popcll(tail)) > P.am) {
                 uint64_t bits = mm;
+                // a window holds the mismatches of the tail plus those up to the tested one: the first
+                // am - |tail| mismatches of this chunk cannot push any window over am
+                for (int skip = P.am - (int)__popcll(tail); skip > 0; --skip) bits &= bits - 1;
                 while (bits) {
                     const int j = __builtin_ctzll(bits) >> 1;
                     const int top = 2 * j + 2;
