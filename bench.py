@@ -49,7 +49,9 @@ def pmc_traffic(scope):
     doc = json.loads(files[-1].read_text())
     for k in KERNEL_OF_SCOPE.get(scope, ()):
         if k in doc.get('kernels', {}):
-            return doc['kernels'][k]['hbm_bytes_per_launch_raw'], f'profiles/{files[-1].name}:{k}'
+            e = doc['kernels'][k]
+            per_step = e['launches'] / max(doc.get('steps_in_run', e['launches']), 1)      # e.g. 3 sort iterations per step
+            return round(e['hbm_bytes_per_launch_raw'] * per_step), f'profiles/{files[-1].name}:{k}'
     return None, None
 
 

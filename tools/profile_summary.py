@@ -52,7 +52,7 @@ def main():
         wk = w / nw if nw else 0.0
         kernels[k] = dict(launches=max(nf, nw), FETCH_SIZE_KB_per_launch=round(fk, 1), WRITE_SIZE_KB_per_launch=round(wk, 1),
                           hbm_bytes_per_launch_raw=round((fk + wk) * 1024), hbm_bytes_per_launch_fetch_x2=round((2 * fk + wk) * 1024))
-    doc = dict(command='python bench.py --steps 5 --warmup 2 --no-cpu-baseline (phage-1k, 1 MI355X)',
+    doc = dict(command='python bench.py --steps 5 --warmup 2 --no-cpu-baseline (phage-1k, 1 MI355X)', steps_in_run=7,
                note='separate --pmc passes for FETCH_SIZE and WRITE_SIZE (TCC slot limits); units KB; fetch_x2 applies the '
                     'gfx950 FETCH_SIZE correction for wide coalesced reads (upper bound for narrow random reads)',
                kernels=kernels)
