@@ -802,6 +802,9 @@ __device__ __forceinline__ void lz_parse_body(PARSE_ARGS) {
                     if (l > bl || (l == bl && rp < bp)) { bl = l; bp = rp; }
                 }
                 a_u += 4; s_u += 4;
+                // positions behind the first one that already has a match cannot become the event: stop their walks
+                const unsigned long long hit = __ballot(best_len > 0 || sbest_len > 0);
+                if (hit && lane > __builtin_ctzll(hit)) { a_u = a_e; s_u = s_e; }
             }
             if (best_len > 0) {
                 const int d = best_pos - pred_l;
