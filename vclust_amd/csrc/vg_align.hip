@@ -321,7 +321,16 @@ __device__ __forceinline__ void rr_chunk(const uint32_t* __restrict__ gpk, const
     *bits_out = bits & ~sm; *mask_out = mask;
 }
 
-__device__ __forceinline__ uint64_t anchor_hash(uint64_t code) { return code * 0x9E3779B97F4A7C15ULL; }
+// Multiplicative hash of an anchor code; bucket = its top B bits, tag = the bits below.  Codes of up to 16
+// bases (the default mal = 11) fit 32 bits: two 32-bit multiplies instead of a 64-bit one (integer
+// multiplies issue at quarter rate, and every reference position and every probed query position pays one).
+__device__ __forceinline__ uint64_t anchor_hash(uint64_t code, bool narrow) {
+    if (narrow) {
+        const uint32_t h = (uint32_t)code * 0x9E3779B1u;
+        return ((uint64_t)h << 32) | (uint32_t)(h * 0x85EBCA77u + (uint32_t)code);
+    }
+    return code * 0x9E3779B97F4A7C15ULL;
+}
 __device__ __forceinline__ uint32_t anchor_bucket(uint64_t h, int B) { return (uint32_t)(h >> (64 - B)); }
 __device__ __forceinline__ uint32_t anchor_tag(uint64_t h, int B, int pos_bits) {
     // up to 14 hash bits below the bucket bits, as many as fit above pos_bits in a 32-bit entry
@@ -412,7 +421,7 @@ k_build_index_lds(const ref_desc* __restrict__ refs, const int* __restrict__ slo
                     if (p + w <= rd.n_rr && ((ml >> j) & ((1ULL << w) - 1)) == 0) {
                         const uint64_t x = s2 ? ((lo >> s2) | (hi << (64 - s2))) : lo;
                         if (phase == 0) {
-                            const uint64_t h = anchor_hash(x & amask);
+                            const uint64_t h = anchor_hash(x & amask, mal <= 16);
                             bt = anchor_bucket(h, rd.B) | (anchor_tag(h, rd.B, rd.pos_bits) << 18);
                         } else bt = (uint32_t)(x & smask);
                         atomicAdd(&tab[(bt & 0x3ffffu) >> (big ? tsh : 0)], 1u);
@@ -588,7 +597,7 @@ k_index_pass(const ref_desc* __restrict__ refs, const int* __restrict__ slot_lis
         uint64_t m = (uint64_t)mk[p >> 5] | ((uint64_t)mk[(p >> 5) + 1] << 32);
         m >>= (p & 31);
         if (p + mal <= rd.n_rr && (m & ((1ULL << mal) - 1)) == 0) {
-            const uint64_t h = anchor_hash(x & amask);
+            const uint64_t h = anchor_hash(x & amask, mal <= 16);
             uint32_t b = anchor_bucket(h, rd.B);
             uint32_t slot = atomicAdd(&atab_pool[rd.atab + b], 1u);
             if (fill) aent_pool[rd.aent + slot] = (uint32_t)p | (anchor_tag(h, rd.B, rd.pos_bits) << rd.pos_bits);
@@ -748,7 +757,7 @@ __device__ __forceinline__ void lz_parse_body(PARSE_ARGS) {
             uint32_t a_u = 0, a_e = 0, s_u = 0, s_e = 0, tag = 0;
             const uint32_t posmask = (1u << rd.pos_bits) - 1u;
             if (do_a) {
-                const uint64_t h = anchor_hash(xq & amask);
+                const uint64_t h = anchor_hash(xq & amask, P.mal <= 16);
                 const uint32_t b = anchor_bucket(h, rd.B);
                 tag = anchor_tag(h, rd.B, rd.pos_bits);
                 a_u = b ? atab[b - 1] : 0u; a_e = atab[b];
