@@ -214,3 +214,24 @@ def test_degenerate_genome_sets():
         assert orc.lz_pair_stat(seqs[q], seqs[r]) == (int(s['n_match']), int(s['aln_len']), int(s['n_regions'])), (q, r)
     ident = [s for t, s in zip(tasks, stats) if {int(t['q']), int(t['r'])} == {0, 1}]
     assert all(int(s['n_match']) == 3000 and int(s['aln_len']) == 3000 and int(s['n_regions']) == 1 for s in ident)
+
+
+def test_index_budget_batches_do_not_change_results():
+    """vg_set_index_budget: with the smallest budget (64 MiB) the ~100 MB of indexes of 160 x 40 kb
+    references are built in several batches (several build + parse launches); rows and regions equal the
+    single-batch run."""
+    from vclust_amd import _lib
+    lib = _lib.load()
+    codes, offsets, names = synth.make_families(16, 10, length=40000, seed=9)
+    gs = api.GenomeSet.from_codes(codes, offsets, names)
+    tasks = gs.align_tasks(synth.family_pairs(16, 10))
+    ref_stats, ref_regions = gs.lz_align(tasks, want_regions=True)
+    lib.vg_set_index_budget((64 << 20) + 1)
+    try:
+        stats, regions = gs.lz_align(tasks, want_regions=True)
+        stats2 = gs.lz_align(tasks)
+    finally:
+        lib.vg_set_index_budget(24 << 30)
+    assert np.array_equal(stats, ref_stats) and np.array_equal(stats2, ref_stats)
+    key = lambda r: tuple(int(x) for x in r)
+    assert sorted(map(key, regions)) == sorted(map(key, ref_regions))
