@@ -170,6 +170,9 @@ def main():
                             frac=round(achieved / HBM_PEAK_GBS, 6), traffic=traffic, traffic_source=traffic_src,
                             avg_launch_ms=round(avg_ms, 4), algorithmic_bytes_per_launch=round(alg_bytes),
                             kernels={e['name']: round(e['total_ms'] / max(e['launches'], 1), 4) for e in prof})
+            if dom['name'] == 'radix_sort_pairs':
+                roofline['note'] = ('one "launch" = one rocprim::radix_sort_pairs call = 1 histogram kernel + one onesweep kernel per '
+                                    '8 sorted key bits (3 at this size); traffic sums the onesweep kernels')
             # whole path: B_pre = sum(L/4 + 16 (L-k+1)) + 16 P, B_aln = sum over ordered pairs ((Lq+Lr)/4 + 20)
             b_pre = float(np.sum(lens / 4.0 + 16.0 * np.maximum(lens - args.k + 1, 0))) + 16.0 * n_pairs
             tk = state['tasks']
