@@ -279,3 +279,31 @@ def test_genome_with_thousands_of_partners():
     assert len(np.unique((pairs['a'].astype(np.int64) << 32) | pairs['b'])) == len(pairs)
     expect = 16 + _common_prefix_len(left) + _common_prefix_len(right)
     assert np.array_equal(pairs['shared'].astype(np.int64), expect[pairs['a'], pairs['b']])
+
+
+def test_shards_on_low_complexity_sequence():
+    """Poly-A / tandem repeats put all k-mers of a stretch into ONE shard: its staging slots overflow and the
+    call must fall back to the recomputing emit pass; the shards still add up to the oracle's counts."""
+    rng = np.random.default_rng(77)
+    a = rng.integers(0, 4, size=6000, dtype=np.uint8)
+    unit = rng.integers(0, 4, size=5, dtype=np.uint8)
+    seqs = [np.concatenate([a[:2000], np.zeros(3000, np.uint8), a[2000:4000]]),          # poly-A block
+            np.concatenate([a[1000:3000], np.tile(unit, 500), a[:1500]]),                  # 5-base tandem repeat
+            a.copy()]
+    offsets = np.zeros(len(seqs) + 1, dtype=np.int64); offsets[1:] = np.cumsum([len(s) for s in seqs])
+    codes = np.concatenate(seqs)
+    gs = api.GenomeSet.from_codes(codes, offsets)
+    osizes, opairs = orc.shared_all(codes, offsets, k=25)
+    tot = np.zeros(len(seqs), dtype=np.int64); acc = {}; scopes = set()
+    api.profile_enable(True); api.profile_reset()
+    try:
+        for s in range(8):
+            sz, pr = gs.kmer_shared(k=25, shard=s, n_shards=8)
+            tot += sz
+            for p in pr:
+                acc[(int(p['a']), int(p['b']))] = acc.get((int(p['a']), int(p['b'])), 0) + int(p['shared'])
+        scopes = {e['name'] for e in api.profile_get()}
+    finally:
+        api.profile_enable(False)
+    assert list(tot) == list(osizes) and acc == opairs
+    assert 'kmer_emit_recompute' in scopes and 'kmer_emit' in scopes, scopes

@@ -152,8 +152,9 @@ __device__ __forceinline__ unsigned long long spread16x4(unsigned long long x) {
 // four positions per thread: a wave covers 256 consecutive positions = four 64-position masks
 __global__ void __launch_bounds__(256)
 k_kmer_count(kmer_args A, unsigned long long* __restrict__ wave_mask, uint32_t* __restrict__ wave_cnt,
-             int* __restrict__ kept_per_genome) {
+             int* __restrict__ kept_per_genome, uint64_t* __restrict__ stage, int stage_cap, unsigned int* __restrict__ stage_over) {
     const int lane = threadIdx.x & 63;
+    const unsigned long long below = (1ULL << lane) - 1ULL;
     for (int64_t p0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; p0 < A.P + 252; p0 += (int64_t)gridDim.x * blockDim.x * 4) {
         // P is a multiple of 64, not of 256: the last wave may be partly outside
         uint64_t kk[4] = {SENT, SENT, SENT, SENT}; uint32_t g = 0;
@@ -168,11 +169,35 @@ k_kmer_count(kmer_args A, unsigned long long* __restrict__ wave_mask, uint32_t* 
             wave_mask[wbase + lane] = mk; wave_cnt[wbase + lane] = (uint32_t)__popcll(mk);
         }
         const int mine = (kk[0] != SENT) + (kk[1] != SENT) + (kk[2] != SENT) + (kk[3] != SENT);
+        if (stage && mine) {
+            // the kept k-mers of the wave's 256 positions, compacted in position order into the chunk's slots:
+            // the emit pass becomes a copy (k_kmer_gather) instead of a second k-mer computation
+            int r = __popcll(b0 & below) + __popcll(b1 & below) + __popcll(b2 & below) + __popcll(b3 & below);
+            uint64_t* dst = stage + (size_t)(wbase >> 2) * stage_cap;
+            bool over = false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (kk[j] != SENT) { if (r < stage_cap) dst[r] = kk[j]; else over = true; ++r; }
+            if (over) atomicOr(stage_over, 1u);
+        }
         const uint32_t g0 = __shfl(g, 0);
         if (__all(g == g0 || p0 >= A.P)) {
             const int tot = __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
             if (lane == 0 && tot) atomicAdd(&kept_per_genome[g0], tot);
         } else if (mine) atomicAdd(&kept_per_genome[g], mine);
+    }
+}
+
+// staged k-mers of every 256-position chunk -> their final places (c = row number = sort payload)
+__global__ void __launch_bounds__(256)
+k_kmer_gather(const uint64_t* __restrict__ stage, int stage_cap, const uint32_t* __restrict__ wave_base, int64_t W,
+              uint64_t* __restrict__ keys, uint32_t* __restrict__ pos) {
+    const int lane = threadIdx.x & 63;
+    const int64_t n_chunks = (W + 3) >> 2;
+    for (int64_t ch = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; ch < n_chunks; ch += ((int64_t)gridDim.x * blockDim.x) >> 6) {
+        const uint32_t base = wave_base[ch << 2];
+        const uint32_t cnt = wave_base[min<int64_t>((ch + 1) << 2, W)] - base;
+        const uint64_t* src = stage + (size_t)ch * stage_cap;
+        for (uint32_t t = lane; t < cnt; t += 64) { keys[base + t] = src[t]; pos[base + t] = base + t; }
     }
 }
 
@@ -674,17 +699,26 @@ static void run_extract_sort(vg_genomes* g, int k, double fraction, int shard, i
         const int64_t W = P / 64;
         out.wave_mask.alloc((size_t)W + 1); dbuf<uint32_t> wave_cnt((size_t)W + 1); out.wave_base.alloc((size_t)W + 1);
         VG_HIP(hipMemsetAsync(wave_cnt.p + W, 0, sizeof(uint32_t), s));
+        // slots per 256-position chunk for the kept k-mers (twice the expectation + slack; a chunk that
+        // overflows sends the call to the recomputing emit pass)
+        const double keep = (use_frac ? fraction : 1.0) / n_shards;
+        const int stage_cap = (int)std::min<double>(256.0, std::ceil(2.0 * 256.0 * keep) + 24.0);
+        const int64_t n_chunks = (W + 3) / 4;
+        dbuf<uint64_t> stage((size_t)n_chunks * stage_cap);
+        dbuf<unsigned int> d_over(1); d_over.zero(s);
         {
             vg_prof_scope ps("kmer_count", (double)P * (3.0 / 8.0 + 12.0 / 64.0));
-            hipLaunchKernelGGL(k_kmer_count, dim3(grid_for((P + 255) / 4)), dim3(256), 0, s, A, out.wave_mask.p, wave_cnt.p, out.kept.p);
+            hipLaunchKernelGGL(k_kmer_count, dim3(grid_for((P + 255) / 4)), dim3(256), 0, s, A, out.wave_mask.p, wave_cnt.p, out.kept.p,
+                               stage.p, stage_cap, d_over.p);
         }
         size_t tb = 0;
         VG_HIP(rocprim::exclusive_scan(nullptr, tb, wave_cnt.p, out.wave_base.p, 0u, (size_t)W + 1, rocprim::plus<uint32_t>(), s));
         dbuf<char> tmp(tb);
         VG_HIP(rocprim::exclusive_scan((void*)tmp.p, tb, wave_cnt.p, out.wave_base.p, 0u, (size_t)W + 1, rocprim::plus<uint32_t>(), s));
-        uint32_t total = 0;
+        uint32_t total = 0; unsigned int over = 0;
         std::vector<int> kept_h((size_t)std::max(1, g->n));
         VG_HIP(hipMemcpyAsync(&total, out.wave_base.p + W, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        d_over.download(&over, 1, s);
         out.kept.download(kept_h.data(), (size_t)g->n, s);
         VG_HIP(hipStreamSynchronize(s));
         int64_t total64 = 0; for (int i = 0; i < g->n; ++i) total64 += kept_h[i];
@@ -692,8 +726,11 @@ static void run_extract_sort(vg_genomes* g, int k, double fraction, int shard, i
         nv = total; n_sort = (int64_t)total;
         const size_t na = (size_t)std::max<int64_t>(n_sort, 1);
         keys_a.alloc(na); keys_b.alloc(na); pos_a.alloc(na + 4); pos_b.alloc(na);
-        if (n_sort > 0) {
-            vg_prof_scope ps("kmer_emit", (double)P * 3.0 / 8.0 + (double)n_sort * 12.0);
+        if (n_sort > 0 && !over) {
+            vg_prof_scope ps("kmer_emit", (double)n_sort * (8.0 + 12.0));
+            hipLaunchKernelGGL(k_kmer_gather, dim3(grid_for(n_chunks * 64)), dim3(256), 0, s, stage.p, stage_cap, out.wave_base.p, W, keys_a.p, pos_a.p);
+        } else if (n_sort > 0) {
+            vg_prof_scope ps("kmer_emit_recompute", (double)P * 3.0 / 8.0 + (double)n_sort * 12.0);
             if (n_sort * 4 <= P) hipLaunchKernelGGL(k_kmer_emit_sparse, dim3(grid_for(P / 8)), dim3(256), 0, s, A, out.wave_mask.p, out.wave_base.p, keys_a.p, pos_a.p);
             else hipLaunchKernelGGL(k_kmer_emit, dim3(grid_for(P)), dim3(256), 0, s, A, out.wave_mask.p, out.wave_base.p, keys_a.p, pos_a.p);
         }
