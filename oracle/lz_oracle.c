@@ -64,6 +64,7 @@ void vo_lz_default_variant(vo_lz_variant* v) {
     v->reg_on_span = 1;
     v->rend_mode = 2;
     v->trace = 0;
+    v->anchor_margin = 0;
 }
 
 static inline uint64_t mix64(uint64_t x) {
@@ -226,56 +227,58 @@ int vo_lz_parse(const vo_ref_index* ix, const uint8_t* qry, int64_t qn,
     while (i < lim) {
         int64_t best_pos = 0, best_len = 0;
         int is_close = 0;
-        int do_long = (pred < 0) || v->anchor_while_predicting == 2;
-        int do_close = (pred >= 0);
-        for (int pass = 0; pass < 2; ++pass) {
-            if (pass == 1) {
-                if (v->anchor_while_predicting == 1 && pred >= 0 && best_len == 0) { do_long = 1; do_close = 0; }
-                else break;
+        int64_t a_len = 0, a_pos = 0, s_len = 0, s_pos = 0;
+        int want_anchor = (pred < 0) || v->anchor_while_predicting >= 2;
+        int want_seed = (pred >= 0);
+        if (want_seed && qs[i] != UINT64_MAX) {      /* R3 */
+            int32_t b0 = ix->s_off[qs[i]], b1 = ix->s_off[qs[i] + 1];
+            int64_t best_d = 0;
+            for (int32_t j = b0; j < b1; ++j) {
+                int64_t rp = ix->s_pos[j];
+                int64_t d = rp - pred; int ok;
+                if (v->seed_window == 2) ok = (rp - (pred - lit) >= -v->seed_back && d <= seed_fwd);
+                else if (v->seed_window == 1) ok = (rp - (pred - lit) >= -v->seed_back && rp - (pred - lit) <= seed_fwd);
+                else ok = (d >= -p->mrd && d <= p->mrd);
+                if (!ok) continue;
+                int64_t l = equal_len(&c, rp, i);
+                if (l < p->msl) continue;
+                int64_t ad = d < 0 ? -d : d;
+                int take = 0;
+                if (s_len == 0) take = 1;
+                else if (v->seed_choice == 0) take = l > s_len;
+                else if (v->seed_choice == 1) take = (ad < best_d) || (ad == best_d && l > s_len);
+                else if (v->seed_choice == 2) take = 0;
+                else take = (l > s_len) || (l == s_len && ad < best_d);
+                if (take) { s_len = l; s_pos = rp; best_d = ad; }
             }
-            if (do_long && best_len == 0) {          /* R2 */
-                if (ql[i] != UINT64_MAX) {
-                    uint32_t h = (uint32_t)mix64(ql[i]) & ix->a_mask;
-                    for (; ix->a_tab[h] >= 0; h = (h + 1) & ix->a_mask) {
-                        int64_t rp = ix->a_tab[h];
-                        if (ix->a_code[rp] != ql[i]) continue;
-                        int64_t l = equal_len(&c, rp, i);
-                        if (l < p->mal) continue;
-                        if (l > best_len || (l == best_len && (v->anchor_tie ? rp > best_pos : rp < best_pos))) {
-                            best_len = l; best_pos = rp;
-                        }
-                    }
-                }
-                if (best_len > 0) {
-                    int64_t d = best_pos - pred;
-                    is_close = (pred >= 0 && d >= -p->mrd && d <= p->mrd);
+        }
+        if (v->anchor_while_predicting == 1 && pred >= 0 && s_len == 0) want_anchor = 1;
+        if (want_anchor && ql[i] != UINT64_MAX) {    /* R2 */
+            uint32_t h = (uint32_t)mix64(ql[i]) & ix->a_mask;
+            for (; ix->a_tab[h] >= 0; h = (h + 1) & ix->a_mask) {
+                int64_t rp = ix->a_tab[h];
+                if (ix->a_code[rp] != ql[i]) continue;
+                int64_t l = equal_len(&c, rp, i);
+                if (l < p->mal) continue;
+                if (l > a_len || (l == a_len && (v->anchor_tie ? rp > a_pos : rp < a_pos))) {
+                    a_len = l; a_pos = rp;
                 }
             }
-            if (do_close && best_len == 0) {         /* R3 */
-                if (qs[i] != UINT64_MAX) {
-                    int32_t b0 = ix->s_off[qs[i]], b1 = ix->s_off[qs[i] + 1];
-                    int64_t best_d = 0;
-                    for (int32_t j = b0; j < b1; ++j) {
-                        int64_t rp = ix->s_pos[j];
-                        int64_t d = rp - pred; int ok;
-                        if (v->seed_window == 2) ok = (rp - (pred - lit) >= -v->seed_back && d <= seed_fwd);
-                        else if (v->seed_window == 1) ok = (rp - (pred - lit) >= -v->seed_back && rp - (pred - lit) <= seed_fwd);
-                        else ok = (d >= -p->mrd && d <= p->mrd);
-                        if (!ok) continue;
-                        int64_t l = equal_len(&c, rp, i);
-                        if (l < p->msl) continue;
-                        int64_t ad = d < 0 ? -d : d;
-                        int take = 0;
-                        if (best_len == 0) take = 1;
-                        else if (v->seed_choice == 0) take = l > best_len;
-                        else if (v->seed_choice == 1) take = (ad < best_d) || (ad == best_d && l > best_len);
-                        else if (v->seed_choice == 2) take = 0;
-                        else take = (l > best_len) || (l == best_len && ad < best_d);
-                        if (take) { best_len = l; best_pos = rp; best_d = ad; }
-                    }
-                }
-                if (best_len > 0) is_close = 1;
+        }
+        if (pred < 0) { best_len = a_len; best_pos = a_pos; }
+        else {
+            int take_anchor;
+            switch (v->anchor_while_predicting) {
+            case 0: take_anchor = 0; break;
+            case 1: take_anchor = (s_len == 0 && a_len > 0); break;
+            case 2: take_anchor = (a_len > 0); break;
+            default: take_anchor = (a_len > 0) && (s_len == 0 || a_len > s_len + v->anchor_margin); break;
             }
+            if (take_anchor) {
+                best_len = a_len; best_pos = a_pos;
+                int64_t d = best_pos - pred;
+                is_close = (d >= -p->mrd && d <= p->mrd);
+            } else if (s_len > 0) { best_len = s_len; best_pos = s_pos; is_close = 1; }
         }
 
         if (best_len > 0) {
@@ -309,6 +312,26 @@ int vo_lz_parse(const vo_ref_index* ix, const uint8_t* qry, int64_t qn,
                         if (ro >= 0 && ro < ix->n_rr && ix->rr[ro] == q[qp]) ++pre;
                         if (rn >= 0 && rn < ix->n_rr && ix->rr[rn] == q[qp]) --suf;
                         if (pre + suf > m) m = pre + suf;
+                    }
+                }
+                else if (v->gap_mode == 4) {
+                    /* one indel, placed where it keeps most matches: the g literals are laid against the
+                     * reference symbols [pred0, best_pos + best_len): a prefix on the old diagonal, a
+                     * suffix flush with the END of the new match, and when the literal run is longer
+                     * than that reference stretch the surplus literals in between match nothing */
+                    int64_t pred0 = pred - g, reflen = best_pos + best_len - pred0;
+                    int64_t skip = g > reflen ? g - reflen : 0;
+                    int64_t dn = best_pos + best_len - i;            /* literal at q -> rr[q + dn] */
+                    if (reflen < 0) m = count_eq(&c, i - g, pred0, g);
+                    else {
+                        int64_t suf = count_eq(&c, i - g + skip, i - g + skip + dn, g - skip), pre = 0;
+                        m = suf;
+                        for (int64_t a = 0; a < g - skip; ++a) {
+                            int64_t qp = i - g + a, ro = pred0 + a, qs2 = i - g + a + skip, rn = qs2 + dn;
+                            if (ro >= 0 && ro < ix->n_rr && ix->rr[ro] == q[qp]) ++pre;
+                            if (rn >= 0 && rn < ix->n_rr && ix->rr[rn] == q[qs2]) --suf;
+                            if (pre + suf > m) m = pre + suf;
+                        }
                     }
                 }
                 cur.n_match += (int32_t)m;

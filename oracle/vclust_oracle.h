@@ -90,6 +90,7 @@ typedef struct {
     int reg_on_span;             /* region kept on query span (1) or on matches (0) */
     int rend_mode;               /* 0 true end, 1 max with chained ends, 2 also max with the gap end on the old diagonal */
     int trace;
+    int anchor_margin;           /* anchor_while_predicting 3: a far anchor beats a seed when longer by more than this */
 } vo_lz_variant;
 
 typedef struct {
