@@ -216,6 +216,7 @@ int vo_lz_parse(const vo_ref_index* ix, const uint8_t* qry, int64_t qn,
     int64_t lit = 0;          /* literals since the last match */
     int64_t i = 0;
     int64_t kept_end = 0;     /* query end (exclusive) of the last kept region */
+    int64_t vend = 0;         /* virtual reference end of the open region (rend rule) */
     int64_t lim = v->loop_le ? qn - p->mal + 1 : qn - p->mal;
     const int64_t seed_fwd = v->seed_fwd >= 0 ? v->seed_fwd : p->mrd - 1;
 
@@ -285,7 +286,8 @@ int vo_lz_parse(const vo_ref_index* ix, const uint8_t* qry, int64_t qn,
             if (v->trace) fprintf(stderr, "i=%lld %s pos=%lld len=%lld pred=%lld lit=%lld\n", (long long)i + 1,
                                   is_close ? "CLOSE" : "DIST", (long long)best_pos, (long long)best_len,
                                   (long long)pred, (long long)lit);
-            int64_t gap_end_ref = pred - 1;
+            int64_t gap_end_ref = pred - 1, gap_suffix_matches = 0, gap_len = lit, gap_pred0 = pred - lit;
+            (void)gap_pred0;
             if (!is_close) {
                 /* distant match: close the previous region, open a new one (R5) */
                 CLOSE_REGION();
@@ -320,34 +322,43 @@ int vo_lz_parse(const vo_ref_index* ix, const uint8_t* qry, int64_t qn,
                      * suffix flush with the END of the new match, and when the literal run is longer
                      * than that reference stretch the surplus literals in between match nothing */
                     int64_t pred0 = pred - g, reflen = best_pos + best_len - pred0;
-                    int64_t skip = g > reflen ? g - reflen : 0;
+                    int64_t skip = (reflen >= 0 && g > reflen) ? g - reflen : 0;
                     int64_t dn = best_pos + best_len - i;            /* literal at q -> rr[q + dn] */
-                    if (reflen < 0) m = count_eq(&c, i - g, pred0, g);
-                    else {
-                        int64_t suf = count_eq(&c, i - g + skip, i - g + skip + dn, g - skip), pre = 0;
-                        m = suf;
-                        for (int64_t a = 0; a < g - skip; ++a) {
-                            int64_t qp = i - g + a, ro = pred0 + a, qs2 = i - g + a + skip, rn = qs2 + dn;
-                            if (ro >= 0 && ro < ix->n_rr && ix->rr[ro] == q[qp]) ++pre;
-                            if (rn >= 0 && rn < ix->n_rr && ix->rr[rn] == q[qs2]) --suf;
-                            if (pre + suf > m) m = pre + suf;
-                        }
+                    int64_t suf = count_eq(&c, i - g + skip, i - g + skip + dn, g - skip), pre = 0;
+                    m = suf; gap_suffix_matches = suf;
+                    for (int64_t a = 0; a < g - skip; ++a) {
+                        int64_t qp = i - g + a, ro = pred0 + a, qs2 = i - g + a + skip, rn = qs2 + dn;
+                        if (ro >= 0 && ro < ix->n_rr && ix->rr[ro] == q[qp]) ++pre;
+                        if (rn >= 0 && rn < ix->n_rr && ix->rr[rn] == q[qs2]) --suf;
+                        if (pre + suf >= m) { m = pre + suf; gap_suffix_matches = suf; }   /* ties: longest prefix */
                     }
                 }
                 cur.n_match += (int32_t)m;
             }
             cur.n_match += (int32_t)best_len;
             i += best_len; pred = best_pos + best_len; lit = 0;
+            int64_t e = 0, e_mm = 0;
             if (!is_close || v->fwd_after_close) {
-                int64_t e = ext_fwd(&c, i, pred);
-                cur.n_match += (int32_t)count_eq(&c, i, pred, e);
+                e = ext_fwd(&c, i, pred);
+                int64_t em = count_eq(&c, i, pred, e);
+                cur.n_match += (int32_t)em; e_mm = e - em;
                 i += e; pred += e;
             }
             cur.qend = (int32_t)(i - 1);
-            if (is_close && v->rend_mode) {
+            if (is_close && v->rend_mode >= 3) {
+                /* virtual reference end: every query symbol moves it except those matched on the new
+                 * diagonal (suffix of the gap, the match itself, matches of its extension) */
+                int64_t base;
+                if (v->rend_mode == 3) base = gap_end_ref + 1;                 /* from the true position */
+                else if (v->rend_mode == 4) base = vend + gap_len;             /* cumulative */
+                else base = (vend > gap_end_ref + 1 - gap_len ? vend : gap_end_ref + 1 - gap_len) + gap_len;
+                vend = base - gap_suffix_matches + e_mm;
+                if (pred - 1 > cur.rend) cur.rend = (int32_t)(pred - 1);
+                if (vend - 1 > cur.rend) cur.rend = (int32_t)(vend - 1);
+            } else if (is_close && v->rend_mode) {
                 if (pred - 1 > cur.rend) cur.rend = (int32_t)(pred - 1);
                 if (v->rend_mode == 2 && gap_end_ref > cur.rend) cur.rend = (int32_t)gap_end_ref;
-            } else cur.rend = (int32_t)(pred - 1);
+            } else { cur.rend = (int32_t)(pred - 1); vend = pred; }
         } else {
             ++i; ++lit;
             if (pred >= 0) ++pred;
