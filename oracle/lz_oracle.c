@@ -65,6 +65,7 @@ void vo_lz_default_variant(vo_lz_variant* v) {
     v->rend_mode = 2;
     v->trace = 0;
     v->anchor_margin = 0;
+    v->anchor_min_pred = 0;
 }
 
 static inline uint64_t mix64(uint64_t x) {
@@ -273,7 +274,7 @@ int vo_lz_parse(const vo_ref_index* ix, const uint8_t* qry, int64_t qn,
             case 0: take_anchor = 0; break;
             case 1: take_anchor = (s_len == 0 && a_len > 0); break;
             case 2: take_anchor = (a_len > 0); break;
-            default: take_anchor = (a_len > 0) && (s_len == 0 || a_len > s_len + v->anchor_margin); break;
+            default: take_anchor = (a_len > 0) && (s_len == 0 ? a_len >= v->anchor_min_pred : a_len > s_len + v->anchor_margin); break;
             }
             if (take_anchor) {
                 best_len = a_len; best_pos = a_pos;
@@ -286,7 +287,7 @@ int vo_lz_parse(const vo_ref_index* ix, const uint8_t* qry, int64_t qn,
             if (v->trace) fprintf(stderr, "i=%lld %s pos=%lld len=%lld pred=%lld lit=%lld\n", (long long)i + 1,
                                   is_close ? "CLOSE" : "DIST", (long long)best_pos, (long long)best_len,
                                   (long long)pred, (long long)lit);
-            int64_t gap_end_ref = pred - 1, gap_suffix_matches = 0, gap_len = lit, gap_pred0 = pred - lit;
+            int64_t gap_end_ref = pred - 1, gap_suffix_matches = 0, gap_prefix_matches = 0, gap_len = lit, gap_pred0 = pred - lit;
             (void)gap_pred0;
             if (!is_close) {
                 /* distant match: close the previous region, open a new one (R5) */
@@ -325,12 +326,12 @@ int vo_lz_parse(const vo_ref_index* ix, const uint8_t* qry, int64_t qn,
                     int64_t skip = (reflen >= 0 && g > reflen) ? g - reflen : 0;
                     int64_t dn = best_pos + best_len - i;            /* literal at q -> rr[q + dn] */
                     int64_t suf = count_eq(&c, i - g + skip, i - g + skip + dn, g - skip), pre = 0;
-                    m = suf; gap_suffix_matches = suf;
+                    m = suf; gap_suffix_matches = suf; gap_prefix_matches = 0;
                     for (int64_t a = 0; a < g - skip; ++a) {
                         int64_t qp = i - g + a, ro = pred0 + a, qs2 = i - g + a + skip, rn = qs2 + dn;
                         if (ro >= 0 && ro < ix->n_rr && ix->rr[ro] == q[qp]) ++pre;
                         if (rn >= 0 && rn < ix->n_rr && ix->rr[rn] == q[qs2]) --suf;
-                        if (pre + suf >= m) { m = pre + suf; gap_suffix_matches = suf; }   /* ties: longest prefix */
+                        if (pre + suf >= m) { m = pre + suf; gap_suffix_matches = suf; gap_prefix_matches = pre; }   /* ties: longest prefix */
                     }
                 }
                 cur.n_match += (int32_t)m;
@@ -351,7 +352,13 @@ int vo_lz_parse(const vo_ref_index* ix, const uint8_t* qry, int64_t qn,
                 int64_t base;
                 if (v->rend_mode == 3) base = gap_end_ref + 1;                 /* from the true position */
                 else if (v->rend_mode == 4) base = vend + gap_len;             /* cumulative */
-                else base = (vend > gap_end_ref + 1 - gap_len ? vend : gap_end_ref + 1 - gap_len) + gap_len;
+                else if (v->rend_mode == 5) base = (vend > gap_end_ref + 1 - gap_len ? vend : gap_end_ref + 1 - gap_len) + gap_len;
+                else {
+                    /* a symbol that matches nothing moves the end by one; one matched on the old diagonal
+                     * pulls it up to its own reference position; one matched on the new diagonal leaves it */
+                    int64_t t = gap_end_ref + 1, w = vend + gap_len - gap_prefix_matches;
+                    base = t > w ? t : w;
+                }
                 vend = base - gap_suffix_matches + e_mm;
                 if (pred - 1 > cur.rend) cur.rend = (int32_t)(pred - 1);
                 if (vend - 1 > cur.rend) cur.rend = (int32_t)(vend - 1);

@@ -22,7 +22,7 @@ int main(int argc, char** argv) {
 #define K(name) if (!strcmp(k, #name)) v.name = val;
         K(sep_len) K(anchor_while_predicting) K(bwd_bound_kept) K(bwd_exact_first) K(seed_window)
         K(seed_back) K(seed_fwd) K(seed_choice) K(lit_reset_ge) K(gap_mode) K(fwd_after_close)
-        K(loop_le) K(anchor_tie) K(reg_on_span) K(rend_mode) K(trace) K(anchor_margin)
+        K(loop_le) K(anchor_tie) K(reg_on_span) K(rend_mode) K(trace) K(anchor_margin) K(anchor_min_pred)
 #undef K
         if (!strcmp(k, "q")) only_q = eq + 1;
         if (!strcmp(k, "r")) only_r = eq + 1;

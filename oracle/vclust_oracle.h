@@ -91,6 +91,7 @@ typedef struct {
     int rend_mode;               /* 0 true end, 1 max with chained ends, 2 also max with the gap end on the old diagonal */
     int trace;
     int anchor_margin;           /* anchor_while_predicting 3: a far anchor beats a seed when longer by more than this */
+    int anchor_min_pred;         /* anchor_while_predicting 3: minimum length of an anchor taken while a prediction is alive and no seed was found */
 } vo_lz_variant;
 
 typedef struct {
