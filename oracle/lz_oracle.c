@@ -362,6 +362,7 @@ int vo_lz_parse(const vo_ref_index* ix, const uint8_t* qry, int64_t qn,
                 vend = base - gap_suffix_matches + e_mm;
                 if (pred - 1 > cur.rend) cur.rend = (int32_t)(pred - 1);
                 if (vend - 1 > cur.rend) cur.rend = (int32_t)(vend - 1);
+                if (best_pos < cur.rstart) cur.rstart = (int32_t)best_pos;   /* a chained anchor may lie before the region's start */
             } else if (is_close && v->rend_mode) {
                 if (pred - 1 > cur.rend) cur.rend = (int32_t)(pred - 1);
                 if (v->rend_mode == 2 && gap_end_ref > cur.rend) cur.rend = (int32_t)gap_end_ref;
