@@ -245,7 +245,7 @@ int vo_align(const vo_genome_set* s, const char* out_path, const vo_align_params
                 vo_fmt_num(100.0 * g->n_match / alnlen, buf);
                 fprintf(fa, "%s\t%s\t%s\t%d\t%d\t%d\t%lld\t%lld\t%d\t%d\n", G(st[t].q).name, G(st[t].r).name,
                         buf, alnlen, g->qstart + 1, g->qend + 1,
-                        (long long)vo_rr_to_fwd1(ix, g->rstart), (long long)vo_rr_to_fwd1(ix, g->rend),
+                        (long long)vo_rr_to_fwd1(ix, g->rstart), (long long)vo_rr_to_fwd1s(ix, g->rend, vo_rr_is_rev(ix, g->rstart)),
                         g->n_match, g->n_mismatch);
             }
             free(rl[t].r);

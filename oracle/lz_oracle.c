@@ -48,24 +48,23 @@ struct vo_ref_index {
 
 void vo_lz_default_variant(vo_lz_variant* v) {
     memset(v, 0, sizeof(*v));
-    v->sep_len = 1;
-    v->anchor_while_predicting = 2;  /* R2: anchor search first, always */
+    v->sep_len = 0;                  /* R1: 0 = mrd + mqd + 1 symbols: nothing ever reaches across the strands */
+    v->anchor_while_predicting = 3;  /* R2 */
     v->bwd_bound_kept = 1;           /* R5 */
     v->bwd_exact_first = 1;          /* R5 */
     v->seed_window = 2;              /* R3 */
     v->seed_back = 0;
     v->seed_fwd = -1;                /* -1: mrd - 1 */
-    v->seed_choice = 0;
+    v->seed_choice = 3;              /* R3: longest, then closest to the prediction */
     v->lit_reset_ge = 0;             /* R6: '>' */
-    v->gap_mode = 0;                 /* R7 */
+    v->gap_mode = 4;                 /* R7 */
     v->fwd_after_close = 1;
     v->loop_le = 0;
     v->anchor_tie = 0;
     v->reg_on_span = 1;
-    v->rend_mode = 2;
+    v->rend_mode = 6;                /* R9 */
     v->trace = 0;
-    v->anchor_margin = 0;
-    v->anchor_min_pred = 0;
+    v->anchor_margin = -1;           /* R2: -1 = msl - 1 */
 }
 
 static inline uint64_t mix64(uint64_t x) {
@@ -88,7 +87,7 @@ static void kmer_codes(const uint8_t* s, int64_t n, int w, uint64_t* out) {
 vo_ref_index* vo_lz_build_index(const uint8_t* ref, int64_t len,
                                 const vo_lz_params* p, const vo_lz_variant* v) {
     vo_ref_index* ix = (vo_ref_index*)calloc(1, sizeof(*ix));
-    int sep = v->sep_len > 0 ? v->sep_len : 1;
+    int sep = v->sep_len > 0 ? v->sep_len : p->mrd + p->mqd + 1;
     int pad = p->mrd + p->mal + 8;
     ix->len = len; ix->mal = p->mal; ix->msl = p->msl;
     ix->rc_off = len + sep;
@@ -137,11 +136,15 @@ void vo_lz_free_index(vo_ref_index* ix) {
     free(ix->rr); free(ix->a_tab); free(ix->a_code); free(ix->s_off); free(ix->s_pos); free(ix);
 }
 
-int64_t vo_rr_to_fwd1(const vo_ref_index* ix, int64_t p) {
-    if (p < ix->len) return p + 1;
-    return ix->len - (p - ix->rc_off);   /* 1-based forward coordinate of an rc position */
+/* Regions leave vo_lz_parse in the canonical space  forward | one N | reverse complement
+ * (whatever separator the index uses inside), the same space the HIP path reports. */
+int vo_rr_is_rev(const vo_ref_index* ix, int64_t p) { return p > ix->len; }
+/* 1-based forward coordinate of canonical position p on the given strand (a region's strand is the
+ * strand of its rstart; its rend is a virtual end and may lie past the end of that strand) */
+int64_t vo_rr_to_fwd1s(const vo_ref_index* ix, int64_t p, int rev) {
+    return rev ? ix->len - (p - (ix->len + 1)) : p + 1;
 }
-int vo_rr_is_rev(const vo_ref_index* ix, int64_t p) { return p >= ix->rc_off; }
+int64_t vo_rr_to_fwd1(const vo_ref_index* ix, int64_t p) { return vo_rr_to_fwd1s(ix, p, vo_rr_is_rev(ix, p)); }
 
 typedef struct {
     const vo_ref_index* ix;
@@ -220,6 +223,7 @@ int vo_lz_parse(const vo_ref_index* ix, const uint8_t* qry, int64_t qn,
     int64_t vend = 0;         /* virtual reference end of the open region (rend rule) */
     int64_t lim = v->loop_le ? qn - p->mal + 1 : qn - p->mal;
     const int64_t seed_fwd = v->seed_fwd >= 0 ? v->seed_fwd : p->mrd - 1;
+    const int64_t margin = v->anchor_margin >= 0 ? v->anchor_margin : p->msl - 1;
 
 #define CLOSE_REGION() do { if (in_region) { \
         cur.n_mismatch = (cur.qend - cur.qstart + 1) - cur.n_match; \
@@ -274,7 +278,7 @@ int vo_lz_parse(const vo_ref_index* ix, const uint8_t* qry, int64_t qn,
             case 0: take_anchor = 0; break;
             case 1: take_anchor = (s_len == 0 && a_len > 0); break;
             case 2: take_anchor = (a_len > 0); break;
-            default: take_anchor = (a_len > 0) && (s_len == 0 ? a_len >= v->anchor_min_pred : a_len > s_len + v->anchor_margin); break;
+            default: take_anchor = (a_len > 0) && (s_len == 0 || a_len > s_len + margin); break;
             }
             if (take_anchor) {
                 best_len = a_len; best_pos = a_pos;
@@ -375,6 +379,8 @@ int vo_lz_parse(const vo_ref_index* ix, const uint8_t* qry, int64_t qn,
     }
     CLOSE_REGION();
 #undef CLOSE_REGION
+    for (int k = 0; k < regs.n; ++k)          /* internal RR -> canonical space */
+        if (regs.r[k].rstart >= ix->rc_off) { regs.r[k].rstart -= (int32_t)(ix->rc_off - ix->len - 1); regs.r[k].rend -= (int32_t)(ix->rc_off - ix->len - 1); }
     free(q); free(ql); free(qs);
     *out = regs.r; *n_out = regs.n;
     return 0;

@@ -22,7 +22,7 @@ int main(int argc, char** argv) {
 #define K(name) if (!strcmp(k, #name)) v.name = val;
         K(sep_len) K(anchor_while_predicting) K(bwd_bound_kept) K(bwd_exact_first) K(seed_window)
         K(seed_back) K(seed_fwd) K(seed_choice) K(lit_reset_ge) K(gap_mode) K(fwd_after_close)
-        K(loop_le) K(anchor_tie) K(reg_on_span) K(rend_mode) K(trace) K(anchor_margin) K(anchor_min_pred)
+        K(loop_le) K(anchor_tie) K(reg_on_span) K(rend_mode) K(trace) K(anchor_margin)
 #undef K
         if (!strcmp(k, "q")) only_q = eq + 1;
         if (!strcmp(k, "r")) only_r = eq + 1;
@@ -47,7 +47,7 @@ int main(int argc, char** argv) {
                 char buf[64]; vo_fmt_num(100.0 * g->n_match / alnlen, buf);
                 printf("%s\t%s\t%s\t%d\t%d\t%d\t%lld\t%lld\t%d\t%d\n", gs.g[q].name, gs.g[r].name, buf, alnlen,
                        g->qstart + 1, g->qend + 1,
-                       (long long)vo_rr_to_fwd1(ix, g->rstart), (long long)vo_rr_to_fwd1(ix, g->rend),
+                       (long long)vo_rr_to_fwd1(ix, g->rstart), (long long)vo_rr_to_fwd1s(ix, g->rend, vo_rr_is_rev(ix, g->rstart)),
                        g->n_match, g->n_mismatch);
             }
             free(regs);

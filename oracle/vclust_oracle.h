@@ -91,12 +91,11 @@ typedef struct {
     int rend_mode;               /* 0 true end, 1 max with chained ends, 2 also max with the gap end on the old diagonal */
     int trace;
     int anchor_margin;           /* anchor_while_predicting 3: a far anchor beats a seed when longer by more than this */
-    int anchor_min_pred;         /* anchor_while_predicting 3: minimum length of an anchor taken while a prediction is alive and no seed was found */
 } vo_lz_variant;
 
 typedef struct {
     int32_t qstart, qend;   /* 0-based inclusive, query coordinates */
-    int32_t rstart, rend;   /* 0-based inclusive in RR coordinates (fwd | sep | rc) */
+    int32_t rstart, rend;   /* 0-based inclusive in the canonical space fwd | N | rc */
     int32_t n_match;
     int32_t n_mismatch;     /* = qend-qstart+1-n_match */
 } vo_region;
@@ -111,8 +110,10 @@ void vo_lz_free_index(vo_ref_index* idx);
 int  vo_lz_parse(const vo_ref_index* idx, const uint8_t* qry, int64_t qlen,
                  const vo_lz_params* p, const vo_lz_variant* v,
                  vo_region** out, int* n_out);
-/* forward-strand 1-based coordinates of a region end point in RR space */
+/* regions are reported in the canonical space fwd | N | rc; 1-based forward coordinates of a position
+ * on a given strand (a region's strand is that of its rstart; rend may lie past the strand's end) */
 int64_t vo_rr_to_fwd1(const vo_ref_index* idx, int64_t rr_pos);
+int64_t vo_rr_to_fwd1s(const vo_ref_index* idx, int64_t rr_pos, int rev);
 int     vo_rr_is_rev(const vo_ref_index* idx, int64_t rr_pos);
 
 /* ---------- whole align stage (lz-ani all2all) ---------- */

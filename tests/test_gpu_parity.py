@@ -128,6 +128,33 @@ def test_align_files_equal_oracle(tmp_path, golden_dir):
     assert sorted(open(aln).read().splitlines()) == sorted(open(ref_aln).read().splitlines())
 
 
+def test_hip_output_against_reference_goldens(tmp_path, golden_dir):
+    """The HIP path against the reference's own files (example/output/ani.tsv:1-133, ani.aln.tsv:1-5694,
+    ani.ids.tsv), not against the oracle: every golden region is reproduced (all seven integers + pident),
+    one surplus region is reported, and 130 of the 132 ani.tsv rows are byte-identical (the two rows of the
+    pair holding the surplus region differ) -- the same counts tests/test_oracle_golden.py pins for the oracle."""
+    import collections
+    from test_oracle_golden import KNOWN_SURPLUS
+    mine = tmp_path / 'ani.tsv'; aln = tmp_path / 'ani.aln.tsv'
+    api.align([golden_dir / 'multifasta.fna'], mine, is_multifasta=True, columns=api.ALIGN_FIELDS[:11], out_aln=aln)
+    assert filecmp.cmp(tmp_path / 'ani.ids.tsv', golden_dir / 'output' / 'ani.ids.tsv', shallow=False)
+    g = (golden_dir / 'output' / 'ani.tsv').read_text().splitlines(); m = mine.read_text().splitlines()
+    assert len(g) == len(m) == 133 and g[0] == m[0]
+    diff = sorted(a.split('\t')[2:4] for a, b in zip(g, m) if a != b)
+    assert diff == [['NC_010807.alt3', 'NC_025457'], ['NC_025457', 'NC_010807.alt3']], diff
+
+    def load(path):
+        d = collections.defaultdict(set)
+        for line in open(path).read().splitlines()[1:]:
+            c = line.split('\t')
+            d[(c[0], c[1])].add(tuple(int(x) for x in c[3:10]) + (c[2],))
+        return d
+    gr = load(golden_dir / 'output' / 'ani.aln.tsv'); mr = load(aln)
+    assert sum(len(v) for v in gr.values()) == 5693
+    assert [(k, x) for k, v in gr.items() for x in v if x not in mr.get(k, ())] == []
+    assert {(k, x[:7]) for k, v in mr.items() for x in v if x not in gr.get(k, ())} == KNOWN_SURPLUS
+
+
 @pytest.fixture(scope='module')
 def small_synth():
     codes, offsets, names = synth.make_families(6, 4, length=6000, seed=7)

@@ -86,14 +86,14 @@ struct pair_ctx {
     const uint32_t* rpk; const uint32_t* rmk; int n_rr; int L; int r_has_n;
 };
 
-// mismatch mask (even bits) of the 32 positions q[qp+j] vs rr[rp+j]; out-of-range, separator
-// and N positions are mismatches.  qp/rp may be negative or run past the end.
-__device__ __forceinline__ uint64_t mism32(const pair_ctx& c, int qp, int rp) {
-    // valid slots: 0 <= qp+j < qlen, 0 <= rp+j < n_rr, rp+j != L
-    const int lo = max(-qp, -rp); const int hi = min(c.qlen - qp, c.n_rr - rp);
-    const int sj = c.L - rp;
-    if (lo <= 0 && hi >= 32 && (unsigned)sj >= 32u) {
-        // fast path: the whole chunk lies inside both sequences and misses the separator
+// mismatch mask (even bits) of the 32 positions q[qp+j] vs rr[rp+j]; positions outside the query or
+// outside the reference window [rlo, rhi), and N positions, are mismatches.  qp/rp may be negative or
+// run past the end.  The window is one strand of RR (forward [0, L) or reverse complement
+// [L+1, n_rr)): matches, extensions and gap scores never cross from one strand into the other.
+__device__ __forceinline__ uint64_t mism32(const pair_ctx& c, int qp, int rp, int rlo, int rhi) {
+    const int lo = max(-qp, rlo - rp); const int hi = min(c.qlen - qp, rhi - rp);
+    if (lo <= 0 && hi >= 32) {
+        // fast path: the whole chunk lies inside both sequences
         const uint64_t d = load32(c.qpk, qp) ^ load32(c.rpk, rp);
         uint64_t mm = (d | (d >> 1)) & EVEN;
         if (c.q_has_n) mm |= spread(loadm32(c.qmk, qp));
@@ -102,8 +102,7 @@ __device__ __forceinline__ uint64_t mism32(const pair_ctx& c, int qp, int rp) {
     }
     const uint64_t ok = slots(lo, hi);
     if (ok == 0) return EVEN;
-    uint64_t bad = EVEN & ~ok;
-    if (sj >= 0 && sj < 32) bad |= 1ULL << (2 * sj);
+    const uint64_t bad = EVEN & ~ok;
     const int qs = qp < 0 ? 0 : qp, rs = rp < 0 ? 0 : rp;     // clamp loads; shifted back below
     uint64_t xq = load32(c.qpk, qs), xr = load32(c.rpk, rs);
     if (qp < 0) xq <<= 2 * (-qp);
@@ -114,12 +113,15 @@ __device__ __forceinline__ uint64_t mism32(const pair_ctx& c, int qp, int rp) {
     if (c.r_has_n) { uint64_t sp = spread(loadm32(c.rmk, rs)); if (rp < 0) sp <<= 2 * (-rp); mm |= sp; }
     return (mm | bad) & EVEN;
 }
+// the strand of RR that holds position rp
+__device__ __forceinline__ int strand_lo(const pair_ctx& c, int rp) { return rp > c.L ? c.L + 1 : 0; }
+__device__ __forceinline__ int strand_hi(const pair_ctx& c, int rp) { return rp > c.L ? c.n_rr : c.L; }
 
 // exact match length from (qp, rp), lane-local, at most cap bases examined (multiple of 32)
 __device__ __forceinline__ int match_len_lane(const pair_ctx& c, int qp, int rp, int cap) {
     int l = 0;
     while (l < cap) {
-        uint64_t mm = mism32(c, qp + l, rp + l);
+        uint64_t mm = mism32(c, qp + l, rp + l, strand_lo(c, rp), strand_hi(c, rp));
         if (mm) return l + (__builtin_ctzll(mm) >> 1);
         l += 32;
     }
@@ -170,19 +172,19 @@ __device__ __forceinline__ int wave_sum(int v) {
 // (one XOR of 2-bit words), 2 048 per round; only mismatch positions can start a violation.
 // mismatch mask of round 0 of extend(), split out so that a caller can issue the loads of several
 // extensions back to back (one memory round trip instead of one per extension)
-__device__ __forceinline__ uint64_t extend_mask0(const pair_ctx& c, int qp, int rp, int dir, int bound, int lane) {
+__device__ __forceinline__ uint64_t extend_mask0(const pair_ctx& c, int qp, int rp, int dir, int bound, int lane, int rlo, int rhi) {
     uint64_t mm = EVEN;
     const int e0 = 32 * lane;
     if (e0 < bound) {
-        if (dir > 0) mm = mism32(c, qp + e0, rp + e0);
-        else mm = rev2(mism32(c, qp - e0 - 32, rp - e0 - 32)) & EVEN;        // slot j <-> position e0 + j
+        if (dir > 0) mm = mism32(c, qp + e0, rp + e0, rlo, rhi);
+        else mm = rev2(mism32(c, qp - e0 - 32, rp - e0 - 32, rlo, rhi)) & EVEN;        // slot j <-> position e0 + j
         const int rem = bound - e0; if (rem < 32) mm |= EVEN & ~slots(0, rem);
     }
     return mm;
 }
 
 __device__ __forceinline__ int extend(const pair_ctx& c, const lz_dev_params& P, int qp, int rp, int dir, int bound,
-                                      int lane, int* n_match, uint64_t mm_first) {
+                                      int lane, int* n_match, uint64_t mm_first, int rlo, int rhi) {
     int accepted = 0, matches_total = 0;
     int first_mm = -1;            // position of the first mismatch (end of the exact run)
     uint64_t carry_mm = 0;        // mismatch bits of the previous 32 positions (0 before e = 0)
@@ -197,8 +199,8 @@ __device__ __forceinline__ int extend(const pair_ctx& c, const lz_dev_params& P,
             mm = EVEN;
             const int e0 = base + 32 * lane;
             if (e0 < bound) {
-                if (dir > 0) mm = mism32(c, qp + e0, rp + e0);
-                else mm = rev2(mism32(c, qp - e0 - 32, rp - e0 - 32)) & EVEN;    // slot j <-> position e0 + j
+                if (dir > 0) mm = mism32(c, qp + e0, rp + e0, rlo, rhi);
+                else mm = rev2(mism32(c, qp - e0 - 32, rp - e0 - 32, rlo, rhi)) & EVEN;    // slot j <-> position e0 + j
                 const int rem = bound - e0; if (rem < 32) mm |= EVEN & ~slots(0, rem);
             }
         }
@@ -269,19 +271,79 @@ __device__ __forceinline__ int extend(const pair_ctx& c, const lz_dev_params& P,
     return accepted;
 }
 
-// number of equal symbols of q[qp..qp+n) vs rr[rp..rp+n) (whole wave, uniform result)
-__device__ __forceinline__ int count_eq_wave(const pair_ctx& c, int qp, int rp, int n, int lane) {
-    int tot = 0;
-    for (int base = 0; base < n; base += 2048) {
-        int e0 = base + 32 * lane; int part = 0;
-        if (e0 < n) {
-            uint64_t mm = mism32(c, qp + e0, rp + e0);
-            int rem = n - e0; if (rem < 32) mm |= EVEN & ~slots(0, rem);
-            part = 32 - __popcll(mm & EVEN);
+// even-bit mask (one base per 2 bits) -> one bit per base
+__device__ __forceinline__ uint32_t squeeze(uint64_t x) {
+    x &= EVEN;
+    x = (x | (x >> 1)) & 0x3333333333333333ULL;
+    x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0FULL;
+    x = (x | (x >> 4)) & 0x00FF00FF00FF00FFULL;
+    x = (x | (x >> 8)) & 0x0000FFFF0000FFFFULL;
+    x = (x | (x >> 16)) & 0x00000000FFFFFFFFULL;
+    return (uint32_t)x;
+}
+__device__ __forceinline__ uint64_t low_bits64(int n) { return n >= 64 ? ~0ULL : (n <= 0 ? 0ULL : ((1ULL << n) - 1)); }
+
+// Score of the g literals q[i-g .. i) in front of a chained match (ev_pos, len) whose predecessor ended at
+// reference position pred0 (oracle/lz_oracle.c, gap rule): the literals are laid against the reference
+// stretch [pred0, E), E = ev_pos + len, with ONE indel placed where it keeps most matches -- a prefix of
+// `a` literals on the old diagonal (literal k <-> pred0 + k), a suffix flush with E (literal k <-> E - g + k),
+// and, when the run is longer than the stretch, skip = g - (E - pred0) literals in between that match
+// nothing.  Ties take the longest prefix.  Returns the matches; *pm / *sm = those of the prefix / suffix.
+// Bit-parallel: lane l compares 32 literals on both diagonals; 64 split points are ranked per round by
+// the 64 lanes from two 64-bit match masks (wave-uniform reads, no LDS).
+__device__ __forceinline__ int gap_score(const pair_ctx& c, int i, int g, int pred0, int E, int lane, int rlo, int rhi,
+                                         int* pm_out, int* sm_out) {
+    const int reflen = E - pred0;
+    const int skip = (reflen >= 0 && g > reflen) ? g - reflen : 0;
+    const int q0 = i - g;
+    // match masks: bit k of window w = literal 64 w + k matches
+    uint32_t ok_o = 0, ok_n = 0;
+    {
+        const int e0 = 32 * lane;
+        if (e0 < g) {
+            const uint32_t in = (g - e0 >= 32) ? 0xffffffffu : ((1u << (g - e0)) - 1u);
+            ok_o = ~squeeze(mism32(c, q0 + e0, pred0 + e0, rlo, rhi)) & in;
+            ok_n = ~squeeze(mism32(c, q0 + e0, E - g + e0, rlo, rhi)) & in;
         }
-        tot += wave_sum(part);
     }
-    return tot;
+    int tot_n = 0;
+    for (int w2 = 0; 32 * w2 < g; ++w2) tot_n += __popc(lane32(ok_n, w2));
+    int best_v = -1, best_pm = 0, best_sm = 0;
+    const int nbits = 32 - __builtin_clz((unsigned)g | 1u);
+    int po = 0;                                   // old-diagonal matches in windows before w
+    const int n_split = g - skip;                 // split points a = 0 .. n_split
+    for (int w = 0; 64 * w <= n_split; ++w) {
+        const uint64_t O = (uint64_t)lane32(ok_o, 2 * w) | ((uint64_t)lane32(ok_o, (2 * w + 1) & 63) << 32);
+        const int a = 64 * w + lane;
+        const int s0 = 64 * w + skip;             // suffix start of lane 0 of this round
+        const int ws = s0 >> 6;
+        const uint64_t N0 = (uint64_t)lane32(ok_n, (2 * ws) & 63) | ((uint64_t)lane32(ok_n, (2 * ws + 1) & 63) << 32);
+        const uint64_t N1 = (uint64_t)lane32(ok_n, (2 * ws + 2) & 63) | ((uint64_t)lane32(ok_n, (2 * ws + 3) & 63) << 32);
+        int pn0 = 0;                              // new-diagonal matches in windows before ws
+        for (int w2 = 0; w2 < 2 * ws && 32 * w2 < g; ++w2) pn0 += __popc(lane32(ok_n, w2));
+        const int pn1 = pn0 + __popcll(N0);
+        const int sp = s0 + lane;                 // suffix start of this lane
+        const bool second = (sp >> 6) > ws;
+        const int before = second ? pn1 + __popcll(N1 & low_bits64(sp & 63)) : pn0 + __popcll(N0 & low_bits64(sp & 63));
+        const int pre = po + __popcll(O & low_bits64(lane));
+        const int suf = tot_n - before;
+        // wave maximum of pre + suf over the valid split points, ties -> largest a: ballots only
+        const bool valid = a <= n_split;
+        const int v = pre + suf;
+        unsigned long long act = __ballot(valid);
+        if (act) {
+            for (int b = nbits - 1; b >= 0; --b) {
+                const unsigned long long m = __ballot(valid && ((v >> b) & 1)) & act;
+                if (m) act = m;
+            }
+            const int wl = 63 - __builtin_clzll(act);
+            const int vmax = (int)lane32((uint32_t)v, wl);
+            if (vmax >= best_v) { best_v = vmax; best_pm = (int)lane32((uint32_t)pre, wl); best_sm = (int)lane32((uint32_t)suf, wl); }
+        }
+        po += __popcll(O);
+    }
+    *pm_out = best_pm; *sm_out = best_sm;
+    return best_pm + best_sm;
 }
 
 // ------------------------------------------------------------------ index construction
@@ -707,7 +769,7 @@ __device__ __forceinline__ void lz_parse_body(PARSE_ARGS) {
     const bool prof = (ABL & 128) != 0; const int psel = (ABL >> 8) & 7;
     long long pc[6] = {0, 0, 0, 0, 0, 0}; long long tp = prof ? (long long)clock64() : 0;
 #define PROF_MARK(k) do { if (DEV && prof) { long long tn_ = (long long)clock64(); pc[k] += tn_ - tp; tp = tn_; } } while (0)
-    bool in_region = false; int r_qstart = 0, r_rstart = 0, r_qend = 0, r_rend = -1, r_match = 0;
+    bool in_region = false; int r_qstart = 0, r_rstart = 0, r_qend = 0, r_rend = -1, r_match = 0, vend = 0;
     int kept_end = seg_start;
     uint32_t M = 0, A = 0, NR = 0;
 
@@ -767,7 +829,8 @@ __device__ __forceinline__ void lz_parse_body(PARSE_ARGS) {
                 s_u = b ? stab[b - 1] : 0u; s_e = stab[b];
             }
             const int pred0 = pred - lit;                        // reference end of the previous match
-            int sbest_len = 0, sbest_pos = 0, ncap_a = 0, ncap_s = 0;
+            const bool pred_rc = pred0 > c.L;                    // strand of the prediction
+            int sbest_len = 0, sbest_pos = 0, sbest_ad = 0, ncap_a = 0, ncap_s = 0;
             while (a_u < a_e || s_u < s_e) {
                 if (DEV) { ++n_ab; }
                 uint32_t ea0 = 0, ea1 = 0, ea2 = 0, ea3 = 0; int es0 = 0, es1 = 0, es2 = 0, es3 = 0;
@@ -785,11 +848,14 @@ __device__ __forceinline__ void lz_parse_body(PARSE_ARGS) {
                     cm |= (a_u + 3 < a_e && (ea3 >> rd.pos_bits) == tag) ? 8u : 0u;
                 }
                 if (ls) {
-                    const int hi = pred_l + P.mrd - 1;
-                    cm |= (es0 >= pred0 && es0 <= hi) ? 16u : 0u;
-                    cm |= (s_u + 1 < s_e && es1 >= pred0 && es1 <= hi) ? 32u : 0u;
-                    cm |= (s_u + 2 < s_e && es2 >= pred0 && es2 <= hi) ? 64u : 0u;
-                    cm |= (s_u + 3 < s_e && es3 >= pred0 && es3 <= hi) ? 128u : 0u;
+                    // R3 window: not before the end of the previous match, less than mrd ahead of the advancing
+                    // prediction, and on the prediction's strand
+                    const int lo = pred0;
+                    const int hi = pred_rc ? pred_l + P.mrd - 1 : min(pred_l + P.mrd - 1, c.L - 1);
+                    cm |= (es0 >= lo && es0 <= hi) ? 16u : 0u;
+                    cm |= (s_u + 1 < s_e && es1 >= lo && es1 <= hi) ? 32u : 0u;
+                    cm |= (s_u + 2 < s_e && es2 >= lo && es2 <= hi) ? 64u : 0u;
+                    cm |= (s_u + 3 < s_e && es3 >= lo && es3 <= hi) ? 128u : 0u;
                 }
                 while (cm) {
                     const int j = __builtin_ctz(cm); cm &= cm - 1;
@@ -808,16 +874,26 @@ __device__ __forceinline__ void lz_parse_body(PARSE_ARGS) {
                             if (bl == 32) bl = match_len_lane(c, qi, bp, 1 << 30);
                         }
                     }
-                    if (l > bl || (l == bl && rp < bp)) { bl = l; bp = rp; }
+                    if (seed) {
+                        // longest; ties -> closest to the prediction, then smallest position
+                        const int ad = abs(rp - pred_l);
+                        if (l > bl || (l == bl && (ad < sbest_ad || (ad == sbest_ad && rp < bp)))) { bl = l; bp = rp; sbest_ad = ad; }
+                    } else if (l > bl || (l == bl && rp < bp)) { bl = l; bp = rp; }      // longest; ties -> smallest position
                 }
                 a_u += 4; s_u += 4;
                 // positions behind the first one that already has a match cannot become the event: stop their walks
                 const unsigned long long hit = __ballot(best_len > 0 || sbest_len > 0);
                 if (hit && lane > __builtin_ctzll(hit)) { a_u = a_e; s_u = s_e; }
             }
-            if (best_len > 0) {
+            // R2/R3 choice: without a prediction the anchor; with one the seed, unless an anchor is longer
+            // than the seed by at least msl (a far, long match beats a short close one)
+            if (best_len > 0 && sbest_len > 0 && best_pos != sbest_pos && best_len >= 32 && sbest_len + P.msl > 32) {
+                if (best_len == 32) best_len = match_len_lane(c, qi, best_pos, 1 << 30);
+                if (sbest_len == 32) sbest_len = match_len_lane(c, qi, sbest_pos, 1 << 30);
+            }
+            if (best_len > 0 && (sbest_len == 0 || best_len >= sbest_len + P.msl)) {
                 const int d = best_pos - pred_l;
-                hit_close = alive_l && d >= -P.mrd && d <= P.mrd;
+                hit_close = alive_l && ((best_pos > c.L) == pred_rc) && d >= -P.mrd && d <= P.mrd;
             } else if (sbest_len > 0) { best_len = sbest_len; best_pos = sbest_pos; hit_close = true; }
         }
         const unsigned long long hb = __ballot(best_len > 0);
@@ -846,34 +922,55 @@ __device__ __forceinline__ void lz_parse_body(PARSE_ARGS) {
         i += f; lit += f; if (alive) { pred += f; if (lit > P.mqd) alive = false; }
         const int gap_end_ref = pred - 1;
         const int ev_i = i;
-        // first-round loads of the left extension / gap scoring and of the right extension are
-        // independent: issue them together, then run the window logic
+        const int ev_len = (int)lane32((uint32_t)best_len, f);        // exact length, capped at 32 unless it had to be ranked
+        // everything below stays on the strand of the match
+        const int rlo = strand_lo(c, ev_pos), rhi = strand_hi(c, ev_pos);
+        // first-round loads of the left extension and of the right extension are independent: issue them
+        // together, then run the window logic
         // (closing the open region may move kept_end: use the value it will have)
         const int kept_after = (in_region && r_qend - r_qstart + 1 >= P.reg) ? r_qend + 1 : kept_end;
         const int bwd_bound = ev_close ? 0 : i - kept_after;
-        const uint64_t mm_b = (!ev_close && !(ABL & 2)) ? extend_mask0(c, i, ev_pos, -1, bwd_bound, lane) : EVEN;
-        const uint64_t mm_f = extend_mask0(c, i, ev_pos, +1, 1 << 30, lane);
-        int gap_m = 0;
-        if (ev_close && lit > 0 && !(ABL & 8)) gap_m = count_eq_wave(c, i - lit, pred - lit, lit, lane);   // R7: old diagonal
+        const uint64_t mm_b = (!ev_close && !(ABL & 2)) ? extend_mask0(c, i, ev_pos, -1, bwd_bound, lane, rlo, rhi) : EVEN;
+        const uint64_t mm_f = extend_mask0(c, i, ev_pos, +1, 1 << 30, lane, rlo, rhi);
         PROF_MARK(1);
         if (!ev_close) {
             // R5: new region, extended to the left (exact, then approximate), not into the last kept region
             close_region();
             int bm = 0;
-            const int b = (ABL & 2) ? 0 : extend(c, P, i, ev_pos, -1, bwd_bound, lane, &bm, mm_b);
+            const int b = (ABL & 2) ? 0 : extend(c, P, i, ev_pos, -1, bwd_bound, lane, &bm, mm_b, rlo, rhi);
             r_qstart = i - b; r_rstart = ev_pos - b; r_match = bm; r_rend = -1;
             in_region = true;
-        } else r_match += gap_m;
-        PROF_MARK(2);
-        {   // the match itself and R4, one pass
-            int fm = 0;
-            const int fe = (ABL & 4) ? P.mal : extend(c, P, i, ev_pos, +1, 1 << 30, lane, &fm, mm_f);
-            r_match += fm; i += fe; pred = ev_pos + fe; lit = 0; alive = true;
         }
+        PROF_MARK(2);
+        int fe, fm = 0;
+        {   // the match itself and R4, one pass
+            fe = (ABL & 4) ? P.mal : extend(c, P, i, ev_pos, +1, 1 << 30, lane, &fm, mm_f, rlo, rhi);
+            r_match += fm;
+        }
+        if (ev_close) {
+            // R7: the literal run in front of a chained match, laid against [pred0, end of the exact match)
+            int pm = 0, sm = 0;
+            if (lit > 0 && !(ABL & 8)) {
+                // exact length of the match = position of the first mismatch of the forward pass
+                int xl = ev_len;
+                if (xl >= 32) {
+                    const unsigned long long mb = __ballot(mm_f != 0);
+                    xl = mb ? 32 * __builtin_ctzll(mb) + (__builtin_ctzll(lane64(mm_f, __builtin_ctzll(mb))) >> 1) : 2048;
+                    if (xl >= 2048) xl = match_len_lane(c, i, ev_pos, 1 << 30);
+                }
+                r_match += gap_score(c, i, lit, pred - lit, ev_pos + xl, lane, rlo, rhi, &pm, &sm);
+            }
+            // reference end of the region: a symbol that matches nothing moves it by one, one matched on the
+            // old diagonal pulls it up to its own position, one matched on the new diagonal leaves it
+            const int tru = gap_end_ref + 1, vir = vend + lit - pm;
+            vend = max(tru, vir) - sm + (fe - fm);
+            r_rend = max(r_rend, max(ev_pos + fe - 1, vend - 1));
+            r_rstart = min(r_rstart, ev_pos);
+        }
+        i += fe; pred = ev_pos + fe; lit = 0; alive = true;
+        if (!ev_close) { r_rend = pred - 1; vend = pred; }
         PROF_MARK(3);
         r_qend = i - 1;
-        if (ev_close) { r_rend = max(r_rend, max(pred - 1, gap_end_ref)); }
-        else r_rend = pred - 1;
         if (S > 1) {
             // After an event at (ev_i, ev_pos) the scan state is (i, pred, lit = 0, alive): a function of the
             // event alone.  The open regions of two parses that meet in the same event may have started

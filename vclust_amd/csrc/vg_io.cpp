@@ -352,7 +352,10 @@ extern "C" int vg_write_ani(const vg_genomes* g, const vg_task* tasks, const vg_
             if ((int64_t)r.task >= n_tasks) continue;
             const vg_task& tk = tasks[r.task];
             int64_t L = g->len[tk.r];
-            auto fwd1 = [&](int64_t rr) { return rr < L ? rr + 1 : L - (rr - (L + 1)); };   // fwd | N | rc space -> 1-based forward
+            // fwd | N | rc space -> 1-based forward; the strand of a region is that of its rstart (rend is a
+            // virtual end and may lie past the end of the strand)
+            const bool rev = r.rstart > L;
+            auto fwd1 = [&](int64_t rr) { return rev ? L - (rr - (L + 1)) : rr + 1; };
             int alnlen = r.qend - r.qstart + 1; char buf[64];
             vg_fmt_num(100.0 * r.n_match / alnlen, buf);
             fprintf(fa, "%s\t%s\t%s\t%d\t%d\t%d\t%lld\t%lld\t%d\t%d\n", g->names[tk.q].c_str(), g->names[tk.r].c_str(), buf, alnlen,
