@@ -155,6 +155,15 @@ int vg_write_ani(const vg_genomes* g, const vg_task* tasks, const vg_pair_stat* 
 int vg_align(const char* const* fasta_paths, int n_paths, const char* out_path,
              const vg_align_params* p);
 
+/* ------------------------------------------------------------------ synthetic input --- */
+/* Workload generator of SURVEY.md 8(d) (bench / test input; no reference call site: the reference ships no
+ * generator).  Same draws as vclust_amd/synth.py (splitmix64, counter based), multithreaded.  The family plan
+ * -- family index, members, ancestor length per family -- comes from the caller.  *codes_out (bases 0..3 of
+ * all genomes) and *offsets_out (n_genomes + 1) are released with vg_free(). */
+int vg_synth_plan(const int64_t* fam_idx, const int32_t* members, const int32_t* lengths, int64_t n_fam,
+                  uint64_t seed, double p_lo, double p_hi, int n_indels, int n_threads,
+                  uint8_t** codes_out, int64_t** offsets_out, int64_t* n_genomes);
+
 /* ------------------------------------------------------------------ measurement ------- */
 /* per-kernel HIP-event timing on the library's stream (bench.py's roofline leg) */
 void vg_profile_enable(int on);

@@ -258,3 +258,56 @@ int vo_align(const vo_genome_set* s, const char* out_path, const vo_align_params
     free(st); free(roff); free(rtask); free(pairs); free(ord); free(rank);
     return 0;
 }
+
+
+/* ---- the whole path in memory: prefilter counts -> thresholds -> LZ parse of both directions of every kept
+ * pair (genomes in memory -> integer rows in memory; no files).  Same scope as the HIP path's device-resident
+ * step, so it is what bench.py times as cpu_baseline and what the full-set parity tests compare with.
+ * Ids are input-order genome indices; rows come in pair order, (q=a,r=b) then (q=b,r=a) with a > b. ---- */
+int vo_path_rows(const vo_genome_set* s, int k, int min_kmers, double min_ident, const vo_lz_params* lz,
+                 vo_pair_stat** rows_out, int64_t* n_rows) {
+    int n = s->n;
+    int64_t* sizes = (int64_t*)calloc(n > 0 ? n : 1, sizeof(int64_t));
+    vo_pair_count* pairs; int64_t np;
+    vo_shared_all(s, k, 1.0, sizes, &pairs, &np);
+    int64_t kept = 0;
+    for (int64_t i = 0; i < np; ++i) {
+        if ((int64_t)pairs[i].shared < min_kmers) continue;
+        if (vo_ani_shorter(pairs[i].shared, sizes[pairs[i].a], sizes[pairs[i].b], k) < min_ident) continue;
+        pairs[kept++] = pairs[i];
+    }
+    int64_t nt = 2 * kept;
+    vo_pair_stat* st = (vo_pair_stat*)calloc(nt > 0 ? nt : 1, sizeof(vo_pair_stat));
+    for (int64_t i = 0; i < kept; ++i) {
+        st[2 * i].q = pairs[i].a; st[2 * i].r = pairs[i].b;
+        st[2 * i + 1].q = pairs[i].b; st[2 * i + 1].r = pairs[i].a;
+    }
+    free(pairs); free(sizes);
+    int64_t* roff = (int64_t*)calloc(n + 1, sizeof(int64_t));
+    for (int64_t t = 0; t < nt; ++t) roff[st[t].r + 1]++;
+    for (int r = 0; r < n; ++r) roff[r + 1] += roff[r];
+    int64_t* rtask = (int64_t*)malloc(sizeof(int64_t) * (nt > 0 ? nt : 1));
+    int64_t* cur = (int64_t*)malloc(sizeof(int64_t) * (n + 1));
+    memcpy(cur, roff, sizeof(int64_t) * (n + 1));
+    for (int64_t t = 0; t < nt; ++t) rtask[cur[st[t].r]++] = t;
+    free(cur);
+    vo_lz_variant var; vo_lz_default_variant(&var);
+    #pragma omp parallel for schedule(dynamic, 1)
+    for (int r = 0; r < n; ++r) {
+        if (roff[r] == roff[r + 1]) continue;
+        vo_ref_index* ix = vo_lz_build_index(s->g[r].seq, s->g[r].len, lz, &var);
+        for (int64_t x = roff[r]; x < roff[r + 1]; ++x) {
+            int64_t t = rtask[x];
+            vo_region* regs; int nr;
+            vo_lz_parse(ix, s->g[st[t].q].seq, s->g[st[t].q].len, lz, &var, &regs, &nr);
+            uint32_t m = 0, a = 0;
+            for (int y = 0; y < nr; ++y) { m += regs[y].n_match; a += regs[y].qend - regs[y].qstart + 1; }
+            st[t].n_match = m; st[t].aln_len = a; st[t].n_regions = (uint32_t)nr;
+            free(regs);
+        }
+        vo_lz_free_index(ix);
+    }
+    free(roff); free(rtask);
+    *rows_out = st; *n_rows = nt;
+    return 0;
+}

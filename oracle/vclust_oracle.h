@@ -134,6 +134,11 @@ int vo_align(const vo_genome_set* s, const char* out_path, const vo_align_params
 int vo_lz_pair_stat(const uint8_t* qry, int64_t qlen, const uint8_t* ref, int64_t rlen,
                     const vo_lz_params* p, uint32_t* n_match, uint32_t* aln_len, uint32_t* n_regions);
 
+/* the whole path in memory (prefilter counts -> thresholds -> both directions of every kept pair), ids in
+ * input order, rows (q=a,r=b),(q=b,r=a) per kept pair a > b; *rows_out is malloc'd.  OpenMP over references. */
+int vo_path_rows(const vo_genome_set* s, int k, int min_kmers, double min_ident, const vo_lz_params* lz,
+                 vo_pair_stat** rows_out, int64_t* n_rows);
+
 /* ---------- formatting ---------- */
 /* writes the LZ-ANI style number into buf (>= 32 bytes), returns length */
 int vo_fmt_num(double x, char* buf);

@@ -27,6 +27,10 @@ class LzParams(C.Structure):
     _fields_ = [(n, C.c_int) for n in ('mal', 'msl', 'mrd', 'mqd', 'reg', 'aw', 'am', 'ar')]
 
 
+class PairStat(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ('q', 'r', 'n_match', 'aln_len', 'n_regions')]
+
+
 class PairCount(C.Structure):
     _fields_ = [('a', C.c_uint32), ('b', C.c_uint32), ('shared', C.c_uint32)]
 
@@ -55,6 +59,9 @@ def lib():
         L.vo_lz_pair_stat.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(LzParams),
                                       C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.vo_lz_pair_stat.restype = C.c_int
+        L.vo_path_rows.argtypes = [C.POINTER(GenomeSet), C.c_int, C.c_int, C.c_double, C.POINTER(LzParams),
+                                   C.POINTER(C.POINTER(PairStat)), C.POINTER(C.c_int64)]
+        L.vo_path_rows.restype = C.c_int
         L.vo_fmt_num.argtypes = [C.c_double, C.c_char_p]
         L.vo_fmt_num.restype = C.c_int
         L.vo_fmt_len_ratio.argtypes = [C.c_int64, C.c_int64, C.c_char_p]
@@ -120,6 +127,21 @@ def lz_pair_stat(q, r, lz=None):
     lib().vo_lz_pair_stat(q.ctypes.data_as(C.c_void_p), len(q), r.ctypes.data_as(C.c_void_p), len(r),
                           C.byref(prm), C.byref(m), C.byref(a), C.byref(n))
     return m.value, a.value, n.value
+
+
+def path_rows(codes, offsets, k=25, min_kmers=20, min_ident=0.7, lz=None, threads=None):
+    """Whole path in memory -> structured array (q, r, n_match, aln_len, n_regions), ids in input order."""
+    import os
+    if threads:
+        os.environ['OMP_NUM_THREADS'] = str(threads)
+    gs, keep = _make_set(codes, offsets)
+    prm = LzParams(**{**DEFAULT_LZ, **(lz or {})})
+    pp = C.POINTER(PairStat)(); n = C.c_int64()
+    lib().vo_path_rows(C.byref(gs), k, min_kmers, float(min_ident), C.byref(prm), C.byref(pp), C.byref(n))
+    dt = np.dtype([('q', '<u4'), ('r', '<u4'), ('n_match', '<u4'), ('aln_len', '<u4'), ('n_regions', '<u4')])
+    out = np.ctypeslib.as_array(C.cast(pp, C.POINTER(C.c_uint32)), shape=(max(n.value, 1) * 5,))[:n.value * 5].copy().view(dt)
+    lib().free(C.cast(pp, C.c_void_p))
+    return out
 
 
 def read_fasta_codes(path, multisample=True):

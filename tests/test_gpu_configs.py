@@ -1,0 +1,129 @@
+"""BASELINE.json configs[1..4] through the HIP path, each to the parity bar its size allows:
+configs[1] in full against the oracle (every row, files byte-compared); configs[2] at full size
+(properties + an oracle sample); configs[3] / [4] at a reduced count with their own flag sets
+(size-independent properties, determinism, oracle sample).  Everything calls through the C ABI."""
+import filecmp
+
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+from vclust_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _rows_dict(tasks, stats):
+    return {(int(t['q']), int(t['r'])): (int(s['n_match']), int(s['aln_len']), int(s['n_regions'])) for t, s in zip(tasks, stats)}
+
+
+def _gpu_path(gs, k, min_kmers, min_ident):
+    sizes, pairs = gs.kmer_shared(k=k, min_shared=min_kmers)
+    cand = gs.filter_pairs(sizes, pairs, k=k, min_kmers=min_kmers, min_ident=min_ident)
+    tasks = gs.align_tasks(cand)
+    return sizes, pairs, cand, tasks, gs.lz_align(tasks)
+
+
+def test_config1_phage_1k_every_row_and_files(tmp_path):
+    """configs[1]: 1 000 x 40 kb, k=25: all 9 000 ordered alignments equal the oracle's rows, and the files
+    written by the product from a FASTA on disk (fltr.txt, ani.tsv, ani.ids.tsv) equal the oracle CLI's byte for byte."""
+    codes, offsets, names, _ = synth.make_workload('phage-1k')
+    gs = api.GenomeSet.from_codes(codes, offsets, names)
+    sizes, pairs, cand, tasks, stats = _gpu_path(gs, 25, 20, 0.7)
+    assert len(tasks) == 9000
+    ref = orc.path_rows(codes, offsets, k=25, min_kmers=20, min_ident=0.7)
+    want = {(int(r['q']), int(r['r'])): (int(r['n_match']), int(r['aln_len']), int(r['n_regions'])) for r in ref}
+    assert _rows_dict(tasks, stats) == want
+    fa = tmp_path / 'p1k.fna'
+    synth.write_fasta(fa, codes, offsets, names)
+    api.prefilter([fa], tmp_path / 'fltr.txt', is_multifasta=True)
+    api.align([fa], tmp_path / 'ani.tsv', is_multifasta=True, columns=api.ALIGN_FIELDS[:11], filter_path=tmp_path / 'fltr.txt')
+    orc.run_cli('prefilter', '-o', tmp_path / 'o_fltr.txt', fa)
+    orc.run_cli('align', '--filter', tmp_path / 'o_fltr.txt', '0', '-o', tmp_path / 'o_ani.tsv', fa)
+    assert filecmp.cmp(tmp_path / 'fltr.txt', tmp_path / 'o_fltr.txt', shallow=False)
+    assert filecmp.cmp(tmp_path / 'ani.tsv', tmp_path / 'o_ani.tsv', shallow=False)
+    assert filecmp.cmp(tmp_path / 'ani.ids.tsv', tmp_path / 'o_ani.ids.tsv', shallow=False)
+
+
+def test_config2_imgvr_10k_full_size():
+    """configs[2]: 10 000 mixed 5-200 kb contigs, --min-ident 0.7: within-family pairs only, row invariants,
+    determinism, and an oracle sample over short, long and random references."""
+    codes, offsets, names, _ = synth.make_workload('imgvr-10k')
+    fam = np.array([int(n[3:9]) for n in names])
+    gs = api.GenomeSet.from_codes(codes, offsets, names)
+    sizes, pairs, cand, tasks, stats = _gpu_path(gs, 25, 20, 0.7)
+    assert len(gs) == 10000
+    assert np.all(fam[cand['a']] == fam[cand['b']])
+    n_expected = sum(c * (c - 1) // 2 for c in np.bincount(fam))
+    assert 0.97 * n_expected <= len(cand) <= n_expected
+    lens = gs.lengths()
+    assert np.all(stats['n_match'] <= stats['aln_len']) and np.all(stats['aln_len'] <= lens[tasks['q']])
+    assert np.array_equal(stats, gs.lz_align(tasks))
+    order = np.argsort(lens[tasks['r']])
+    idx = np.concatenate([order[:8], order[-8:], np.random.default_rng(3).choice(len(tasks), 24, replace=False)])
+    for i in idx:
+        q, r = int(tasks[i]['q']), int(tasks[i]['r'])
+        assert orc.lz_pair_stat(codes[offsets[q]:offsets[q + 1]], codes[offsets[r]:offsets[r + 1]]) == tuple(int(x) for x in stats[i]), (q, r)
+
+
+def test_config3_phage_100k_slice():
+    """configs[3] (100 000 x 40 kb) at 20 000 genomes: same generator and flags as the bench's default workload;
+    exactly the within-family pairs, row invariants, bit-identical second run, oracle sample.  (The full
+    100 000 run is the bench line; its pair count is checked there: 450 000.)"""
+    nf = 2000
+    codes, offsets, names, _ = synth.make_workload('phage-100k', nf)
+    gs = api.GenomeSet.from_codes(codes, offsets, names)
+    sizes, pairs, cand, tasks, stats = _gpu_path(gs, 25, 20, 0.7)
+    assert {(int(p['a']), int(p['b'])) for p in cand} == {(int(p['a']), int(p['b'])) for p in synth.family_pairs(nf, 10)}
+    lens = gs.lengths()
+    assert np.all(stats['n_regions'] >= 1) and np.all(stats['n_match'] <= stats['aln_len']) and np.all(stats['aln_len'] <= lens[tasks['q']])
+    assert np.array_equal(stats, gs.lz_align(tasks))
+    for i in np.random.default_rng(5).choice(len(tasks), 40, replace=False):
+        q, r = int(tasks[i]['q']), int(tasks[i]['r'])
+        assert orc.lz_pair_stat(codes[offsets[q]:offsets[q + 1]], codes[offsets[r]:offsets[r + 1]]) == tuple(int(x) for x in stats[i]), (q, r)
+
+
+def test_config4_contigs_shape_with_dereplication_flags(tmp_path):
+    """configs[4] shape (log-uniform 2-100 kb contigs, --min-kmers 30, then --out-ani 0.95 --out-qcov 0.85:
+    the reference's large.yml:65-72 flag set) at 100 000 contigs: prefilter invariants at that size, and on a
+    4 000-contig slice the product's files equal the oracle CLI's under the same flags."""
+    codes, offsets, names, _ = synth.make_workload('contigs-1M', 100000)
+    fam = np.array([int(n[3:9]) for n in names])
+    gs = api.GenomeSet.from_codes(codes, offsets, names)
+    sizes, pairs = gs.kmer_shared(k=25, min_shared=30)
+    cand = gs.filter_pairs(sizes, pairs, k=25, min_kmers=30, min_ident=0.7)
+    assert len(gs) == 100000 and np.all(fam[cand['a']] == fam[cand['b']]) and np.all(cand['shared'] >= 30)
+    n_expected = sum(c * (c - 1) // 2 for c in np.bincount(fam))
+    assert 0.95 * n_expected <= len(cand) <= n_expected
+    tasks = gs.align_tasks(cand)
+    stats = gs.lz_align(tasks)
+    lens = gs.lengths()
+    assert np.all(stats['n_match'] <= stats['aln_len']) and np.all(stats['aln_len'] <= lens[tasks['q']])
+    # slice: byte-compare the files under the dereplication flags
+    n = 4000
+    fa = tmp_path / 'c4k.fna'
+    synth.write_fasta(fa, codes[:offsets[n]], offsets[:n + 1], names[:n])
+    api.prefilter([fa], tmp_path / 'fltr.txt', is_multifasta=True, min_kmers=30)
+    api.align([fa], tmp_path / 'ani.tsv', is_multifasta=True, columns=api.ALIGN_FIELDS[:11], filter_path=tmp_path / 'fltr.txt',
+              out_filters={'ani': 0.95, 'qcov': 0.85})
+    orc.run_cli('prefilter', '--min-kmers', 30, '-o', tmp_path / 'o_fltr.txt', fa)
+    orc.run_cli('align', '--filter', tmp_path / 'o_fltr.txt', '0', '--out-ani', 0.95, '--out-qcov', 0.85, '-o', tmp_path / 'o_ani.tsv', fa)
+    assert filecmp.cmp(tmp_path / 'fltr.txt', tmp_path / 'o_fltr.txt', shallow=False)
+    assert filecmp.cmp(tmp_path / 'ani.tsv', tmp_path / 'o_ani.tsv', shallow=False)
+    assert sum(1 for _ in open(tmp_path / 'ani.tsv')) > 100
+
+
+def test_many_regions_per_task(tmp_path):
+    """--out-aln on strongly diverged pairs: far more than 64 regions per ordered pair on average.  The region
+    buffer is sized from the rows (no fixed capacity): every region arrives, in the oracle's multiset."""
+    codes, offsets, names = synth.make_families(3, 6, length=60000, seed=17, p_lo=0.10, p_hi=0.16, n_indels=40)
+    gs = api.GenomeSet.from_codes(codes, offsets, names)
+    tasks = gs.align_tasks(synth.family_pairs(3, 6))
+    stats, regions = gs.lz_align(tasks, want_regions=True)
+    assert len(regions) == int(stats['n_regions'].sum()) and len(regions) > 64 * len(tasks)
+    fa = tmp_path / 'div.fna'
+    synth.write_fasta(fa, codes, offsets, names)
+    api.align([fa], tmp_path / 'ani.tsv', is_multifasta=True, columns=api.ALIGN_FIELDS[:11], out_aln=tmp_path / 'aln.tsv')
+    orc.run_cli('align', '-o', tmp_path / 'o.tsv', '--out-aln', tmp_path / 'o_aln.tsv', fa)
+    assert filecmp.cmp(tmp_path / 'ani.tsv', tmp_path / 'o.tsv', shallow=False)
+    assert sorted(open(tmp_path / 'aln.tsv').read().splitlines()) == sorted(open(tmp_path / 'o_aln.tsv').read().splitlines())

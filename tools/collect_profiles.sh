@@ -1,19 +1,24 @@
 #!/bin/bash
-# Run on the GPU box (via gpurun): rocprofv3 kernel stats + separate PMC passes of the default bench.
-# Usage: tools/collect_profiles.sh <round-tag>   -> gpurun_out/prof_<tag>/{stats,fetch,write}/ + summaries
+# Run on the GPU box (via gpurun): rocprofv3 kernel stats + separate PMC passes of the bench.
+# Usage: tools/collect_profiles.sh <round-tag> [workload] [n] [steps]
+#   -> gpurun_out/prof_<tag>_<workload>/{stats,fetch,write}/ + summary/ (copy summary/* into profiles/)
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
+WL=${2:-phage-100k}
+N=${3:-}
+STEPS=${4:-3}
 REPO=$(pwd)
-OUT=$REPO/gpurun_out/prof_$TAG
+NAME=$WL${N:+/$N}
+OUT=$REPO/gpurun_out/prof_${TAG}_${WL}${N:+_$N}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-CMD="python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+CMD="python $REPO/bench.py --workload $WL ${N:+--n $N} --steps $STEPS --warmup 1 --no-cpu-baseline --no-cli-wall"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $CMD > "$OUT/stats.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -- $CMD > "$OUT/fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write" -- $CMD > "$OUT/write.log" 2>&1
 cd "$REPO"
-python tools/profile_summary.py "$OUT" "$TAG"
+python tools/profile_summary.py "$OUT" "$TAG" "$NAME" "$STEPS"
 # keep the merge small: raw traces are large
 find "$OUT" -name '*kernel_trace.csv' -size +8M -delete
 find "$OUT" -name '*counter_collection.csv' -size +8M -delete

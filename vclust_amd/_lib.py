@@ -92,6 +92,8 @@ SYMBOLS = {
     'vg_write_ani': (C.c_int, [C.c_void_p, P(Task), P(PairStat), C.c_int64, P(Region), C.c_int64,
                                C.c_char_p, P(AlignParams)]),
     'vg_align': (C.c_int, [P(C.c_char_p), C.c_int, C.c_char_p, P(AlignParams)]),
+    'vg_synth_plan': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_double, C.c_double, C.c_int,
+                                C.c_int, P(C.c_void_p), P(C.c_void_p), P(C.c_int64)]),
     'vg_profile_enable': (None, [C.c_int]),
     'vg_profile_reset': (None, []),
     'vg_profile_get': (C.c_int, [P(KernelTime), C.c_int]),

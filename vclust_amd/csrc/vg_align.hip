@@ -728,9 +728,9 @@ struct seg_rec { int i_ev, ev_pos; uint32_t VM, VA, VN; };     // VN: bit 31 = o
     const uint32_t* __restrict__ atab_pool, const uint32_t* __restrict__ aent_pool, \
     const uint32_t* __restrict__ stab_pool, const uint32_t* __restrict__ sent_pool, \
     lz_dev_params P, vg_pair_stat* __restrict__ stats, \
-    vg_region* __restrict__ regions, unsigned long long* __restrict__ region_cursor, unsigned long long region_cap
+    vg_region* __restrict__ regions, const unsigned long long* __restrict__ region_off
 #define PARSE_ARG_NAMES tasks, n_tasks, refs, packed, nmask, base_off, glen, g_has_n, rr_pool, mask_pool, atab_pool, aent_pool, \
-    stab_pool, sent_pool, P, stats, regions, region_cursor, region_cap
+    stab_pool, sent_pool, P, stats, regions, region_off
 
 template <int S, bool DEV>
 __device__ __forceinline__ void lz_parse_body(PARSE_ARGS) {
@@ -779,12 +779,10 @@ __device__ __forceinline__ void lz_parse_body(PARSE_ARGS) {
             if (span >= P.reg) {
                 M += (uint32_t)r_match; A += (uint32_t)span; NR += 1; kept_end = r_qend + 1;
                 if (regions && lane == 0) {
-                    unsigned long long o = atomicAdd(region_cursor, 1ULL);
-                    if (o < region_cap) {
-                        vg_region rg; rg.task = tk.out_idx; rg.qstart = r_qstart; rg.qend = r_qend;
-                        rg.rstart = r_rstart; rg.rend = r_rend; rg.n_match = r_match;
-                        regions[o] = rg;
-                    }
+                    // slot = this task's offset (prefix sum of the stats pass) + regions kept so far: exact size, fixed order
+                    vg_region rg; rg.task = tk.out_idx; rg.qstart = r_qstart; rg.qend = r_qend;
+                    rg.rstart = r_rstart; rg.rend = r_rend; rg.n_match = r_match;
+                    regions[region_off[t] + (NR - 1)] = rg;
                 }
             }
             in_region = false;
@@ -1070,6 +1068,7 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
     for (int64_t t = 0; t < n_tasks; ++t)
         if (tasks[t].q >= (uint32_t)g->n || tasks[t].r >= (uint32_t)g->n) throw vg_error(VG_EINVAL, "task id out of range");
     for (int i = 0; i < g->n; ++i) if (g->len[i] > (1 << 29)) throw vg_error(VG_EOVERFLOW, "genome longer than 2^29 bases");
+    if (n_tasks >= (1LL << 32)) throw vg_error(VG_EOVERFLOW, "more than 2^32 - 1 ordered pairs in one call: split the task list");
 
     // group tasks by reference: counting sort on the reference id (stable, O(n))
     std::vector<int64_t> order((size_t)n_tasks);
@@ -1085,9 +1084,8 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
 
     dbuf<vg_pair_stat> d_stats((size_t)n_tasks);
     const bool want_regions = regions != nullptr;
-    unsigned long long region_cap = want_regions ? std::max<unsigned long long>(1 << 20, (unsigned long long)n_tasks * 64) : 0;
-    dbuf<vg_region> d_regions((size_t)std::max<unsigned long long>(region_cap, 1));
-    dbuf<unsigned long long> d_rcur(1); d_rcur.zero(s);
+    std::vector<vg_region> h_regions;                 // all kept regions, batch after batch
+    std::vector<vg_pair_stat> h_stats;                // host copy of the rows (sizes the region buffer)
 
     int64_t pos = 0;
     while (pos < n_tasks) {
@@ -1182,21 +1180,45 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
             static const char* seg_env = getenv("VG_LZ_SEGMENTS");
             const bool uneven = q_max * nt > 3 * q_sum;
             const bool segments = seg_env ? atoi(seg_env) > 1 : (nt <= g_segment_task_limit || uneven);
-            if (segments && !want_regions && P.ablate == 0) {
+            const unsigned long long* no_off = nullptr;
+            if (segments && P.ablate == 0 && nt < (1LL << 31)) {
                 const int64_t nblk = (nt + 7) / 8 * 8;
                 hipLaunchKernelGGL(k_lz_parse_seg, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p, nt, d_refs.p, g->d_packed.p, g->d_nmask.p,
                                    g->d_base_off.p, g->d_len.p, g->d_has_n.p, rr_pool.p, mask_pool.p, atab_pool.p, aent_pool.p, stab_pool.p,
-                                   sent_pool.p, P, d_stats.p, (vg_region*)nullptr, d_rcur.p, region_cap);
+                                   sent_pool.p, P, d_stats.p, (vg_region*)nullptr, no_off);
             } else {
                 const int64_t nblk = ((nt + 3) / 4 + 7) / 8 * 8;
-if (P.ablate) {
+                if (P.ablate) {
                     hipLaunchKernelGGL(k_lz_parse_dev, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p, nt, d_refs.p, g->d_packed.p, g->d_nmask.p,
                                    g->d_base_off.p, g->d_len.p, g->d_has_n.p, rr_pool.p, mask_pool.p, atab_pool.p, aent_pool.p, stab_pool.p,
-                                   sent_pool.p, P, d_stats.p, want_regions ? d_regions.p : (vg_region*)nullptr, d_rcur.p, region_cap);
+                                   sent_pool.p, P, d_stats.p, (vg_region*)nullptr, no_off);
                 } else {
                     hipLaunchKernelGGL(k_lz_parse, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p, nt, d_refs.p, g->d_packed.p, g->d_nmask.p,
                                    g->d_base_off.p, g->d_len.p, g->d_has_n.p, rr_pool.p, mask_pool.p, atab_pool.p, aent_pool.p, stab_pool.p,
-                                   sent_pool.p, P, d_stats.p, want_regions ? d_regions.p : (vg_region*)nullptr, d_rcur.p, region_cap);
+                                   sent_pool.p, P, d_stats.p, (vg_region*)nullptr, no_off);
+                }
+            }
+            if (want_regions) {
+                // --out-aln: the rows just computed give every task's region count, so the region buffer is
+                // sized exactly (prefix sum) and every region has a fixed slot; the parse runs a second time
+                // and writes them (one wave per pair: regions are emitted in query order)
+                h_stats.resize((size_t)n_tasks);
+                d_stats.download(h_stats.data(), (size_t)n_tasks, s);
+                VG_HIP(hipStreamSynchronize(s));
+                std::vector<unsigned long long> off((size_t)nt + 1, 0);
+                for (int64_t t = 0; t < nt; ++t) off[(size_t)t + 1] = off[(size_t)t] + h_stats[td[(size_t)t].out_idx].n_regions;
+                const unsigned long long nr = off[(size_t)nt];
+                if (nr) {
+                    dbuf<unsigned long long> d_off((size_t)nt + 1); d_off.upload(off.data(), off.size(), s);
+                    dbuf<vg_region> d_regions((size_t)nr);
+                    const int64_t nblk = ((nt + 3) / 4 + 7) / 8 * 8;
+                    hipLaunchKernelGGL(k_lz_parse, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p, nt, d_refs.p, g->d_packed.p, g->d_nmask.p,
+                                   g->d_base_off.p, g->d_len.p, g->d_has_n.p, rr_pool.p, mask_pool.p, atab_pool.p, aent_pool.p, stab_pool.p,
+                                   sent_pool.p, P, d_stats.p, d_regions.p, (const unsigned long long*)d_off.p);
+                    const size_t at = h_regions.size();
+                    h_regions.resize(at + (size_t)nr);
+                    d_regions.download(h_regions.data() + at, (size_t)nr, s);
+                    VG_HIP(hipStreamSynchronize(s));
                 }
             }
         }
@@ -1207,13 +1229,10 @@ if (P.ablate) {
     d_stats.download(stats, (size_t)n_tasks, s);
     VG_HIP(hipStreamSynchronize(s));
     if (want_regions) {
-        unsigned long long nr = 0; d_rcur.download(&nr, 1, s); VG_HIP(hipStreamSynchronize(s));
-        if (nr > region_cap) throw vg_error(VG_EOVERFLOW, "region buffer overflow");
-        vg_region* o = (vg_region*)malloc(sizeof(vg_region) * std::max<size_t>(1, (size_t)nr));
+        vg_region* o = (vg_region*)malloc(sizeof(vg_region) * std::max<size_t>(1, h_regions.size()));
         if (!o) throw vg_error(VG_ENOMEM, "out of host memory");
-        if (nr) d_regions.download(o, (size_t)nr, s);
-        VG_HIP(hipStreamSynchronize(s));
-        *regions = o; if (n_regions) *n_regions = (int64_t)nr;
+        if (!h_regions.empty()) memcpy(o, h_regions.data(), sizeof(vg_region) * h_regions.size());
+        *regions = o; if (n_regions) *n_regions = (int64_t)h_regions.size();
     }
     VG_API_END
 }

@@ -17,6 +17,7 @@ extern "C" int vg_prefilter(const char* const* fasta_paths, int n_paths, const c
     VG_API_BEGIN
     if (!fasta_paths || n_paths <= 0 || !out_path || !p) throw vg_error(VG_EINVAL, "vg_prefilter: null argument");
     if (p->k < 15 || p->k > 30) throw vg_error(VG_EINVAL, "k must be in 15..30");
+    if (!(p->kmers_fraction > 0.0) || p->kmers_fraction > 1.0) throw vg_error(VG_EINVAL, "kmers_fraction must be in (0,1]");
     vg_require_device();
     genomes_guard gg;
     check(vg_genomes_load(fasta_paths, n_paths, p->is_multifasta, p->num_threads, &gg.g));
@@ -24,9 +25,9 @@ extern "C" int vg_prefilter(const char* const* fasta_paths, int n_paths, const c
     free_guard pairs; int64_t np = 0;
     // on a single device the --min-kmers cut can be applied on the GPU already
     uint32_t min_emit = (uint32_t)std::max(1, p->min_kmers);
-    check(vg_kmer_shared(gg.g, p->k, p->kmers_fraction > 0 ? p->kmers_fraction : 1.0, 0, 1, min_emit, sizes.data(),
+    check(vg_kmer_shared(gg.g, p->k, p->kmers_fraction, 0, 1, min_emit, sizes.data(),
                          (vg_pair_count**)&pairs.p, &np));
-    check(vg_write_fltr(gg.g, p->k, p->kmers_fraction > 0 ? p->kmers_fraction : 1.0, p->min_kmers, p->min_ident, p->max_seqs,
+    check(vg_write_fltr(gg.g, p->k, p->kmers_fraction, p->min_kmers, p->min_ident, p->max_seqs,
                         sizes.data(), (const vg_pair_count*)pairs.p, np, out_path));
     VG_API_END
 }

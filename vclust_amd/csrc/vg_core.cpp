@@ -33,7 +33,12 @@ extern "C" int vg_set_device(int device) {
     int n = vg_device_count();
     if (n <= 0) throw vg_error(VG_ENODEV, "no HIP device visible: libvclust_gpu has no CPU fallback");
     if (device < 0 || device >= n) throw vg_error(VG_EINVAL, "device index out of range");
-    if (g_stream && device != g_device) { (void)hipStreamDestroy(g_stream); g_stream = nullptr; }
+    if (g_device >= 0 && device != g_device) {
+        // cached blocks belong to the device they were allocated on: give them back before switching
+        // (genome sets re-upload themselves on their next use, vg_genomes_to_device)
+        vg_dev_trim();
+        if (g_stream) { (void)hipStreamDestroy(g_stream); g_stream = nullptr; }
+    }
     VG_HIP(hipSetDevice(device));
     g_device = device;
     VG_API_END
