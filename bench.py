@@ -13,7 +13,7 @@ Default workload: `phage-100k` of SURVEY.md 8(d) (BASELINE configs[3]: 10 000 fa
 seed 3), which fits one MI355X.  N > 1: the SAME set (strong scaling; `--scaling weak` multiplies the families
 by N instead): the prefilter is sharded by k-mer hash range (partial counts all-gathered over RCCL and summed
 on the device), the align tasks are dealt by reference range (each rank indexes 1/N of the genomes), and the
-per-pair integer rows are all-gathered.  Other workloads: --workload phage-1k | imgvr-10k | contigs-1M (+ --n).
+per-pair integer rows are all-gathered.  Other workloads: --workload phage-1k | imgvr-10k | contigs-1M (+ --count).
 """
 import argparse
 import json
@@ -104,13 +104,13 @@ def main():
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--workload', choices=sorted(synth.WORKLOADS), default='phage-100k')
-    ap.add_argument('--n', type=int, default=None, help='scale the workload: families (phage sets) or contigs')
+    ap.add_argument('--count', type=int, default=None, help='scale the workload: families (phage sets) or contigs')
     ap.add_argument('--scaling', choices=['strong', 'weak'], default='strong',
                     help='N > 1: strong = the same set on N GPUs; weak = N x the set')
     ap.add_argument('--k', type=int, default=25)
     ap.add_argument('--min-kmers', type=int, default=None, help='default 20 (30 for contigs-1M, large.yml:65-72)')
     ap.add_argument('--min-ident', type=float, default=0.7)
-    ap.add_argument('--cpu-sample-families', type=int, default=150)
+    ap.add_argument('--cpu-sample-families', type=int, default=400)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-cli-wall', action='store_true')
     args = ap.parse_args()
@@ -129,7 +129,7 @@ def main():
     api.set_device(local_rank % api.device_count())
 
     wl = synth.WORKLOADS[args.workload]
-    base_n = args.n if args.n is not None else (wl['n_families'] if wl['kind'] == 'families' else wl['n'])
+    base_n = args.count if args.count is not None else (wl['n_families'] if wl['kind'] == 'families' else wl['n'])
     n_units = base_n * (world if args.scaling == 'weak' else 1)
     codes, offsets, names, desc = synth.make_workload(args.workload, n_units)
     min_kmers = args.min_kmers if args.min_kmers is not None else (30 if args.workload == 'contigs-1M' else 20)
@@ -199,7 +199,7 @@ def main():
             alg = stage_bytes[stage] / launches_per_step / max(world, 1)
             achieved = alg / (avg_ms * 1e-3) / 1e9
             impl = dom['bytes'] / dom['launches']
-            traffic, src = pmc_traffic(args.workload if args.n is None else f'{args.workload}/{args.n}', kern) if world == 1 else (None, None)
+            traffic, src = pmc_traffic(args.workload if args.count is None else f'{args.workload}/{args.count}', kern) if world == 1 else (None, None)
             roofline = dict(
                 bound='hbm', kernel=kern, scope=dom['name'], achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit='GB/s',
                 frac=round(achieved / HBM_PEAK_GBS, 6), traffic=traffic, traffic_source=src,
@@ -214,11 +214,11 @@ def main():
                           frac=round((b_pre + b_aln) / step_s / 1e9 / HBM_PEAK_GBS, 6),
                           note='B_pre + B_aln of SURVEY 8(d) / whole step incl. host time' + (', all ranks' if world > 1 else '')))
         cpu = None
-        if world == 1 and not args.no_cpu_baseline and wl['kind'] == 'families':
+        if world == 1 and not args.counto_cpu_baseline and wl['kind'] == 'families':
             cpu = cpu_baseline(min(args.cpu_sample_families, n_units), wl['members'], wl['length'], wl['seed'],
                                min(os.cpu_count() or 1, 256), args.k, min_kmers, args.min_ident)
         e2e = None
-        if world == 1 and not args.no_cli_wall:
+        if world == 1 and not args.counto_cli_wall:
             try:
                 e2e = cli_wall(codes, offsets, names, n_pairs)
             except Exception as exc:      # the device-resident figure stands on its own

@@ -44,6 +44,9 @@ void        vg_free(void* p);
  * process for all later calls (one process per GPU) */
 int vg_device_count(void);
 int vg_set_device(int device);
+/* the library keeps released device blocks in a cache (no hipMalloc on the hot path); this returns them to
+ * the driver, e.g. before another process needs the HBM */
+void vg_release_device_memory(void);
 
 /* ------------------------------------------------------------------ genome sets ------- */
 typedef struct vg_genomes vg_genomes;

@@ -153,12 +153,13 @@ def test_two_ranks_write_the_same_files(tmp_path):
 
 
 def test_bench_two_ranks_smoke():
-    p = _torchrun(2, ROOT / 'bench.py', '--gpus', '2', '--steps', '1', '--warmup', '1', '--families', '6', '--no-cpu-baseline')
+    p = _torchrun(2, ROOT / 'bench.py', '--gpus', '2', '--steps', '1', '--warmup', '1', '--workload', 'phage-1k', '--count', '6',
+                  '--no-cpu-baseline', '--no-cli-wall')
     assert p.returncode == 0, p.stderr[-2000:]
     import json
     line = [l for l in p.stdout.splitlines() if l.startswith('{')][-1]
     d = json.loads(line)
-    assert d['n_gpus'] == 2 and d['config']['pairs_per_step'] == 2 * 6 * 45 and d['value'] > 0
+    assert d['n_gpus'] == 2 and d['config']['pairs_per_step'] == 6 * 45 and d['value'] > 0 and d['scaling'] == 'strong'
 
 
 def test_rccl_collectives_one_rank():

@@ -12,7 +12,7 @@ NAME=$WL${N:+/$N}
 OUT=$REPO/gpurun_out/prof_${TAG}_${WL}${N:+_$N}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-CMD="python $REPO/bench.py --workload $WL ${N:+--n $N} --steps $STEPS --warmup 1 --no-cpu-baseline --no-cli-wall"
+CMD="python $REPO/bench.py --workload $WL ${N:+--count $N} --steps $STEPS --warmup 1 --no-cpu-baseline --no-cli-wall"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $CMD > "$OUT/stats.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -- $CMD > "$OUT/fetch.log" 2>&1

@@ -66,6 +66,7 @@ SYMBOLS = {
     'vg_free': (None, [C.c_void_p]),
     'vg_device_count': (C.c_int, []),
     'vg_set_device': (C.c_int, [C.c_int]),
+    'vg_release_device_memory': (None, []),
     'vg_genomes_load': (C.c_int, [P(C.c_char_p), C.c_int, C.c_int, C.c_int, P(C.c_void_p)]),
     'vg_genomes_from_codes': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, P(C.c_char_p), P(C.c_void_p)]),
     'vg_genomes_free': (None, [C.c_void_p]),

@@ -231,6 +231,10 @@ def align(paths, out_path, is_multifasta, columns, filter_path=None, filter_thre
     check(lib.vg_align(arr, len(paths), os.fsencode(str(out_path)), C.byref(p)))
 
 
+def release_device_memory():
+    _lib.load().vg_release_device_memory()
+
+
 # ---------------------------------------------------------------- measurement
 def profile_enable(on=True):
     _lib.load().vg_profile_enable(int(bool(on)))

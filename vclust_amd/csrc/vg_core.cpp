@@ -109,6 +109,8 @@ void vg_dev_trim() {
     if (!blocks.empty()) { (void)hipDeviceSynchronize(); for (void* b : blocks) (void)hipFree(b); }
 }
 
+extern "C" void vg_release_device_memory(void) { vg_dev_trim(); }
+
 // ---------------------------------------------------------------- profiling
 struct prof_entry { double ms = 0; int64_t launches = 0; double bytes = 0; int order = 0; };
 struct pending_ev { std::string name; hipEvent_t e0, e1; double bytes; };
