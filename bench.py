@@ -214,11 +214,11 @@ def main():
                           frac=round((b_pre + b_aln) / step_s / 1e9 / HBM_PEAK_GBS, 6),
                           note='B_pre + B_aln of SURVEY 8(d) / whole step incl. host time' + (', all ranks' if world > 1 else '')))
         cpu = None
-        if world == 1 and not args.counto_cpu_baseline and wl['kind'] == 'families':
+        if world == 1 and not args.no_cpu_baseline and wl['kind'] == 'families':
             cpu = cpu_baseline(min(args.cpu_sample_families, n_units), wl['members'], wl['length'], wl['seed'],
                                min(os.cpu_count() or 1, 256), args.k, min_kmers, args.min_ident)
         e2e = None
-        if world == 1 and not args.counto_cli_wall:
+        if world == 1 and not args.no_cli_wall:
             try:
                 e2e = cli_wall(codes, offsets, names, n_pairs)
             except Exception as exc:      # the device-resident figure stands on its own

@@ -634,6 +634,344 @@ k_spgemm_dense(const uint64_t* __restrict__ rowinfo, const uint32_t* __restrict_
     }
 }
 
+// ------------------------------------------------------------------ K1b + K2a, bucket pipeline
+// The inverted index without a general radix sort (this replaces rocprim::radix_sort_pairs + k_group_runs on
+// the hot path).  Keys are scrambled, so their top bits are uniform: one or two MSD partition levels
+// (<= 2^11 and <= 2^10 ways) cut the k-mers into buckets of ~2 000 that are sorted inside the LDS, where the
+// runs of equal k-mers are found and (genome list, row descriptors) written exactly as k_group_runs does.
+//   level 1   k_part_count<SRC>    per super-tile histogram of the top B1 key bits -> table T1[b][st]
+//             exclusive scan of T1 (bucket-major = output order: the scanned entries ARE the write offsets)
+//             k_part_scatter<SRC>  k-mers computed a second time straight from the packed bases (no key array,
+//                                  no iota), tiles of 8 192 sorted by bucket in the LDS, written out as
+//                                  contiguous segments (write combining) in three u32 planes: w0 = top 32
+//                                  key bits, w1 = the rest, pay = base position
+//   level 2   the same on the level-1 planes in chunks, joint digit (b1, b2); only w0 is read for counting
+//   buckets   k_bucket_runs        LDS sort by (w0, w1, pay), runs, duplicates, gen[] and row descriptors
+// No global atomics, deterministic output.  A bucket that does not fit the LDS (a k-mer present thousands of
+// times) or an input too small / too skewed for the chunking sends the call to the general path.
+constexpr int PT_THREADS = 1024;
+constexpr int PT_TILE = 8192;            // elements staged per trip: 96 KiB of LDS + bins
+constexpr int PT_PER = PT_TILE / PT_THREADS;
+constexpr int PT_MAXBINS = 4096;         // 2^11 ways at level 1; two level-1 buckets x 2^11 ways at level 2
+constexpr int BK_CAP = 1536;             // largest bucket the LDS sort takes (22 KiB of LDS: seven workgroups per CU)
+constexpr int BK_THREADS = 256;
+
+struct part_src {                        // where the elements of a partition level come from
+    kmer_args A;                         // level 1, dense: padded base positions (k-mers computed on the fly)
+    const uint64_t* keys; const uint32_t* pos;      // level 1, compact: kept k-mers and their row numbers
+    const uint32_t* w0; const uint32_t* w1; const uint32_t* pay;   // level 2: the level-1 planes
+    int64_t n;                           // number of source slots (positions or elements)
+    int k2;                              // key bits = 2k
+};
+enum { SRC_DENSE = 0, SRC_ARRAYS = 1, SRC_PLANES = 2 };
+
+__device__ __forceinline__ void key_words(uint64_t key, int k2, uint32_t* w0, uint32_t* w1) {
+    // (w0 : w1) = the key, top aligned in 64 bits
+    const uint64_t t = key << (64 - k2);
+    *w0 = (uint32_t)(t >> 32); *w1 = (uint32_t)t;
+}
+
+// exclusive prefix sum over the 1 024 threads of a workgroup (scratch: 16 words of LDS)
+__device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t* s_wave, uint32_t* total) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if (lane >= o) x += y; }
+    if (lane == 63) s_wave[wv] = x;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const uint32_t s = s_wave[i]; if (i < wv) base += s; tot += s; }
+    __syncthreads();
+    if (total) *total = tot;
+    return base + x - v;
+}
+
+// the PT_PER elements of thread t in a tile starting at source slot t0: slot = t0 + j * 1024 + t (planes,
+// arrays) or the four consecutive positions 4 * (...) (dense: one sequence window serves four k-mers)
+template <int SRC>
+__device__ __forceinline__ void load_tile(const part_src& S, int64_t t0, int64_t t_end, uint32_t w0[PT_PER], uint32_t w1[PT_PER],
+                                          uint32_t pay[PT_PER], bool ok[PT_PER], uint32_t* genome4 /* dense: genome of each group of 4 */) {
+    if (SRC == SRC_DENSE) {
+#pragma unroll
+        for (int q = 0; q < PT_PER / 4; ++q) {
+            const int64_t p0 = t0 + ((int64_t)q * PT_THREADS + threadIdx.x) * 4;
+            uint64_t kk[4] = {SENT, SENT, SENT, SENT}; uint32_t g = 0;
+            if (p0 < t_end) kmers4(S.A, p0, kk, &g);
+            genome4[q] = g;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ok[4 * q + j] = kk[j] != SENT;
+                key_words(kk[j], S.k2, &w0[4 * q + j], &w1[4 * q + j]);
+                pay[4 * q + j] = (uint32_t)(p0 + j);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < PT_PER; ++j) {
+            const int64_t i = t0 + (int64_t)j * PT_THREADS + threadIdx.x;
+            ok[j] = i < t_end;
+            w0[j] = 0; w1[j] = 0; pay[j] = 0;
+            if (ok[j]) {
+                if (SRC == SRC_ARRAYS) { key_words(S.keys[i], S.k2, &w0[j], &w1[j]); pay[j] = S.pos[i]; }
+                else { w0[j] = S.w0[i]; w1[j] = S.w1[i]; pay[j] = S.pay[i]; }
+            }
+        }
+    }
+}
+
+// level-1 histogram: one super-tile (st_tiles tiles) per trip; T[b * n_st + st] = elements of bucket b.
+// The dense source also counts the kept k-mers per genome (set sizes) on the way.
+template <int SRC>
+__global__ void __launch_bounds__(PT_THREADS)
+k_part_count(part_src S, int B1, int st_tiles, int64_t n_st, uint32_t* __restrict__ T, int* __restrict__ kept_per_genome) {
+    __shared__ uint32_t hist[PT_MAXBINS];
+    const int nb = 1 << B1;
+    const int lane = threadIdx.x & 63;
+    for (int64_t st = blockIdx.x; st < n_st; st += gridDim.x) {
+        for (int b = threadIdx.x; b < nb; b += PT_THREADS) hist[b] = 0;
+        __syncthreads();
+        const int64_t s0 = st * st_tiles * PT_TILE, s1 = min(S.n, s0 + (int64_t)st_tiles * PT_TILE);
+        for (int64_t t0 = s0; t0 < s1; t0 += PT_TILE) {
+            uint32_t w0[PT_PER], w1[PT_PER], pay[PT_PER], g4[PT_PER / 4 + 1]; bool ok[PT_PER];
+            load_tile<SRC>(S, t0, s1, w0, w1, pay, ok, g4);
+#pragma unroll
+            for (int j = 0; j < PT_PER; ++j) if (ok[j]) atomicAdd(&hist[B1 ? (w0[j] >> (32 - B1)) : 0u], 1u);
+            if (SRC == SRC_DENSE && kept_per_genome) {
+#pragma unroll
+                for (int q = 0; q < PT_PER / 4; ++q) {
+                    const int mine = (int)ok[4 * q] + (int)ok[4 * q + 1] + (int)ok[4 * q + 2] + (int)ok[4 * q + 3];
+                    const uint32_t g = g4[q]; const uint32_t g0 = __shfl(g, 0);
+                    if (__all(g == g0)) {
+                        int tot = mine;
+                        for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+                        if (lane == 0 && tot) atomicAdd(&kept_per_genome[g0], tot);
+                    } else if (mine) atomicAdd(&kept_per_genome[g], mine);
+                }
+            }
+        }
+        __syncthreads();
+        for (int b = threadIdx.x; b < nb; b += PT_THREADS) T[(int64_t)b * n_st + st] = hist[b];
+        __syncthreads();
+    }
+}
+
+// level-2 histogram over the level-1 planes in chunks of ch_tiles tiles: joint digit (b1, b2); a chunk touches
+// at most two level-1 buckets (the host chooses the chunk size accordingly; *bad is set otherwise).
+// table entry of (b1, b2, chunk c): tb[b1] + b2 * nch[b1] + (c - cfirst[b1])
+__global__ void __launch_bounds__(PT_THREADS)
+k_part_count2(part_src S, int B1, int B2, int ch_tiles, int64_t n_ch, const uint32_t* __restrict__ cfirst, const uint32_t* __restrict__ nch,
+              const uint64_t* __restrict__ tb, uint32_t* __restrict__ T, unsigned int* __restrict__ bad) {
+    __shared__ uint32_t hist[PT_MAXBINS];
+    const int nb2 = 1 << B2;
+    for (int64_t c = blockIdx.x; c < n_ch; c += gridDim.x) {
+        for (int b = threadIdx.x; b < 2 * nb2; b += PT_THREADS) hist[b] = 0;
+        __syncthreads();
+        const int64_t s0 = c * ch_tiles * PT_TILE, s1 = min(S.n, s0 + (int64_t)ch_tiles * PT_TILE);
+        const uint32_t bfirst = S.w0[s0] >> (32 - B1);
+        for (int64_t i = s0 + threadIdx.x; i < s1; i += PT_THREADS) {
+            const uint32_t w = S.w0[i];
+            const uint32_t d = (w >> (32 - B1 - B2)) - (bfirst << B2);
+            if (d < (uint32_t)(2 * nb2)) atomicAdd(&hist[d], 1u); else atomicOr(bad, 1u);
+        }
+        __syncthreads();
+        for (int d = threadIdx.x; d < 2 * nb2; d += PT_THREADS) {
+            const uint32_t v = hist[d];
+            if (!v) continue;
+            const uint32_t b1 = bfirst + (uint32_t)(d >> B2), b2 = (uint32_t)(d & (nb2 - 1));
+            T[tb[b1] + (uint64_t)b2 * nch[b1] + (uint64_t)(c - cfirst[b1])] = v;
+        }
+        __syncthreads();
+    }
+}
+
+// scatter of one level: tiles are sorted by bin in the LDS and leave as contiguous segments.
+// LEVEL 1: bins = level-1 buckets, write offsets Ts[b * n_st + st].  LEVEL 2: bins = (b1 - bfirst, b2).
+template <int SRC, int LEVEL>
+__global__ void __launch_bounds__(PT_THREADS)
+k_part_scatter(part_src S, int B1, int B2, int unit_tiles, int64_t n_units, const uint32_t* __restrict__ Ts,
+               const uint32_t* __restrict__ cfirst, const uint32_t* __restrict__ nch, const uint64_t* __restrict__ tb,
+               uint32_t* __restrict__ o_w0, uint32_t* __restrict__ o_w1, uint32_t* __restrict__ o_pay, int narrow_shift) {
+    __shared__ uint32_t s_w0[PT_TILE], s_w1[PT_TILE], s_pay[PT_TILE];
+    __shared__ uint32_t thist[PT_MAXBINS], tstart[PT_MAXBINS], cursor[PT_MAXBINS];
+    __shared__ uint32_t s_wave[16];
+    const int nbins = LEVEL == 1 ? (1 << B1) : (2 << B2);
+    for (int64_t u = blockIdx.x; u < n_units; u += gridDim.x) {
+        const int64_t s0 = u * unit_tiles * PT_TILE, s1 = min(S.n, s0 + (int64_t)unit_tiles * PT_TILE);
+        uint32_t bfirst = 0;
+        if (LEVEL == 2) bfirst = S.w0[s0] >> (32 - B1);
+        __syncthreads();
+        for (int b = threadIdx.x; b < nbins; b += PT_THREADS) {
+            uint32_t off = 0;
+            if (LEVEL == 1) off = Ts[(int64_t)b * n_units + u];
+            else {
+                const uint32_t b1 = bfirst + (uint32_t)(b >> B2), b2 = (uint32_t)(b & ((1 << B2) - 1));
+                if (b1 < (1u << B1) && nch[b1] && (uint64_t)u >= cfirst[b1] && (uint64_t)u < (uint64_t)cfirst[b1] + nch[b1])
+                    off = Ts[tb[b1] + (uint64_t)b2 * nch[b1] + ((uint64_t)u - cfirst[b1])];
+            }
+            cursor[b] = off;
+        }
+        for (int64_t t0 = s0; t0 < s1; t0 += PT_TILE) {
+            for (int b = threadIdx.x; b < nbins; b += PT_THREADS) thist[b] = 0;
+            __syncthreads();
+            uint32_t w0[PT_PER], w1[PT_PER], pay[PT_PER], g4[PT_PER / 4 + 1], bin[PT_PER], rk[PT_PER]; bool ok[PT_PER];
+            load_tile<SRC>(S, t0, s1, w0, w1, pay, ok, g4);
+#pragma unroll
+            for (int j = 0; j < PT_PER; ++j) {
+                bin[j] = 0; rk[j] = 0;
+                if (ok[j]) {
+                    bin[j] = LEVEL == 1 ? (B1 ? (w0[j] >> (32 - B1)) : 0u) : ((w0[j] >> (32 - B1 - B2)) - (bfirst << B2));
+                    rk[j] = atomicAdd(&thist[bin[j]], 1u);
+                }
+            }
+            __syncthreads();
+            // exclusive scan of the tile histogram (nbins <= 4 096: four bins per thread)
+            {
+                constexpr int BPT = PT_MAXBINS / PT_THREADS;
+                uint32_t c[BPT], tot = 0;
+#pragma unroll
+                for (int u = 0; u < BPT; ++u) { const int b = BPT * (int)threadIdx.x + u; c[u] = b < nbins ? thist[b] : 0u; tot += c[u]; }
+                uint32_t run = block_scan_1024(tot, s_wave, nullptr);
+#pragma unroll
+                for (int u = 0; u < BPT; ++u) { const int b = BPT * (int)threadIdx.x + u; if (b < nbins) tstart[b] = run; run += c[u]; }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < PT_PER; ++j) if (ok[j]) {
+                const uint32_t slot = tstart[bin[j]] + rk[j];
+                s_w0[slot] = w0[j]; s_w1[slot] = w1[j]; s_pay[slot] = pay[j];
+            }
+            __syncthreads();
+            const uint32_t n_tile = tstart[nbins - 1] + thist[nbins - 1];
+            for (uint32_t slot = threadIdx.x; slot < n_tile; slot += PT_THREADS) {
+                const uint32_t w = s_w0[slot];
+                const uint32_t b = LEVEL == 1 ? (B1 ? (w >> (32 - B1)) : 0u) : ((w >> (32 - B1 - B2)) - (bfirst << B2));
+                const uint32_t dst = cursor[b] + (slot - tstart[b]);
+                if (narrow_shift >= 0) {
+                    // the bucket fixes the top narrow_shift key bits and at most 32 remain: one word carries them
+                    o_w0[dst] = (uint32_t)(((((uint64_t)w << 32) | s_w1[slot]) << narrow_shift) >> 32);
+                } else { o_w0[dst] = w; o_w1[dst] = s_w1[slot]; }
+                o_pay[dst] = s_pay[slot];
+            }
+            __syncthreads();
+            for (int b = threadIdx.x; b < nbins; b += PT_THREADS) cursor[b] += thist[b];
+            __syncthreads();
+        }
+    }
+}
+
+// start offset of every final bucket (nbk + 1 entries) from the scanned tables
+__global__ void k_bucket_offsets(int levels, int B1, int B2, int64_t n_st, const uint32_t* __restrict__ T1s, const uint32_t* __restrict__ off1,
+                                 const uint32_t* __restrict__ nch, const uint64_t* __restrict__ tb, const uint32_t* __restrict__ T2s,
+                                 uint32_t n_total, uint32_t* __restrict__ boff) {
+    const int64_t nbk = levels == 1 ? (1LL << B1) : (1LL << (B1 + B2));
+    for (int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; d <= nbk; d += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t v;
+        if (d == nbk) v = n_total;
+        else if (levels == 1) v = T1s[d * n_st];
+        else {
+            const uint32_t b1 = (uint32_t)(d >> B2), b2 = (uint32_t)(d & ((1 << B2) - 1));
+            v = nch[b1] ? T2s[tb[b1] + (uint64_t)b2 * nch[b1]] : off1[b1];
+        }
+        boff[d] = v;
+    }
+}
+
+// One workgroup per bucket.  The bucket's keys agree on their top `pbits` bits and are uniform below them, so a
+// counting sort on the NEXT 10 bits (LDS histogram, scan, scatter from registers) leaves sub-bins that hold one
+// or two runs of equal k-mers, contiguous in the LDS; every entry then ranks itself inside its sub-bin by
+// comparing with the few members.  From the same loop it learns its run: start in the fully sorted list,
+// length, its place in position order, and the entry in front of it (duplicate test).  Output exactly as
+// k_group_runs: gen[] at the final place, one row descriptor scattered; the sorted keys are never written.
+constexpr int BK_SUBBITS = 9;
+constexpr int BK_SUB = 1 << BK_SUBBITS;
+constexpr int BK_PER = BK_CAP / BK_THREADS;
+constexpr int BK_MAXBIN = 768;           // a sub-bin beyond this (one k-mer occurring hundreds of times) takes the general path
+__global__ void __launch_bounds__(BK_THREADS)
+k_bucket_runs(const uint32_t* __restrict__ w0, const uint32_t* __restrict__ w1, const uint32_t* __restrict__ pay,
+              const uint32_t* __restrict__ boff, int64_t n_buckets, int pbits, const uint32_t* __restrict__ blk2g, int blk_shift,
+              uint32_t* __restrict__ gen, uint64_t* __restrict__ rowinfo, compact_map M, int* __restrict__ dup_per_genome,
+              unsigned int* __restrict__ overflow) {
+    __shared__ uint64_t sk[BK_CAP];          // (w0 << 32) | w1, in sub-bin order
+    __shared__ uint32_t sp[BK_CAP];
+    __shared__ uint32_t cnt[BK_SUB + 1], start[BK_SUB + 1];
+    __shared__ uint32_t s_wave[BK_THREADS / 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int64_t bk = blockIdx.x; bk < n_buckets; bk += gridDim.x) {
+        const uint32_t b0 = boff[bk], b1 = boff[bk + 1];
+        const int n = (int)(b1 - b0);
+        if (n <= 1) continue;                                  // empty, or one singleton k-mer
+        if (n > BK_CAP) { if (threadIdx.x == 0) atomicOr(overflow, 1u); continue; }
+        __syncthreads();
+        for (int b = threadIdx.x; b <= BK_SUB; b += BK_THREADS) cnt[b] = 0;
+        __syncthreads();
+        uint64_t key[BK_PER]; uint32_t pj[BK_PER]; uint32_t sb[BK_PER], ar[BK_PER];
+#pragma unroll
+        for (int q = 0; q < BK_PER; ++q) {
+            const int j = q * BK_THREADS + threadIdx.x;
+            sb[q] = 0; ar[q] = 0; key[q] = 0; pj[q] = 0;
+            if (j < n) {
+                const uint32_t a = w0[b0 + j], c = w1 ? w1[b0 + j] : 0u;      // w1 == nullptr: w0 holds the bits below the bucket's
+                key[q] = ((uint64_t)a << 32) | c; pj[q] = pay[b0 + j];
+                sb[q] = (uint32_t)((key[q] << pbits) >> (64 - BK_SUBBITS));
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < BK_PER; ++q) if (q * BK_THREADS + (int)threadIdx.x < n) ar[q] = atomicAdd(&cnt[sb[q]], 1u);
+        __syncthreads();
+        {   // exclusive scan of the sub-bin counters: BK_SUB / BK_THREADS per thread
+            constexpr int CPT = BK_SUB / BK_THREADS;
+            uint32_t c4[CPT], tot = 0;
+#pragma unroll
+            for (int u = 0; u < CPT; ++u) { c4[u] = cnt[CPT * threadIdx.x + u]; tot += c4[u]; }
+            uint32_t x = tot;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if (lane >= o) x += y; }
+            if (lane == 63) s_wave[wv] = x;
+            __syncthreads();
+            uint32_t base = 0;
+            for (int i = 0; i < wv; ++i) base += s_wave[i];
+            uint32_t run = base + x - tot;
+#pragma unroll
+            for (int u = 0; u < CPT; ++u) { start[CPT * threadIdx.x + u] = run; run += c4[u]; }
+            if (threadIdx.x == BK_THREADS - 1) start[BK_SUB] = run;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < BK_PER; ++q) if (q * BK_THREADS + (int)threadIdx.x < n) {
+            const uint32_t slot = start[sb[q]] + ar[q];
+            sk[slot] = key[q]; sp[slot] = pj[q];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < BK_PER; ++q) {
+            if (q * BK_THREADS + (int)threadIdx.x >= n) continue;
+            const uint32_t s0 = start[sb[q]], s1 = start[sb[q] + 1];
+            if (s1 - s0 < 2) continue;                           // alone in its sub-bin: a singleton k-mer
+            if (s1 - s0 > BK_MAXBIN) { atomicOr(overflow, 1u); continue; }
+            const uint64_t kq = key[q]; const uint32_t pq = pj[q];
+            uint32_t lt = 0, eq = 0, before = 0; uint32_t prev_pay = 0; bool has_prev = false;
+            for (uint32_t t = s0; t < s1; ++t) {
+                const uint64_t kt = sk[t];
+                lt += kt < kq;
+                if (kt == kq) {
+                    ++eq;
+                    const uint32_t pt = sp[t];
+                    if (pt < pq) { ++before; if (!has_prev || pt > prev_pay) { prev_pay = pt; has_prev = true; } }
+                }
+            }
+            if (eq < 2) continue;                                // singleton k-mer: no partner, nobody reads its gen[] slot
+            const uint32_t g = M.cblk ? genome_of_compact(M, pq) : blk2g[pq >> blk_shift];
+            const bool dup = has_prev && (M.cblk ? genome_of_compact(M, prev_pay) : blk2g[prev_pay >> blk_shift]) == g;
+            const uint32_t rs = b0 + s0 + lt;                    // first entry of this k-mer's run in the sorted list
+            gen[rs + before] = g | (dup ? DUP_BIT : 0u);
+            if (dup) { atomicAdd(&dup_per_genome[g], 1); continue; }
+            if (before == 0) continue;                           // the run's smallest genome: no partner b < a
+            rowinfo[pq] = ((uint64_t)rs << RUNLEN_BITS) | eq;
+        }
+    }
+}
+
 inline int grid_for(int64_t n, int block = 256, int max_blocks = 256 * 16) {
     int64_t b = (n + block - 1) / block;
     if (b < 1) b = 1;
@@ -674,7 +1012,7 @@ static void finish_sort(sorted_index& si, int k) {
     si.low_bit = 0;
 }
 
-static void run_extract_sort(vg_genomes* g, int k, double fraction, int shard, int n_shards, sorted_index& out, bool finish = true) {
+static void run_extract_sort(vg_genomes* g, int k, double fraction, int shard, int n_shards, sorted_index& out, bool finish = true, bool do_sort = true) {
     hipStream_t s = vg_stream();
     const int64_t P = g->padded_total();
     out.kept.alloc((size_t)std::max(1, g->n)); out.kept.zero(s);
@@ -746,6 +1084,12 @@ static void run_extract_sort(vg_genomes* g, int k, double fraction, int shard, i
     unsigned int sort_bits = n_sort <= (5LL << 23) ? 24u : (n_sort <= (5LL << 31) ? 32u : 40u);
     if (sort_bits > end_bit) sort_bits = end_bit;
     const unsigned int begin_bit = end_bit - sort_bits;
+    if (!do_sort) {
+        // the bucket pipeline takes the kept k-mers as they are (compact mode only: every entry is a real k-mer)
+        VG_HIP(hipStreamSynchronize(s));
+        out.keys = std::move(keys_a); out.pos = std::move(pos_a); out.n_valid = (int64_t)nv; out.low_bit = (int)end_bit;
+        return;
+    }
     if (n_sort > 0) {
         size_t tmp_bytes = 0;
         VG_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_a.p, keys_b.p, pos_a.p, pos_b.p, (size_t)n_sort, begin_bit, end_bit, s));
@@ -760,25 +1104,173 @@ static void run_extract_sort(vg_genomes* g, int k, double fraction, int shard, i
     if (finish) finish_sort(out, k);
 }
 
+
+// ---- the bucket pipeline (see the kernels above).  Source: the packed bases themselves (dense) or the kept
+// k-mers of a shard / fraction (keys, row numbers).  Fills gen[] and rowinfo[] like k_group_runs; false = the
+// input does not suit it (tiny, skewed, a bucket beyond the LDS): the caller takes the general path.
+static int g_index_path = -1;      // -1 = not read yet; 0 = radix (rocPRIM) path forced; 1 = buckets
+static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_args& A, const uint64_t* keys, const uint32_t* pos, int64_t n_src,
+                                const compact_map& cmap, int* d_kept, dbuf<uint32_t>& gen, dbuf<uint64_t>& rowinfo, int64_t n_rows_info,
+                                int* d_dups, int64_t* n_valid_out) {
+    hipStream_t s = vg_stream();
+    if (g_index_path < 0) { const char* e = getenv("VG_INDEX_PATH"); g_index_path = (e && !strcmp(e, "radix")) ? 0 : 1; }
+    if (!g_index_path || n_src < (1 << 16) || n_src >= (1LL << 32)) return false;
+    int total_bits = 0; while ((n_src >> total_bits) > 1024 && total_bits < 22) ++total_bits;
+    if ((n_src >> total_bits) > 1024) return false;
+    const int levels = total_bits > 11 ? 2 : 1;
+    const int B2 = levels == 2 ? std::min(11, total_bits / 2) : 0;
+    const int B1 = total_bits - B2;
+    const int nb1 = 1 << B1, nb2 = 1 << B2;
+    const bool narrow = levels == 2 && 2 * k - total_bits <= 32;      // level-2 output: one key word instead of two
+    part_src S; memset(&S, 0, sizeof S);
+    S.A = A; S.keys = keys; S.pos = pos; S.n = n_src; S.k2 = 2 * k;
+    int st_tiles = (int)std::max<int64_t>(1, std::min<int64_t>(8, n_src / ((int64_t)PT_TILE * 2048)));
+    const int64_t n_st = (n_src + (int64_t)st_tiles * PT_TILE - 1) / ((int64_t)st_tiles * PT_TILE);
+    const size_t t1n = (size_t)nb1 * (size_t)n_st;
+    dbuf<uint32_t> T1(t1n + 1), T1s(t1n + 1);
+    dbuf<uint32_t> a_w0, a_w1, a_pay, b_w0, b_w1, b_pay;
+    uint32_t n1 = 0;
+    {
+        vg_prof_scope ps("kmer_partition", (double)n_src * (dense ? 2 * 3.0 / 8.0 : 8.0 + 12.0) + (double)n_src * 12.0);
+        VG_HIP(hipMemsetAsync(T1.p + t1n, 0, sizeof(uint32_t), s));
+        const int grid_c = (int)std::min<int64_t>(n_st, 512);
+        if (dense) hipLaunchKernelGGL(k_part_count<SRC_DENSE>, dim3(grid_c), dim3(PT_THREADS), 0, s, S, B1, st_tiles, n_st, T1.p, d_kept);
+        else hipLaunchKernelGGL(k_part_count<SRC_ARRAYS>, dim3(grid_c), dim3(PT_THREADS), 0, s, S, B1, st_tiles, n_st, T1.p, (int*)nullptr);
+        size_t tb = 0;
+        VG_HIP(rocprim::exclusive_scan(nullptr, tb, T1.p, T1s.p, 0u, t1n + 1, rocprim::plus<uint32_t>(), s));
+        dbuf<char> tmp(tb);
+        VG_HIP(rocprim::exclusive_scan((void*)tmp.p, tb, T1.p, T1s.p, 0u, t1n + 1, rocprim::plus<uint32_t>(), s));
+        VG_HIP(hipMemcpyAsync(&n1, T1s.p + t1n, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        VG_HIP(hipStreamSynchronize(s));
+        *n_valid_out = (int64_t)n1;
+        if (n1 == 0) return true;
+        a_w0.alloc((size_t)n1 + 8); a_w1.alloc((size_t)n1 + 8); a_pay.alloc((size_t)n1 + 8);
+        const int grid_s = (int)std::min<int64_t>(n_st, 256);
+        if (dense) hipLaunchKernelGGL((k_part_scatter<SRC_DENSE, 1>), dim3(grid_s), dim3(PT_THREADS), 0, s, S, B1, 0, st_tiles, n_st, (const uint32_t*)T1s.p,
+                                      (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint64_t*)nullptr, a_w0.p, a_w1.p, a_pay.p, -1);
+        else hipLaunchKernelGGL((k_part_scatter<SRC_ARRAYS, 1>), dim3(grid_s), dim3(PT_THREADS), 0, s, S, B1, 0, st_tiles, n_st, (const uint32_t*)T1s.p,
+                                (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint64_t*)nullptr, a_w0.p, a_w1.p, a_pay.p, -1);
+    }
+    const int64_t nbk = levels == 1 ? nb1 : (int64_t)nb1 * nb2;
+    dbuf<uint32_t> boff((size_t)nbk + 1);
+    const uint32_t* f_w0 = a_w0.p; const uint32_t* f_w1 = a_w1.p; const uint32_t* f_pay = a_pay.p;
+    if (levels == 1) {
+        hipLaunchKernelGGL(k_bucket_offsets, dim3(grid_for(nbk + 1)), dim3(256), 0, s, 1, B1, 0, n_st, (const uint32_t*)T1s.p, (const uint32_t*)nullptr,
+                           (const uint32_t*)nullptr, (const uint64_t*)nullptr, (const uint32_t*)nullptr, n1, boff.p);
+    } else {
+        // level-1 bucket bounds -> chunking of level 2
+        std::vector<uint32_t> off1((size_t)nb1 + 1);
+        VG_HIP(hipMemcpy2DAsync(off1.data(), sizeof(uint32_t), T1s.p, (size_t)n_st * sizeof(uint32_t), sizeof(uint32_t), (size_t)nb1, hipMemcpyDeviceToHost, s));
+        VG_HIP(hipStreamSynchronize(s));
+        off1[(size_t)nb1] = n1;
+        uint32_t min_bucket = 0xffffffffu;
+        for (int b = 0; b < nb1; ++b) min_bucket = std::min(min_bucket, off1[(size_t)b + 1] - off1[(size_t)b]);
+        const int ch_tiles = (int)std::min<uint32_t>(8, min_bucket / PT_TILE);
+        if (ch_tiles < 1) return false;                       // a chunk could touch more than two level-1 buckets
+        const int64_t ST2 = (int64_t)ch_tiles * PT_TILE;
+        const int64_t n_ch = ((int64_t)n1 + ST2 - 1) / ST2;
+        std::vector<uint32_t> cfirst((size_t)nb1), nch((size_t)nb1); std::vector<uint64_t> tbv((size_t)nb1 + 1);
+        uint64_t tot = 0;
+        for (int b = 0; b < nb1; ++b) {
+            cfirst[(size_t)b] = (uint32_t)(off1[(size_t)b] / ST2);
+            nch[(size_t)b] = (uint32_t)((off1[(size_t)b + 1] - 1) / ST2 - cfirst[(size_t)b] + 1);
+            tbv[(size_t)b] = tot; tot += (uint64_t)nch[(size_t)b] * nb2;
+        }
+        tbv[(size_t)nb1] = tot;
+        if (tot >= (1ULL << 31)) return false;
+        dbuf<uint32_t> d_off1((size_t)nb1 + 1), d_cfirst((size_t)nb1), d_nch((size_t)nb1); dbuf<uint64_t> d_tb((size_t)nb1 + 1);
+        d_off1.upload(off1.data(), off1.size(), s); d_cfirst.upload(cfirst.data(), cfirst.size(), s); d_nch.upload(nch.data(), nch.size(), s);
+        d_tb.upload(tbv.data(), tbv.size(), s);
+        dbuf<uint32_t> T2((size_t)tot + 1), T2s((size_t)tot + 1); dbuf<unsigned int> d_bad(1);
+        T2.zero(s); d_bad.zero(s);
+        part_src S2; memset(&S2, 0, sizeof S2);
+        S2.w0 = a_w0.p; S2.w1 = a_w1.p; S2.pay = a_pay.p; S2.n = (int64_t)n1; S2.k2 = 2 * k;
+        unsigned int bad = 0;
+        {
+            vg_prof_scope ps("kmer_partition2", (double)n1 * (4.0 + 12.0 + (narrow ? 8.0 : 12.0)));
+            hipLaunchKernelGGL(k_part_count2, dim3((int)std::min<int64_t>(n_ch, 512)), dim3(PT_THREADS), 0, s, S2, B1, B2, ch_tiles, n_ch,
+                               (const uint32_t*)d_cfirst.p, (const uint32_t*)d_nch.p, (const uint64_t*)d_tb.p, T2.p, d_bad.p);
+            size_t tb2 = 0;
+            VG_HIP(rocprim::exclusive_scan(nullptr, tb2, T2.p, T2s.p, 0u, (size_t)tot + 1, rocprim::plus<uint32_t>(), s));
+            dbuf<char> tmp2(tb2);
+            VG_HIP(rocprim::exclusive_scan((void*)tmp2.p, tb2, T2.p, T2s.p, 0u, (size_t)tot + 1, rocprim::plus<uint32_t>(), s));
+            d_bad.download(&bad, 1, s);
+            b_w0.alloc((size_t)n1 + 8); if (!narrow) b_w1.alloc((size_t)n1 + 8); b_pay.alloc((size_t)n1 + 8);
+            VG_HIP(hipStreamSynchronize(s));
+            if (bad) return false;
+            hipLaunchKernelGGL((k_part_scatter<SRC_PLANES, 2>), dim3((int)std::min<int64_t>(n_ch, 256)), dim3(PT_THREADS), 0, s, S2, B1, B2, ch_tiles, n_ch,
+                               (const uint32_t*)T2s.p, (const uint32_t*)d_cfirst.p, (const uint32_t*)d_nch.p, (const uint64_t*)d_tb.p, b_w0.p, b_w1.p, b_pay.p,
+                               narrow ? total_bits : -1);
+        }
+        hipLaunchKernelGGL(k_bucket_offsets, dim3(grid_for(nbk + 1)), dim3(256), 0, s, 2, B1, B2, n_st, (const uint32_t*)T1s.p, (const uint32_t*)d_off1.p,
+                           (const uint32_t*)d_nch.p, (const uint64_t*)d_tb.p, (const uint32_t*)T2s.p, n1, boff.p);
+        VG_HIP(hipStreamSynchronize(s));                       // the tables and level-1 planes go out of scope below
+        f_w0 = b_w0.p; f_w1 = narrow ? nullptr : b_w1.p; f_pay = b_pay.p;
+        a_w0.release(); a_w1.release(); a_pay.release();
+    }
+    if (gen.n < (size_t)n1 + 4) gen.alloc((size_t)n1 + 4);
+    if (rowinfo.n < (size_t)n_rows_info) rowinfo.alloc((size_t)n_rows_info);
+    VG_HIP(hipMemsetAsync(rowinfo.p, 0, (size_t)n_rows_info * sizeof(uint64_t), s));
+    dbuf<unsigned int> d_over(1); d_over.zero(s);
+    unsigned int over = 0;
+    {
+        vg_prof_scope ps("bucket_sort_runs", (double)n1 * ((narrow ? 8 : 12) + 4 + 8));
+        hipLaunchKernelGGL(k_bucket_runs, dim3((int)std::min<int64_t>(nbk, 256 * 16)), dim3(BK_THREADS), 0, s, f_w0, f_w1, f_pay, (const uint32_t*)boff.p, nbk,
+                           narrow ? 0 : total_bits, (const uint32_t*)g->d_blk2g.p, g->align_shift, gen.p, rowinfo.p, cmap, d_dups, d_over.p);
+    }
+    d_over.download(&over, 1, s);
+    VG_HIP(hipStreamSynchronize(s));
+    return over == 0;
+}
+
 // one pass over the k-mers of one shard: per-genome set sizes and (a, b, shared) of every pair
 static void kmer_shared_pass(vg_genomes* g, int k, double fraction, int shard, int n_shards, uint32_t min_shared,
                              int64_t* set_sizes, std::vector<vg_pair_count>& host_pairs) {
     hipStream_t s = vg_stream();
     const int n = g->n;
     sorted_index si;
-    run_extract_sort(g, k, fraction, shard, n_shards, si, false);
-    const int64_t nv = si.n_valid;
     const int64_t P = g->padded_total();
-    const int64_t n_rows_info = si.compact ? std::max<int64_t>(nv, 1) : P;      // row descriptors: per kept k-mer or per base
-    // row descriptors and genome list live in the sort's input buffers (32 + 16 GB less at 100 k genomes)
-    dbuf<uint64_t> rowinfo = si.spare64.n >= (size_t)n_rows_info ? std::move(si.spare64) : dbuf<uint64_t>((size_t)n_rows_info);
-    VG_HIP(hipMemsetAsync(rowinfo.p, 0, (size_t)n_rows_info * sizeof(uint64_t), s));
-    const compact_map cmap{ si.compact ? si.goff.p : nullptr, si.compact ? si.cblk.p : nullptr };
-    const uint32_t* wbase = si.compact ? si.wave_base.p : nullptr;
-    dbuf<uint32_t> gen = si.spare32.n >= (size_t)std::max<int64_t>(nv, 1) + 4 ? std::move(si.spare32) : dbuf<uint32_t>((size_t)std::max<int64_t>(nv, 1) + 4);
+    const bool dense_src = !(fraction < 1.0) && n_shards == 1;
+    int64_t nv = 0, n_rows_info = 0;
+    dbuf<uint64_t> rowinfo; dbuf<uint32_t> gen;
     dbuf<int> d_dups((size_t)n); d_dups.zero(s);
     constexpr unsigned int BIG_CAP = 4096;
     dbuf<uint64_t> big_runs(2 * BIG_CAP); dbuf<unsigned int> d_nbig(1); d_nbig.zero(s);
+    unsigned int n_big = 0;
+    std::vector<int> kept((size_t)n), dups((size_t)n);
+    // ---- the bucket pipeline first (own MSD partition + LDS sort); the general radix path when it declines
+    bool bucket_ok = false;
+    {
+        dbuf<int> kept_b((size_t)n); kept_b.zero(s);
+        kmer_args A{ g->d_packed.p, g->d_nmask.p, g->d_blk2g.p, g->d_base_off.p, g->d_len.p, P, k, 0, ~0ULL, 0u, 1u, g->align_shift };
+        if (dense_src) {
+            if (P < (1LL << 32)) {
+                n_rows_info = P;
+                const compact_map none{ nullptr, nullptr };
+                bucket_ok = build_index_buckets(g, k, true, A, nullptr, nullptr, P, none, kept_b.p, gen, rowinfo, n_rows_info, d_dups.p, &nv);
+                if (bucket_ok) kept_b.download(kept.data(), (size_t)n, s);
+            }
+        } else {
+            run_extract_sort(g, k, fraction, shard, n_shards, si, false, /*do_sort=*/false);
+            nv = si.n_valid; n_rows_info = std::max<int64_t>(nv, 1);
+            const compact_map cm{ si.goff.p, si.cblk.p };
+            int64_t nv2 = 0;
+            bucket_ok = build_index_buckets(g, k, false, A, si.keys.p, si.pos.p, nv, cm, nullptr, gen, rowinfo, n_rows_info, d_dups.p, &nv2);
+            if (bucket_ok) si.kept.download(kept.data(), (size_t)n, s);
+        }
+        if (bucket_ok) { d_dups.download(dups.data(), (size_t)n, s); VG_HIP(hipStreamSynchronize(s)); }
+    }
+    if (!bucket_ok) {
+    d_dups.zero(s);
+    si = sorted_index();
+    run_extract_sort(g, k, fraction, shard, n_shards, si, false);
+    nv = si.n_valid;
+    n_rows_info = si.compact ? std::max<int64_t>(nv, 1) : P;      // row descriptors: per kept k-mer or per base
+    // row descriptors and genome list live in the sort's input buffers (32 + 16 GB less at 100 k genomes)
+    rowinfo = si.spare64.n >= (size_t)n_rows_info ? std::move(si.spare64) : dbuf<uint64_t>((size_t)n_rows_info);
+    VG_HIP(hipMemsetAsync(rowinfo.p, 0, (size_t)n_rows_info * sizeof(uint64_t), s));
+    const compact_map cmap{ si.compact ? si.goff.p : nullptr, si.compact ? si.cblk.p : nullptr };
+    gen = si.spare32.n >= (size_t)std::max<int64_t>(nv, 1) + 4 ? std::move(si.spare32) : dbuf<uint32_t>((size_t)std::max<int64_t>(nv, 1) + 4);
     constexpr unsigned int LONG_CAP = 1u << 16;
     dbuf<int64_t> long_list(LONG_CAP); dbuf<unsigned int> d_nlong(1), d_full(1); d_nlong.zero(s); d_full.zero(s);
     if (nv > 0) {
@@ -786,8 +1278,7 @@ static void kmer_shared_pass(vg_genomes* g, int k, double fraction, int shard, i
         hipLaunchKernelGGL(k_group_runs, dim3(grid_for(nv, GS_TILE)), dim3(256), 0, s, si.keys.p, si.pos.p, g->d_blk2g.p, g->align_shift, nv,
                            si.low_bit, gen.p, rowinfo.p, cmap, d_dups.p, long_list.p, d_nlong.p, LONG_CAP);
     }
-    unsigned int n_long = 0, need_full = 0, n_big = 0;
-    std::vector<int> kept((size_t)n), dups((size_t)n);
+    unsigned int n_long = 0, need_full = 0;
     d_nlong.download(&n_long, 1, s); si.kept.download(kept.data(), (size_t)n, s); d_dups.download(dups.data(), (size_t)n, s);
     VG_HIP(hipStreamSynchronize(s));
     if (n_long > 0 && n_long <= LONG_CAP) {
@@ -811,6 +1302,9 @@ static void kmer_shared_pass(vg_genomes* g, int k, double fraction, int shard, i
         d_nbig.download(&n_big, 1, s); d_dups.download(dups.data(), (size_t)n, s);
         VG_HIP(hipStreamSynchronize(s));
     }
+    }
+    const bool compact_rows = !dense_src;
+    const uint32_t* wbase = compact_rows ? si.wave_base.p : nullptr;
     if (n_big > BIG_CAP) throw vg_error(VG_EOVERFLOW, "too many k-mers shared by >= 2^24 entries");
     for (int i = 0; i < n; ++i) set_sizes[i] = (int64_t)kept[i] - dups[i];
     si.keys.release();
