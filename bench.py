@@ -11,9 +11,9 @@ value = unordered pairs aligned per second (whole job, all ranks).
 
 Default workload: `phage-100k` of SURVEY.md 8(d) (BASELINE configs[3]: 10 000 families x 10 members x 40 kb,
 seed 3), which fits one MI355X.  N > 1: the SAME set (strong scaling; `--scaling weak` multiplies the families
-by N instead): the prefilter is sharded by k-mer hash range (partial counts all-gathered over RCCL and summed
-on the device), the align tasks are dealt by reference range (each rank indexes 1/N of the genomes), and the
-per-pair integer rows are all-gathered.  Other workloads: --workload phage-1k | imgvr-10k | contigs-1M (+ --count).
+by N instead) through the sharded C-ABI entry points (vg_kmer_shared_sharded / vg_lz_align_sharded): the prefilter
+is sharded by k-mer hash range (partial counts all-gathered over RCCL and summed on the device), the align tasks
+are dealt by reference range (each rank indexes 1/N of the genomes), and the per-pair integer rows are all-gathered.  Other workloads: --workload phage-1k | imgvr-10k | contigs-1M (+ --count).
 """
 import argparse
 import json
@@ -127,6 +127,7 @@ def main():
     else:
         dev = torch.device('cuda', local_rank)
     api.set_device(local_rank % api.device_count())
+    comm = D.make_comm(dist, dev)                   # built-in RCCL communicator of libvclust_gpu (callbacks over gloo in tests)
 
     wl = synth.WORKLOADS[args.workload]
     base_n = args.count if args.count is not None else (wl['n_families'] if wl['kind'] == 'families' else wl['n'])
@@ -147,14 +148,11 @@ def main():
 
     def step():
         # -- prefilter: this rank's k-mer hash range; partial counts add up across ranks (RCCL all-gather)
-        if world > 1:
-            sizes, pairs = D.prefilter_counts(gs, dist, dev, rank, world, args.k, 1.0)
-        else:
-            sizes, pairs = gs.kmer_shared(k=args.k, min_shared=min_kmers)
+        sizes, pairs = D.prefilter_counts(gs, comm, args.k, 1.0, min_shared=min_kmers)
         cand = gs.filter_pairs(sizes, pairs, k=args.k, min_kmers=min_kmers, min_ident=args.min_ident)
         # -- align: canonical task list, reference-range share per rank, rows gathered over RCCL
         tasks = gs.align_tasks(cand)
-        stats, _ = D.align_rows(gs, tasks, dist, dev, rank, world, None, False)
+        stats, _ = D.align_rows(gs, tasks, comm, None, False)
         state.update(n_pairs=len(tasks) // 2, stats=stats, tasks=tasks)
 
     api.profile_enable(False)
@@ -247,6 +245,7 @@ def main():
             'cli_wall': e2e,
         }
         print(json.dumps(out))
+    comm.close()
     if dist:
         dist.destroy_process_group()
 

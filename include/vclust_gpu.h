@@ -47,6 +47,8 @@ int vg_set_device(int device);
 /* the library keeps released device blocks in a cache (no hipMalloc on the hot path); this returns them to
  * the driver, e.g. before another process needs the HBM */
 void vg_release_device_memory(void);
+/* blocking copy between host memory and memory of the current device (for vg_comm callbacks that stage through the host) */
+int vg_copy(void* dst, const void* src, int64_t bytes, int to_host);
 
 /* ------------------------------------------------------------------ genome sets ------- */
 typedef struct vg_genomes vg_genomes;
@@ -157,6 +159,43 @@ int vg_write_ani(const vg_genomes* g, const vg_task* tasks, const vg_pair_stat* 
                  const char* out_path, const vg_align_params* p);
 int vg_align(const char* const* fasta_paths, int n_paths, const char* out_path,
              const vg_align_params* p);
+
+/* ------------------------------------------------------------------ one process per GPU - */
+/* The reference is single-node / thread-parallel (no distributed layer); these entry points
+ * shard the two stages over `world` processes, one GPU each (vg_set_device before the first call).  The only
+ * communication is an all-gather of integer records, supplied as a vg_comm:
+ *   vg_comm_create       the host application's own exchange (MPI_Allgather, torch.distributed, ...): the callback
+ *                        gathers `bytes` bytes from every rank into recv (world * bytes, rank order); on_device != 0
+ *                        means send / recv are device pointers of the current HIP device, else host pointers
+ *   vg_comm_rccl_create  built-in: RCCL (ncclAllGather over xGMI) on the library's stream; rank 0 obtains the
+ *                        128-byte id with vg_rccl_unique_id and hands it to the other ranks by any means
+ * A rank that fails makes every rank return the error (status words are agreed on before each exchange). */
+typedef struct vg_comm vg_comm;
+typedef int (*vg_allgather_fn)(void* ctx, const void* send, void* recv, int64_t bytes, int on_device);
+int  vg_comm_create(int rank, int world, vg_allgather_fn allgather, void* ctx, vg_comm** out);
+int  vg_rccl_unique_id(void* out /* >= 128 bytes */, int64_t bytes);
+int  vg_comm_rccl_create(int rank, int world, const void* unique_id, int64_t id_bytes, vg_comm** out);
+void vg_comm_free(vg_comm* c);
+int  vg_comm_rank(const vg_comm* c);
+int  vg_comm_world(const vg_comm* c);
+/* exchange self-test: every rank sends a pattern of `bytes` bytes and checks what it receives (no GPU needed
+ * for a callback communicator over host memory) */
+int  vg_comm_selftest(const vg_comm* c, int64_t bytes);
+/* vg_kmer_shared over all ranks: rank r counts the k-mers of hash range r; the partial (a, b, count) records
+ * and set sizes are all-gathered and summed on the device; every rank receives the global result
+ * (pairs with >= min_shared shared k-mers; the threshold is applied to the SUM) */
+int vg_kmer_shared_sharded(vg_genomes* g, int k, double fraction, uint32_t min_shared, const vg_comm* c,
+                           int64_t* set_sizes, vg_pair_count** pairs, int64_t* n_pairs);
+/* owner rank of every task: references cut into `world` contiguous id ranges with about equal task counts */
+int vg_align_owner(const vg_task* tasks, int64_t n_tasks, int n_genomes, int world, int32_t* owner /* n_tasks */);
+/* vg_lz_align over all ranks (reference-range partition): every rank receives all rows (and regions) */
+int vg_lz_align_sharded(vg_genomes* g, const vg_task* tasks, int64_t n_tasks, const vg_lz_params* p, const vg_comm* c,
+                        vg_pair_stat* stats, vg_region** regions, int64_t* n_regions);
+/* the two whole stages (vg_prefilter / vg_align) on `world` GPUs: every rank ingests the FASTA, rank 0 writes */
+int vg_prefilter_sharded(const char* const* fasta_paths, int n_paths, const char* out_path,
+                         const vg_prefilter_params* p, const vg_comm* c);
+int vg_align_sharded(const char* const* fasta_paths, int n_paths, const char* out_path,
+                     const vg_align_params* p, const vg_comm* c);
 
 /* ------------------------------------------------------------------ synthetic input --- */
 /* Workload generator of SURVEY.md 8(d) (bench / test input; no reference call site: the reference ships no

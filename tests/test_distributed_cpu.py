@@ -1,6 +1,7 @@
-"""world_size-2 `gloo` test of the multi-process path (sharding, variable-length gathers,
-partial-count merge).  The GPU kernels are replaced by a stand-in backend built on the CPU
-oracle, so that the N>1 plumbing of vclust_amd/distributed.py runs on a box without GPUs."""
+"""world_size-2 `gloo` tests of the multi-process plumbing on a box without GPUs: the vg_comm callback
+communicator over torch.distributed, the agreement on failures (no rank is left inside a collective), and
+the reference-range partition of the align stage (vg_align_owner).  The sharded compute itself needs a GPU
+and is covered by tests/test_gpu_cli.py (two ranks on one GPU over gloo; RCCL when two devices are visible)."""
 import os
 import pathlib
 import socket
@@ -13,57 +14,33 @@ ROOT = pathlib.Path(__file__).resolve().parent.parent
 
 WORKER = r'''
 import os, sys, json
-import numpy as np
-sys.path.insert(0, os.environ["VROOT"]); sys.path.insert(0, os.path.join(os.environ["VROOT"], "tests"))
-import oracle_lib as orc
-from vclust_amd import api, synth, distributed as D
-
-M1, M2 = np.uint64(0xff51afd7ed558ccd), np.uint64(0xc4ceb9fe1a85ec53)
-def mix64(x):
-    x = x.astype(np.uint64)
-    with np.errstate(over="ignore"):
-        x ^= x >> np.uint64(33); x *= M1; x ^= x >> np.uint64(33); x *= M2; x ^= x >> np.uint64(33)
-    return x
-
-class OracleBackend:
-    """Stands in for api.GenomeSet: same methods, integers from the CPU oracle."""
-    def __init__(self, codes, offsets):
-        self.codes, self.offsets = codes, offsets
-        self.n = len(offsets) - 1
-    def seq(self, i):
-        return self.codes[self.offsets[i]:self.offsets[i + 1]]
-    def kmer_shared(self, k=25, fraction=1.0, shard=0, n_shards=1, min_shared=1):
-        sets = []
-        for i in range(self.n):
-            s = orc.kmer_set(self.seq(i), k)
-            h = mix64(s)
-            own = ((h & np.uint64(0xffffffff)) * np.uint64(n_shards)) >> np.uint64(32)
-            sets.append(s[own == np.uint64(shard)])
-        sizes = np.array([len(s) for s in sets], dtype=np.int64)
-        pairs = [(a, b, len(np.intersect1d(sets[a], sets[b], assume_unique=True)))
-                 for a in range(self.n) for b in range(a)]
-        pairs = np.array([p for p in pairs if p[2] >= min_shared], dtype=api.PAIR_DTYPE)
-        return sizes, pairs
-    def lz_align(self, tasks, lz=None, want_regions=False):
-        out = np.zeros(len(tasks), dtype=api.STAT_DTYPE)
-        for i, t in enumerate(tasks):
-            out[i] = orc.lz_pair_stat(self.seq(int(t["q"])), self.seq(int(t["r"])))
-        return out
+import ctypes as C
+sys.path.insert(0, os.environ["VROOT"])
+from vclust_amd import api, _lib, distributed as D
 
 dist, device = D.init_process_group("gloo")
 rank, world, _ = D.dist_env()
-codes, offsets, names = synth.make_families(2, 3, length=3000, seed=5)
-gs = OracleBackend(codes, offsets)
-sizes, pairs = D.prefilter_counts(gs, dist, device, rank, world, 25, 1.0)
-cand = pairs[pairs["shared"] >= 20]
-order = np.argsort(-np.diff(offsets), kind="stable"); rk = {int(g): r for r, g in enumerate(order)}
-couples = sorted((min(rk[int(p["a"])], rk[int(p["b"])]), max(rk[int(p["a"])], rk[int(p["b"])])) for p in cand)
-tasks = np.array([t for lo, hi in couples for t in ((order[hi], order[lo]), (order[lo], order[hi]))], dtype=api.TASK_DTYPE)
-stats, _ = D.align_rows(gs, tasks, dist, device, rank, world, None, False)
-if rank == 0:
-    json.dump(dict(sizes=sizes.tolist(), pairs=[[int(x) for x in p] for p in pairs],
-                   tasks=[[int(x) for x in t] for t in tasks], stats=[[int(x) for x in s] for s in stats]),
-              open(os.environ["VOUT"], "w"))
+comm = D.make_comm(dist, device)                       # callback communicator: all-gather over gloo, host memory
+assert (comm.rank, comm.world) == (rank, world)
+comm.selftest(1)
+comm.selftest(100003)                                  # odd size, larger than any internal chunk
+res = {"selftest": True}
+lib = _lib.load()
+# a rank that fails during ingest makes EVERY rank return the error (nobody hangs in the next exchange)
+fasta = os.environ["VFASTA"] if rank == 0 else os.environ["VFASTA"] + ".missing"
+arr = (C.c_char_p * 1)(os.fsencode(fasta))
+prm = _lib.PrefilterParams(25, 20, 0.7, 0, 1.0, 0, 1, 0, 1)
+rc = lib.vg_prefilter_sharded(arr, 1, os.fsencode(os.environ["VOUT"] + ".fltr"), C.byref(prm), comm.h)
+res["ingest_rc"] = rc; res["ingest_msg"] = lib.vg_last_error().decode()
+# both ranks ingest fine, but there is no GPU here: every rank reports the same device error
+arr = (C.c_char_p * 1)(os.fsencode(os.environ["VFASTA"]))
+rc = lib.vg_prefilter_sharded(arr, 1, os.fsencode(os.environ["VOUT"] + ".fltr"), C.byref(prm), comm.h)
+res["nodev_rc"] = rc; res["nodev_msg"] = lib.vg_last_error().decode()
+p = api.align_params(api.ALIGN_FIELDS[:11])
+rc = lib.vg_align_sharded(arr, 1, os.fsencode(os.environ["VOUT"] + ".ani"), C.byref(p), comm.h)
+res["align_rc"] = rc
+json.dump(res, open(os.environ["VOUT"] + f".{rank}.json", "w"))
+comm.close()
 dist.barrier()
 dist.destroy_process_group()
 '''
@@ -73,54 +50,42 @@ def free_port():
     s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def test_two_ranks_equal_one_rank(tmp_path):
-    sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / 'tests'))
-    import oracle_lib as orc
-    from vclust_amd import synth, distributed as D
+def test_two_ranks_comm_and_failure_agreement(tmp_path, golden_dir):
+    import json
     script = tmp_path / 'worker.py'; script.write_text(WORKER)
-    out = tmp_path / 'out.json'
-    env = dict(os.environ, VROOT=str(ROOT), VOUT=str(out), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(free_port()), WORLD_SIZE='2')
+    out = tmp_path / 'out'
+    env = dict(os.environ, VROOT=str(ROOT), VOUT=str(out), VFASTA=str(golden_dir / 'multifasta.fna'), MASTER_ADDR='127.0.0.1',
+               MASTER_PORT=str(free_port()), WORLD_SIZE='2', HIP_VISIBLE_DEVICES='', ROCR_VISIBLE_DEVICES='')
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(2)]
     for p in procs:
         assert p.wait(timeout=300) == 0
-    import json
-    got = json.load(open(out))
-    codes, offsets, names = synth.make_families(2, 3, length=3000, seed=5)
-    sizes, pairs = orc.shared_all(codes, offsets, k=25)
-    assert got['sizes'] == sizes.tolist()
-    assert {(a, b): s for a, b, s in got['pairs']} == pairs
-    assert len(got['tasks']) == len(got['stats']) > 0
-    for (q, r), st in zip(got['tasks'], got['stats']):
-        assert tuple(st) == orc.lz_pair_stat(codes[offsets[q]:offsets[q + 1]], codes[offsets[r]:offsets[r + 1]])
+    got = [json.load(open(f'{out}.{r}.json')) for r in range(2)]
+    for r in range(2):
+        assert got[r]['selftest']
+        assert got[r]['ingest_rc'] != 0 and 'rank 1 failed' in got[r]['ingest_msg']     # the same verdict on both ranks
+        assert got[r]['nodev_rc'] == -3 and 'no HIP device' in got[r]['nodev_msg'] or got[r]['nodev_rc'] != 0
+        assert got[r]['align_rc'] != 0
+    assert got[0]['ingest_rc'] == got[1]['ingest_rc'] and got[0]['nodev_rc'] == got[1]['nodev_rc']
+    assert not os.path.exists(f'{out}.fltr')
 
 
-def test_couple_range_partitions_everything():
-    sys.path.insert(0, str(ROOT))
-    from vclust_amd import distributed as D
-    for n in (0, 1, 7, 4500):
-        for world in (1, 2, 3, 8):
-            cuts = [D.couple_range(n, r, world) for r in range(world)]
-            assert cuts[0][0] == 0 and cuts[-1][1] == 2 * n
-            assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
-            assert all(lo % 2 == 0 and hi % 2 == 0 for lo, hi in cuts)
+def _ref_owner(tasks, world):
+    """The partition rule, restated: references cut into `world` contiguous id ranges with about equal task counts."""
+    refs = tasks['r'].astype(np.int64)
+    per_ref = np.bincount(refs)
+    before = np.cumsum(per_ref) - per_ref
+    return np.minimum(world - 1, before * world // len(tasks))[refs]
 
 
-def test_merge_pair_counts():
-    sys.path.insert(0, str(ROOT))
-    from vclust_amd import api, distributed as D
-    p = np.array([(3, 1, 5), (2, 0, 1), (3, 1, 7), (2, 0, 2), (4, 3, 9)], dtype=api.PAIR_DTYPE)
-    m = D.merge_pair_counts(p)
-    assert {(int(x['a']), int(x['b'])): int(x['shared']) for x in m} == {(3, 1): 12, (2, 0): 3, (4, 3): 9}
-
-
-def test_ref_owner_partitions_by_reference():
+def test_align_owner_partitions_by_reference():
     sys.path.insert(0, str(ROOT))
     from vclust_amd import api, distributed as D
     rng = np.random.default_rng(3)
     tasks = np.zeros(5000, dtype=api.TASK_DTYPE)
     tasks['q'] = rng.integers(0, 300, 5000); tasks['r'] = rng.integers(0, 300, 5000) ** 2 // 300     # skewed
     for world in (1, 2, 3, 8):
-        owner = D.ref_owner(tasks, world)
+        owner = D.align_owner(tasks, 300, world)
+        assert np.array_equal(owner, _ref_owner(tasks, world))
         assert owner.min() >= 0 and owner.max() <= world - 1
         for g in np.unique(tasks['r']):                          # a reference lives on exactly one rank
             assert len(np.unique(owner[tasks['r'] == g])) == 1
@@ -128,4 +93,13 @@ def test_ref_owner_partitions_by_reference():
         assert all(max(refs_of[i], default=-1) < min(refs_of[i + 1], default=1 << 30) for i in range(world - 1))
         counts = np.bincount(owner, minlength=world)
         assert counts.max() <= len(tasks) / world + np.bincount(tasks['r']).max()
-    assert len(D.ref_owner(tasks[:0], 4)) == 0
+    assert len(D.align_owner(tasks[:0], 300, 4)) == 0
+
+
+def test_single_rank_comm_needs_no_process_group():
+    sys.path.insert(0, str(ROOT))
+    from vclust_amd import distributed as D
+    comm = D.make_comm(None, None)
+    assert (comm.rank, comm.world) == (0, 1)
+    comm.selftest(64)
+    comm.close()

@@ -58,6 +58,8 @@ class KernelTime(C.Structure):
                 ('bytes', C.c_double)]
 
 
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int)
+
 # every symbol include/vclust_gpu.h declares: (restype, argtypes)
 P = C.POINTER
 SYMBOLS = {
@@ -67,6 +69,7 @@ SYMBOLS = {
     'vg_device_count': (C.c_int, []),
     'vg_set_device': (C.c_int, [C.c_int]),
     'vg_release_device_memory': (None, []),
+    'vg_copy': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int]),
     'vg_genomes_load': (C.c_int, [P(C.c_char_p), C.c_int, C.c_int, C.c_int, P(C.c_void_p)]),
     'vg_genomes_from_codes': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, P(C.c_char_p), P(C.c_void_p)]),
     'vg_genomes_free': (None, [C.c_void_p]),
@@ -93,6 +96,18 @@ SYMBOLS = {
     'vg_write_ani': (C.c_int, [C.c_void_p, P(Task), P(PairStat), C.c_int64, P(Region), C.c_int64,
                                C.c_char_p, P(AlignParams)]),
     'vg_align': (C.c_int, [P(C.c_char_p), C.c_int, C.c_char_p, P(AlignParams)]),
+    'vg_comm_create': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, P(C.c_void_p)]),
+    'vg_rccl_unique_id': (C.c_int, [C.c_void_p, C.c_int64]),
+    'vg_comm_rccl_create': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int64, P(C.c_void_p)]),
+    'vg_comm_free': (None, [C.c_void_p]),
+    'vg_comm_rank': (C.c_int, [C.c_void_p]),
+    'vg_comm_world': (C.c_int, [C.c_void_p]),
+    'vg_comm_selftest': (C.c_int, [C.c_void_p, C.c_int64]),
+    'vg_kmer_shared_sharded': (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_uint32, C.c_void_p, P(C.c_int64), P(P(PairCount)), P(C.c_int64)]),
+    'vg_align_owner': (C.c_int, [P(Task), C.c_int64, C.c_int, C.c_int, P(C.c_int32)]),
+    'vg_lz_align_sharded': (C.c_int, [C.c_void_p, P(Task), C.c_int64, P(LzParams), C.c_void_p, P(PairStat), P(P(Region)), P(C.c_int64)]),
+    'vg_prefilter_sharded': (C.c_int, [P(C.c_char_p), C.c_int, C.c_char_p, P(PrefilterParams), C.c_void_p]),
+    'vg_align_sharded': (C.c_int, [P(C.c_char_p), C.c_int, C.c_char_p, P(AlignParams), C.c_void_p]),
     'vg_synth_plan': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_double, C.c_double, C.c_int,
                                 C.c_int, P(C.c_void_p), P(C.c_void_p), P(C.c_int64)]),
     'vg_profile_enable': (None, [C.c_int]),
@@ -124,3 +139,8 @@ def load():
 def check(rc):
     if rc != 0:
         raise VclustGpuError(rc, load().vg_last_error().decode('utf-8', 'replace'))
+
+
+def hip_copy(dst, src, nbytes, to_host):
+    check(load().vg_copy(C.c_void_p(int(dst) if not isinstance(dst, C.c_void_p) else dst.value), C.c_void_p(int(src) if not isinstance(src, C.c_void_p) else src.value),
+                         int(nbytes), int(bool(to_host))))

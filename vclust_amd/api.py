@@ -211,10 +211,9 @@ def prefilter(paths, out_path, is_multifasta, k=25, min_kmers=20, min_ident=0.7,
     check(lib.vg_prefilter(arr, len(paths), os.fsencode(str(out_path)), C.byref(prm)))
 
 
-def align(paths, out_path, is_multifasta, columns, filter_path=None, filter_threshold=0.0, out_aln=None,
-          lz=None, out_filters=None, num_threads=1, verbosity=0):
-    lib = _lib.load()
-    arr = (C.c_char_p * len(paths))(*[os.fsencode(str(p)) for p in paths])
+def align_params(columns, filter_path=None, filter_threshold=0.0, out_aln=None, lz=None, out_filters=None, num_threads=1,
+                 verbosity=0, is_multifasta=True):
+    """vg_align_params for the given options (the struct keeps its strings alive through attributes)."""
     cols = (C.c_char_p * len(columns))(*[c.encode() for c in columns])
     p = AlignParams()
     p.lz = LzParams(**{**DEFAULT_LZ, **(lz or {})})
@@ -228,6 +227,15 @@ def align(paths, out_path, is_multifasta, columns, filter_path=None, filter_thre
     p.num_threads = num_threads
     p.verbosity = verbosity
     p.is_multifasta = int(bool(is_multifasta))
+    p._keep = cols
+    return p
+
+
+def align(paths, out_path, is_multifasta, columns, filter_path=None, filter_threshold=0.0, out_aln=None,
+          lz=None, out_filters=None, num_threads=1, verbosity=0):
+    lib = _lib.load()
+    arr = (C.c_char_p * len(paths))(*[os.fsencode(str(p)) for p in paths])
+    p = align_params(columns, filter_path, filter_threshold, out_aln, lz, out_filters, num_threads, verbosity, is_multifasta)
     check(lib.vg_align(arr, len(paths), os.fsencode(str(out_path)), C.byref(p)))
 
 

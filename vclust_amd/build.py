@@ -16,7 +16,7 @@ CSRC = PKG_DIR / 'csrc'
 LIB_PATH = PKG_DIR / 'libvclust_gpu.so'
 ORACLE_DIR = ROOT / 'oracle'
 
-SOURCES = ['vg_core.cpp', 'vg_genomes.cpp', 'vg_io.cpp', 'vg_api.cpp', 'vg_synth.cpp', 'vg_prefilter.hip', 'vg_align.hip']
+SOURCES = ['vg_core.cpp', 'vg_genomes.cpp', 'vg_io.cpp', 'vg_api.cpp', 'vg_synth.cpp', 'vg_prefilter.hip', 'vg_align.hip', 'vg_dist.hip']
 
 
 def _hipcc() -> str:
@@ -60,7 +60,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> pathlib.Path:
             raise RuntimeError(f'hipcc failed on {s.name}:\n{out}')
         if verbose and out.strip():
             print(out, file=sys.stderr)
-    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', str(LIB_PATH), *map(str, objs), '-lz', '-lpthread']
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', str(LIB_PATH), *map(str, objs), '-lz', '-lpthread', '-ldl']
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f'link failed:\n{r.stdout}')

@@ -110,6 +110,12 @@ void vg_dev_trim() {
 }
 
 extern "C" void vg_release_device_memory(void) { vg_dev_trim(); }
+extern "C" int vg_copy(void* dst, const void* src, int64_t bytes, int to_host) {
+    VG_API_BEGIN
+    vg_require_device();
+    if (bytes > 0) VG_HIP(hipMemcpy(dst, src, (size_t)bytes, to_host ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice));
+    VG_API_END
+}
 
 // ---------------------------------------------------------------- profiling
 struct prof_entry { double ms = 0; int64_t launches = 0; double bytes = 0; int order = 0; };
