@@ -237,7 +237,7 @@ int vo_align(const vo_genome_set* s, const char* out_path, const vo_align_params
         if (!fa) return -1;
         fprintf(fa, "query\treference\tpident\talnlen\tqstart\tqend\trstart\trend\tnt_match\tnt_mismatch\n");
         for (int64_t t = 0; t < nt; ++t) {
-            qsort(rl[t].r, rl[t].n, sizeof(vo_region), cmp_region_out);
+            if (rl[t].n > 0) qsort(rl[t].r, rl[t].n, sizeof(vo_region), cmp_region_out);
             vo_ref_index* ix = idx_of[st[t].r];
             for (int k = 0; k < rl[t].n; ++k) {
                 vo_region* g = &rl[t].r[k];

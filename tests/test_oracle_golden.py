@@ -169,3 +169,28 @@ def test_edge_inputs():
     assert orc.lz_pair_stat(np.full(100, 4, np.uint8), a) == (0, 0, 0)   # all N
     assert len(orc.kmer_set(a[:10], 25)) == 0
     assert len(orc.kmer_set(np.full(100, 4, np.uint8), 25)) == 0
+
+
+def test_oracle_under_sanitizers(tmp_path, golden_dir):
+    """The checker itself is checked: oracle_cli built with -fsanitize=address,undefined (oracle/Makefile `asan`)
+    runs prefilter + align (with the alignment table) on the example and on a ragged / N-rich input without a
+    report, and writes the same files as the plain build."""
+    import shutil
+    import subprocess
+    if shutil.which('gcc') is None:
+        pytest.skip('no gcc')
+    r = subprocess.run(['make', '-C', str(orc.ORACLE_DIR), 'asan'], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    asan = orc.ORACLE_DIR / '_build' / 'oracle_cli_asan'
+    env = dict(**__import__('os').environ, ASAN_OPTIONS='detect_leaks=0:abort_on_error=1', UBSAN_OPTIONS='halt_on_error=1', OMP_NUM_THREADS='2')
+    ragged = tmp_path / 'ragged.fna'
+    ragged.write_text('>a\nACGTNNNNACGTACGTACGTTTGACCAGTAGGCATGCATGCATCGATCGATTTAGC\n>b desc\nACG\n>c\n\n>d\n' + 'ACGTTGCA' * 40 + '\n')
+    for fasta, name in ((golden_dir / 'multifasta.fna', 'ex'), (ragged, 'rg')):
+        for cli, tag in ((asan, 'asan'), (orc.CLI, 'plain')):
+            p = subprocess.run([str(cli), 'prefilter', '-o', str(tmp_path / f'{name}_{tag}.fltr'), str(fasta)], env=env, stderr=subprocess.PIPE, text=True)
+            assert p.returncode == 0 and 'runtime error' not in p.stderr and 'AddressSanitizer' not in p.stderr, p.stderr[-2000:]
+            p = subprocess.run([str(cli), 'align', '-o', str(tmp_path / f'{name}_{tag}.tsv'), '--out-aln', str(tmp_path / f'{name}_{tag}.aln'), str(fasta)],
+                               env=env, stderr=subprocess.PIPE, text=True)
+            assert p.returncode == 0 and 'runtime error' not in p.stderr and 'AddressSanitizer' not in p.stderr, p.stderr[-2000:]
+        for ext in ('fltr', 'tsv', 'aln'):
+            assert filecmp.cmp(tmp_path / f'{name}_asan.{ext}', tmp_path / f'{name}_plain.{ext}', shallow=False)

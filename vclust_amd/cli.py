@@ -269,6 +269,25 @@ def _require_binary(path):
 
 
 # ------------------------------------------------------------------ handlers
+def prefilter_call(args):
+    """What the front-end hands to vg_prefilter for validated prefilter arguments -- the counterpart of the
+    reference's three argv lists (cmd_kmerdb_build / _all2all / _distance, vclust.py:915-1055)."""
+    return dict(paths=args.fasta_paths, out_path=args.output_path, is_multifasta=args.is_multifasta, k=args.k,
+                min_kmers=args.min_kmers, min_ident=args.min_ident, kmers_fraction=args.kmers_fraction,
+                max_seqs=args.max_seqs, num_threads=args.num_threads)
+
+
+def align_call(args):
+    """What the front-end hands to vg_align for validated align arguments -- the counterpart of cmd_lzani
+    (vclust.py:1058-1181): `--out-filter` only for values > 0 (:1170-1176), `--multisample-fasta true` iff there
+    is exactly one input path (:1159-1160)."""
+    lz = {k: getattr(args, k) for k in ('mal', 'msl', 'mrd', 'mqd', 'reg', 'aw', 'am', 'ar')}
+    out_filters = {k: getattr(args, k) for k in ('tani', 'gani', 'ani', 'qcov', 'rcov') if getattr(args, k) > 0}
+    return dict(paths=args.fasta_paths, out_path=args.output_path, is_multifasta=args.is_multifasta,
+                columns=ALIGN_OUTFMT[args.outfmt], filter_path=args.filter_path, filter_threshold=args.filter_threshold,
+                out_aln=args.aln_path, lz=lz, out_filters=out_filters, num_threads=args.num_threads)
+
+
 def handle_prefilter(args, parser, logger):
     args = validate_args_prefilter(args, parser)
     args = validate_args_fasta_input(args, parser)
@@ -278,15 +297,12 @@ def handle_prefilter(args, parser, logger):
             f'--kmers-fraction {args.kmers_fraction} --max-seqs {args.max_seqs} [{world} GPU] -> {args.output_path}')
 
     def work():
+        kw = prefilter_call(args)
+        paths, out_path, multi = kw.pop('paths'), kw.pop('out_path'), kw.pop('is_multifasta')
         if world == 1:
-            api.prefilter(args.fasta_paths, args.output_path, args.is_multifasta, k=args.k, min_kmers=args.min_kmers,
-                          min_ident=args.min_ident, batch_size=args.batch_size, kmers_fraction=args.kmers_fraction,
-                          max_seqs=args.max_seqs, num_threads=args.num_threads, verbosity=args.verbosity_level)
+            api.prefilter(paths, out_path, multi, batch_size=args.batch_size, verbosity=args.verbosity_level, **kw)
         else:
-            distributed.prefilter(args.fasta_paths, args.output_path, args.is_multifasta, k=args.k,
-                                  min_kmers=args.min_kmers, min_ident=args.min_ident,
-                                  kmers_fraction=args.kmers_fraction, max_seqs=args.max_seqs,
-                                  num_threads=args.num_threads)
+            distributed.prefilter(paths, out_path, multi, **kw)
     run_native(desc, work, args.verbosity_level, logger)
 
 
@@ -294,20 +310,18 @@ def handle_align(args, parser, logger):
     args = validate_args_fasta_input(args, parser)
     from . import api, distributed
     rank, world, local_rank = _dist_env()
-    lz = {k: getattr(args, k) for k in ('mal', 'msl', 'mrd', 'mqd', 'reg', 'aw', 'am', 'ar')}
-    out_filters = {k: getattr(args, k) for k in ('tani', 'gani', 'ani', 'qcov', 'rcov') if getattr(args, k) > 0}
-    desc = ('libvclust_gpu align ' + ' '.join(f'--{k} {v}' for k, v in lz.items())
+    call = align_call(args)
+    desc = ('libvclust_gpu align ' + ' '.join(f'--{k} {v}' for k, v in call['lz'].items())
             + (f' --filter {args.filter_path} {args.filter_threshold}' if args.filter_path else '')
             + f' [{world} GPU] -> {args.output_path}')
 
     def work():
-        kw = dict(columns=ALIGN_OUTFMT[args.outfmt], filter_path=args.filter_path,
-                  filter_threshold=args.filter_threshold, out_aln=args.aln_path, lz=lz, out_filters=out_filters,
-                  num_threads=args.num_threads)
+        kw = dict(call)
+        paths, out_path, multi = kw.pop('paths'), kw.pop('out_path'), kw.pop('is_multifasta')
         if world == 1:
-            api.align(args.fasta_paths, args.output_path, args.is_multifasta, verbosity=args.verbosity_level, **kw)
+            api.align(paths, out_path, multi, verbosity=args.verbosity_level, **kw)
         else:
-            distributed.align(args.fasta_paths, args.output_path, args.is_multifasta, **kw)
+            distributed.align(paths, out_path, multi, **kw)
     run_native(desc, work, args.verbosity_level, logger)
 
 
