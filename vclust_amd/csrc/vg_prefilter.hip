@@ -659,7 +659,7 @@ constexpr int BK_THREADS = 256;
 struct part_src {                        // where the elements of a partition level come from
     kmer_args A;                         // level 1, dense: padded base positions (k-mers computed on the fly)
     const uint64_t* keys; const uint32_t* pos;      // level 1, compact: kept k-mers and their row numbers
-    const uint32_t* w0; const uint32_t* w1; const uint32_t* pay;   // level 2: the level-1 planes
+    const uint32_t* rec;                 // level 2: the level-1 records (w0, w1, pay), 12 bytes each
     int64_t n;                           // number of source slots (positions or elements)
     int k2;                              // key bits = 2k
 };
@@ -714,7 +714,7 @@ __device__ __forceinline__ void load_tile(const part_src& S, int64_t t0, int64_t
             w0[j] = 0; w1[j] = 0; pay[j] = 0;
             if (ok[j]) {
                 if (SRC == SRC_ARRAYS) { key_words(S.keys[i], S.k2, &w0[j], &w1[j]); pay[j] = S.pos[i]; }
-                else { w0[j] = S.w0[i]; w1[j] = S.w1[i]; pay[j] = S.pay[i]; }
+                else { const uint32_t* r = S.rec + 3 * i; w0[j] = r[0]; w1[j] = r[1]; pay[j] = r[2]; }
             }
         }
     }
@@ -768,9 +768,9 @@ k_part_count2(part_src S, int B1, int B2, int ch_tiles, int64_t n_ch, const uint
         for (int b = threadIdx.x; b < 2 * nb2; b += PT_THREADS) hist[b] = 0;
         __syncthreads();
         const int64_t s0 = c * ch_tiles * PT_TILE, s1 = min(S.n, s0 + (int64_t)ch_tiles * PT_TILE);
-        const uint32_t bfirst = S.w0[s0] >> (32 - B1);
+        const uint32_t bfirst = S.rec[3 * s0] >> (32 - B1);
         for (int64_t i = s0 + threadIdx.x; i < s1; i += PT_THREADS) {
-            const uint32_t w = S.w0[i];
+            const uint32_t w = S.rec[3 * i];
             const uint32_t d = (w >> (32 - B1 - B2)) - (bfirst << B2);
             if (d < (uint32_t)(2 * nb2)) atomicAdd(&hist[d], 1u); else atomicOr(bad, 1u);
         }
@@ -791,7 +791,7 @@ template <int SRC, int LEVEL>
 __global__ void __launch_bounds__(PT_THREADS)
 k_part_scatter(part_src S, int B1, int B2, int unit_tiles, int64_t n_units, const uint32_t* __restrict__ Ts,
                const uint32_t* __restrict__ cfirst, const uint32_t* __restrict__ nch, const uint64_t* __restrict__ tb,
-               uint32_t* __restrict__ o_w0, uint32_t* __restrict__ o_w1, uint32_t* __restrict__ o_pay, int narrow_shift) {
+               uint32_t* __restrict__ o_rec, int narrow_shift) {
     __shared__ uint32_t s_w0[PT_TILE], s_w1[PT_TILE], s_pay[PT_TILE];
     __shared__ uint32_t thist[PT_MAXBINS], tstart[PT_MAXBINS], cursor[PT_MAXBINS];
     __shared__ uint32_t s_wave[16];
@@ -799,7 +799,7 @@ k_part_scatter(part_src S, int B1, int B2, int unit_tiles, int64_t n_units, cons
     for (int64_t u = blockIdx.x; u < n_units; u += gridDim.x) {
         const int64_t s0 = u * unit_tiles * PT_TILE, s1 = min(S.n, s0 + (int64_t)unit_tiles * PT_TILE);
         uint32_t bfirst = 0;
-        if (LEVEL == 2) bfirst = S.w0[s0] >> (32 - B1);
+        if (LEVEL == 2) bfirst = S.rec[3 * s0] >> (32 - B1);
         __syncthreads();
         for (int b = threadIdx.x; b < nbins; b += PT_THREADS) {
             uint32_t off = 0;
@@ -843,15 +843,20 @@ k_part_scatter(part_src S, int B1, int B2, int unit_tiles, int64_t n_units, cons
             }
             __syncthreads();
             const uint32_t n_tile = tstart[nbins - 1] + thist[nbins - 1];
-            for (uint32_t slot = threadIdx.x; slot < n_tile; slot += PT_THREADS) {
+            // records leave as a flat word stream: consecutive threads write consecutive words of consecutive
+            // records, so a bin's segment of the tile is ONE contiguous run of 12 (8) bytes per element
+            const uint32_t ow = narrow_shift >= 0 ? 2u : 3u;
+            for (uint32_t f = threadIdx.x; f < n_tile * ow; f += PT_THREADS) {
+                const uint32_t slot = f / ow, cpt = f - slot * ow;
                 const uint32_t w = s_w0[slot];
                 const uint32_t b = LEVEL == 1 ? (B1 ? (w >> (32 - B1)) : 0u) : ((w >> (32 - B1 - B2)) - (bfirst << B2));
-                const uint32_t dst = cursor[b] + (slot - tstart[b]);
+                const uint64_t dst = (uint64_t)(cursor[b] + (slot - tstart[b])) * ow + cpt;
+                uint32_t v;
                 if (narrow_shift >= 0) {
                     // the bucket fixes the top narrow_shift key bits and at most 32 remain: one word carries them
-                    o_w0[dst] = (uint32_t)(((((uint64_t)w << 32) | s_w1[slot]) << narrow_shift) >> 32);
-                } else { o_w0[dst] = w; o_w1[dst] = s_w1[slot]; }
-                o_pay[dst] = s_pay[slot];
+                    v = cpt == 0 ? (uint32_t)(((((uint64_t)w << 32) | s_w1[slot]) << narrow_shift) >> 32) : s_pay[slot];
+                } else v = cpt == 0 ? w : (cpt == 1 ? s_w1[slot] : s_pay[slot]);
+                o_rec[dst] = v;
             }
             __syncthreads();
             for (int b = threadIdx.x; b < nbins; b += PT_THREADS) cursor[b] += thist[b];
@@ -888,7 +893,7 @@ constexpr int BK_SUB = 1 << BK_SUBBITS;
 constexpr int BK_PER = BK_CAP / BK_THREADS;
 constexpr int BK_MAXBIN = 768;           // a sub-bin beyond this (one k-mer occurring hundreds of times) takes the general path
 __global__ void __launch_bounds__(BK_THREADS)
-k_bucket_runs(const uint32_t* __restrict__ w0, const uint32_t* __restrict__ w1, const uint32_t* __restrict__ pay,
+k_bucket_runs(const uint32_t* __restrict__ rec, int stride /* 3: (w0, w1, pay); 2: (key bits below the bucket's, pay) */,
               const uint32_t* __restrict__ boff, int64_t n_buckets, int pbits, const uint32_t* __restrict__ blk2g, int blk_shift,
               uint32_t* __restrict__ gen, uint64_t* __restrict__ rowinfo, compact_map M, int* __restrict__ dup_per_genome,
               unsigned int* __restrict__ overflow) {
@@ -911,8 +916,9 @@ k_bucket_runs(const uint32_t* __restrict__ w0, const uint32_t* __restrict__ w1, 
             const int j = q * BK_THREADS + threadIdx.x;
             sb[q] = 0; ar[q] = 0; key[q] = 0; pj[q] = 0;
             if (j < n) {
-                const uint32_t a = w0[b0 + j], c = w1 ? w1[b0 + j] : 0u;      // w1 == nullptr: w0 holds the bits below the bucket's
-                key[q] = ((uint64_t)a << 32) | c; pj[q] = pay[b0 + j];
+                const uint32_t* r = rec + (uint64_t)(b0 + j) * stride;
+                const uint32_t a = r[0], c = stride == 3 ? r[1] : 0u;
+                key[q] = ((uint64_t)a << 32) | c; pj[q] = r[stride - 1];
                 sb[q] = (uint32_t)((key[q] << pbits) >> (64 - BK_SUBBITS));
             }
         }
@@ -1128,7 +1134,7 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
     const int64_t n_st = (n_src + (int64_t)st_tiles * PT_TILE - 1) / ((int64_t)st_tiles * PT_TILE);
     const size_t t1n = (size_t)nb1 * (size_t)n_st;
     dbuf<uint32_t> T1(t1n + 1), T1s(t1n + 1);
-    dbuf<uint32_t> a_w0, a_w1, a_pay, b_w0, b_w1, b_pay;
+    dbuf<uint32_t> a_rec, b_rec;
     uint32_t n1 = 0;
     {
         vg_prof_scope ps("kmer_partition", (double)n_src * (dense ? 2 * 3.0 / 8.0 : 8.0 + 12.0) + (double)n_src * 12.0);
@@ -1144,16 +1150,16 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
         VG_HIP(hipStreamSynchronize(s));
         *n_valid_out = (int64_t)n1;
         if (n1 == 0) return true;
-        a_w0.alloc((size_t)n1 + 8); a_w1.alloc((size_t)n1 + 8); a_pay.alloc((size_t)n1 + 8);
+        a_rec.alloc(3 * (size_t)n1 + 8);
         const int grid_s = (int)std::min<int64_t>(n_st, 256);
         if (dense) hipLaunchKernelGGL((k_part_scatter<SRC_DENSE, 1>), dim3(grid_s), dim3(PT_THREADS), 0, s, S, B1, 0, st_tiles, n_st, (const uint32_t*)T1s.p,
-                                      (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint64_t*)nullptr, a_w0.p, a_w1.p, a_pay.p, -1);
+                                      (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint64_t*)nullptr, a_rec.p, -1);
         else hipLaunchKernelGGL((k_part_scatter<SRC_ARRAYS, 1>), dim3(grid_s), dim3(PT_THREADS), 0, s, S, B1, 0, st_tiles, n_st, (const uint32_t*)T1s.p,
-                                (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint64_t*)nullptr, a_w0.p, a_w1.p, a_pay.p, -1);
+                                (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint64_t*)nullptr, a_rec.p, -1);
     }
     const int64_t nbk = levels == 1 ? nb1 : (int64_t)nb1 * nb2;
     dbuf<uint32_t> boff((size_t)nbk + 1);
-    const uint32_t* f_w0 = a_w0.p; const uint32_t* f_w1 = a_w1.p; const uint32_t* f_pay = a_pay.p;
+    const uint32_t* f_rec = a_rec.p; int f_stride = 3;
     if (levels == 1) {
         hipLaunchKernelGGL(k_bucket_offsets, dim3(grid_for(nbk + 1)), dim3(256), 0, s, 1, B1, 0, n_st, (const uint32_t*)T1s.p, (const uint32_t*)nullptr,
                            (const uint32_t*)nullptr, (const uint64_t*)nullptr, (const uint32_t*)nullptr, n1, boff.p);
@@ -1184,7 +1190,7 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
         dbuf<uint32_t> T2((size_t)tot + 1), T2s((size_t)tot + 1); dbuf<unsigned int> d_bad(1);
         T2.zero(s); d_bad.zero(s);
         part_src S2; memset(&S2, 0, sizeof S2);
-        S2.w0 = a_w0.p; S2.w1 = a_w1.p; S2.pay = a_pay.p; S2.n = (int64_t)n1; S2.k2 = 2 * k;
+        S2.rec = a_rec.p; S2.n = (int64_t)n1; S2.k2 = 2 * k;
         unsigned int bad = 0;
         {
             vg_prof_scope ps("kmer_partition2", (double)n1 * (4.0 + 12.0 + (narrow ? 8.0 : 12.0)));
@@ -1195,18 +1201,18 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
             dbuf<char> tmp2(tb2);
             VG_HIP(rocprim::exclusive_scan((void*)tmp2.p, tb2, T2.p, T2s.p, 0u, (size_t)tot + 1, rocprim::plus<uint32_t>(), s));
             d_bad.download(&bad, 1, s);
-            b_w0.alloc((size_t)n1 + 8); if (!narrow) b_w1.alloc((size_t)n1 + 8); b_pay.alloc((size_t)n1 + 8);
+            b_rec.alloc((narrow ? 2 : 3) * (size_t)n1 + 8);
             VG_HIP(hipStreamSynchronize(s));
             if (bad) return false;
             hipLaunchKernelGGL((k_part_scatter<SRC_PLANES, 2>), dim3((int)std::min<int64_t>(n_ch, 256)), dim3(PT_THREADS), 0, s, S2, B1, B2, ch_tiles, n_ch,
-                               (const uint32_t*)T2s.p, (const uint32_t*)d_cfirst.p, (const uint32_t*)d_nch.p, (const uint64_t*)d_tb.p, b_w0.p, b_w1.p, b_pay.p,
+                               (const uint32_t*)T2s.p, (const uint32_t*)d_cfirst.p, (const uint32_t*)d_nch.p, (const uint64_t*)d_tb.p, b_rec.p,
                                narrow ? total_bits : -1);
         }
         hipLaunchKernelGGL(k_bucket_offsets, dim3(grid_for(nbk + 1)), dim3(256), 0, s, 2, B1, B2, n_st, (const uint32_t*)T1s.p, (const uint32_t*)d_off1.p,
                            (const uint32_t*)d_nch.p, (const uint64_t*)d_tb.p, (const uint32_t*)T2s.p, n1, boff.p);
         VG_HIP(hipStreamSynchronize(s));                       // the tables and level-1 planes go out of scope below
-        f_w0 = b_w0.p; f_w1 = narrow ? nullptr : b_w1.p; f_pay = b_pay.p;
-        a_w0.release(); a_w1.release(); a_pay.release();
+        f_rec = b_rec.p; f_stride = narrow ? 2 : 3;
+        a_rec.release();
     }
     if (gen.n < (size_t)n1 + 4) gen.alloc((size_t)n1 + 4);
     if (rowinfo.n < (size_t)n_rows_info) rowinfo.alloc((size_t)n_rows_info);
@@ -1215,7 +1221,7 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
     unsigned int over = 0;
     {
         vg_prof_scope ps("bucket_sort_runs", (double)n1 * ((narrow ? 8 : 12) + 4 + 8));
-        hipLaunchKernelGGL(k_bucket_runs, dim3((int)std::min<int64_t>(nbk, 256 * 16)), dim3(BK_THREADS), 0, s, f_w0, f_w1, f_pay, (const uint32_t*)boff.p, nbk,
+        hipLaunchKernelGGL(k_bucket_runs, dim3((int)std::min<int64_t>(nbk, 256 * 16)), dim3(BK_THREADS), 0, s, f_rec, f_stride, (const uint32_t*)boff.p, nbk,
                            narrow ? 0 : total_bits, (const uint32_t*)g->d_blk2g.p, g->align_shift, gen.p, rowinfo.p, cmap, d_dups, d_over.p);
     }
     d_over.download(&over, 1, s);
