@@ -37,7 +37,8 @@ struct ref_desc {
     int32_t B;         // anchor bucket bits
     int32_t genome;    // genome id
     int32_t has_n;     // reference genome contains N
-    int32_t pos_bits;  // anchor entry = pos | tag << pos_bits (tag = next hash bits after the bucket)
+    int32_t pos_bits;  // index entry = pos | tag << pos_bits
+    int32_t tag_bits;  // tag = the first tag_bits / 2 bases behind the msl-mer (<= mal - msl bases, <= 14 bits, <= 32 - pos_bits)
 };
 
 struct lz_dev_params { int mal, msl, mrd, mqd, reg, aw, am, ar; int ablate; };   // ablate: developer timing experiments only
@@ -394,6 +395,13 @@ __device__ __forceinline__ uint64_t anchor_hash(uint64_t code, bool narrow) {
     return code * 0x9E3779B97F4A7C15ULL;
 }
 __device__ __forceinline__ uint32_t anchor_bucket(uint64_t h, int B) { return (uint32_t)(h >> (64 - B)); }
+// Tag of the index entry of RR position p (x = the bases from p on, first base in the low bits): the bases
+// that follow its msl-mer.  An anchor lookup keeps the entries whose tag equals the query's: they agree with
+// the query on msl + tag_bits / 2 bases without a look at the sequence (the exact length decides the rest).
+__device__ __forceinline__ uint32_t seed_tag(uint64_t x, int p, int n_rr, int L, int msl, int tag_bits) {
+    (void)p; (void)n_rr; (void)L;
+    return tag_bits ? (uint32_t)((x >> (2 * msl)) & ((1u << tag_bits) - 1u)) : 0u;
+}
 __device__ __forceinline__ uint32_t anchor_tag(uint64_t h, int B, int pos_bits) {
     // up to 14 hash bits below the bucket bits, as many as fit above pos_bits in a 32-bit entry
     const int tb = (32 - pos_bits) < 14 ? (32 - pos_bits) : 14;
@@ -457,7 +465,7 @@ k_build_index_lds(const ref_desc* __restrict__ refs, const int* __restrict__ slo
         }
         __threadfence_block();
         __syncthreads();
-        for (int phase = 0; phase < 2; ++phase) {
+        for (int phase = 1; phase < 2; ++phase) {          // one index: msl-mer buckets, entries tagged with the bases that follow
             const int nbits = phase == 0 ? rd.B : 2 * msl;
             const int w = phase == 0 ? mal : msl;
             uint32_t* gtab = phase == 0 ? atab_pool + rd.atab : stab_pool + rd.stab;
@@ -485,7 +493,7 @@ k_build_index_lds(const ref_desc* __restrict__ refs, const int* __restrict__ slo
                         if (phase == 0) {
                             const uint64_t h = anchor_hash(x & amask, mal <= 16);
                             bt = anchor_bucket(h, rd.B) | (anchor_tag(h, rd.B, rd.pos_bits) << 18);
-                        } else bt = (uint32_t)(x & smask);
+                        } else bt = (uint32_t)(x & smask) | (seed_tag(x, p, rd.n_rr, rd.L, msl, rd.tag_bits) << 18);
                         atomicAdd(&tab[(bt & 0x3ffffu) >> (big ? tsh : 0)], 1u);
                     }
                     out[j] = bt;
@@ -535,7 +543,7 @@ k_build_index_lds(const ref_desc* __restrict__ refs, const int* __restrict__ slo
                                 const uint32_t bt = bts[j];
                                 const int b2 = (int)(bt & 0x3ffffu);
                                 if (bt == 0xffffffffu || b2 < w_lo || b2 >= w_hi) continue;
-                                const uint32_t ent = (uint32_t)(p0 + j) | (phase == 0 ? ((bt >> 18) << rd.pos_bits) : 0u);
+                                const uint32_t ent = (uint32_t)(p0 + j) | ((bt >> 18) << rd.pos_bits);
                                 const uint32_t slot = atomicAdd(&tab[b2], 1u);
                                 if (direct) gent[slot] = ent; else stage[slot - base] = ent;
                             }
@@ -604,7 +612,7 @@ k_build_index_lds(const ref_desc* __restrict__ refs, const int* __restrict__ slo
                 lds_scan_exclusive(tab, nbw, part);
                 for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
                     const uint2 e = binned[base + i];
-                    const uint32_t ent = e.y | (phase == 0 ? ((e.x >> 18) << rd.pos_bits) : 0u);
+                    const uint32_t ent = e.y | ((e.x >> 18) << rd.pos_bits);
                     const uint32_t slot = atomicAdd(&tab[(e.x & 0x3ffffu) - b_lo], 1u);
                     if (direct) gent[base + slot] = ent; else stage[slot] = ent;
                 }
@@ -645,8 +653,8 @@ k_index_pass(const ref_desc* __restrict__ refs, const int* __restrict__ slot_lis
              uint32_t* __restrict__ atab_pool, uint32_t* __restrict__ aent_pool, uint32_t* __restrict__ stab_pool,
              uint32_t* __restrict__ sent_pool) {
     const int64_t total = chunk_off[n_list] * 32;
-    const uint64_t amask = (mal >= 32) ? ~0ULL : ((1ULL << (2 * mal)) - 1);
     const uint64_t smask = (1ULL << (2 * msl)) - 1;
+    (void)mal; (void)atab_pool; (void)aent_pool;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         int64_t chunk = t >> 5;
         int lo = 0, hi = n_list - 1;
@@ -658,16 +666,10 @@ k_index_pass(const ref_desc* __restrict__ refs, const int* __restrict__ slot_lis
         uint64_t x = load32(pk, p);
         uint64_t m = (uint64_t)mk[p >> 5] | ((uint64_t)mk[(p >> 5) + 1] << 32);
         m >>= (p & 31);
-        if (p + mal <= rd.n_rr && (m & ((1ULL << mal) - 1)) == 0) {
-            const uint64_t h = anchor_hash(x & amask, mal <= 16);
-            uint32_t b = anchor_bucket(h, rd.B);
-            uint32_t slot = atomicAdd(&atab_pool[rd.atab + b], 1u);
-            if (fill) aent_pool[rd.aent + slot] = (uint32_t)p | (anchor_tag(h, rd.B, rd.pos_bits) << rd.pos_bits);
-        }
         if (p + msl <= rd.n_rr && (m & ((1ULL << msl) - 1)) == 0) {
             uint32_t b = (uint32_t)(x & smask);
             uint32_t slot = atomicAdd(&stab_pool[rd.stab + b], 1u);
-            if (fill) sent_pool[rd.sent + slot] = (uint32_t)p;
+            if (fill) sent_pool[rd.sent + slot] = (uint32_t)p | (seed_tag(x, (int)p, rd.n_rr, rd.L, msl, rd.tag_bits) << rd.pos_bits);
         }
     }
 }
@@ -678,8 +680,8 @@ k_scan_tables(const ref_desc* __restrict__ refs, const int* __restrict__ slot_li
               uint32_t* __restrict__ atab_pool, uint32_t* __restrict__ stab_pool) {
     __shared__ uint32_t part[256];
     __shared__ uint32_t carry;
-    const ref_desc rd = refs[slot_list[blockIdx.x >> 1]];
-    const bool seed = blockIdx.x & 1;
+    const ref_desc rd = refs[slot_list[blockIdx.x]];
+    const bool seed = true;                                  // one table per reference: the msl-mer buckets
     uint32_t* tab = seed ? stab_pool + rd.stab : atab_pool + rd.atab;
     const int64_t n = seed ? (1LL << (2 * msl)) : (1LL << rd.B);
     if (threadIdx.x == 0) carry = 0;
@@ -807,81 +809,78 @@ __device__ __forceinline__ void lz_parse_body(PARSE_ARGS) {
                 q_ok_s = q_ok_s && (m & ((1ULL << P.msl) - 1)) == 0;
                 qbad |= spread((uint32_t)m);
             }
-            // R2 (anchor = longest exact match >= mal over all occurrences of the mal-mer) and R3 (seed
-            // >= msl near the prediction, only for positions without an anchor) walk their buckets
-            // together, four entries of each per trip, so that a trip costs one memory round for the
-            // entries and one per verified candidate.  Both rank candidates the same way: longest
-            // exact match, ties -> smallest reference position.
+            // R2 (anchor = longest exact match >= mal over all occurrences of the mal-mer) and R3 (seed >= msl
+            // near the prediction) read ONE bucket: the entries of the query's msl-mer, four per trip.  An
+            // entry is an anchor candidate when its tag (the bases behind the msl-mer) equals the query's, a
+            // seed candidate when it lies in the prediction's window; a candidate is verified once.
             const bool do_a = q_ok_a && !(ABL & 16);
             const bool do_s = alive_l && q_ok_s && !(ABL & 1);
-            uint32_t a_u = 0, a_e = 0, s_u = 0, s_e = 0, tag = 0;
-            const uint32_t posmask = (1u << rd.pos_bits) - 1u;
-            if (do_a) {
-                const uint64_t h = anchor_hash(xq & amask, P.mal <= 16);
-                const uint32_t b = anchor_bucket(h, rd.B);
-                tag = anchor_tag(h, rd.B, rd.pos_bits);
-                a_u = b ? atab[b - 1] : 0u; a_e = atab[b];
-            }
-            if (do_s) {
+            uint32_t s_u = 0, s_e = 0;
+            const uint32_t posmask = (rd.pos_bits >= 32) ? 0xffffffffu : ((1u << rd.pos_bits) - 1u);
+            const uint32_t qtag = rd.tag_bits ? (uint32_t)((xq >> (2 * P.msl)) & ((1u << rd.tag_bits) - 1u)) : 0u;
+            if ((do_a || do_s) && q_ok_s) {
                 const uint32_t b = (uint32_t)(xq & smask);
                 s_u = b ? stab[b - 1] : 0u; s_e = stab[b];
             }
             const int pred0 = pred - lit;                        // reference end of the previous match
             const bool pred_rc = pred0 > c.L;                    // strand of the prediction
+            // R3 window: not before the end of the previous match, less than mrd ahead of the advancing
+            // prediction, and on the prediction's strand
+            const int win_lo = pred0;
+            const int win_hi = pred_rc ? pred_l + P.mrd - 1 : min(pred_l + P.mrd - 1, c.L - 1);
             int sbest_len = 0, sbest_pos = 0, sbest_ad = 0, ncap_a = 0, ncap_s = 0;
-            while (a_u < a_e || s_u < s_e) {
+            while (s_u < s_e) {
                 if (DEV) { ++n_ab; }
-                uint32_t ea0 = 0, ea1 = 0, ea2 = 0, ea3 = 0; int es0 = 0, es1 = 0, es2 = 0, es3 = 0;
-                const bool la = a_u < a_e, ls = s_u < s_e;
-                // four consecutive entries = one 16-byte load (the pools carry four entries of slack; entries past
+                // four consecutive entries = one 16-byte load (the pool carries four entries of slack; entries past
                 // the bucket end are ignored below)
-                if (la) { uint4 v; __builtin_memcpy(&v, aent + a_u, 16); ea0 = v.x; ea1 = v.y; ea2 = v.z; ea3 = v.w; }
-                if (ls) { uint4 v; __builtin_memcpy(&v, sent + s_u, 16); es0 = (int)v.x; es1 = (int)v.y; es2 = (int)v.z; es3 = (int)v.w; }
-                // candidate slots: bits 0..3 anchors (tag collisions fail the length test), 4..7 seeds
-                unsigned cm = 0;
-                if (la) {
-                    cm |= ((ea0 >> rd.pos_bits) == tag) ? 1u : 0u;
-                    cm |= (a_u + 1 < a_e && (ea1 >> rd.pos_bits) == tag) ? 2u : 0u;
-                    cm |= (a_u + 2 < a_e && (ea2 >> rd.pos_bits) == tag) ? 4u : 0u;
-                    cm |= (a_u + 3 < a_e && (ea3 >> rd.pos_bits) == tag) ? 8u : 0u;
+                uint4 v; __builtin_memcpy(&v, sent + s_u, 16);
+                const uint32_t e4[4] = { v.x, v.y, v.z, v.w };
+                unsigned am = 0, sm = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (s_u + j >= s_e) continue;
+                    const int ps = (int)(e4[j] & posmask);
+                    if (do_a && (rd.tag_bits == 0 || (e4[j] >> rd.pos_bits) == qtag)) am |= 1u << j;
+                    if (do_s && ps >= win_lo && ps <= win_hi) sm |= 1u << j;
                 }
-                if (ls) {
-                    // R3 window: not before the end of the previous match, less than mrd ahead of the advancing
-                    // prediction, and on the prediction's strand
-                    const int lo = pred0;
-                    const int hi = pred_rc ? pred_l + P.mrd - 1 : min(pred_l + P.mrd - 1, c.L - 1);
-                    cm |= (es0 >= lo && es0 <= hi) ? 16u : 0u;
-                    cm |= (s_u + 1 < s_e && es1 >= lo && es1 <= hi) ? 32u : 0u;
-                    cm |= (s_u + 2 < s_e && es2 >= lo && es2 <= hi) ? 64u : 0u;
-                    cm |= (s_u + 3 < s_e && es3 >= lo && es3 <= hi) ? 128u : 0u;
-                }
+                unsigned cm = am | sm;
                 while (cm) {
                     const int j = __builtin_ctz(cm); cm &= cm - 1;
-                    const bool seed = j >= 4;
-                    const int ja = j & 3;
-                    const uint32_t eas = ja == 0 ? ea0 : ja == 1 ? ea1 : ja == 2 ? ea2 : ea3;
-                    const int ess = ja == 0 ? es0 : ja == 1 ? es1 : ja == 2 ? es2 : es3;
-                    const int rp = seed ? ess : (int)(eas & posmask);
-                    int l = match_len32_q(c, xq, qbad, rp);
-                    int& bl = seed ? sbest_len : best_len; int& bp = seed ? sbest_pos : best_pos; int& nc = seed ? ncap_s : ncap_a;
-                    if (l < (seed ? P.msl : P.mal)) continue;
-                    if (l >= 32) {
-                        // rare: several long candidates need their exact lengths to be ranked
-                        if (nc++ > 0 || bl >= 32) {
-                            l = match_len_lane(c, qi, rp, 1 << 30);
-                            if (bl == 32) bl = match_len_lane(c, qi, bp, 1 << 30);
+                    const uint32_t ej = j == 0 ? e4[0] : j == 1 ? e4[1] : j == 2 ? e4[2] : e4[3];
+                    const int rp = (int)(ej & posmask);
+                    const int l0 = match_len32_q(c, xq, qbad, rp);
+                    if ((am >> j) & 1u) {
+                        int l = l0;
+                        if (l >= P.mal) {
+                            if (l >= 32) {
+                                // rare: several long candidates need their exact lengths to be ranked
+                                if (ncap_a++ > 0 || best_len >= 32) {
+                                    l = match_len_lane(c, qi, rp, 1 << 30);
+                                    if (best_len == 32) best_len = match_len_lane(c, qi, best_pos, 1 << 30);
+                                }
+                            }
+                            if (l > best_len || (l == best_len && rp < best_pos)) { best_len = l; best_pos = rp; }      // longest; ties -> smallest position
                         }
                     }
-                    if (seed) {
-                        // longest; ties -> closest to the prediction, then smallest position
-                        const int ad = abs(rp - pred_l);
-                        if (l > bl || (l == bl && (ad < sbest_ad || (ad == sbest_ad && rp < bp)))) { bl = l; bp = rp; sbest_ad = ad; }
-                    } else if (l > bl || (l == bl && rp < bp)) { bl = l; bp = rp; }      // longest; ties -> smallest position
+                    if ((sm >> j) & 1u) {
+                        int l = l0;
+                        if (l >= P.msl) {
+                            if (l >= 32) {
+                                if (ncap_s++ > 0 || sbest_len >= 32) {
+                                    l = match_len_lane(c, qi, rp, 1 << 30);
+                                    if (sbest_len == 32) sbest_len = match_len_lane(c, qi, sbest_pos, 1 << 30);
+                                }
+                            }
+                            // longest; ties -> closest to the prediction, then smallest position
+                            const int ad = abs(rp - pred_l);
+                            if (l > sbest_len || (l == sbest_len && (ad < sbest_ad || (ad == sbest_ad && rp < sbest_pos)))) { sbest_len = l; sbest_pos = rp; sbest_ad = ad; }
+                        }
+                    }
                 }
-                a_u += 4; s_u += 4;
+                s_u += 4;
                 // positions behind the first one that already has a match cannot become the event: stop their walks
                 const unsigned long long hit = __ballot(best_len > 0 || sbest_len > 0);
-                if (hit && lane > __builtin_ctzll(hit)) { a_u = a_e; s_u = s_e; }
+                if (hit && lane > __builtin_ctzll(hit)) s_u = s_e;
             }
             // R2/R3 choice: without a prediction the anchor; with one the seed, unless an anchor is longer
             // than the seed by at least msl (a far, long match beats a short close one)
@@ -1101,14 +1100,15 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
             int B = 8; while ((1LL << (B + 1)) <= n_rr && B + 1 <= 2 * p->mal && B < 26) ++B;
             if (small && B > 14) B = std::min(18, std::max(14, B - g_bucket_shift));
             const int64_t chunks = (n_rr + RR_PAD + 31) / 32 + 2;
-            const int64_t need = chunks * 12 + ((1LL << B) + n_rr + stab_n + n_rr) * 4;
+            const int64_t need = chunks * 12 + (stab_n + n_rr) * 4;
             if (!refs.empty() && bytes + need > g_index_budget_bytes) break;
             ref_desc rd; memset(&rd, 0, sizeof rd);
             rd.rr_w = rr_words; rd.mask_w = mask_words; rd.atab = atab_n; rd.aent = aent_n; rd.stab = stab_tot; rd.sent = sent_n;
             rd.L = (int32_t)L; rd.n_rr = (int32_t)n_rr; rd.B = B; rd.genome = (int32_t)r; rd.has_n = g->has_n[r];
             { int pb = 1; while ((1LL << pb) < n_rr) ++pb; rd.pos_bits = pb; }
+            rd.tag_bits = std::max(0, std::min({ 2 * (p->mal - p->msl), 14, 32 - rd.pos_bits }));
             refs.push_back(rd);
-            rr_words += chunks * 2; mask_words += chunks; atab_n += 1LL << B; aent_n += n_rr; stab_tot += stab_n; sent_n += n_rr;
+            rr_words += chunks * 2; mask_words += chunks; stab_tot += stab_n; sent_n += n_rr;
             chunk_off.push_back(chunk_off.back() + chunks);
             bytes += need;
             while (end < n_tasks && tasks[order[end]].r == r) ++end;
@@ -1124,7 +1124,7 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
             }
         }
         dbuf<ref_desc> d_refs((size_t)n_refs); d_refs.upload(refs.data(), refs.size(), s);
-        dbuf<uint32_t> rr_pool((size_t)rr_words + 8), mask_pool((size_t)mask_words + 8), atab_pool((size_t)atab_n), aent_pool((size_t)aent_n + 4),
+        dbuf<uint32_t> rr_pool((size_t)rr_words + 8), mask_pool((size_t)mask_words + 8), atab_pool((size_t)atab_n + 4), aent_pool((size_t)aent_n + 4),
             stab_pool((size_t)stab_tot), sent_pool((size_t)sent_n + 4);
         dbuf<task_dev> d_tasks(td.size()); d_tasks.upload(td.data(), td.size(), s);
         // split the batch: LDS counting sort for ordinary references, global path for the rest
@@ -1142,8 +1142,8 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
         if (!large_list.empty()) { d_large.upload(large_list.data(), large_list.size(), s); d_lchunk.upload(large_chunks.data(), large_chunks.size(), s); }
         const int64_t total_chunks = chunk_off.back();
         {
-            vg_prof_scope ps("lz_build_index", (double)total_chunks * 32 * (0.375 + 0.375 + 8));
-            if (!large_list.empty()) { atab_pool.zero(s); stab_pool.zero(s); }
+            vg_prof_scope ps("lz_build_index", (double)total_chunks * 32 * (0.375 + 0.375 + 4));
+            if (!large_list.empty()) stab_pool.zero(s);
             if (!small_list.empty()) {
                 int64_t max_rr = 0; for (int i : small_list) max_rr = std::max<int64_t>(max_rr, refs[i].n_rr);
                 const int nblk = (int)std::min<size_t>(small_list.size(), 512);
@@ -1159,7 +1159,7 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
                                    g->d_nmask.p, g->d_base_off.p, rr_pool.p, mask_pool.p);
                 hipLaunchKernelGGL(k_index_pass, dim3(grid_for(lc * 32)), dim3(256), 0, s, d_refs.p, d_large.p, nl, d_lchunk.p, rr_pool.p,
                                    mask_pool.p, p->mal, p->msl, 0, atab_pool.p, aent_pool.p, stab_pool.p, sent_pool.p);
-                hipLaunchKernelGGL(k_scan_tables, dim3(2 * nl), dim3(256), 0, s, d_refs.p, d_large.p, p->msl, atab_pool.p, stab_pool.p);
+                hipLaunchKernelGGL(k_scan_tables, dim3(nl), dim3(256), 0, s, d_refs.p, d_large.p, p->msl, atab_pool.p, stab_pool.p);
                 hipLaunchKernelGGL(k_index_pass, dim3(grid_for(lc * 32)), dim3(256), 0, s, d_refs.p, d_large.p, nl, d_lchunk.p, rr_pool.p,
                                    mask_pool.p, p->mal, p->msl, 1, atab_pool.p, aent_pool.p, stab_pool.p, sent_pool.p);
             }
