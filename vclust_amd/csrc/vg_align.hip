@@ -1059,21 +1059,23 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
     if (p->mal < 8 || p->mal > 31 || p->msl < 4 || p->msl > 12 || p->msl > p->mal) throw vg_error(VG_EINVAL, "mal must be 8..31, msl 4..12 and <= mal");
     if (p->aw < 1 || p->aw > 32 || p->ar < 1 || p->ar > 16 || p->am < 0 || p->mrd < 0 || p->mqd < 0 || p->reg < 0)
         throw vg_error(VG_EINVAL, "aw must be 1..32, ar 1..16");
+    if (p->mqd > 2000) throw vg_error(VG_EINVAL, "mqd must be <= 2000 (one wave scores a literal run of at most 2 048 symbols)");
     vg_require_device();
     int rc = vg_genomes_to_device(g); if (rc) return rc;
     hipStream_t s = vg_stream();
     if (regions) { *regions = nullptr; if (n_regions) *n_regions = 0; }
     if (n_tasks == 0) return VG_OK;
-    for (int64_t t = 0; t < n_tasks; ++t)
-        if (tasks[t].q >= (uint32_t)g->n || tasks[t].r >= (uint32_t)g->n) throw vg_error(VG_EINVAL, "task id out of range");
     for (int i = 0; i < g->n; ++i) if (g->len[i] > (1 << 29)) throw vg_error(VG_EOVERFLOW, "genome longer than 2^29 bases");
     if (n_tasks >= (1LL << 32)) throw vg_error(VG_EOVERFLOW, "more than 2^32 - 1 ordered pairs in one call: split the task list");
 
-    // group tasks by reference: counting sort on the reference id (stable, O(n))
+    // group tasks by reference: counting sort on the reference id (stable, O(n)); ids are checked on the way
     std::vector<int64_t> order((size_t)n_tasks);
     {
         std::vector<int64_t> start((size_t)g->n + 1, 0);
-        for (int64_t t = 0; t < n_tasks; ++t) start[tasks[t].r + 1]++;
+        for (int64_t t = 0; t < n_tasks; ++t) {
+            if (tasks[t].q >= (uint32_t)g->n || tasks[t].r >= (uint32_t)g->n) throw vg_error(VG_EINVAL, "task id out of range");
+            start[tasks[t].r + 1]++;
+        }
         for (int i = 0; i < g->n; ++i) start[i + 1] += start[i];
         for (int64_t t = 0; t < n_tasks; ++t) order[(size_t)start[tasks[t].r]++] = t;
     }
@@ -1114,6 +1116,7 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
             while (end < n_tasks && tasks[order[end]].r == r) ++end;
         }
         const int n_refs = (int)refs.size();
+        double bytes_alg = 0; int64_t q_max = 0, q_sum = 0;          // SURVEY 8(d) bytes of the batch; longest / total query
         std::vector<task_dev> td((size_t)(end - pos));
         {
             int slot = -1; uint32_t cur = 0xffffffffu;
@@ -1121,6 +1124,9 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
                 const vg_task& tk = tasks[order[t]];
                 if (tk.r != cur) { cur = tk.r; ++slot; }
                 td[(size_t)(t - pos)] = { tk.q, (uint32_t)slot, (uint32_t)order[t], 0 };
+                const int64_t ql = g->len[tk.q];
+                bytes_alg += (double)(ql + g->len[tk.r]) / 4.0 + 20.0;
+                q_max = std::max(q_max, ql); q_sum += ql;
             }
         }
         dbuf<ref_desc> d_refs((size_t)n_refs); d_refs.upload(refs.data(), refs.size(), s);
@@ -1166,12 +1172,6 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
         }
         {
             const int64_t nt = end - pos;
-            double bytes_alg = 0; int64_t q_max = 0, q_sum = 0;
-            for (int64_t t = pos; t < end; ++t) {
-                const int64_t ql = g->len[tasks[order[t]].q];
-                bytes_alg += (double)(ql + g->len[tasks[order[t]].r]) / 4.0 + 20.0;
-                q_max = std::max(q_max, ql); q_sum += ql;
-            }
             vg_prof_scope ps("lz_parse", bytes_alg);
             // Four waves per pair (segments) shorten the critical path: worth it when the launch would
             // otherwise last as long as its slowest pair -- few tasks, or queries several times longer than

@@ -7,6 +7,8 @@
 #include <string>
 #include <vector>
 #include <stdexcept>
+#include <thread>
+#include <exception>
 #include "../../include/vclust_gpu.h"
 
 // ---------------------------------------------------------------- errors
@@ -93,7 +95,16 @@ struct vg_genomes {
     dbuf<uint8_t> d_has_n;
     dbuf<uint32_t> d_blk2g;
     int64_t padded_total() const { return base_off.empty() ? 0 : base_off.back(); }
+    // L1 order (stable sort by length, descending), computed once: order[rank] = input id, rank[id]
+    mutable std::vector<int32_t> len_order, len_rank;
 };
+void vg_length_order(const vg_genomes* g);        // fills g->len_order / g->len_rank on first use
+
+// ---------------------------------------------------------------- host threads
+// fn(lo, hi, t) over [0, n) cut into contiguous chunks, one per thread (the library's host loops over
+// 10^5..10^6 pairs / tasks: a few threads are enough; an exception in a chunk is rethrown on the caller)
+int vg_host_threads();
+template <class F> void vg_parallel_chunks(int64_t n, int n_thr, F fn);
 // append one genome given codes (0..3, >3 = N); used by the FASTA reader and vg_genomes_from_codes
 void vg_genomes_append(vg_genomes* g, const std::string& name, const uint8_t* codes, int64_t len, int n_parts);
 void vg_genomes_finish(vg_genomes* g);
@@ -104,3 +115,13 @@ int vg_choose_align_shift(int64_t total_len, int64_t n);
 int  vg_fmt_num(double x, char* buf);                 // LZ-ANI number format
 int  vg_fmt_len_ratio(int64_t a, int64_t b, char* buf);
 double vg_ani_shorter(int64_t shared, int64_t na, int64_t nb, int k);
+
+template <class F> void vg_parallel_chunks(int64_t n, int n_thr, F fn) {
+    if (n_thr < 1) n_thr = 1;
+    if (n < 4096 || n_thr == 1) { fn((int64_t)0, n, 0); return; }
+    std::vector<std::thread> th; std::vector<std::exception_ptr> err((size_t)n_thr);
+    for (int t = 0; t < n_thr; ++t) th.emplace_back([&, t]() {
+        try { fn(n * t / n_thr, n * (t + 1) / n_thr, t); } catch (...) { err[(size_t)t] = std::current_exception(); } });
+    for (auto& x : th) x.join();
+    for (auto& e : err) if (e) std::rethrow_exception(e);
+}

@@ -5,6 +5,8 @@
 #include <string.h>
 #include <stdlib.h>
 #include <map>
+#include <algorithm>
+#include <thread>
 #include <mutex>
 
 static thread_local char g_err[1024] = "";
@@ -58,6 +60,8 @@ hipStream_t vg_stream() {
     if (!g_stream) VG_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
     return g_stream;
 }
+
+int vg_host_threads() { static int n = (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())); return n; }
 
 // ---------------------------------------------------------------- caching device allocator
 namespace {

@@ -91,17 +91,22 @@ extern "C" int vg_filter_pairs(int k, int min_kmers, double min_ident, const int
                                const vg_pair_count* pairs, int64_t n_pairs, vg_pair_count** out, int64_t* n_out) {
     VG_API_BEGIN
     if (!set_sizes || (!pairs && n_pairs) || !out || !n_out) throw vg_error(VG_EINVAL, "vg_filter_pairs: null argument");
-    std::vector<vg_pair_count> keep;
-    keep.reserve((size_t)n_pairs);
-    for (int64_t i = 0; i < n_pairs; ++i) {
-        const vg_pair_count& p = pairs[i];
-        if ((int64_t)p.a >= n_genomes || (int64_t)p.b >= n_genomes) throw vg_error(VG_EINVAL, "pair id out of range");
-        if ((int64_t)p.shared < min_kmers) continue;
-        if (vg_ani_shorter(p.shared, set_sizes[p.a], set_sizes[p.b], k) >= min_ident) keep.push_back(p);
-    }
-    vg_pair_count* o = (vg_pair_count*)malloc(sizeof(vg_pair_count) * std::max<size_t>(1, keep.size()));
+    const int T = vg_host_threads();
+    std::vector<std::vector<vg_pair_count>> part((size_t)T);
+    vg_parallel_chunks(n_pairs, T, [&](int64_t lo, int64_t hi, int t) {
+        auto& keep = part[(size_t)t];
+        for (int64_t i = lo; i < hi; ++i) {
+            const vg_pair_count& p = pairs[i];
+            if ((int64_t)p.a >= n_genomes || (int64_t)p.b >= n_genomes) throw vg_error(VG_EINVAL, "pair id out of range");
+            if ((int64_t)p.shared < min_kmers) continue;
+            if (vg_ani_shorter(p.shared, set_sizes[p.a], set_sizes[p.b], k) >= min_ident) keep.push_back(p);
+        }
+    });
+    size_t total = 0; for (auto& v : part) total += v.size();
+    vg_pair_count* o = (vg_pair_count*)malloc(sizeof(vg_pair_count) * std::max<size_t>(1, total));
     if (!o) throw vg_error(VG_ENOMEM, "out of host memory");
-    if (!keep.empty()) memcpy(o, keep.data(), sizeof(vg_pair_count) * keep.size());
+    { size_t w = 0; for (auto& v : part) { if (!v.empty()) memcpy(o + w, v.data(), sizeof(vg_pair_count) * v.size()); w += v.size(); } }
+    struct { size_t n; size_t size() const { return n; } } keep{ total };
     *out = o; *n_out = (int64_t)keep.size();
     VG_API_END
 }
@@ -150,11 +155,20 @@ extern "C" int vg_write_fltr(const vg_genomes* g, int k, double fraction, int mi
 }
 
 // ---------------------------------------------------------------- align: order, filter, tasks
+void vg_length_order(const vg_genomes* g) {
+    if ((int)g->len_order.size() == g->n && (int)g->len_rank.size() == g->n) return;
+    std::vector<int32_t> order((size_t)g->n), rank((size_t)g->n);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return g->len[x] > g->len[y]; });
+    for (int i = 0; i < g->n; ++i) rank[(size_t)order[(size_t)i]] = i;
+    g->len_order.swap(order); g->len_rank.swap(rank);
+}
+
 extern "C" int vg_align_order(const vg_genomes* g, int32_t* order) {
     VG_API_BEGIN
     if (!g || !order) throw vg_error(VG_EINVAL, "vg_align_order: null argument");
-    std::iota(order, order + g->n, 0);
-    std::stable_sort(order, order + g->n, [&](int32_t x, int32_t y) { return g->len[x] > g->len[y]; });
+    vg_length_order(g);
+    if (g->n) memcpy(order, g->len_order.data(), sizeof(int32_t) * (size_t)g->n);
     VG_API_END
 }
 
@@ -219,33 +233,51 @@ extern "C" int vg_align_tasks(const vg_genomes* g, const vg_pair_count* pairs, i
                               vg_task** tasks, int64_t* n_tasks) {
     VG_API_BEGIN
     if (!g || (!pairs && n_pairs) || !tasks || !n_tasks) throw vg_error(VG_EINVAL, "vg_align_tasks: null argument");
-    std::vector<int32_t> order(g->n), rank(g->n);
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return g->len[x] > g->len[y]; });
-    for (int i = 0; i < g->n; ++i) rank[order[i]] = i;
+    vg_length_order(g);
+    const std::vector<int32_t>& order = g->len_order; const std::vector<int32_t>& rank = g->len_rank;
     struct rp { int32_t lo, hi; };
-    std::vector<rp> v((size_t)n_pairs);
-    for (int64_t i = 0; i < n_pairs; ++i) {
-        if (pairs[i].a >= (uint32_t)g->n || pairs[i].b >= (uint32_t)g->n) throw vg_error(VG_EINVAL, "pair id out of range");
-        int32_t x = rank[pairs[i].a], y = rank[pairs[i].b];
-        v[(size_t)i] = { std::min(x, y), std::max(x, y) };
-    }
-    {   // sort couples by (lo, hi): two stable counting passes over the ranks
-        std::vector<rp> tmp(v.size());
-        for (int pass = 0; pass < 2; ++pass) {
-            std::vector<size_t> start((size_t)g->n + 1, 0);
-            for (auto& e : v) start[(size_t)(pass == 0 ? e.hi : e.lo) + 1]++;
-            for (int i = 0; i < g->n; ++i) start[i + 1] += start[i];
-            for (auto& e : v) tmp[start[(size_t)(pass == 0 ? e.hi : e.lo)]++] = e;
-            v.swap(tmp);
+    std::vector<rp> v((size_t)n_pairs), tmp((size_t)n_pairs);
+    const int T = vg_host_threads();
+    // couples sorted by (lo, hi): one stable counting pass on lo (per-thread histograms), then every lo group
+    // (a genome's partners: a handful) is sorted on hi
+    std::vector<std::vector<int64_t>> hist((size_t)T, std::vector<int64_t>((size_t)g->n + 1, 0));
+    vg_parallel_chunks(n_pairs, T, [&](int64_t lo, int64_t hi, int t) {
+        auto& h = hist[(size_t)t];
+        for (int64_t i = lo; i < hi; ++i) {
+            if (pairs[i].a >= (uint32_t)g->n || pairs[i].b >= (uint32_t)g->n) throw vg_error(VG_EINVAL, "pair id out of range");
+            const int32_t x = rank[pairs[i].a], y = rank[pairs[i].b];
+            v[(size_t)i] = { std::min(x, y), std::max(x, y) };
+            h[(size_t)v[(size_t)i].lo]++;
         }
+    });
+    std::vector<int64_t> start((size_t)g->n + 1, 0);
+    {   // start[t][key] = global start of key + entries of the threads before t
+        int64_t run = 0;
+        for (int key = 0; key < g->n; ++key) {
+            start[(size_t)key] = run;
+            for (int t = 0; t < T; ++t) { const int64_t c = hist[(size_t)t][(size_t)key]; hist[(size_t)t][(size_t)key] = run; run += c; }
+        }
+        start[(size_t)g->n] = run;
     }
+    vg_parallel_chunks(n_pairs, T, [&](int64_t lo, int64_t hi, int t) {
+        auto& h = hist[(size_t)t];
+        for (int64_t i = lo; i < hi; ++i) tmp[(size_t)h[(size_t)v[(size_t)i].lo]++] = v[(size_t)i];
+    });
+    vg_parallel_chunks((int64_t)g->n, T, [&](int64_t lo, int64_t hi, int) {
+        for (int64_t key = lo; key < hi; ++key) {
+            const int64_t s0 = start[(size_t)key], s1 = start[(size_t)key + 1];
+            if (s1 - s0 > 1) std::sort(tmp.begin() + s0, tmp.begin() + s1, [](const rp& x, const rp& y) { return x.hi < y.hi; });
+        }
+    });
+    v.swap(tmp);
     vg_task* o = (vg_task*)malloc(sizeof(vg_task) * std::max<size_t>(1, 2 * v.size()));
     if (!o) throw vg_error(VG_ENOMEM, "out of host memory");
-    for (size_t i = 0; i < v.size(); ++i) {
-        o[2 * i] = { (uint32_t)order[v[i].hi], (uint32_t)order[v[i].lo] };       // row (q = b, r = a)
-        o[2 * i + 1] = { (uint32_t)order[v[i].lo], (uint32_t)order[v[i].hi] };   // row (q = a, r = b)
-    }
+    vg_parallel_chunks((int64_t)v.size(), T, [&](int64_t lo, int64_t hi, int) {
+        for (int64_t i = lo; i < hi; ++i) {
+            o[2 * i] = { (uint32_t)order[(size_t)v[(size_t)i].hi], (uint32_t)order[(size_t)v[(size_t)i].lo] };       // row (q = b, r = a)
+            o[2 * i + 1] = { (uint32_t)order[(size_t)v[(size_t)i].lo], (uint32_t)order[(size_t)v[(size_t)i].hi] };   // row (q = a, r = b)
+        }
+    });
     *tasks = o; *n_tasks = (int64_t)(2 * v.size());
     VG_API_END
 }
