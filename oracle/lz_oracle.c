@@ -5,26 +5,30 @@
  * --mqd 40 --reg 35 --aw 15 --am 7 --ar 3`).  The native source (3rd_party/lz-ani,
  * .gitmodules:4-6) is absent from the checkout, so this file restates the published
  * LZ-ANI algorithm and was fitted, rule by rule, to the 5 693 golden regions of
- * example/output/ani.aln.tsv (see DESIGN.md "LZ parse rules" for the evidence per rule):
+ * example/output/ani.aln.tsv (see DESIGN.md "LZ parse rules" for the evidence per rule).  Status: all 5 693
+ * regions reproduced with every integer, one surplus region (tests/test_oracle_golden.py):
  *
- *   R1  reference = forward strand | N | reverse complement (query is never reversed).
- *   R2  at every query position i (left to right) look for an ANCHOR: the longest exact
- *       match >= mal over all occurrences of the mal-mer q[i..] in the reference, ties ->
- *       smallest reference position.  The anchor search runs whether or not a prediction
- *       is alive; an anchor within +-mrd of the prediction continues the region, any
- *       other anchor closes the region and opens a new one.
- *   R3  if no anchor and a prediction is alive, look for a SEED: exact match >= msl whose
- *       reference position p satisfies  pred0 <= p  and  p - pred < mrd, where pred0 is
- *       the reference end of the previous match and pred = pred0 + literals skipped;
- *       longest wins, ties -> smallest position.
- *   R4  after every match an approximate extension walks the diagonal while the last aw
- *       symbols hold <= am mismatches and is cut back to the end of the last run of >= ar
- *       matches.
- *   R5  a new region is first extended to the left by the maximal exact match, then by the
- *       same approximate rule, never crossing the end of the last KEPT region.
+ *   R1  reference = forward strand | N ... | reverse complement (query is never reversed); the separator is
+ *       mrd + mqd + 1 symbols, so nothing ever reaches across the strands.
+ *   R2  without a prediction: the ANCHOR at query position i = the longest exact match >= mal over all
+ *       occurrences of the mal-mer q[i..] in the reference, ties -> smallest reference position.
+ *   R3  with a prediction alive: first a SEED, an exact match >= msl whose reference position p satisfies
+ *       pred0 <= p and p - pred < mrd (pred0 = reference end of the previous match, pred = pred0 + literals
+ *       skipped); longest wins, ties -> closest to the prediction, then smallest position.  An anchor is
+ *       taken instead only if it is longer than the seed by at least msl; it continues the region when it
+ *       lies within +-mrd of the prediction, otherwise it closes the region and opens a new one.
+ *   R4  after every match an approximate extension walks the diagonal while the last aw symbols hold <= am
+ *       mismatches and is cut back to the end of the last run of >= ar matches.
+ *   R5  a new region is first extended to the left by the maximal exact match, then by the same approximate
+ *       rule, never crossing the end of the last KEPT region.
  *   R6  more than mqd literals without a match drop the prediction.
- *   R7  query symbols between two chained matches are scored on the old diagonal.
+ *   R7  the g literals in front of a chained match (p, len) are laid against the reference stretch
+ *       [pred0, p + len) with one indel placed where it keeps most matches: a prefix on the old diagonal, a
+ *       suffix flush with the end of the stretch, surplus literals in between match nothing; ties -> longest prefix.
  *   R8  a region is kept when its query span >= reg; nt_mismatch = span - nt_match.
+ *   R9  rend is a virtual reference end: a symbol that matches nothing moves it by one, one matched on the old
+ *       diagonal pulls it up to its own position, one matched on the new diagonal leaves it (never below the
+ *       true end); rstart is the smallest start of the region's matches.
  */
 #include "vclust_oracle.h"
 #include <stdlib.h>
