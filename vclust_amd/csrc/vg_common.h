@@ -34,12 +34,12 @@ void  vg_dev_trim();             // return all cached blocks to the driver
 
 // ---------------------------------------------------------------- device buffers
 template <class T> struct dbuf {
-    T* p = nullptr; size_t n = 0;
+    T* p = nullptr; size_t n = 0; bool owned = true;
     dbuf() {}
     explicit dbuf(size_t count) { alloc(count); }
     dbuf(const dbuf&) = delete; dbuf& operator=(const dbuf&) = delete;
-    dbuf(dbuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
-    dbuf& operator=(dbuf&& o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
+    dbuf(dbuf&& o) noexcept : p(o.p), n(o.n), owned(o.owned) { o.p = nullptr; o.n = 0; o.owned = true; }
+    dbuf& operator=(dbuf&& o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; owned = o.owned; o.p = nullptr; o.n = 0; o.owned = true; } return *this; }
     ~dbuf() { release(); }
     // blocks come from a caching allocator (vg_core.cpp): every kernel and copy of the library is
     // issued on one in-order stream, so a released block can be handed out again without a
@@ -48,7 +48,9 @@ template <class T> struct dbuf {
         release(); n = count;
         if (count) p = (T*)vg_dev_alloc(count * sizeof(T));
     }
-    void release() { if (p) { vg_dev_free(p); p = nullptr; } n = 0; }
+    void release() { if (p && owned) vg_dev_free(p); p = nullptr; n = 0; owned = true; }
+    // non-owning window into another buffer (the owner must outlive it)
+    void view(T* ptr, size_t count) { release(); p = ptr; n = count; owned = false; }
     size_t bytes() const { return n * sizeof(T); }
     void zero(hipStream_t s) { if (n) VG_HIP(hipMemsetAsync(p, 0, bytes(), s)); }
     void upload(const T* h, size_t count, hipStream_t s) { VG_HIP(hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, s)); }

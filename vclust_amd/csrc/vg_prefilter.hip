@@ -1116,8 +1116,8 @@ static void run_extract_sort(vg_genomes* g, int k, double fraction, int shard, i
 // input does not suit it (tiny, skewed, a bucket beyond the LDS): the caller takes the general path.
 static int g_index_path = -1;      // -1 = not read yet; 0 = radix (rocPRIM) path forced; 1 = buckets
 static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_args& A, const uint64_t* keys, const uint32_t* pos, int64_t n_src,
-                                const compact_map& cmap, int* d_kept, dbuf<uint32_t>& gen, dbuf<uint64_t>& rowinfo, int64_t n_rows_info,
-                                int* d_dups, int64_t* n_valid_out) {
+                                const compact_map& cmap, int* d_kept, dbuf<uint32_t>& gen, dbuf<uint64_t>& rowinfo, dbuf<uint32_t>& arena,
+                                int64_t n_rows_info, int* d_dups, int64_t* n_valid_out) {
     hipStream_t s = vg_stream();
     if (g_index_path < 0) { const char* e = getenv("VG_INDEX_PATH"); g_index_path = (e && !strcmp(e, "radix")) ? 0 : 1; }
     if (!g_index_path || n_src < (1 << 16) || n_src >= (1LL << 32)) return false;
@@ -1150,7 +1150,9 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
         VG_HIP(hipStreamSynchronize(s));
         *n_valid_out = (int64_t)n1;
         if (n1 == 0) return true;
-        a_rec.alloc(3 * (size_t)n1 + 8);
+        // two levels: the level-1 records are dead once level 2 has scattered them, and the genome list + row
+        // descriptors are born after that: they take over the same block (48 GB less to allocate at 100 k genomes)
+        a_rec.alloc(levels == 2 ? std::max(3 * (size_t)n1 + 8, 2 * (size_t)n_rows_info + (size_t)n1 + 16) : 3 * (size_t)n1 + 8);
         const int grid_s = (int)std::min<int64_t>(n_st, 256);
         if (dense) hipLaunchKernelGGL((k_part_scatter<SRC_DENSE, 1>), dim3(grid_s), dim3(PT_THREADS), 0, s, S, B1, 0, st_tiles, n_st, (const uint32_t*)T1s.p,
                                       (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint64_t*)nullptr, a_rec.p, -1);
@@ -1212,10 +1214,12 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
                            (const uint32_t*)d_nch.p, (const uint64_t*)d_tb.p, (const uint32_t*)T2s.p, n1, boff.p);
         VG_HIP(hipStreamSynchronize(s));                       // the tables and level-1 planes go out of scope below
         f_rec = b_rec.p; f_stride = narrow ? 2 : 3;
-        a_rec.release();
+        arena = std::move(a_rec);
+        rowinfo.view(reinterpret_cast<uint64_t*>(arena.p), (size_t)n_rows_info);
+        gen.view(arena.p + 2 * (size_t)n_rows_info, (size_t)n1 + 4);
     }
     if (gen.n < (size_t)n1 + 4) gen.alloc((size_t)n1 + 4);
-    if (rowinfo.n < (size_t)n_rows_info) rowinfo.alloc((size_t)n_rows_info);
+    if (rowinfo.n < (size_t)n_rows_info) rowinfo.alloc((size_t)n_rows_info);      // (one level: nothing to take over)
     VG_HIP(hipMemsetAsync(rowinfo.p, 0, (size_t)n_rows_info * sizeof(uint64_t), s));
     dbuf<unsigned int> d_over(1); d_over.zero(s);
     unsigned int over = 0;
@@ -1238,6 +1242,7 @@ static void kmer_shared_pass(vg_genomes* g, int k, double fraction, int shard, i
     const int64_t P = g->padded_total();
     const bool dense_src = !(fraction < 1.0) && n_shards == 1;
     int64_t nv = 0, n_rows_info = 0;
+    dbuf<uint32_t> arena;                            // owner of rowinfo / gen when they are windows of one block
     dbuf<uint64_t> rowinfo; dbuf<uint32_t> gen;
     dbuf<int> d_dups((size_t)n); d_dups.zero(s);
     constexpr unsigned int BIG_CAP = 4096;
@@ -1253,7 +1258,7 @@ static void kmer_shared_pass(vg_genomes* g, int k, double fraction, int shard, i
             if (P < (1LL << 32)) {
                 n_rows_info = P;
                 const compact_map none{ nullptr, nullptr };
-                bucket_ok = build_index_buckets(g, k, true, A, nullptr, nullptr, P, none, kept_b.p, gen, rowinfo, n_rows_info, d_dups.p, &nv);
+                bucket_ok = build_index_buckets(g, k, true, A, nullptr, nullptr, P, none, kept_b.p, gen, rowinfo, arena, n_rows_info, d_dups.p, &nv);
                 if (bucket_ok) kept_b.download(kept.data(), (size_t)n, s);
             }
         } else {
@@ -1261,12 +1266,13 @@ static void kmer_shared_pass(vg_genomes* g, int k, double fraction, int shard, i
             nv = si.n_valid; n_rows_info = std::max<int64_t>(nv, 1);
             const compact_map cm{ si.goff.p, si.cblk.p };
             int64_t nv2 = 0;
-            bucket_ok = build_index_buckets(g, k, false, A, si.keys.p, si.pos.p, nv, cm, nullptr, gen, rowinfo, n_rows_info, d_dups.p, &nv2);
+            bucket_ok = build_index_buckets(g, k, false, A, si.keys.p, si.pos.p, nv, cm, nullptr, gen, rowinfo, arena, n_rows_info, d_dups.p, &nv2);
             if (bucket_ok) si.kept.download(kept.data(), (size_t)n, s);
         }
         if (bucket_ok) { d_dups.download(dups.data(), (size_t)n, s); VG_HIP(hipStreamSynchronize(s)); }
     }
     if (!bucket_ok) {
+    rowinfo.release(); gen.release(); arena.release();
     d_dups.zero(s);
     si = sorted_index();
     run_extract_sort(g, k, fraction, shard, n_shards, si, false);
