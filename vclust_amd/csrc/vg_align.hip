@@ -1,20 +1,24 @@
 // vg_align.hip — LZ-ANI pairwise parse on gfx950.  Replaces `lz-ani all2all`
-// (vclust.py:1142-1181); restates rules R1-R8 of oracle/lz_oracle.c and is
-// parity-checked against it integer for integer.
+// (vclust.py:1142-1181); restates rules R1-R9 of oracle/lz_oracle.c and is
+// parity-checked against it integer for integer (and, through the golden example, against the
+// reference's own ani.tsv / ani.aln.tsv).
 //
 // Design: one 64-lane wavefront owns one ordered pair (query -> reference).  The parse is a
 // sequential left-to-right scan with data-dependent jumps, so the wave speculates: lane l
-// probes query position i+l (anchor lookup, then seed lookup under the prediction that no
-// earlier lane matched); a ballot + find-first picks the first hit, which is exactly the
-// sequential result.  Exact extension, the (aw, am, ar) approximate extension and the gap
-// scoring are bit-parallel: every lane compares 32 bases (one u64 of 2-bit codes) and the
-// window rule is evaluated on mismatch bit masks.  Only integers leave the kernel.
+// probes query position i+l (one walk over the bucket of its msl-mer serves the seed lookup near
+// the prediction and the anchor lookup, and the lane makes the R2/R3 choice between them); a
+// ballot + find-first picks the first hit, which is exactly the sequential result.  Exact
+// extension, the (aw, am, ar) approximate extension and the gap score (best placement of one
+// indel, R7) are bit-parallel: every lane compares 32 bases (one u64 of 2-bit codes), window rule
+// and split points are evaluated on match / mismatch bit masks with ballots.  Only integers leave.
 //
 // Reference side: per reference genome, RR = forward | N | reverse complement is materialised
-// 2-bit packed (+ N mask), with two direct-address indexes built on the device: anchors
-// (mal-mers, hashed into 2^B buckets) and seeds (msl-mers, 4^msl buckets).  This is integer,
-// latency-bound work: no MFMA, the levers are occupancy and L2 locality of the reference
-// (tasks are grouped by reference and dealt to workgroups XCD-aware).
+// 2-bit packed (+ N mask) with ONE direct-address index built on the device: 4^msl buckets of
+// entries pos | tag, tag = the bases behind the msl-mer (an anchor candidate is an entry whose tag
+// equals the query's).  The strands are separate worlds: every extension, window and gap score is
+// clipped to the strand of its match (the oracle's long separator).  Integer, latency-bound work:
+// no MFMA, the levers are occupancy and L2 locality of the reference (tasks are grouped by
+// reference and dealt to workgroups XCD-aware).
 #include "vg_common.h"
 #include <algorithm>
 #include <numeric>
