@@ -127,3 +127,27 @@ def test_many_regions_per_task(tmp_path):
     orc.run_cli('align', '-o', tmp_path / 'o.tsv', '--out-aln', tmp_path / 'o_aln.tsv', fa)
     assert filecmp.cmp(tmp_path / 'ani.tsv', tmp_path / 'o.tsv', shallow=False)
     assert sorted(open(tmp_path / 'aln.tsv').read().splitlines()) == sorted(open(tmp_path / 'o_aln.tsv').read().splitlines())
+
+
+@pytest.mark.parametrize('k', [15, 30])
+def test_bucket_pipeline_key_widths(k):
+    """The own index pipeline at the ends of the k range with two partition levels: k = 15 (30 key bits: the
+    narrow 8-byte level-2 records with few bits left) and k = 30 (60 key bits: the wide 12-byte records),
+    2 000 genomes x 8 kb; sizes and counts equal the oracle's, dense and as four shards (compact source)."""
+    codes, offsets, names = synth.make_families(200, 10, length=8000, seed=23)
+    gs = api.GenomeSet.from_codes(codes, offsets, names)
+    osizes, opairs = orc.shared_all(codes, offsets, k=k)
+    api.profile_enable(True); api.profile_reset()
+    sizes, pairs = gs.kmer_shared(k=k)
+    scopes = {e['name'] for e in api.profile_get()}
+    api.profile_enable(False)
+    assert 'kmer_partition2' in scopes and 'bucket_sort_runs' in scopes and 'radix_sort_pairs' not in scopes
+    assert list(sizes) == list(osizes)
+    assert {(int(p['a']), int(p['b'])): int(p['shared']) for p in pairs} == opairs
+    tot = np.zeros(len(gs), dtype=np.int64); acc = {}
+    for sh in range(4):
+        sz, pr = gs.kmer_shared(k=k, shard=sh, n_shards=4)
+        tot += sz
+        for p in pr:
+            acc[(int(p['a']), int(p['b']))] = acc.get((int(p['a']), int(p['b'])), 0) + int(p['shared'])
+    assert list(tot) == list(osizes) and acc == opairs
