@@ -153,6 +153,9 @@ def test_hip_output_against_reference_goldens(tmp_path, golden_dir):
     assert sum(len(v) for v in gr.values()) == 5693
     assert [(k, x) for k, v in gr.items() for x in v if x not in mr.get(k, ())] == []
     assert {(k, x[:7]) for k, v in mr.items() for x in v if x not in gr.get(k, ())} == KNOWN_SURPLUS
+    # the step after the path: Clusty's golden output follows from the files the HIP path wrote
+    from test_oracle_golden import single_linkage_partition, golden_partition
+    assert single_linkage_partition(mine, tmp_path / 'ani.ids.tsv') == golden_partition(golden_dir)
 
 
 @pytest.fixture(scope='module')

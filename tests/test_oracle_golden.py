@@ -194,3 +194,43 @@ def test_oracle_under_sanitizers(tmp_path, golden_dir):
             assert p.returncode == 0 and 'runtime error' not in p.stderr and 'AddressSanitizer' not in p.stderr, p.stderr[-2000:]
         for ext in ('fltr', 'tsv', 'aln'):
             assert filecmp.cmp(tmp_path / f'{name}_asan.{ext}', tmp_path / f'{name}_plain.{ext}', shallow=False)
+
+
+def single_linkage_partition(ani_tsv, ids_tsv, metric='tani', threshold=0.95):
+    """Test-side restatement of what `vclust cluster --metric tani --tani 0.95` (single linkage, the default
+    algorithm, vclust.py:466-480) does with the two files of the align stage: objects are the
+    rows of the ids file, two objects are linked when a row of ani.tsv has metric >= threshold."""
+    ids = [r[0] for r in read_tsv(ids_tsv)[1:]]
+    parent = {x: x for x in ids}
+
+    def find(x):
+        while parent[x] != x:
+            parent[x] = parent[parent[x]]
+            x = parent[x]
+        return x
+    rows = read_tsv(ani_tsv)
+    col = rows[0].index(metric); qc = rows[0].index('query'); rc = rows[0].index('reference')
+    for r in rows[1:]:
+        if float(r[col]) >= threshold:
+            parent[find(r[qc])] = find(r[rc])
+    groups = collections.defaultdict(set)
+    for x in ids:
+        groups[find(x)].add(x)
+    return sorted(sorted(g) for g in groups.values())
+
+
+def golden_partition(golden_dir):
+    groups = collections.defaultdict(set)
+    for obj, cl in read_tsv(golden_dir / 'output' / 'clusters.tsv')[1:]:
+        groups[cl].add(obj)
+    return sorted(sorted(g) for g in groups.values())
+
+
+def test_cluster_handoff_reproduces_golden_clusters(oracle_align, golden_dir):
+    """The step after the path: ani.tsv + ani.ids.tsv are Clusty's input.  bin/clusty is not part
+    of this repository (CPU tool, out of scope), so the contract is checked on its golden OUTPUT: single
+    linkage at tANI >= 0.95 (the setting that reproduces the golden file from the reference's own ani.tsv) over our files gives the partition of example/output/clusters.tsv -- first over the
+    reference's own ani.tsv (the restatement of the clustering is right), then over ours."""
+    want = golden_partition(golden_dir)
+    assert single_linkage_partition(golden_dir / 'output' / 'ani.tsv', golden_dir / 'output' / 'ani.ids.tsv') == want
+    assert single_linkage_partition(oracle_align / 'ani.tsv', oracle_align / 'ani.ids.tsv') == want
