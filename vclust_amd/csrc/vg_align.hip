@@ -1054,7 +1054,6 @@ inline int grid_for(int64_t n, int block = 256, int max_blocks = 256 * 16) {
 
 static int64_t g_index_budget_bytes = 24LL << 30;
 static int64_t g_segment_task_limit = 32768;
-static int g_bucket_shift = 2;
 
 extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks, const vg_lz_params* p,
                            vg_pair_stat* stats, vg_region** regions, int64_t* n_regions) {
@@ -1092,114 +1091,153 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
     std::vector<vg_region> h_regions;                 // all kept regions, batch after batch
     std::vector<vg_pair_stat> h_stats;                // host copy of the rows (sizes the region buffer)
 
-    int64_t pos = 0;
-    while (pos < n_tasks) {
-        // take references until the index budget is used
+    // ---- plan: references are taken in id order, batch after batch, each batch's indexes under the budget.
+    // (Building batch b + 1 on a second stream while batch b is parsed was measured: the 160 KiB-LDS build
+    // workgroups and the parse waves only split the CUs between them, 321 vs 319 ms at 100 k genomes -- so
+    // the batches run back to back on the library stream, as few and as large as the budget allows.)
+    struct lz_batch {
+        int64_t pos = 0, end = 0;
         std::vector<ref_desc> refs; std::vector<int64_t> chunk_off{ 0 };
-        int64_t rr_words = 0, mask_words = 0, atab_n = 0, aent_n = 0, stab_tot = 0, sent_n = 0, bytes = 0;
-        int64_t end = pos;
+        std::vector<task_dev> td;
+        std::vector<int> small_list, large_list; std::vector<int64_t> large_chunks{ 0 };
+        int64_t rr_words = 0, mask_words = 0, stab_tot = 0, sent_n = 0, scratch_words = 0, stride = 0;
+        int nblk_build = 0;
+        double bytes_alg = 0; int64_t q_max = 0, q_sum = 0;          // SURVEY 8(d) bytes of the batch; longest / total query
+    };
+    auto ref_need = [&](uint32_t r, int64_t* chunks_out) {
+        const int64_t n_rr = 2 * g->len[r] + 1;
+        const int64_t chunks = (n_rr + RR_PAD + 31) / 32 + 2;
+        if (chunks_out) *chunks_out = chunks;
+        return chunks * 12 + (stab_n + n_rr) * 4;
+    };
+    const int64_t batch_budget = g_index_budget_bytes;
+    std::vector<lz_batch> batches;
+    for (int64_t pos = 0; pos < n_tasks;) {
+        batches.emplace_back();
+        lz_batch& B = batches.back();
+        B.pos = pos;
+        int64_t end = pos, bytes = 0;
         while (end < n_tasks) {
-            const uint32_t r = tasks[order[end]].r;
+            const uint32_t r = tasks[order[(size_t)end]].r;
             const int64_t L = g->len[r]; const int64_t n_rr = 2 * L + 1;
-            const bool small = n_rr <= (1 << 21) && p->msl <= 7;
-            // anchor buckets: ~1 entry per bucket for short references, 4-8 per bucket above 2^16 symbols
-            int B = 8; while ((1LL << (B + 1)) <= n_rr && B + 1 <= 2 * p->mal && B < 26) ++B;
-            if (small && B > 14) B = std::min(18, std::max(14, B - g_bucket_shift));
-            const int64_t chunks = (n_rr + RR_PAD + 31) / 32 + 2;
-            const int64_t need = chunks * 12 + (stab_n + n_rr) * 4;
-            if (!refs.empty() && bytes + need > g_index_budget_bytes) break;
+            int64_t chunks = 0; const int64_t need = ref_need(r, &chunks);
+            if (!B.refs.empty() && bytes + need > batch_budget) break;
             ref_desc rd; memset(&rd, 0, sizeof rd);
-            rd.rr_w = rr_words; rd.mask_w = mask_words; rd.atab = atab_n; rd.aent = aent_n; rd.stab = stab_tot; rd.sent = sent_n;
-            rd.L = (int32_t)L; rd.n_rr = (int32_t)n_rr; rd.B = B; rd.genome = (int32_t)r; rd.has_n = g->has_n[r];
+            rd.rr_w = B.rr_words; rd.mask_w = B.mask_words; rd.stab = B.stab_tot; rd.sent = B.sent_n;
+            rd.L = (int32_t)L; rd.n_rr = (int32_t)n_rr; rd.B = 0; rd.genome = (int32_t)r; rd.has_n = g->has_n[r];
             { int pb = 1; while ((1LL << pb) < n_rr) ++pb; rd.pos_bits = pb; }
             rd.tag_bits = std::max(0, std::min({ 2 * (p->mal - p->msl), 14, 32 - rd.pos_bits }));
-            refs.push_back(rd);
-            rr_words += chunks * 2; mask_words += chunks; stab_tot += stab_n; sent_n += n_rr;
-            chunk_off.push_back(chunk_off.back() + chunks);
+            B.refs.push_back(rd);
+            B.rr_words += chunks * 2; B.mask_words += chunks; B.stab_tot += stab_n; B.sent_n += n_rr;
+            B.chunk_off.push_back(B.chunk_off.back() + chunks);
             bytes += need;
-            while (end < n_tasks && tasks[order[end]].r == r) ++end;
+            while (end < n_tasks && tasks[order[(size_t)end]].r == r) ++end;
         }
-        const int n_refs = (int)refs.size();
-        double bytes_alg = 0; int64_t q_max = 0, q_sum = 0;          // SURVEY 8(d) bytes of the batch; longest / total query
-        std::vector<task_dev> td((size_t)(end - pos));
+        B.end = end;
+        B.td.resize((size_t)(end - pos));
         {
             int slot = -1; uint32_t cur = 0xffffffffu;
             for (int64_t t = pos; t < end; ++t) {
-                const vg_task& tk = tasks[order[t]];
+                const vg_task& tk = tasks[order[(size_t)t]];
                 if (tk.r != cur) { cur = tk.r; ++slot; }
-                td[(size_t)(t - pos)] = { tk.q, (uint32_t)slot, (uint32_t)order[t], 0 };
+                B.td[(size_t)(t - pos)] = { tk.q, (uint32_t)slot, (uint32_t)order[(size_t)t], 0 };
                 const int64_t ql = g->len[tk.q];
-                bytes_alg += (double)(ql + g->len[tk.r]) / 4.0 + 20.0;
-                q_max = std::max(q_max, ql); q_sum += ql;
+                B.bytes_alg += (double)(ql + g->len[tk.r]) / 4.0 + 20.0;
+                B.q_max = std::max(B.q_max, ql); B.q_sum += ql;
             }
         }
-        dbuf<ref_desc> d_refs((size_t)n_refs); d_refs.upload(refs.data(), refs.size(), s);
-        dbuf<uint32_t> rr_pool((size_t)rr_words + 8), mask_pool((size_t)mask_words + 8), atab_pool((size_t)atab_n + 4), aent_pool((size_t)aent_n + 4),
-            stab_pool((size_t)stab_tot), sent_pool((size_t)sent_n + 4);
-        dbuf<task_dev> d_tasks(td.size()); d_tasks.upload(td.data(), td.size(), s);
         // split the batch: LDS counting sort for ordinary references, global path for the rest
-        std::vector<int> small_list, large_list; std::vector<int64_t> large_chunks{ 0 };
+        const int n_refs = (int)B.refs.size();
         for (int i = 0; i < n_refs; ++i) {
-            const bool small = refs[i].n_rr <= (1 << 21) && p->msl <= 7;
-            if (small) small_list.push_back(i);
-            else { large_list.push_back(i); large_chunks.push_back(large_chunks.back() + (chunk_off[i + 1] - chunk_off[i])); }
+            const bool small = B.refs[(size_t)i].n_rr <= (1 << 21) && p->msl <= 7;
+            if (small) B.small_list.push_back(i);
+            else { B.large_list.push_back(i); B.large_chunks.push_back(B.large_chunks.back() + (B.chunk_off[(size_t)i + 1] - B.chunk_off[(size_t)i])); }
         }
         // longest references first: the persistent workgroups take them round-robin, so their loads even out
-        std::stable_sort(small_list.begin(), small_list.end(), [&](int x, int y) { return refs[x].n_rr > refs[y].n_rr; });
-        dbuf<int> d_small(std::max<size_t>(1, small_list.size())), d_large(std::max<size_t>(1, large_list.size()));
-        dbuf<int64_t> d_lchunk(large_chunks.size());
-        if (!small_list.empty()) d_small.upload(small_list.data(), small_list.size(), s);
-        if (!large_list.empty()) { d_large.upload(large_list.data(), large_list.size(), s); d_lchunk.upload(large_chunks.data(), large_chunks.size(), s); }
-        const int64_t total_chunks = chunk_off.back();
+        std::stable_sort(B.small_list.begin(), B.small_list.end(), [&](int x, int y) { return B.refs[(size_t)x].n_rr > B.refs[(size_t)y].n_rr; });
+        if (!B.small_list.empty()) {
+            int64_t max_rr = 0; for (int i : B.small_list) max_rr = std::max<int64_t>(max_rr, B.refs[(size_t)i].n_rr);
+            B.nblk_build = (int)std::min<size_t>(B.small_list.size(), 512);
+            B.stride = (max_rr + 63) / 64 * 64;
+            B.scratch_words = (int64_t)B.nblk_build * B.stride * 3;
+        }
+        pos = end;
+    }
+    // ---- one set of device buffers, sized for the largest batch and reused by every batch
+    struct lz_slot {
+        dbuf<ref_desc> d_refs; dbuf<uint32_t> rr_pool, mask_pool, stab_pool, sent_pool, scratch, none; dbuf<task_dev> d_tasks;
+        dbuf<int> d_small, d_large; dbuf<int64_t> d_lchunk;
+    };
+    lz_slot slot;
+    {
+        size_t m_refs = 1, m_rr = 0, m_mask = 0, m_stab = 1, m_sent = 0, m_scr = 1, m_td = 1, m_small = 1, m_large = 1, m_lch = 1;
+        for (auto& B : batches) {
+            m_refs = std::max(m_refs, B.refs.size()); m_rr = std::max(m_rr, (size_t)B.rr_words); m_mask = std::max(m_mask, (size_t)B.mask_words);
+            m_stab = std::max(m_stab, (size_t)B.stab_tot); m_sent = std::max(m_sent, (size_t)B.sent_n); m_scr = std::max(m_scr, (size_t)B.scratch_words);
+            m_td = std::max(m_td, B.td.size()); m_small = std::max(m_small, B.small_list.size()); m_large = std::max(m_large, B.large_list.size());
+            m_lch = std::max(m_lch, B.large_chunks.size());
+        }
+        {
+            lz_slot& L = slot;
+            L.d_refs.alloc(m_refs); L.rr_pool.alloc(m_rr + 8); L.mask_pool.alloc(m_mask + 8); L.stab_pool.alloc(m_stab); L.sent_pool.alloc(m_sent + 4);
+            L.scratch.alloc(m_scr); L.none.alloc(4); L.d_tasks.alloc(m_td); L.d_small.alloc(m_small); L.d_large.alloc(m_large); L.d_lchunk.alloc(m_lch);
+        }
+    }
+    hipStream_t sb = s;
+    static const char* seg_env = getenv("VG_LZ_SEGMENTS");
+    for (size_t bi = 0; bi < batches.size(); ++bi) {
+        lz_batch& B = batches[bi];
+        lz_slot& L = slot;
+        const int n_refs = (int)B.refs.size();
+        L.d_refs.upload(B.refs.data(), B.refs.size(), sb);
+        L.d_tasks.upload(B.td.data(), B.td.size(), sb);
+        if (!B.small_list.empty()) L.d_small.upload(B.small_list.data(), B.small_list.size(), sb);
+        if (!B.large_list.empty()) { L.d_large.upload(B.large_list.data(), B.large_list.size(), sb); L.d_lchunk.upload(B.large_chunks.data(), B.large_chunks.size(), sb); }
+        const int64_t total_chunks = B.chunk_off.back();
         {
             vg_prof_scope ps("lz_build_index", (double)total_chunks * 32 * (0.375 + 0.375 + 4));
-            if (!large_list.empty()) stab_pool.zero(s);
-            if (!small_list.empty()) {
-                int64_t max_rr = 0; for (int i : small_list) max_rr = std::max<int64_t>(max_rr, refs[i].n_rr);
-                const int nblk = (int)std::min<size_t>(small_list.size(), 512);
-                const int64_t stride = (max_rr + 63) / 64 * 64;
-                dbuf<uint32_t> scratch((size_t)nblk * stride * 3);
-                hipLaunchKernelGGL(k_build_index_lds, dim3(nblk), dim3(1024), 0, s, d_refs.p, d_small.p, (int)small_list.size(),
-                                   g->d_packed.p, g->d_nmask.p, g->d_base_off.p, rr_pool.p, mask_pool.p, p->mal, p->msl, atab_pool.p,
-                                   aent_pool.p, stab_pool.p, sent_pool.p, scratch.p, stride);
+            if (!B.large_list.empty()) VG_HIP(hipMemsetAsync(L.stab_pool.p, 0, (size_t)B.stab_tot * sizeof(uint32_t), sb));
+            if (!B.small_list.empty()) {
+                hipLaunchKernelGGL(k_build_index_lds, dim3(B.nblk_build), dim3(1024), 0, sb, L.d_refs.p, L.d_small.p, (int)B.small_list.size(),
+                                   g->d_packed.p, g->d_nmask.p, g->d_base_off.p, L.rr_pool.p, L.mask_pool.p, p->mal, p->msl, L.none.p,
+                                   L.none.p, L.stab_pool.p, L.sent_pool.p, L.scratch.p, B.stride);
             }
-            if (!large_list.empty()) {
-                const int nl = (int)large_list.size(); const int64_t lc = large_chunks.back();
-                hipLaunchKernelGGL(k_build_rr, dim3(grid_for(lc)), dim3(256), 0, s, d_refs.p, d_large.p, nl, d_lchunk.p, g->d_packed.p,
-                                   g->d_nmask.p, g->d_base_off.p, rr_pool.p, mask_pool.p);
-                hipLaunchKernelGGL(k_index_pass, dim3(grid_for(lc * 32)), dim3(256), 0, s, d_refs.p, d_large.p, nl, d_lchunk.p, rr_pool.p,
-                                   mask_pool.p, p->mal, p->msl, 0, atab_pool.p, aent_pool.p, stab_pool.p, sent_pool.p);
-                hipLaunchKernelGGL(k_scan_tables, dim3(nl), dim3(256), 0, s, d_refs.p, d_large.p, p->msl, atab_pool.p, stab_pool.p);
-                hipLaunchKernelGGL(k_index_pass, dim3(grid_for(lc * 32)), dim3(256), 0, s, d_refs.p, d_large.p, nl, d_lchunk.p, rr_pool.p,
-                                   mask_pool.p, p->mal, p->msl, 1, atab_pool.p, aent_pool.p, stab_pool.p, sent_pool.p);
+            if (!B.large_list.empty()) {
+                const int nl = (int)B.large_list.size(); const int64_t lc = B.large_chunks.back();
+                hipLaunchKernelGGL(k_build_rr, dim3(grid_for(lc)), dim3(256), 0, sb, L.d_refs.p, L.d_large.p, nl, L.d_lchunk.p, g->d_packed.p,
+                                   g->d_nmask.p, g->d_base_off.p, L.rr_pool.p, L.mask_pool.p);
+                hipLaunchKernelGGL(k_index_pass, dim3(grid_for(lc * 32)), dim3(256), 0, sb, L.d_refs.p, L.d_large.p, nl, L.d_lchunk.p, L.rr_pool.p,
+                                   L.mask_pool.p, p->mal, p->msl, 0, L.none.p, L.none.p, L.stab_pool.p, L.sent_pool.p);
+                hipLaunchKernelGGL(k_scan_tables, dim3(nl), dim3(256), 0, sb, L.d_refs.p, L.d_large.p, p->msl, L.none.p, L.stab_pool.p);
+                hipLaunchKernelGGL(k_index_pass, dim3(grid_for(lc * 32)), dim3(256), 0, sb, L.d_refs.p, L.d_large.p, nl, L.d_lchunk.p, L.rr_pool.p,
+                                   L.mask_pool.p, p->mal, p->msl, 1, L.none.p, L.none.p, L.stab_pool.p, L.sent_pool.p);
             }
         }
         {
-            const int64_t nt = end - pos;
-            vg_prof_scope ps("lz_parse", bytes_alg);
+            const int64_t nt = B.end - B.pos;
+            vg_prof_scope ps("lz_parse", B.bytes_alg);
             // Four waves per pair (segments) shorten the critical path: worth it when the launch would
             // otherwise last as long as its slowest pair -- few tasks, or queries several times longer than
             // the average one (mixed contig sets).  With many uniform tasks one wave per pair keeps every
             // SIMD busy without the duplicated stretches.
-            static const char* seg_env = getenv("VG_LZ_SEGMENTS");
-            const bool uneven = q_max * nt > 3 * q_sum;
-            const bool segments = seg_env ? atoi(seg_env) > 1 : (nt <= g_segment_task_limit || uneven);
+            const bool uneven = B.q_max * nt > 3 * B.q_sum;
+            const bool segments = seg_env ? atoi(seg_env) > 1 : ((n_tasks <= g_segment_task_limit && nt <= g_segment_task_limit) || uneven);
             const unsigned long long* no_off = nullptr;
             if (segments && P.ablate == 0 && nt < (1LL << 31)) {
                 const int64_t nblk = (nt + 7) / 8 * 8;
-                hipLaunchKernelGGL(k_lz_parse_seg, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p, nt, d_refs.p, g->d_packed.p, g->d_nmask.p,
-                                   g->d_base_off.p, g->d_len.p, g->d_has_n.p, rr_pool.p, mask_pool.p, atab_pool.p, aent_pool.p, stab_pool.p,
-                                   sent_pool.p, P, d_stats.p, (vg_region*)nullptr, no_off);
+                hipLaunchKernelGGL(k_lz_parse_seg, dim3((unsigned)nblk), dim3(256), 0, s, L.d_tasks.p, nt, L.d_refs.p, g->d_packed.p, g->d_nmask.p,
+                                   g->d_base_off.p, g->d_len.p, g->d_has_n.p, L.rr_pool.p, L.mask_pool.p, L.none.p, L.none.p, L.stab_pool.p,
+                                   L.sent_pool.p, P, d_stats.p, (vg_region*)nullptr, no_off);
             } else {
                 const int64_t nblk = ((nt + 3) / 4 + 7) / 8 * 8;
                 if (P.ablate) {
-                    hipLaunchKernelGGL(k_lz_parse_dev, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p, nt, d_refs.p, g->d_packed.p, g->d_nmask.p,
-                                   g->d_base_off.p, g->d_len.p, g->d_has_n.p, rr_pool.p, mask_pool.p, atab_pool.p, aent_pool.p, stab_pool.p,
-                                   sent_pool.p, P, d_stats.p, (vg_region*)nullptr, no_off);
+                    hipLaunchKernelGGL(k_lz_parse_dev, dim3((unsigned)nblk), dim3(256), 0, s, L.d_tasks.p, nt, L.d_refs.p, g->d_packed.p, g->d_nmask.p,
+                                   g->d_base_off.p, g->d_len.p, g->d_has_n.p, L.rr_pool.p, L.mask_pool.p, L.none.p, L.none.p, L.stab_pool.p,
+                                   L.sent_pool.p, P, d_stats.p, (vg_region*)nullptr, no_off);
                 } else {
-                    hipLaunchKernelGGL(k_lz_parse, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p, nt, d_refs.p, g->d_packed.p, g->d_nmask.p,
-                                   g->d_base_off.p, g->d_len.p, g->d_has_n.p, rr_pool.p, mask_pool.p, atab_pool.p, aent_pool.p, stab_pool.p,
-                                   sent_pool.p, P, d_stats.p, (vg_region*)nullptr, no_off);
+                    hipLaunchKernelGGL(k_lz_parse, dim3((unsigned)nblk), dim3(256), 0, s, L.d_tasks.p, nt, L.d_refs.p, g->d_packed.p, g->d_nmask.p,
+                                   g->d_base_off.p, g->d_len.p, g->d_has_n.p, L.rr_pool.p, L.mask_pool.p, L.none.p, L.none.p, L.stab_pool.p,
+                                   L.sent_pool.p, P, d_stats.p, (vg_region*)nullptr, no_off);
                 }
             }
             if (want_regions) {
@@ -1210,15 +1248,15 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
                 d_stats.download(h_stats.data(), (size_t)n_tasks, s);
                 VG_HIP(hipStreamSynchronize(s));
                 std::vector<unsigned long long> off((size_t)nt + 1, 0);
-                for (int64_t t = 0; t < nt; ++t) off[(size_t)t + 1] = off[(size_t)t] + h_stats[td[(size_t)t].out_idx].n_regions;
+                for (int64_t t = 0; t < nt; ++t) off[(size_t)t + 1] = off[(size_t)t] + h_stats[B.td[(size_t)t].out_idx].n_regions;
                 const unsigned long long nr = off[(size_t)nt];
                 if (nr) {
                     dbuf<unsigned long long> d_off((size_t)nt + 1); d_off.upload(off.data(), off.size(), s);
                     dbuf<vg_region> d_regions((size_t)nr);
                     const int64_t nblk = ((nt + 3) / 4 + 7) / 8 * 8;
-                    hipLaunchKernelGGL(k_lz_parse, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p, nt, d_refs.p, g->d_packed.p, g->d_nmask.p,
-                                   g->d_base_off.p, g->d_len.p, g->d_has_n.p, rr_pool.p, mask_pool.p, atab_pool.p, aent_pool.p, stab_pool.p,
-                                   sent_pool.p, P, d_stats.p, d_regions.p, (const unsigned long long*)d_off.p);
+                    hipLaunchKernelGGL(k_lz_parse, dim3((unsigned)nblk), dim3(256), 0, s, L.d_tasks.p, nt, L.d_refs.p, g->d_packed.p, g->d_nmask.p,
+                                   g->d_base_off.p, g->d_len.p, g->d_has_n.p, L.rr_pool.p, L.mask_pool.p, L.none.p, L.none.p, L.stab_pool.p,
+                                   L.sent_pool.p, P, d_stats.p, d_regions.p, (const unsigned long long*)d_off.p);
                     const size_t at = h_regions.size();
                     h_regions.resize(at + (size_t)nr);
                     d_regions.download(h_regions.data() + at, (size_t)nr, s);
@@ -1226,10 +1264,9 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
                 }
             }
         }
-        VG_HIP(hipStreamSynchronize(s));
-        VG_HIP(hipGetLastError());
-        pos = end;
     }
+    VG_HIP(hipStreamSynchronize(s));
+    VG_HIP(hipGetLastError());
     d_stats.download(stats, (size_t)n_tasks, s);
     VG_HIP(hipStreamSynchronize(s));
     if (want_regions) {

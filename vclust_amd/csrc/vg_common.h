@@ -59,8 +59,8 @@ template <class T> struct dbuf {
 
 // ---------------------------------------------------------------- profiling (HIP events on vg_stream)
 struct vg_prof_scope {
-    const char* name; double bytes; hipEvent_t e0 = nullptr, e1 = nullptr; bool on;
-    vg_prof_scope(const char* name, double algorithmic_bytes = 0);
+    const char* name; double bytes; hipEvent_t e0 = nullptr, e1 = nullptr; bool on; hipStream_t stream;
+    vg_prof_scope(const char* name, double algorithmic_bytes = 0, hipStream_t on_stream = nullptr);   // nullptr: the library stream
     ~vg_prof_scope();
 };
 bool vg_profile_on();

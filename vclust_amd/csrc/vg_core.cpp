@@ -131,15 +131,16 @@ static std::mutex g_prof_mu;
 
 bool vg_profile_on() { return g_prof; }
 
-vg_prof_scope::vg_prof_scope(const char* nm, double b) : name(nm), bytes(b), on(g_prof) {
+vg_prof_scope::vg_prof_scope(const char* nm, double b, hipStream_t st) : name(nm), bytes(b), on(g_prof), stream(st) {
     if (!on) return;
-    hipStream_t s = vg_stream();
+    if (!stream) stream = vg_stream();
+    hipStream_t s = stream;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { on = false; return; }
     (void)hipEventRecord(e0, s);
 }
 vg_prof_scope::~vg_prof_scope() {
     if (!on) return;
-    (void)hipEventRecord(e1, vg_stream());
+    (void)hipEventRecord(e1, stream);
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_pending.push_back({ name, e0, e1, bytes });
 }
