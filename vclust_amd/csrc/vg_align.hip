@@ -32,13 +32,10 @@ constexpr uint64_t EVEN = 0x5555555555555555ULL;
 struct ref_desc {
     int64_t rr_w;      // word offset of packed RR
     int64_t mask_w;    // word offset of RR mask
-    int64_t atab;      // offset into anchor bucket table pool (2^B entries: END of each bucket)
-    int64_t aent;      // offset into anchor entry pool
-    int64_t stab;      // seed bucket table (4^msl entries: END of each bucket)
-    int64_t sent;      // seed entry pool
+    int64_t stab;      // offset into the bucket table pool (4^msl entries: END of each bucket)
+    int64_t sent;      // offset into the entry pool (one entry per RR position whose msl-mer is valid)
     int32_t L;         // forward length
     int32_t n_rr;      // 2L + 1
-    int32_t B;         // anchor bucket bits
     int32_t genome;    // genome id
     int32_t has_n;     // reference genome contains N
     int32_t pos_bits;  // index entry = pos | tag << pos_bits
@@ -388,28 +385,11 @@ __device__ __forceinline__ void rr_chunk(const uint32_t* __restrict__ gpk, const
     *bits_out = bits & ~sm; *mask_out = mask;
 }
 
-// Multiplicative hash of an anchor code; bucket = its top B bits, tag = the bits below.  Codes of up to 16
-// bases (the default mal = 11) fit 32 bits: two 32-bit multiplies instead of a 64-bit one (integer
-// multiplies issue at quarter rate, and every reference position and every probed query position pays one).
-__device__ __forceinline__ uint64_t anchor_hash(uint64_t code, bool narrow) {
-    if (narrow) {
-        const uint32_t h = (uint32_t)code * 0x9E3779B1u;
-        return ((uint64_t)h << 32) | (uint32_t)(h * 0x85EBCA77u + (uint32_t)code);
-    }
-    return code * 0x9E3779B97F4A7C15ULL;
-}
-__device__ __forceinline__ uint32_t anchor_bucket(uint64_t h, int B) { return (uint32_t)(h >> (64 - B)); }
 // Tag of the index entry of RR position p (x = the bases from p on, first base in the low bits): the bases
 // that follow its msl-mer.  An anchor lookup keeps the entries whose tag equals the query's: they agree with
 // the query on msl + tag_bits / 2 bases without a look at the sequence (the exact length decides the rest).
-__device__ __forceinline__ uint32_t seed_tag(uint64_t x, int p, int n_rr, int L, int msl, int tag_bits) {
-    (void)p; (void)n_rr; (void)L;
+__device__ __forceinline__ uint32_t seed_tag(uint64_t x, int msl, int tag_bits) {
     return tag_bits ? (uint32_t)((x >> (2 * msl)) & ((1u << tag_bits) - 1u)) : 0u;
-}
-__device__ __forceinline__ uint32_t anchor_tag(uint64_t h, int B, int pos_bits) {
-    // up to 14 hash bits below the bucket bits, as many as fit above pos_bits in a 32-bit entry
-    const int tb = (32 - pos_bits) < 14 ? (32 - pos_bits) : 14;
-    return (uint32_t)((h << B) >> 48) & ((1u << tb) - 1u);
 }
 
 // ---- path A (references up to 2^21 RR symbols, msl <= 7): one 1024-thread workgroup builds RR
@@ -443,7 +423,6 @@ __global__ void __launch_bounds__(1024)
 k_build_index_lds(const ref_desc* __restrict__ refs, const int* __restrict__ slot_list, int n_list,
                   const uint32_t* __restrict__ packed, const uint32_t* __restrict__ nmask, const int64_t* __restrict__ base_off,
                   uint32_t* __restrict__ rr_pool, uint32_t* __restrict__ mask_pool, int mal, int msl,
-                  uint32_t* __restrict__ atab_pool, uint32_t* __restrict__ aent_pool,
                   uint32_t* __restrict__ stab_pool, uint32_t* __restrict__ sent_pool,
                   uint32_t* __restrict__ scratch_pool, int64_t scratch_stride) {
     __shared__ uint32_t tab[LDS_TAB];
@@ -454,8 +433,8 @@ k_build_index_lds(const ref_desc* __restrict__ refs, const int* __restrict__ slo
     // per workgroup: (bucket | tag << 18) per RR position, then the (bucket|tag, position) list by top-level bin
     uint32_t* scratch = scratch_pool + (int64_t)blockIdx.x * scratch_stride * 3;
     uint2* binned = reinterpret_cast<uint2*>(scratch + scratch_stride);
-    const uint64_t amask = (mal >= 32) ? ~0ULL : ((1ULL << (2 * mal)) - 1);
     const uint64_t smask = (1ULL << (2 * msl)) - 1;
+    (void)mal;
     for (int li = blockIdx.x; li < n_list; li += gridDim.x) {
         const ref_desc rd = refs[slot_list[li]];
         const int64_t g0 = base_off[rd.genome];
@@ -469,11 +448,11 @@ k_build_index_lds(const ref_desc* __restrict__ refs, const int* __restrict__ slo
         }
         __threadfence_block();
         __syncthreads();
-        for (int phase = 1; phase < 2; ++phase) {          // one index: msl-mer buckets, entries tagged with the bases that follow
-            const int nbits = phase == 0 ? rd.B : 2 * msl;
-            const int w = phase == 0 ? mal : msl;
-            uint32_t* gtab = phase == 0 ? atab_pool + rd.atab : stab_pool + rd.stab;
-            uint32_t* gent = phase == 0 ? aent_pool + rd.aent : sent_pool + rd.sent;
+        {   // one index: msl-mer buckets, entries tagged with the bases that follow
+            const int nbits = 2 * msl;
+            const int w = msl;
+            uint32_t* gtab = stab_pool + rd.stab;
+            uint32_t* gent = sent_pool + rd.sent;
             const bool big = rd.n_rr >= BIG_RR || nbits > 14;
             // pass 0: bucket (and tag) of every position -> scratch; sizes of the buckets (plain path) or
             // of the 512 top-level bins (big path).  4 consecutive positions out of one 128-bit window.
@@ -494,10 +473,7 @@ k_build_index_lds(const ref_desc* __restrict__ refs, const int* __restrict__ slo
                     uint32_t bt = 0xffffffffu;
                     if (p + w <= rd.n_rr && ((ml >> j) & ((1ULL << w) - 1)) == 0) {
                         const uint64_t x = s2 ? ((lo >> s2) | (hi << (64 - s2))) : lo;
-                        if (phase == 0) {
-                            const uint64_t h = anchor_hash(x & amask, mal <= 16);
-                            bt = anchor_bucket(h, rd.B) | (anchor_tag(h, rd.B, rd.pos_bits) << 18);
-                        } else bt = (uint32_t)(x & smask) | (seed_tag(x, p, rd.n_rr, rd.L, msl, rd.tag_bits) << 18);
+                        bt = (uint32_t)(x & smask) | (seed_tag(x, msl, rd.tag_bits) << 18);
                         atomicAdd(&tab[(bt & 0x3ffffu) >> (big ? tsh : 0)], 1u);
                     }
                     out[j] = bt;
@@ -654,11 +630,11 @@ k_build_rr(const ref_desc* __restrict__ refs, const int* __restrict__ slot_list,
 __global__ void __launch_bounds__(256)
 k_index_pass(const ref_desc* __restrict__ refs, const int* __restrict__ slot_list, int n_list, const int64_t* __restrict__ chunk_off,
              const uint32_t* __restrict__ rr_pool, const uint32_t* __restrict__ mask_pool, int mal, int msl, int fill,
-             uint32_t* __restrict__ atab_pool, uint32_t* __restrict__ aent_pool, uint32_t* __restrict__ stab_pool,
+             uint32_t* __restrict__ stab_pool,
              uint32_t* __restrict__ sent_pool) {
     const int64_t total = chunk_off[n_list] * 32;
     const uint64_t smask = (1ULL << (2 * msl)) - 1;
-    (void)mal; (void)atab_pool; (void)aent_pool;
+    (void)mal;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         int64_t chunk = t >> 5;
         int lo = 0, hi = n_list - 1;
@@ -673,7 +649,7 @@ k_index_pass(const ref_desc* __restrict__ refs, const int* __restrict__ slot_lis
         if (p + msl <= rd.n_rr && (m & ((1ULL << msl) - 1)) == 0) {
             uint32_t b = (uint32_t)(x & smask);
             uint32_t slot = atomicAdd(&stab_pool[rd.stab + b], 1u);
-            if (fill) sent_pool[rd.sent + slot] = (uint32_t)p | (seed_tag(x, (int)p, rd.n_rr, rd.L, msl, rd.tag_bits) << rd.pos_bits);
+            if (fill) sent_pool[rd.sent + slot] = (uint32_t)p | (seed_tag(x, msl, rd.tag_bits) << rd.pos_bits);
         }
     }
 }
@@ -681,13 +657,12 @@ k_index_pass(const ref_desc* __restrict__ refs, const int* __restrict__ slot_lis
 // exclusive scan of each bucket table, one workgroup per (reference, table)
 __global__ void __launch_bounds__(256)
 k_scan_tables(const ref_desc* __restrict__ refs, const int* __restrict__ slot_list, int msl,
-              uint32_t* __restrict__ atab_pool, uint32_t* __restrict__ stab_pool) {
+              uint32_t* __restrict__ stab_pool) {
     __shared__ uint32_t part[256];
     __shared__ uint32_t carry;
     const ref_desc rd = refs[slot_list[blockIdx.x]];
-    const bool seed = true;                                  // one table per reference: the msl-mer buckets
-    uint32_t* tab = seed ? stab_pool + rd.stab : atab_pool + rd.atab;
-    const int64_t n = seed ? (1LL << (2 * msl)) : (1LL << rd.B);
+    uint32_t* tab = stab_pool + rd.stab;                    // one table per reference: the msl-mer buckets
+    const int64_t n = 1LL << (2 * msl);
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
     for (int64_t base = 0; base < n; base += 256 * 8) {
@@ -731,11 +706,10 @@ struct seg_rec { int i_ev, ev_pos; uint32_t VM, VA, VN; };     // VN: bit 31 = o
     const uint32_t* __restrict__ packed, const uint32_t* __restrict__ nmask, const int64_t* __restrict__ base_off, \
     const int64_t* __restrict__ glen, const uint8_t* __restrict__ g_has_n, \
     const uint32_t* __restrict__ rr_pool, const uint32_t* __restrict__ mask_pool, \
-    const uint32_t* __restrict__ atab_pool, const uint32_t* __restrict__ aent_pool, \
     const uint32_t* __restrict__ stab_pool, const uint32_t* __restrict__ sent_pool, \
     lz_dev_params P, vg_pair_stat* __restrict__ stats, \
     vg_region* __restrict__ regions, const unsigned long long* __restrict__ region_off
-#define PARSE_ARG_NAMES tasks, n_tasks, refs, packed, nmask, base_off, glen, g_has_n, rr_pool, mask_pool, atab_pool, aent_pool, \
+#define PARSE_ARG_NAMES tasks, n_tasks, refs, packed, nmask, base_off, glen, g_has_n, rr_pool, mask_pool, \
     stab_pool, sent_pool, P, stats, regions, region_off
 
 template <int S, bool DEV>
@@ -757,9 +731,7 @@ __device__ __forceinline__ void lz_parse_body(PARSE_ARGS) {
     const int64_t qb = base_off[tk.q];
     c.qpk = packed + (qb >> 4); c.qmk = nmask + (qb >> 5); c.qlen = (int)glen[tk.q]; c.q_has_n = g_has_n[tk.q];
     c.rpk = rr_pool + rd.rr_w; c.rmk = mask_pool + rd.mask_w; c.n_rr = rd.n_rr; c.L = rd.L; c.r_has_n = rd.has_n;
-    const uint32_t* atab = atab_pool + rd.atab; const uint32_t* aent = aent_pool + rd.aent;
     const uint32_t* stab = stab_pool + rd.stab; const uint32_t* sent = sent_pool + rd.sent;
-    const uint64_t amask = (P.mal >= 32) ? ~0ULL : ((1ULL << (2 * P.mal)) - 1);
     const uint64_t smask = (1ULL << (2 * P.msl)) - 1;
 
     const long long t_start = (ABL & (32 | 1024)) ? (long long)wall_clock64() : 0;
@@ -1124,7 +1096,7 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
             if (!B.refs.empty() && bytes + need > batch_budget) break;
             ref_desc rd; memset(&rd, 0, sizeof rd);
             rd.rr_w = B.rr_words; rd.mask_w = B.mask_words; rd.stab = B.stab_tot; rd.sent = B.sent_n;
-            rd.L = (int32_t)L; rd.n_rr = (int32_t)n_rr; rd.B = 0; rd.genome = (int32_t)r; rd.has_n = g->has_n[r];
+            rd.L = (int32_t)L; rd.n_rr = (int32_t)n_rr; rd.genome = (int32_t)r; rd.has_n = g->has_n[r];
             { int pb = 1; while ((1LL << pb) < n_rr) ++pb; rd.pos_bits = pb; }
             rd.tag_bits = std::max(0, std::min({ 2 * (p->mal - p->msl), 14, 32 - rd.pos_bits }));
             B.refs.push_back(rd);
@@ -1165,7 +1137,7 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
     }
     // ---- one set of device buffers, sized for the largest batch and reused by every batch
     struct lz_slot {
-        dbuf<ref_desc> d_refs; dbuf<uint32_t> rr_pool, mask_pool, stab_pool, sent_pool, scratch, none; dbuf<task_dev> d_tasks;
+        dbuf<ref_desc> d_refs; dbuf<uint32_t> rr_pool, mask_pool, stab_pool, sent_pool, scratch; dbuf<task_dev> d_tasks;
         dbuf<int> d_small, d_large; dbuf<int64_t> d_lchunk;
     };
     lz_slot slot;
@@ -1180,7 +1152,7 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
         {
             lz_slot& L = slot;
             L.d_refs.alloc(m_refs); L.rr_pool.alloc(m_rr + 8); L.mask_pool.alloc(m_mask + 8); L.stab_pool.alloc(m_stab); L.sent_pool.alloc(m_sent + 4);
-            L.scratch.alloc(m_scr); L.none.alloc(4); L.d_tasks.alloc(m_td); L.d_small.alloc(m_small); L.d_large.alloc(m_large); L.d_lchunk.alloc(m_lch);
+            L.scratch.alloc(m_scr); L.d_tasks.alloc(m_td); L.d_small.alloc(m_small); L.d_large.alloc(m_large); L.d_lchunk.alloc(m_lch);
         }
     }
     hipStream_t sb = s;
@@ -1199,18 +1171,18 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
             if (!B.large_list.empty()) VG_HIP(hipMemsetAsync(L.stab_pool.p, 0, (size_t)B.stab_tot * sizeof(uint32_t), sb));
             if (!B.small_list.empty()) {
                 hipLaunchKernelGGL(k_build_index_lds, dim3(B.nblk_build), dim3(1024), 0, sb, L.d_refs.p, L.d_small.p, (int)B.small_list.size(),
-                                   g->d_packed.p, g->d_nmask.p, g->d_base_off.p, L.rr_pool.p, L.mask_pool.p, p->mal, p->msl, L.none.p,
-                                   L.none.p, L.stab_pool.p, L.sent_pool.p, L.scratch.p, B.stride);
+                                   g->d_packed.p, g->d_nmask.p, g->d_base_off.p, L.rr_pool.p, L.mask_pool.p, p->mal, p->msl,
+                                   L.stab_pool.p, L.sent_pool.p, L.scratch.p, B.stride);
             }
             if (!B.large_list.empty()) {
                 const int nl = (int)B.large_list.size(); const int64_t lc = B.large_chunks.back();
                 hipLaunchKernelGGL(k_build_rr, dim3(grid_for(lc)), dim3(256), 0, sb, L.d_refs.p, L.d_large.p, nl, L.d_lchunk.p, g->d_packed.p,
                                    g->d_nmask.p, g->d_base_off.p, L.rr_pool.p, L.mask_pool.p);
                 hipLaunchKernelGGL(k_index_pass, dim3(grid_for(lc * 32)), dim3(256), 0, sb, L.d_refs.p, L.d_large.p, nl, L.d_lchunk.p, L.rr_pool.p,
-                                   L.mask_pool.p, p->mal, p->msl, 0, L.none.p, L.none.p, L.stab_pool.p, L.sent_pool.p);
-                hipLaunchKernelGGL(k_scan_tables, dim3(nl), dim3(256), 0, sb, L.d_refs.p, L.d_large.p, p->msl, L.none.p, L.stab_pool.p);
+                                   L.mask_pool.p, p->mal, p->msl, 0, L.stab_pool.p, L.sent_pool.p);
+                hipLaunchKernelGGL(k_scan_tables, dim3(nl), dim3(256), 0, sb, L.d_refs.p, L.d_large.p, p->msl, L.stab_pool.p);
                 hipLaunchKernelGGL(k_index_pass, dim3(grid_for(lc * 32)), dim3(256), 0, sb, L.d_refs.p, L.d_large.p, nl, L.d_lchunk.p, L.rr_pool.p,
-                                   L.mask_pool.p, p->mal, p->msl, 1, L.none.p, L.none.p, L.stab_pool.p, L.sent_pool.p);
+                                   L.mask_pool.p, p->mal, p->msl, 1, L.stab_pool.p, L.sent_pool.p);
             }
         }
         {
@@ -1226,17 +1198,17 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
             if (segments && P.ablate == 0 && nt < (1LL << 31)) {
                 const int64_t nblk = (nt + 7) / 8 * 8;
                 hipLaunchKernelGGL(k_lz_parse_seg, dim3((unsigned)nblk), dim3(256), 0, s, L.d_tasks.p, nt, L.d_refs.p, g->d_packed.p, g->d_nmask.p,
-                                   g->d_base_off.p, g->d_len.p, g->d_has_n.p, L.rr_pool.p, L.mask_pool.p, L.none.p, L.none.p, L.stab_pool.p,
+                                   g->d_base_off.p, g->d_len.p, g->d_has_n.p, L.rr_pool.p, L.mask_pool.p, L.stab_pool.p,
                                    L.sent_pool.p, P, d_stats.p, (vg_region*)nullptr, no_off);
             } else {
                 const int64_t nblk = ((nt + 3) / 4 + 7) / 8 * 8;
                 if (P.ablate) {
                     hipLaunchKernelGGL(k_lz_parse_dev, dim3((unsigned)nblk), dim3(256), 0, s, L.d_tasks.p, nt, L.d_refs.p, g->d_packed.p, g->d_nmask.p,
-                                   g->d_base_off.p, g->d_len.p, g->d_has_n.p, L.rr_pool.p, L.mask_pool.p, L.none.p, L.none.p, L.stab_pool.p,
+                                   g->d_base_off.p, g->d_len.p, g->d_has_n.p, L.rr_pool.p, L.mask_pool.p, L.stab_pool.p,
                                    L.sent_pool.p, P, d_stats.p, (vg_region*)nullptr, no_off);
                 } else {
                     hipLaunchKernelGGL(k_lz_parse, dim3((unsigned)nblk), dim3(256), 0, s, L.d_tasks.p, nt, L.d_refs.p, g->d_packed.p, g->d_nmask.p,
-                                   g->d_base_off.p, g->d_len.p, g->d_has_n.p, L.rr_pool.p, L.mask_pool.p, L.none.p, L.none.p, L.stab_pool.p,
+                                   g->d_base_off.p, g->d_len.p, g->d_has_n.p, L.rr_pool.p, L.mask_pool.p, L.stab_pool.p,
                                    L.sent_pool.p, P, d_stats.p, (vg_region*)nullptr, no_off);
                 }
             }
@@ -1255,7 +1227,7 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
                     dbuf<vg_region> d_regions((size_t)nr);
                     const int64_t nblk = ((nt + 3) / 4 + 7) / 8 * 8;
                     hipLaunchKernelGGL(k_lz_parse, dim3((unsigned)nblk), dim3(256), 0, s, L.d_tasks.p, nt, L.d_refs.p, g->d_packed.p, g->d_nmask.p,
-                                   g->d_base_off.p, g->d_len.p, g->d_has_n.p, L.rr_pool.p, L.mask_pool.p, L.none.p, L.none.p, L.stab_pool.p,
+                                   g->d_base_off.p, g->d_len.p, g->d_has_n.p, L.rr_pool.p, L.mask_pool.p, L.stab_pool.p,
                                    L.sent_pool.p, P, d_stats.p, d_regions.p, (const unsigned long long*)d_off.p);
                     const size_t at = h_regions.size();
                     h_regions.resize(at + (size_t)nr);
