@@ -1043,16 +1043,30 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
     for (int i = 0; i < g->n; ++i) if (g->len[i] > (1 << 29)) throw vg_error(VG_EOVERFLOW, "genome longer than 2^29 bases");
     if (n_tasks >= (1LL << 32)) throw vg_error(VG_EOVERFLOW, "more than 2^32 - 1 ordered pairs in one call: split the task list");
 
-    // group tasks by reference: counting sort on the reference id (stable, O(n)); ids are checked on the way
-    std::vector<int64_t> order((size_t)n_tasks);
+    // group tasks by reference: ONE stable counting sort writes the device task records of the whole call,
+    // (query, ordinal of the reference among the references that have tasks, position in the caller's list);
+    // ids are checked on the way.  (The GPU waits for this list: it is built once, not per batch.)
+    std::vector<task_dev> td((size_t)n_tasks);
+    std::vector<int64_t> ref_first((size_t)g->n + 1, 0);     // first sorted task of reference r
+    std::vector<uint32_t> ref_ids;                            // references that have tasks, ascending
+    int64_t q_max = 0; double q_sum = 0, bytes_alg_all = 0;
     {
-        std::vector<int64_t> start((size_t)g->n + 1, 0);
         for (int64_t t = 0; t < n_tasks; ++t) {
             if (tasks[t].q >= (uint32_t)g->n || tasks[t].r >= (uint32_t)g->n) throw vg_error(VG_EINVAL, "task id out of range");
-            start[tasks[t].r + 1]++;
+            ref_first[tasks[t].r + 1]++;
         }
-        for (int i = 0; i < g->n; ++i) start[i + 1] += start[i];
-        for (int64_t t = 0; t < n_tasks; ++t) order[(size_t)start[tasks[t].r]++] = t;
+        std::vector<uint32_t> ord((size_t)g->n, 0);
+        for (int i = 0; i < g->n; ++i) {
+            if (ref_first[(size_t)i + 1]) { ord[(size_t)i] = (uint32_t)ref_ids.size(); ref_ids.push_back((uint32_t)i); }
+            ref_first[(size_t)i + 1] += ref_first[(size_t)i];
+        }
+        std::vector<int64_t> cur(ref_first.begin(), ref_first.end() - 1);
+        for (int64_t t = 0; t < n_tasks; ++t) {
+            const vg_task& tk = tasks[t];
+            td[(size_t)cur[tk.r]++] = { tk.q, ord[tk.r], (uint32_t)t, 0 };
+            const int64_t ql = g->len[tk.q];
+            q_max = std::max(q_max, ql); q_sum += (double)ql; bytes_alg_all += (double)(ql + g->len[tk.r]) / 4.0 + 20.0;
+        }
     }
     const char* abl = getenv("VG_LZ_ABLATE");
     const lz_dev_params P{ p->mal, p->msl, p->mrd, p->mqd, p->reg, p->aw, p->am, p->ar, abl ? atoi(abl) : 0 };
@@ -1068,9 +1082,9 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
     // workgroups and the parse waves only split the CUs between them, 321 vs 319 ms at 100 k genomes -- so
     // the batches run back to back on the library stream, as few and as large as the budget allows.)
     struct lz_batch {
-        int64_t pos = 0, end = 0;
-        std::vector<ref_desc> refs; std::vector<int64_t> chunk_off{ 0 };
-        std::vector<task_dev> td;
+        int64_t pos = 0, end = 0;            // sorted task range
+        int first_ref = 0, n_refs = 0;       // reference ordinals [first_ref, first_ref + n_refs)
+        std::vector<int64_t> chunk_off{ 0 };
         std::vector<int> small_list, large_list; std::vector<int64_t> large_chunks{ 0 };
         int64_t rr_words = 0, mask_words = 0, stab_tot = 0, sent_n = 0, scratch_words = 0, stride = 0;
         int nblk_build = 0;
@@ -1084,85 +1098,82 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
     };
     const int64_t batch_budget = g_index_budget_bytes;
     std::vector<lz_batch> batches;
-    for (int64_t pos = 0; pos < n_tasks;) {
+    std::vector<ref_desc> all_refs(ref_ids.size());           // indexed by the reference ordinal the task records carry
+    for (size_t ri = 0; ri < ref_ids.size();) {
         batches.emplace_back();
         lz_batch& B = batches.back();
-        B.pos = pos;
-        int64_t end = pos, bytes = 0;
-        while (end < n_tasks) {
-            const uint32_t r = tasks[order[(size_t)end]].r;
+        B.first_ref = (int)ri;
+        B.pos = ref_first[ref_ids[ri]];
+        int64_t bytes = 0;
+        while (ri < ref_ids.size()) {
+            const uint32_t r = ref_ids[ri];
             const int64_t L = g->len[r]; const int64_t n_rr = 2 * L + 1;
             int64_t chunks = 0; const int64_t need = ref_need(r, &chunks);
-            if (!B.refs.empty() && bytes + need > batch_budget) break;
+            if (B.n_refs > 0 && bytes + need > batch_budget) break;
             ref_desc rd; memset(&rd, 0, sizeof rd);
             rd.rr_w = B.rr_words; rd.mask_w = B.mask_words; rd.stab = B.stab_tot; rd.sent = B.sent_n;
             rd.L = (int32_t)L; rd.n_rr = (int32_t)n_rr; rd.genome = (int32_t)r; rd.has_n = g->has_n[r];
             { int pb = 1; while ((1LL << pb) < n_rr) ++pb; rd.pos_bits = pb; }
             rd.tag_bits = std::max(0, std::min({ 2 * (p->mal - p->msl), 14, 32 - rd.pos_bits }));
-            B.refs.push_back(rd);
+            all_refs[ri] = rd;
             B.rr_words += chunks * 2; B.mask_words += chunks; B.stab_tot += stab_n; B.sent_n += n_rr;
             B.chunk_off.push_back(B.chunk_off.back() + chunks);
-            bytes += need;
-            while (end < n_tasks && tasks[order[(size_t)end]].r == r) ++end;
+            bytes += need; ++B.n_refs; ++ri;
         }
-        B.end = end;
-        B.td.resize((size_t)(end - pos));
-        {
-            int slot = -1; uint32_t cur = 0xffffffffu;
-            for (int64_t t = pos; t < end; ++t) {
-                const vg_task& tk = tasks[order[(size_t)t]];
-                if (tk.r != cur) { cur = tk.r; ++slot; }
-                B.td[(size_t)(t - pos)] = { tk.q, (uint32_t)slot, (uint32_t)order[(size_t)t], 0 };
-                const int64_t ql = g->len[tk.q];
-                B.bytes_alg += (double)(ql + g->len[tk.r]) / 4.0 + 20.0;
-                B.q_max = std::max(B.q_max, ql); B.q_sum += ql;
-            }
-        }
+        B.end = ri < ref_ids.size() ? ref_first[ref_ids[ri]] : n_tasks;
+        B.bytes_alg = bytes_alg_all * (double)(B.end - B.pos) / (double)n_tasks;       // the call's SURVEY 8(d) bytes, by task share
+        B.q_max = q_max; B.q_sum = (int64_t)(q_sum * (double)(B.end - B.pos) / (double)n_tasks);
+        const int n_refs = B.n_refs;
         // split the batch: LDS counting sort for ordinary references, global path for the rest
-        const int n_refs = (int)B.refs.size();
         for (int i = 0; i < n_refs; ++i) {
-            const bool small = B.refs[(size_t)i].n_rr <= (1 << 21) && p->msl <= 7;
-            if (small) B.small_list.push_back(i);
-            else { B.large_list.push_back(i); B.large_chunks.push_back(B.large_chunks.back() + (B.chunk_off[(size_t)i + 1] - B.chunk_off[(size_t)i])); }
+            const int gi = B.first_ref + i;                      // ordinal = index into all_refs / the device array
+            const bool small = all_refs[(size_t)gi].n_rr <= (1 << 21) && p->msl <= 7;
+            if (small) B.small_list.push_back(gi);
+            else { B.large_list.push_back(gi); B.large_chunks.push_back(B.large_chunks.back() + (B.chunk_off[(size_t)i + 1] - B.chunk_off[(size_t)i])); }
         }
         // longest references first: the persistent workgroups take them round-robin, so their loads even out
-        std::stable_sort(B.small_list.begin(), B.small_list.end(), [&](int x, int y) { return B.refs[(size_t)x].n_rr > B.refs[(size_t)y].n_rr; });
+        // (nothing to even out when the lengths are within 25 % of each other)
+        {
+            int32_t mn = INT32_MAX, mx = 0;
+            for (int i : B.small_list) { mn = std::min(mn, all_refs[(size_t)i].n_rr); mx = std::max(mx, all_refs[(size_t)i].n_rr); }
+            if (!B.small_list.empty() && (int64_t)mx * 4 > (int64_t)mn * 5) {
+                std::vector<uint64_t> keyed(B.small_list.size());
+                for (size_t i = 0; i < keyed.size(); ++i) keyed[i] = ((uint64_t)(0x7fffffffu - (uint32_t)all_refs[(size_t)B.small_list[i]].n_rr) << 32) | (uint32_t)B.small_list[i];
+                std::sort(keyed.begin(), keyed.end());           // length descending, ordinal ascending (= the stable order)
+                for (size_t i = 0; i < keyed.size(); ++i) B.small_list[i] = (int)(uint32_t)keyed[i];
+            }
+        }
         if (!B.small_list.empty()) {
-            int64_t max_rr = 0; for (int i : B.small_list) max_rr = std::max<int64_t>(max_rr, B.refs[(size_t)i].n_rr);
+            int64_t max_rr = 0; for (int i : B.small_list) max_rr = std::max<int64_t>(max_rr, all_refs[(size_t)i].n_rr);
             B.nblk_build = (int)std::min<size_t>(B.small_list.size(), 512);
             B.stride = (max_rr + 63) / 64 * 64;
             B.scratch_words = (int64_t)B.nblk_build * B.stride * 3;
         }
-        pos = end;
     }
-    // ---- one set of device buffers, sized for the largest batch and reused by every batch
-    struct lz_slot {
-        dbuf<ref_desc> d_refs; dbuf<uint32_t> rr_pool, mask_pool, stab_pool, sent_pool, scratch; dbuf<task_dev> d_tasks;
-        dbuf<int> d_small, d_large; dbuf<int64_t> d_lchunk;
-    };
+    // ---- the task records and reference descriptors of the whole call go up once; one set of index buffers,
+    // sized for the largest batch, is reused by every batch
+    dbuf<ref_desc> d_refs(std::max<size_t>(1, all_refs.size())); dbuf<task_dev> d_tasks((size_t)n_tasks);
+    if (!all_refs.empty()) d_refs.upload(all_refs.data(), all_refs.size(), s);
+    d_tasks.upload(td.data(), td.size(), s);
+    struct lz_slot { dbuf<uint32_t> rr_pool, mask_pool, stab_pool, sent_pool, scratch; dbuf<int> d_small, d_large; dbuf<int64_t> d_lchunk; };
     lz_slot slot;
     {
-        size_t m_refs = 1, m_rr = 0, m_mask = 0, m_stab = 1, m_sent = 0, m_scr = 1, m_td = 1, m_small = 1, m_large = 1, m_lch = 1;
+        size_t m_rr = 0, m_mask = 0, m_stab = 1, m_sent = 0, m_scr = 1, m_small = 1, m_large = 1, m_lch = 1;
         for (auto& B : batches) {
-            m_refs = std::max(m_refs, B.refs.size()); m_rr = std::max(m_rr, (size_t)B.rr_words); m_mask = std::max(m_mask, (size_t)B.mask_words);
+            m_rr = std::max(m_rr, (size_t)B.rr_words); m_mask = std::max(m_mask, (size_t)B.mask_words);
             m_stab = std::max(m_stab, (size_t)B.stab_tot); m_sent = std::max(m_sent, (size_t)B.sent_n); m_scr = std::max(m_scr, (size_t)B.scratch_words);
-            m_td = std::max(m_td, B.td.size()); m_small = std::max(m_small, B.small_list.size()); m_large = std::max(m_large, B.large_list.size());
+            m_small = std::max(m_small, B.small_list.size()); m_large = std::max(m_large, B.large_list.size());
             m_lch = std::max(m_lch, B.large_chunks.size());
         }
-        {
-            lz_slot& L = slot;
-            L.d_refs.alloc(m_refs); L.rr_pool.alloc(m_rr + 8); L.mask_pool.alloc(m_mask + 8); L.stab_pool.alloc(m_stab); L.sent_pool.alloc(m_sent + 4);
-            L.scratch.alloc(m_scr); L.d_tasks.alloc(m_td); L.d_small.alloc(m_small); L.d_large.alloc(m_large); L.d_lchunk.alloc(m_lch);
-        }
+        lz_slot& L = slot;
+        L.rr_pool.alloc(m_rr + 8); L.mask_pool.alloc(m_mask + 8); L.stab_pool.alloc(m_stab); L.sent_pool.alloc(m_sent + 4);
+        L.scratch.alloc(m_scr); L.d_small.alloc(m_small); L.d_large.alloc(m_large); L.d_lchunk.alloc(m_lch);
     }
     hipStream_t sb = s;
     static const char* seg_env = getenv("VG_LZ_SEGMENTS");
     for (size_t bi = 0; bi < batches.size(); ++bi) {
         lz_batch& B = batches[bi];
         lz_slot& L = slot;
-        const int n_refs = (int)B.refs.size();
-        L.d_refs.upload(B.refs.data(), B.refs.size(), sb);
-        L.d_tasks.upload(B.td.data(), B.td.size(), sb);
         if (!B.small_list.empty()) L.d_small.upload(B.small_list.data(), B.small_list.size(), sb);
         if (!B.large_list.empty()) { L.d_large.upload(B.large_list.data(), B.large_list.size(), sb); L.d_lchunk.upload(B.large_chunks.data(), B.large_chunks.size(), sb); }
         const int64_t total_chunks = B.chunk_off.back();
@@ -1170,18 +1181,18 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
             vg_prof_scope ps("lz_build_index", (double)total_chunks * 32 * (0.375 + 0.375 + 4));
             if (!B.large_list.empty()) VG_HIP(hipMemsetAsync(L.stab_pool.p, 0, (size_t)B.stab_tot * sizeof(uint32_t), sb));
             if (!B.small_list.empty()) {
-                hipLaunchKernelGGL(k_build_index_lds, dim3(B.nblk_build), dim3(1024), 0, sb, L.d_refs.p, L.d_small.p, (int)B.small_list.size(),
+                hipLaunchKernelGGL(k_build_index_lds, dim3(B.nblk_build), dim3(1024), 0, sb, d_refs.p, L.d_small.p, (int)B.small_list.size(),
                                    g->d_packed.p, g->d_nmask.p, g->d_base_off.p, L.rr_pool.p, L.mask_pool.p, p->mal, p->msl,
                                    L.stab_pool.p, L.sent_pool.p, L.scratch.p, B.stride);
             }
             if (!B.large_list.empty()) {
                 const int nl = (int)B.large_list.size(); const int64_t lc = B.large_chunks.back();
-                hipLaunchKernelGGL(k_build_rr, dim3(grid_for(lc)), dim3(256), 0, sb, L.d_refs.p, L.d_large.p, nl, L.d_lchunk.p, g->d_packed.p,
+                hipLaunchKernelGGL(k_build_rr, dim3(grid_for(lc)), dim3(256), 0, sb, d_refs.p, L.d_large.p, nl, L.d_lchunk.p, g->d_packed.p,
                                    g->d_nmask.p, g->d_base_off.p, L.rr_pool.p, L.mask_pool.p);
-                hipLaunchKernelGGL(k_index_pass, dim3(grid_for(lc * 32)), dim3(256), 0, sb, L.d_refs.p, L.d_large.p, nl, L.d_lchunk.p, L.rr_pool.p,
+                hipLaunchKernelGGL(k_index_pass, dim3(grid_for(lc * 32)), dim3(256), 0, sb, d_refs.p, L.d_large.p, nl, L.d_lchunk.p, L.rr_pool.p,
                                    L.mask_pool.p, p->mal, p->msl, 0, L.stab_pool.p, L.sent_pool.p);
-                hipLaunchKernelGGL(k_scan_tables, dim3(nl), dim3(256), 0, sb, L.d_refs.p, L.d_large.p, p->msl, L.stab_pool.p);
-                hipLaunchKernelGGL(k_index_pass, dim3(grid_for(lc * 32)), dim3(256), 0, sb, L.d_refs.p, L.d_large.p, nl, L.d_lchunk.p, L.rr_pool.p,
+                hipLaunchKernelGGL(k_scan_tables, dim3(nl), dim3(256), 0, sb, d_refs.p, L.d_large.p, p->msl, L.stab_pool.p);
+                hipLaunchKernelGGL(k_index_pass, dim3(grid_for(lc * 32)), dim3(256), 0, sb, d_refs.p, L.d_large.p, nl, L.d_lchunk.p, L.rr_pool.p,
                                    L.mask_pool.p, p->mal, p->msl, 1, L.stab_pool.p, L.sent_pool.p);
             }
         }
@@ -1197,17 +1208,17 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
             const unsigned long long* no_off = nullptr;
             if (segments && P.ablate == 0 && nt < (1LL << 31)) {
                 const int64_t nblk = (nt + 7) / 8 * 8;
-                hipLaunchKernelGGL(k_lz_parse_seg, dim3((unsigned)nblk), dim3(256), 0, s, L.d_tasks.p, nt, L.d_refs.p, g->d_packed.p, g->d_nmask.p,
+                hipLaunchKernelGGL(k_lz_parse_seg, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p + B.pos, nt, d_refs.p, g->d_packed.p, g->d_nmask.p,
                                    g->d_base_off.p, g->d_len.p, g->d_has_n.p, L.rr_pool.p, L.mask_pool.p, L.stab_pool.p,
                                    L.sent_pool.p, P, d_stats.p, (vg_region*)nullptr, no_off);
             } else {
                 const int64_t nblk = ((nt + 3) / 4 + 7) / 8 * 8;
                 if (P.ablate) {
-                    hipLaunchKernelGGL(k_lz_parse_dev, dim3((unsigned)nblk), dim3(256), 0, s, L.d_tasks.p, nt, L.d_refs.p, g->d_packed.p, g->d_nmask.p,
+                    hipLaunchKernelGGL(k_lz_parse_dev, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p + B.pos, nt, d_refs.p, g->d_packed.p, g->d_nmask.p,
                                    g->d_base_off.p, g->d_len.p, g->d_has_n.p, L.rr_pool.p, L.mask_pool.p, L.stab_pool.p,
                                    L.sent_pool.p, P, d_stats.p, (vg_region*)nullptr, no_off);
                 } else {
-                    hipLaunchKernelGGL(k_lz_parse, dim3((unsigned)nblk), dim3(256), 0, s, L.d_tasks.p, nt, L.d_refs.p, g->d_packed.p, g->d_nmask.p,
+                    hipLaunchKernelGGL(k_lz_parse, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p + B.pos, nt, d_refs.p, g->d_packed.p, g->d_nmask.p,
                                    g->d_base_off.p, g->d_len.p, g->d_has_n.p, L.rr_pool.p, L.mask_pool.p, L.stab_pool.p,
                                    L.sent_pool.p, P, d_stats.p, (vg_region*)nullptr, no_off);
                 }
@@ -1220,13 +1231,13 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
                 d_stats.download(h_stats.data(), (size_t)n_tasks, s);
                 VG_HIP(hipStreamSynchronize(s));
                 std::vector<unsigned long long> off((size_t)nt + 1, 0);
-                for (int64_t t = 0; t < nt; ++t) off[(size_t)t + 1] = off[(size_t)t] + h_stats[B.td[(size_t)t].out_idx].n_regions;
+                for (int64_t t = 0; t < nt; ++t) off[(size_t)t + 1] = off[(size_t)t] + h_stats[td[(size_t)(B.pos + t)].out_idx].n_regions;
                 const unsigned long long nr = off[(size_t)nt];
                 if (nr) {
                     dbuf<unsigned long long> d_off((size_t)nt + 1); d_off.upload(off.data(), off.size(), s);
                     dbuf<vg_region> d_regions((size_t)nr);
                     const int64_t nblk = ((nt + 3) / 4 + 7) / 8 * 8;
-                    hipLaunchKernelGGL(k_lz_parse, dim3((unsigned)nblk), dim3(256), 0, s, L.d_tasks.p, nt, L.d_refs.p, g->d_packed.p, g->d_nmask.p,
+                    hipLaunchKernelGGL(k_lz_parse, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p + B.pos, nt, d_refs.p, g->d_packed.p, g->d_nmask.p,
                                    g->d_base_off.p, g->d_len.p, g->d_has_n.p, L.rr_pool.p, L.mask_pool.p, L.stab_pool.p,
                                    L.sent_pool.p, P, d_stats.p, d_regions.p, (const unsigned long long*)d_off.p);
                     const size_t at = h_regions.size();
