@@ -61,7 +61,10 @@ hipStream_t vg_stream() {
     return g_stream;
 }
 
-int vg_host_threads() { static int n = (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())); return n; }
+int vg_host_threads() {
+    static int n = [] { const char* e = getenv("VG_HOST_THREADS"); int v = e ? atoi(e) : (int)std::min(8u, std::thread::hardware_concurrency()); return std::max(1, std::min(v, 64)); }();
+    return n;
+}
 
 // ---------------------------------------------------------------- caching device allocator
 namespace {
