@@ -843,20 +843,20 @@ k_part_scatter(part_src S, int B1, int B2, int unit_tiles, int64_t n_units, cons
             }
             __syncthreads();
             const uint32_t n_tile = tstart[nbins - 1] + thist[nbins - 1];
-            // records leave as a flat word stream: consecutive threads write consecutive words of consecutive
-            // records, so a bin's segment of the tile is ONE contiguous run of 12 (8) bytes per element
-            const uint32_t ow = narrow_shift >= 0 ? 2u : 3u;
-            for (uint32_t f = threadIdx.x; f < n_tile * ow; f += PT_THREADS) {
-                const uint32_t slot = f / ow, cpt = f - slot * ow;
+            // one record per thread and trip, stored with ONE 12-byte (8-byte) instruction: consecutive threads
+            // hold consecutive slots, so a wave writes each bin's segment of the tile as one contiguous run
+            for (uint32_t slot = threadIdx.x; slot < n_tile; slot += PT_THREADS) {
                 const uint32_t w = s_w0[slot];
                 const uint32_t b = LEVEL == 1 ? (B1 ? (w >> (32 - B1)) : 0u) : ((w >> (32 - B1 - B2)) - (bfirst << B2));
-                const uint64_t dst = (uint64_t)(cursor[b] + (slot - tstart[b])) * ow + cpt;
-                uint32_t v;
+                const uint64_t dst = (uint64_t)cursor[b] + (slot - tstart[b]);
                 if (narrow_shift >= 0) {
                     // the bucket fixes the top narrow_shift key bits and at most 32 remain: one word carries them
-                    v = cpt == 0 ? (uint32_t)(((((uint64_t)w << 32) | s_w1[slot]) << narrow_shift) >> 32) : s_pay[slot];
-                } else v = cpt == 0 ? w : (cpt == 1 ? s_w1[slot] : s_pay[slot]);
-                o_rec[dst] = v;
+                    const uint2 v = make_uint2((uint32_t)(((((uint64_t)w << 32) | s_w1[slot]) << narrow_shift) >> 32), s_pay[slot]);
+                    __builtin_memcpy(o_rec + 2 * dst, &v, 8);
+                } else {
+                    const uint32_t v[3] = { w, s_w1[slot], s_pay[slot] };
+                    __builtin_memcpy(o_rec + 3 * dst, v, 12);
+                }
             }
             __syncthreads();
             for (int b = threadIdx.x; b < nbins; b += PT_THREADS) cursor[b] += thist[b];
