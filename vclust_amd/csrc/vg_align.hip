@@ -1013,8 +1013,8 @@ __device__ __forceinline__ void lz_parse_body(PARSE_ARGS) {
 #define PARSE_KERNEL(NAME, S, DEV, WAVES) \
     __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) NAME(PARSE_ARGS) { \
         lz_parse_body<S, DEV>(PARSE_ARG_NAMES); }
-PARSE_KERNEL(k_lz_parse, 1, false, 6)
-PARSE_KERNEL(k_lz_parse_seg, 4, false, 6)
+PARSE_KERNEL(k_lz_parse, 1, false, 8)
+PARSE_KERNEL(k_lz_parse_seg, 4, false, 8)
 PARSE_KERNEL(k_lz_parse_dev, 1, true, 3)
 
 inline int grid_for(int64_t n, int block = 256, int max_blocks = 256 * 16) {
