@@ -1,5 +1,5 @@
 """Randomised parity fuzzing of the HIP path against the CPU oracle (longer than the test suite).
-usage: fuzz_parity.py [n_cases] [seed]"""
+usage: fuzz_parity.py [n_cases] [seed] [big]     (big: sets of 2-30 M positions -- both partition levels of the index pipeline)"""
 import sys, pathlib, time
 import numpy as np
 root = pathlib.Path(__file__).resolve().parent.parent
@@ -9,11 +9,13 @@ from vclust_amd import api, synth
 api.set_device(0)
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+big = len(sys.argv) > 3
 bad = 0
 t0 = time.time()
 for case in range(n_cases):
     rng = np.random.default_rng(seed0 + case)
     nf = int(rng.integers(1, 5)); mem = int(rng.integers(2, 6))
+    if big: nf = int(rng.integers(40, 400))
     lo = int(rng.choice([300, 2000, 9000, 30000])); hi = lo * int(rng.integers(1, 5))
     p_hi = float(rng.choice([0.02, 0.12, 0.25, 0.4]))
     codes, offsets, names = synth.make_families(nf, mem, seed=seed0 + case, length_range=(lo, hi), p_hi=p_hi)
@@ -39,6 +41,7 @@ for case in range(n_cases):
                   aw=int(rng.integers(8, 24)), am=int(rng.integers(2, 10)), ar=int(rng.integers(2, 6)))
         lz['am'] = min(lz['am'], lz['aw'] - 1)
     tasks = gs.align_tasks(gs.read_filter(None)) if len(gs) <= 8 else gs.align_tasks(synth.family_pairs(nf, mem))
+    if big and len(tasks) > 400: tasks = tasks[np.sort(rng.choice(len(tasks) // 2, 200, replace=False))[:, None] * 2 + np.arange(2)].reshape(-1)
     stats = gs.lz_align(tasks, lz=lz)
     for t, s in zip(tasks, stats):
         q, r = int(t['q']), int(t['r'])
