@@ -203,7 +203,17 @@ def main():
             kern, stage = SCOPES.get(dom['name'], (dom['name'], 'align'))
             launches_per_step = dom['launches'] / args.steps
             avg_ms = dom['total_ms'] / dom['launches']
-            alg = stage_bytes[stage] / launches_per_step / max(world, 1)
+            stage_ms = sum(v for k, v in per_step.items() if SCOPES.get(k, (k, 'align'))[1] == stage)
+            stage_frac = stage_bytes[stage] / max(world, 1) / (stage_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            if stage == 'index':
+                # the inverted index is ONE logical pass of SURVEY 8(d) (16 B per position) implemented as several
+                # kernels (partition levels + bucket sort): a kernel of it is priced with its time share of the stage
+                alg = stage_bytes[stage] / max(world, 1) * (dom['total_ms'] / args.steps / stage_ms) / launches_per_step
+                basis = ('SURVEY 8(d) bytes of the "index" stage (16 B per position) x this kernel\'s share of the stage time, per launch, '
+                         '/ its HIP-event time on the library stream: equals the stage\'s fraction')
+            else:
+                alg = stage_bytes[stage] / launches_per_step / max(world, 1)
+                basis = f'SURVEY 8(d) bytes of the "{stage}" stage, per launch, / this kernel\'s HIP-event time on the library stream'
             achieved = alg / (avg_ms * 1e-3) / 1e9
             impl = dom['bytes'] / dom['launches']
             traffic, src = pmc_traffic(args.workload if args.count is None else f'{args.workload}/{args.count}', kern) if world == 1 else (None, None)
@@ -211,8 +221,9 @@ def main():
                 bound='hbm', kernel=kern, scope=dom['name'], achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit='GB/s',
                 frac=round(achieved / HBM_PEAK_GBS, 6), traffic=traffic, traffic_source=src,
                 avg_launch_ms=round(avg_ms, 4), launches_per_step=round(launches_per_step, 3),
-                algorithmic_bytes_per_launch=round(alg),
-                basis=f'SURVEY 8(d) bytes of the "{stage}" stage this kernel implements, per launch, / its HIP-event time on the library stream',
+                algorithmic_bytes_per_launch=round(alg), basis=basis,
+                stage=dict(name=stage, ms_per_step=round(stage_ms, 3), algorithmic_bytes_per_step=round(stage_bytes[stage] / max(world, 1)),
+                           frac=round(stage_frac, 6)),
                 implementation_bytes_per_launch=round(impl),
                 implementation_frac=round(impl / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
                 ms_per_step_by_scope={k: round(v, 3) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
