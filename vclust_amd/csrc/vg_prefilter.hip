@@ -892,13 +892,17 @@ constexpr int BK_SUBBITS = 9;
 constexpr int BK_SUB = 1 << BK_SUBBITS;
 constexpr int BK_PER = BK_CAP / BK_THREADS;
 constexpr int BK_MAXBIN = 768;           // a sub-bin beyond this (one k-mer occurring hundreds of times) takes the general path
+// NARROW: 8-byte records (key bits below the bucket's in one word, position): an entry is ONE u64 `key << 32 | pos`
+// in the LDS, so the ranking loop reads a single word per sub-bin member and every relation it needs (smaller
+// key, equal key, equal key at a smaller position, the predecessor in the run) is a compare of that word.
+template <bool NARROW>
 __global__ void __launch_bounds__(BK_THREADS)
 k_bucket_runs(const uint32_t* __restrict__ rec, int stride /* 3: (w0, w1, pay); 2: (key bits below the bucket's, pay) */,
               const uint32_t* __restrict__ boff, int64_t n_buckets, int pbits, const uint32_t* __restrict__ blk2g, int blk_shift,
               uint32_t* __restrict__ gen, uint64_t* __restrict__ rowinfo, compact_map M, int* __restrict__ dup_per_genome,
               unsigned int* __restrict__ overflow) {
-    __shared__ uint64_t sk[BK_CAP];          // (w0 << 32) | w1, in sub-bin order
-    __shared__ uint32_t sp[BK_CAP];
+    __shared__ uint64_t sk[BK_CAP];                  // NARROW: key << 32 | pos; else (w0 << 32) | w1 -- in sub-bin order
+    __shared__ uint32_t sp[NARROW ? 1 : BK_CAP];
     __shared__ uint32_t cnt[BK_SUB + 1], start[BK_SUB + 1];
     __shared__ uint32_t s_wave[BK_THREADS / 64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -917,9 +921,10 @@ k_bucket_runs(const uint32_t* __restrict__ rec, int stride /* 3: (w0, w1, pay); 
             sb[q] = 0; ar[q] = 0; key[q] = 0; pj[q] = 0;
             if (j < n) {
                 const uint32_t* r = rec + (uint64_t)(b0 + j) * stride;
-                const uint32_t a = r[0], c = stride == 3 ? r[1] : 0u;
-                key[q] = ((uint64_t)a << 32) | c; pj[q] = r[stride - 1];
-                sb[q] = (uint32_t)((key[q] << pbits) >> (64 - BK_SUBBITS));
+                const uint32_t a = r[0], c = (!NARROW && stride == 3) ? r[1] : 0u;
+                pj[q] = r[stride - 1];
+                key[q] = NARROW ? (((uint64_t)a << 32) | pj[q]) : (((uint64_t)a << 32) | c);
+                sb[q] = NARROW ? (a >> (32 - BK_SUBBITS)) : (uint32_t)((key[q] << pbits) >> (64 - BK_SUBBITS));
             }
         }
 #pragma unroll
@@ -946,7 +951,7 @@ k_bucket_runs(const uint32_t* __restrict__ rec, int stride /* 3: (w0, w1, pay); 
 #pragma unroll
         for (int q = 0; q < BK_PER; ++q) if (q * BK_THREADS + (int)threadIdx.x < n) {
             const uint32_t slot = start[sb[q]] + ar[q];
-            sk[slot] = key[q]; sp[slot] = pj[q];
+            sk[slot] = key[q]; if (!NARROW) sp[slot] = pj[q];
         }
         __syncthreads();
 #pragma unroll
@@ -957,13 +962,30 @@ k_bucket_runs(const uint32_t* __restrict__ rec, int stride /* 3: (w0, w1, pay); 
             if (s1 - s0 > BK_MAXBIN) { atomicOr(overflow, 1u); continue; }
             const uint64_t kq = key[q]; const uint32_t pq = pj[q];
             uint32_t lt = 0, eq = 0, before = 0; uint32_t prev_pay = 0; bool has_prev = false;
-            for (uint32_t t = s0; t < s1; ++t) {
-                const uint64_t kt = sk[t];
-                lt += kt < kq;
-                if (kt == kq) {
-                    ++eq;
-                    const uint32_t pt = sp[t];
-                    if (pt < pq) { ++before; if (!has_prev || pt > prev_pay) { prev_pay = pt; has_prev = true; } }
+            if (NARROW) {
+                const uint32_t kh = (uint32_t)(kq >> 32);
+                uint64_t best = 0;                               // largest entry of the same k-mer below this one
+#pragma unroll 4
+                for (uint32_t t = s0; t < s1; ++t) {
+                    const uint64_t vt = sk[t];
+                    const uint32_t th = (uint32_t)(vt >> 32);
+                    lt += th < kh;
+                    const bool same = th == kh;
+                    eq += same;
+                    const bool below = same && vt < kq;
+                    before += below;
+                    if (below && vt >= best) { best = vt; has_prev = true; }
+                }
+                prev_pay = (uint32_t)best;
+            } else {
+                for (uint32_t t = s0; t < s1; ++t) {
+                    const uint64_t kt = sk[t];
+                    lt += kt < kq;
+                    if (kt == kq) {
+                        ++eq;
+                        const uint32_t pt = sp[t];
+                        if (pt < pq) { ++before; if (!has_prev || pt > prev_pay) { prev_pay = pt; has_prev = true; } }
+                    }
                 }
             }
             if (eq < 2) continue;                                // singleton k-mer: no partner, nobody reads its gen[] slot
@@ -1225,8 +1247,10 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
     unsigned int over = 0;
     {
         vg_prof_scope ps("bucket_sort_runs", (double)n1 * ((narrow ? 8 : 12) + 4 + 8));
-        hipLaunchKernelGGL(k_bucket_runs, dim3((int)std::min<int64_t>(nbk, 256 * 16)), dim3(BK_THREADS), 0, s, f_rec, f_stride, (const uint32_t*)boff.p, nbk,
-                           narrow ? 0 : total_bits, (const uint32_t*)g->d_blk2g.p, g->align_shift, gen.p, rowinfo.p, cmap, d_dups, d_over.p);
+        if (narrow) hipLaunchKernelGGL(k_bucket_runs<true>, dim3((int)std::min<int64_t>(nbk, 256 * 16)), dim3(BK_THREADS), 0, s, f_rec, f_stride, (const uint32_t*)boff.p, nbk,
+                                       0, (const uint32_t*)g->d_blk2g.p, g->align_shift, gen.p, rowinfo.p, cmap, d_dups, d_over.p);
+        else hipLaunchKernelGGL(k_bucket_runs<false>, dim3((int)std::min<int64_t>(nbk, 256 * 16)), dim3(BK_THREADS), 0, s, f_rec, f_stride, (const uint32_t*)boff.p, nbk,
+                                total_bits, (const uint32_t*)g->d_blk2g.p, g->align_shift, gen.p, rowinfo.p, cmap, d_dups, d_over.p);
     }
     d_over.download(&over, 1, s);
     VG_HIP(hipStreamSynchronize(s));
