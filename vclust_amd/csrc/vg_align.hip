@@ -606,6 +606,149 @@ k_build_index_lds(const ref_desc* __restrict__ refs, const int* __restrict__ slo
     }
 }
 
+// ---- path A0 (references up to REG_MAX_RR symbols -- genomes below 49 kb --, msl <= 7): the same counting sort
+// with every position's (bucket, tag) and then (slot, tag) held in REGISTERS (96 per thread: three quarters of
+// the CU's register file) and the genome / RR held in the LDS, so that after the one coalesced read of the
+// genome nothing is read from global memory again.  Slots are handed out once (LDS atomics); once the bucket
+// table has been written out the whole LDS becomes the staging buffer, and the entries leave through two or
+// three fixed slot-range windows (no atomics, no window search, no scratch).  Barriers order the LDS only
+// (lds_sync), so the stores of one window -- and of one reference -- drain while the next is being prepared.
+constexpr int REG_IT = 24;                              // trips of 4 positions x 1024 threads
+constexpr int REG_MAX_RR = 4 * 1024 * REG_IT - 256;     // 98 048 RR symbols
+constexpr int REG_RR_WORDS = REG_MAX_RR / 16 + 32;
+constexpr int REG_MK_WORDS = REG_MAX_RR / 32 + 16;
+constexpr int REG_GEN_WORDS = 12288;                    // genome words + mask + scan scratch (before the windows)
+constexpr int REG_LDS_WORDS = LDS_TAB + REG_GEN_WORDS + REG_RR_WORDS + REG_MK_WORDS;
+constexpr int REG_STAGE = REG_LDS_WORDS / 1024 * 1024;  // entries per staging window: the whole LDS block
+constexpr int REG_SLOT_BITS = 17;                       // slot < n_rr < 2^17; tag (<= 14 bits) above it
+
+// workgroup barrier that waits for this wave's LDS traffic only: global stores stay in flight
+__device__ __forceinline__ void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// exclusive scan of tab[0, n) by 1024 threads (16 waves, each a contiguous slice, 64 consecutive entries per
+// trip: no bank conflicts); returns the total.  wtot: 16 words of scratch.
+__device__ __forceinline__ uint32_t lds_scan_exclusive_waves(uint32_t* tab, int n, uint32_t* wtot) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int per_wave = (((n + 15) >> 4) + 63) & ~63;
+    uint32_t carry = 0;
+    for (int r = 0; r < per_wave; r += 64) {
+        const int i = w * per_wave + r + lane;
+        const uint32_t v = i < n ? tab[i] : 0u;
+        uint32_t inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+        if (i < n) tab[i] = carry + inc - v;
+        carry += __shfl(inc, 63);
+    }
+    if (lane == 0) wtot[w] = carry;
+    lds_sync();
+    uint32_t off = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { const uint32_t t = wtot[k]; if (k < w) off += t; total += t; }
+    for (int r = 0; r < per_wave; r += 64) { const int i = w * per_wave + r + lane; if (i < n) tab[i] += off; }
+    lds_sync();
+    return total;
+}
+
+__global__ void __launch_bounds__(1024)
+k_build_index_reg(const ref_desc* __restrict__ refs, const int* __restrict__ slot_list, int n_list,
+                  const uint32_t* __restrict__ packed, const uint32_t* __restrict__ nmask, const int64_t* __restrict__ base_off,
+                  uint32_t* __restrict__ rr_pool, uint32_t* __restrict__ mask_pool, int msl,
+                  uint32_t* __restrict__ stab_pool, uint32_t* __restrict__ sent_pool) {
+    __shared__ uint32_t lds[REG_LDS_WORDS];
+    uint32_t* const tab = lds;                                   // bucket table
+    uint32_t* const gw = lds + LDS_TAB;                          // genome words, mask, scan scratch
+    uint32_t* const gm = gw + 3328; uint32_t* const wtot = gw + 8192;
+    uint32_t* const s_rr = gw + REG_GEN_WORDS;                   // RR = fwd | N | rc of the reference
+    uint32_t* const s_mk = s_rr + REG_RR_WORDS;
+    uint32_t* const stage = lds;                                 // the windows use all of it
+    const uint64_t smask = (1ULL << (2 * msl)) - 1;
+    const int nb = 1 << (2 * msl);
+    for (int li = blockIdx.x; li < n_list; li += gridDim.x) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));                            // per-position constants are recomputed per reference, not kept (and spilled) across the loop
+        const ref_desc rd = refs[slot_list[li]];
+        const int64_t g0 = base_off[rd.genome];
+        const uint32_t* gpk = packed + (g0 >> 4); const uint32_t* gmk = nmask + (g0 >> 5);
+        uint32_t* pk = rr_pool + rd.rr_w; uint32_t* mk = mask_pool + rd.mask_w;
+        uint32_t* gtab = stab_pool + rd.stab; uint32_t* gent = sent_pool + rd.sent;
+        const int n_gw = (rd.L >> 4) + 4, n_gm = (rd.L >> 5) + 3;
+        for (int i = tid; i < n_gw; i += 1024) gw[i] = gpk[i];
+        for (int i = tid; i < n_gm; i += 1024) gm[i] = gmk[i];
+        for (int i = tid; i < nb; i += 1024) tab[i] = 0;
+        lds_sync();
+        const int chunks = (rd.n_rr + RR_PAD + 31) / 32 + 2;
+        for (int ch = tid; ch < chunks; ch += 1024) {
+            uint64_t bits; uint32_t m;
+            rr_chunk(gw, gm, rd.L, ch, &bits, &m);
+            pk[2 * ch] = (uint32_t)bits; pk[2 * ch + 1] = (uint32_t)(bits >> 32); mk[ch] = m;
+            s_rr[2 * ch] = (uint32_t)bits; s_rr[2 * ch + 1] = (uint32_t)(bits >> 32); s_mk[ch] = m;
+        }
+        lds_sync();
+        // pass 0: bucket | tag << 18 of every position (4 consecutive positions out of one 128-bit window), bucket sizes
+        uint32_t reg[REG_IT][4];
+        const int n4 = (rd.n_rr + 3) & ~3;
+#pragma unroll
+        for (int it = 0; it < REG_IT; ++it) {
+            const int p0 = 4 * (tid + 1024 * it);
+            reg[it][0] = reg[it][1] = reg[it][2] = reg[it][3] = 0xffffffffu;
+            if (p0 < n4) {
+                const int wi = p0 >> 4; const int sh = 2 * (p0 & 15);
+                const uint64_t lo = (uint64_t)s_rr[wi] | ((uint64_t)s_rr[wi + 1] << 32);
+                const uint64_t hi = (uint64_t)s_rr[wi + 2] | ((uint64_t)s_rr[wi + 3] << 32);
+                const uint64_t ml = ((uint64_t)s_mk[p0 >> 5] | ((uint64_t)s_mk[(p0 >> 5) + 1] << 32)) >> (p0 & 31);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int p = p0 + j; const int s2 = sh + 2 * j;
+                    if (p + msl <= rd.n_rr && ((ml >> j) & ((1ULL << msl) - 1)) == 0) {
+                        const uint64_t x = s2 ? ((lo >> s2) | (hi << (64 - s2))) : lo;
+                        const uint32_t bt = (uint32_t)(x & smask) | (seed_tag(x, msl, rd.tag_bits) << 18);
+                        atomicAdd(&tab[bt & 0x3ffffu], 1u);
+                        reg[it][j] = bt;
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        lds_sync();
+        const uint32_t total = lds_scan_exclusive_waves(tab, nb, wtot);     // tab[b] = first slot of bucket b
+        // every entry takes its slot (an invalid position keeps 0xffffffff: its slot field lies beyond every
+        // window); afterwards tab[b] = END of bucket b
+#pragma unroll
+        for (int it = 0; it < REG_IT; ++it) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t bt = reg[it][j];
+                if (bt != 0xffffffffu) reg[it][j] = atomicAdd(&tab[bt & 0x3ffffu], 1u) | ((bt >> 18) << REG_SLOT_BITS);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        lds_sync();
+        for (int i = tid; i < nb; i += 1024) gtab[i] = tab[i];
+        lds_sync();
+        for (uint32_t base = 0; base < total; base += REG_STAGE) {
+            uint32_t t4 = 4u * (uint32_t)tid;
+            asm volatile("" : "+v"(t4));                         // nothing below is hoisted out of the window loop (it would triple the live registers)
+#pragma unroll
+            for (int it = 0; it < REG_IT; ++it) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    uint32_t v = reg[it][j];
+                    asm volatile("" : "+v"(v));
+                    const uint32_t d = (v & ((1u << REG_SLOT_BITS) - 1u)) - base;
+                    if (d < (uint32_t)REG_STAGE)
+                        stage[d] = (t4 + (uint32_t)(4096 * it + j)) | ((v >> REG_SLOT_BITS) << rd.pos_bits);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            lds_sync();
+            const uint32_t cnt = min((uint32_t)REG_STAGE, total - base);
+            for (uint32_t i = tid; i < cnt; i += 1024) gent[base + i] = stage[i];
+            lds_sync();
+        }
+    }
+}
+
 // ---- path B (large references / long seeds): global-memory counting sort
 __global__ void __launch_bounds__(256)
 k_build_rr(const ref_desc* __restrict__ refs, const int* __restrict__ slot_list, int n_list,
@@ -1026,6 +1169,8 @@ inline int grid_for(int64_t n, int block = 256, int max_blocks = 256 * 16) {
 
 static int64_t g_index_budget_bytes = 24LL << 30;
 static int64_t g_segment_task_limit = 32768;
+// VG_LZ_BUILD=lds: the scratch-based LDS build also for short references (tests compare the two)
+static const bool g_no_reg_build = [] { const char* e = getenv("VG_LZ_BUILD"); return e && strcmp(e, "lds") == 0; }();
 
 extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks, const vg_lz_params* p,
                            vg_pair_stat* stats, vg_region** regions, int64_t* n_regions) {
@@ -1085,7 +1230,7 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
         int64_t pos = 0, end = 0;            // sorted task range
         int first_ref = 0, n_refs = 0;       // reference ordinals [first_ref, first_ref + n_refs)
         std::vector<int64_t> chunk_off{ 0 };
-        std::vector<int> small_list, large_list; std::vector<int64_t> large_chunks{ 0 };
+        std::vector<int> reg_list, small_list, large_list; std::vector<int64_t> large_chunks{ 0 };
         int64_t rr_words = 0, mask_words = 0, stab_tot = 0, sent_n = 0, scratch_words = 0, stride = 0;
         int nblk_build = 0;
         double bytes_alg = 0; int64_t q_max = 0, q_sum = 0;          // SURVEY 8(d) bytes of the batch; longest / total query
@@ -1128,21 +1273,23 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
         for (int i = 0; i < n_refs; ++i) {
             const int gi = B.first_ref + i;                      // ordinal = index into all_refs / the device array
             const bool small = all_refs[(size_t)gi].n_rr <= (1 << 21) && p->msl <= 7;
-            if (small) B.small_list.push_back(gi);
+            if (small && all_refs[(size_t)gi].n_rr <= REG_MAX_RR && !g_no_reg_build) B.reg_list.push_back(gi);
+            else if (small) B.small_list.push_back(gi);
             else { B.large_list.push_back(gi); B.large_chunks.push_back(B.large_chunks.back() + (B.chunk_off[(size_t)i + 1] - B.chunk_off[(size_t)i])); }
         }
         // longest references first: the persistent workgroups take them round-robin, so their loads even out
         // (nothing to even out when the lengths are within 25 % of each other)
-        {
+        auto longest_first = [&](std::vector<int>& list) {
             int32_t mn = INT32_MAX, mx = 0;
-            for (int i : B.small_list) { mn = std::min(mn, all_refs[(size_t)i].n_rr); mx = std::max(mx, all_refs[(size_t)i].n_rr); }
-            if (!B.small_list.empty() && (int64_t)mx * 4 > (int64_t)mn * 5) {
-                std::vector<uint64_t> keyed(B.small_list.size());
-                for (size_t i = 0; i < keyed.size(); ++i) keyed[i] = ((uint64_t)(0x7fffffffu - (uint32_t)all_refs[(size_t)B.small_list[i]].n_rr) << 32) | (uint32_t)B.small_list[i];
+            for (int i : list) { mn = std::min(mn, all_refs[(size_t)i].n_rr); mx = std::max(mx, all_refs[(size_t)i].n_rr); }
+            if (!list.empty() && (int64_t)mx * 4 > (int64_t)mn * 5) {
+                std::vector<uint64_t> keyed(list.size());
+                for (size_t i = 0; i < keyed.size(); ++i) keyed[i] = ((uint64_t)(0x7fffffffu - (uint32_t)all_refs[(size_t)list[i]].n_rr) << 32) | (uint32_t)list[i];
                 std::sort(keyed.begin(), keyed.end());           // length descending, ordinal ascending (= the stable order)
-                for (size_t i = 0; i < keyed.size(); ++i) B.small_list[i] = (int)(uint32_t)keyed[i];
+                for (size_t i = 0; i < keyed.size(); ++i) list[i] = (int)(uint32_t)keyed[i];
             }
-        }
+        };
+        longest_first(B.reg_list); longest_first(B.small_list);
         if (!B.small_list.empty()) {
             int64_t max_rr = 0; for (int i : B.small_list) max_rr = std::max<int64_t>(max_rr, all_refs[(size_t)i].n_rr);
             B.nblk_build = (int)std::min<size_t>(B.small_list.size(), 512);
@@ -1155,31 +1302,37 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
     dbuf<ref_desc> d_refs(std::max<size_t>(1, all_refs.size())); dbuf<task_dev> d_tasks((size_t)n_tasks);
     if (!all_refs.empty()) d_refs.upload(all_refs.data(), all_refs.size(), s);
     d_tasks.upload(td.data(), td.size(), s);
-    struct lz_slot { dbuf<uint32_t> rr_pool, mask_pool, stab_pool, sent_pool, scratch; dbuf<int> d_small, d_large; dbuf<int64_t> d_lchunk; };
+    struct lz_slot { dbuf<uint32_t> rr_pool, mask_pool, stab_pool, sent_pool, scratch; dbuf<int> d_reg, d_small, d_large; dbuf<int64_t> d_lchunk; };
     lz_slot slot;
     {
-        size_t m_rr = 0, m_mask = 0, m_stab = 1, m_sent = 0, m_scr = 1, m_small = 1, m_large = 1, m_lch = 1;
+        size_t m_rr = 0, m_mask = 0, m_stab = 1, m_sent = 0, m_scr = 1, m_reg = 1, m_small = 1, m_large = 1, m_lch = 1;
         for (auto& B : batches) {
             m_rr = std::max(m_rr, (size_t)B.rr_words); m_mask = std::max(m_mask, (size_t)B.mask_words);
             m_stab = std::max(m_stab, (size_t)B.stab_tot); m_sent = std::max(m_sent, (size_t)B.sent_n); m_scr = std::max(m_scr, (size_t)B.scratch_words);
-            m_small = std::max(m_small, B.small_list.size()); m_large = std::max(m_large, B.large_list.size());
+            m_reg = std::max(m_reg, B.reg_list.size()); m_small = std::max(m_small, B.small_list.size()); m_large = std::max(m_large, B.large_list.size());
             m_lch = std::max(m_lch, B.large_chunks.size());
         }
         lz_slot& L = slot;
         L.rr_pool.alloc(m_rr + 8); L.mask_pool.alloc(m_mask + 8); L.stab_pool.alloc(m_stab); L.sent_pool.alloc(m_sent + 4);
-        L.scratch.alloc(m_scr); L.d_small.alloc(m_small); L.d_large.alloc(m_large); L.d_lchunk.alloc(m_lch);
+        L.scratch.alloc(m_scr); L.d_reg.alloc(m_reg); L.d_small.alloc(m_small); L.d_large.alloc(m_large); L.d_lchunk.alloc(m_lch);
     }
     hipStream_t sb = s;
     static const char* seg_env = getenv("VG_LZ_SEGMENTS");
     for (size_t bi = 0; bi < batches.size(); ++bi) {
         lz_batch& B = batches[bi];
         lz_slot& L = slot;
+        if (!B.reg_list.empty()) L.d_reg.upload(B.reg_list.data(), B.reg_list.size(), sb);
         if (!B.small_list.empty()) L.d_small.upload(B.small_list.data(), B.small_list.size(), sb);
         if (!B.large_list.empty()) { L.d_large.upload(B.large_list.data(), B.large_list.size(), sb); L.d_lchunk.upload(B.large_chunks.data(), B.large_chunks.size(), sb); }
         const int64_t total_chunks = B.chunk_off.back();
         {
             vg_prof_scope ps("lz_build_index", (double)total_chunks * 32 * (0.375 + 0.375 + 4));
             if (!B.large_list.empty()) VG_HIP(hipMemsetAsync(L.stab_pool.p, 0, (size_t)B.stab_tot * sizeof(uint32_t), sb));
+            if (!B.reg_list.empty()) {
+                hipLaunchKernelGGL(k_build_index_reg, dim3((unsigned)std::min<size_t>(B.reg_list.size(), 512)), dim3(1024), 0, sb, d_refs.p, L.d_reg.p,
+                                   (int)B.reg_list.size(), g->d_packed.p, g->d_nmask.p, g->d_base_off.p, L.rr_pool.p, L.mask_pool.p, p->msl,
+                                   L.stab_pool.p, L.sent_pool.p);
+            }
             if (!B.small_list.empty()) {
                 hipLaunchKernelGGL(k_build_index_lds, dim3(B.nblk_build), dim3(1024), 0, sb, d_refs.p, L.d_small.p, (int)B.small_list.size(),
                                    g->d_packed.p, g->d_nmask.p, g->d_base_off.p, L.rr_pool.p, L.mask_pool.p, p->mal, p->msl,
