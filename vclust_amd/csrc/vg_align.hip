@@ -620,10 +620,23 @@ constexpr int REG_MK_WORDS = REG_MAX_RR / 32 + 16;
 constexpr int REG_GEN_WORDS = 12288;                    // genome words + mask + scan scratch (before the windows)
 constexpr int REG_LDS_WORDS = LDS_TAB + REG_GEN_WORDS + REG_RR_WORDS + REG_MK_WORDS;
 constexpr int REG_STAGE = REG_LDS_WORDS / 1024 * 1024;  // entries per staging window: the whole LDS block
+constexpr int REG_STAGE0 = (REG_LDS_WORDS - LDS_TAB) / 1024 * 1024;   // slots staged while the table is still live
 constexpr int REG_SLOT_BITS = 17;                       // slot < n_rr < 2^17; tag (<= 14 bits) above it
 
 // workgroup barrier that waits for this wave's LDS traffic only: global stores stay in flight
 __device__ __forceinline__ void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// inclusive scan over the 64 lanes of a wave with DPP adds (row shifts, then the two row broadcasts): six
+// dependent VALU instructions instead of six LDS-crossbar round trips
+__device__ __forceinline__ uint32_t wave_scan_inclusive(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);     // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);     // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);     // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);     // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);    // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);    // row_bcast:31 into rows 2 and 3
+    return v;
+}
 
 // exclusive scan of tab[0, n) by 1024 threads (16 waves, each a contiguous slice, 64 consecutive entries per
 // trip: no bank conflicts); returns the total.  wtot: 16 words of scratch.
@@ -634,11 +647,9 @@ __device__ __forceinline__ uint32_t lds_scan_exclusive_waves(uint32_t* tab, int 
     for (int r = 0; r < per_wave; r += 64) {
         const int i = w * per_wave + r + lane;
         const uint32_t v = i < n ? tab[i] : 0u;
-        uint32_t inc = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+        const uint32_t inc = wave_scan_inclusive(v);
         if (i < n) tab[i] = carry + inc - v;
-        carry += __shfl(inc, 63);
+        carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
     }
     if (lane == 0) wtot[w] = carry;
     lds_sync();
@@ -713,20 +724,34 @@ k_build_index_reg(const ref_desc* __restrict__ refs, const int* __restrict__ slo
         lds_sync();
         const uint32_t total = lds_scan_exclusive_waves(tab, nb, wtot);     // tab[b] = first slot of bucket b
         // every entry takes its slot (an invalid position keeps 0xffffffff: its slot field lies beyond every
-        // window); afterwards tab[b] = END of bucket b
+        // window); afterwards tab[b] = END of bucket b.  The entries of the first REG_STAGE0 slots are staged
+        // right away, in the LDS that the table does not occupy (one window sweep less).
+        uint32_t* const stage0 = lds + LDS_TAB;
+        {
+            uint32_t t4 = 4u * (uint32_t)tid;
+            asm volatile("" : "+v"(t4));
 #pragma unroll
-        for (int it = 0; it < REG_IT; ++it) {
+            for (int it = 0; it < REG_IT; ++it) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t bt = reg[it][j];
-                if (bt != 0xffffffffu) reg[it][j] = atomicAdd(&tab[bt & 0x3ffffu], 1u) | ((bt >> 18) << REG_SLOT_BITS);
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t bt = reg[it][j];
+                    if (bt != 0xffffffffu) {
+                        const uint32_t slot = atomicAdd(&tab[bt & 0x3ffffu], 1u);
+                        reg[it][j] = slot | ((bt >> 18) << REG_SLOT_BITS);
+                        if (slot < (uint32_t)REG_STAGE0) stage0[slot] = (t4 + (uint32_t)(4096 * it + j)) | ((bt >> 18) << rd.pos_bits);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
         lds_sync();
         for (int i = tid; i < nb; i += 1024) gtab[i] = tab[i];
+        {
+            const uint32_t cnt0 = min((uint32_t)REG_STAGE0, total);
+            for (uint32_t i = tid; i < cnt0; i += 1024) gent[i] = stage0[i];
+        }
         lds_sync();
-        for (uint32_t base = 0; base < total; base += REG_STAGE) {
+        for (uint32_t base = REG_STAGE0; base < total; base += REG_STAGE) {
             uint32_t t4 = 4u * (uint32_t)tid;
             asm volatile("" : "+v"(t4));                         // nothing below is hoisted out of the window loop (it would triple the live registers)
 #pragma unroll
