@@ -69,7 +69,8 @@ bool vg_profile_on();
 // Layout (host and HBM): bases 2-bit packed, 16 per uint32 word, little end first
 // (base i of the padded stream sits in word i/16, bits 2*(i%16)..+1); N mask 1 bit per base,
 // 32 per word.  Every genome starts at a multiple of VG_ALIGN bases of the padded stream;
-// padding bases are A with mask bit 1.
+// padding bases are A with mask bit 1, and every genome is followed by at least one (a k-mer window that
+// leaves its genome therefore always contains a masked base).
 constexpr int64_t VG_ALIGN = 64;        // minimum alignment; the set's block size is 1 << align_shift
 // std::vector storage without the value-initialising fill (resize() leaves new elements untouched):
 // the 2-bit arrays of a big set are zeroed / written by many threads, not by one

@@ -25,8 +25,7 @@ void vg_genomes_append(vg_genomes* g, const std::string& name, const uint8_t* co
     if (g->base_off.empty()) g->base_off.push_back(0);
     int64_t off = g->base_off.back();
     const int64_t al = 1LL << g->align_shift;
-    int64_t padded = (len + al - 1) / al * al;
-    if (padded == 0) padded = al;
+    const int64_t padded = (len / al + 1) * al;      // at least one masked base behind every genome: no k-mer window reaches the next one
     g->packed.resize((off + padded) / 16, 0u);
     g->nmask.resize((off + padded) / 32, 0u);
     uint32_t* pk = g->packed.data() + off / 16;
@@ -241,7 +240,7 @@ extern "C" int vg_genomes_load(const char* const* paths, int n_paths, int multis
     const int64_t al = 1LL << g->align_shift;
     g->base_off.push_back(0);
     for (auto& d : gd) {
-        int64_t padded = (d.len + al - 1) / al * al; if (padded == 0) padded = al;
+        const int64_t padded = (d.len / al + 1) * al;          // >= 1 masked base behind the genome (see vg_genomes_append)
         for (int64_t b = g->base_off.back() >> g->align_shift; b < (g->base_off.back() + padded) >> g->align_shift; ++b) g->blk2g.push_back((uint32_t)g->n);
         g->base_off.push_back(g->base_off.back() + padded);
         g->len.push_back(d.len); g->n_parts.push_back((int32_t)(d.r1 - d.r0)); g->has_n.push_back(0);

@@ -42,13 +42,13 @@ struct kmer_args {
 };
 
 // scrambled canonical k-mer starting at padded base position p, or SENT (window crosses the genome
-// end, contains N, or the k-mer is not kept by --kmers-fraction / belongs to another shard)
+// end, contains N, or the k-mer is not kept by --kmers-fraction / belongs to another shard).  Every genome
+// is followed by at least one masked padding base, so "crosses the end" IS "contains a masked base": the
+// mask is the only validity test (no length / offset lookups behind the genome id).
 __device__ __forceinline__ uint64_t kmer_at(const kmer_args& A, int64_t p, uint32_t* genome) {
     const uint64_t kmask = (A.k == 32) ? ~0ULL : ((1ULL << (2 * A.k)) - 1);
     const uint32_t g = A.blk2g[p >> A.blk_shift];
     *genome = g;
-    const int64_t local = p - A.base_off[g];
-    if (local + A.k > A.len[g]) return SENT;
     const int64_t mw = p >> 5; const int msh = (int)(p & 31);
     const uint64_t m = (uint64_t)A.nmask[mw] | ((uint64_t)A.nmask[mw + 1] << 32);
     if (((m >> msh) & ((1ULL << A.k) - 1)) != 0) return SENT;
@@ -73,21 +73,15 @@ __device__ __forceinline__ uint64_t kmer_at(const kmer_args& A, int64_t p, uint3
 
 // the four k-mers starting at padded positions p0 .. p0+3 (p0 a multiple of 4): one genome lookup,
 // one 128-bit sequence window and one 64-bit N window serve all four
-__device__ __forceinline__ void kmers4(const kmer_args& A, int64_t p0, uint64_t out[4], uint32_t* genome) {
+// (sequence window lo:hi = the 64 bases from the 16-base word that holds p0, m = the N mask bits from p0 on)
+__device__ __forceinline__ void kmers4_window(const kmer_args& A, int64_t p0, uint64_t lo, uint64_t hi, uint64_t m, uint64_t out[4]) {
     const uint64_t kmask = (A.k == 32) ? ~0ULL : ((1ULL << (2 * A.k)) - 1);
-    const uint32_t g = A.blk2g[p0 >> A.blk_shift];
-    *genome = g;
-    const int64_t room = A.len[g] - (p0 - A.base_off[g]) - A.k;      // position p0 + j is valid iff j <= room
-    const int64_t mw = p0 >> 5; const int msh = (int)(p0 & 31);
-    const uint64_t m = ((uint64_t)A.nmask[mw] | ((uint64_t)A.nmask[mw + 1] << 32)) >> msh;   // msh <= 28: 36+ bits left
-    const int64_t w = p0 >> 4; const int sh = 2 * (int)(p0 & 15);    // 0, 8, 16 or 24
-    const uint64_t lo = (uint64_t)A.packed[w] | ((uint64_t)A.packed[w + 1] << 32);
-    const uint64_t hi = (uint64_t)A.packed[w + 2] | ((uint64_t)A.packed[w + 3] << 32);
+    const int sh = 2 * (int)(p0 & 15);                                // 0, 8, 16 or 24
     const uint64_t nk = (1ULL << A.k) - 1;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         uint64_t key = SENT;
-        if (j <= room && ((m >> j) & nk) == 0) {
+        if (((m >> j) & nk) == 0) {
             const int s2 = sh + 2 * j;
             uint64_t x = s2 ? ((lo >> s2) | (hi << (64 - s2))) : lo;
             x &= kmask;
@@ -104,6 +98,15 @@ __device__ __forceinline__ void kmers4(const kmer_args& A, int64_t p0, uint64_t 
         }
         out[j] = key;
     }
+}
+__device__ __forceinline__ void kmers4(const kmer_args& A, int64_t p0, uint64_t out[4], uint32_t* genome) {
+    *genome = A.blk2g[p0 >> A.blk_shift];
+    const int64_t mw = p0 >> 5; const int msh = (int)(p0 & 31);
+    const uint64_t m = ((uint64_t)A.nmask[mw] | ((uint64_t)A.nmask[mw + 1] << 32)) >> msh;   // msh <= 28: 36+ bits left
+    const int64_t w = p0 >> 4;
+    const uint64_t lo = (uint64_t)A.packed[w] | ((uint64_t)A.packed[w + 1] << 32);
+    const uint64_t hi = (uint64_t)A.packed[w + 2] | ((uint64_t)A.packed[w + 3] << 32);
+    kmers4_window(A, p0, lo, hi, m, out);
 }
 
 // Dense form (all k-mers kept: one shard, fraction 1): four consecutive padded base positions per
@@ -671,6 +674,11 @@ __device__ __forceinline__ void key_words(uint64_t key, int k2, uint32_t* w0, ui
     *w0 = (uint32_t)(t >> 32); *w1 = (uint32_t)t;
 }
 
+// workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains the wave's global
+// stores (s_waitcnt vmcnt(0)), which serialises "store the tile" with "prepare the next one"; the kernels below
+// order nothing but LDS contents between their phases, so their stores stay in flight across the barrier.
+__device__ __forceinline__ void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // exclusive prefix sum over the 1 024 threads of a workgroup (scratch: 16 words of LDS)
 __device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t* s_wave, uint32_t* total) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -678,11 +686,11 @@ __device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t* s_wave
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if (lane >= o) x += y; }
     if (lane == 63) s_wave[wv] = x;
-    __syncthreads();
+    lds_sync();
     uint32_t base = 0, tot = 0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { const uint32_t s = s_wave[i]; if (i < wv) base += s; tot += s; }
-    __syncthreads();
+    lds_sync();
     if (total) *total = tot;
     return base + x - v;
 }
@@ -715,6 +723,65 @@ __device__ __forceinline__ void load_tile(const part_src& S, int64_t t0, int64_t
             if (ok[j]) {
                 if (SRC == SRC_ARRAYS) { key_words(S.keys[i], S.k2, &w0[j], &w1[j]); pay[j] = S.pos[i]; }
                 else { const uint32_t* r = S.rec + 3 * i; w0[j] = r[0]; w1[j] = r[1]; pay[j] = r[2]; }
+            }
+        }
+    }
+}
+
+// The same tile in two steps, for the scatter kernel: fetch_tile only issues the loads (the raw words of the
+// NEXT tile travel while the current one is sorted in the LDS), decode_tile turns them into (w0, w1, pay).
+constexpr int PT_RAW = 3 * PT_PER;
+template <int SRC>
+__device__ __forceinline__ void fetch_tile(const part_src& S, int64_t t0, int64_t t_end, uint32_t raw[PT_RAW]) {
+    if (SRC == SRC_DENSE) {
+#pragma unroll
+        for (int q = 0; q < PT_PER / 4; ++q) {
+            const int64_t p0 = t0 + ((int64_t)q * PT_THREADS + threadIdx.x) * 4;
+            if (p0 < t_end) {
+                __builtin_memcpy(&raw[6 * q], S.A.packed + (p0 >> 4), 16);
+                raw[6 * q + 4] = S.A.nmask[p0 >> 5]; raw[6 * q + 5] = S.A.nmask[(p0 >> 5) + 1];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < PT_PER; ++j) {
+            const int64_t i = t0 + (int64_t)j * PT_THREADS + threadIdx.x;
+            if (i < t_end) {
+                if (SRC == SRC_ARRAYS) { __builtin_memcpy(&raw[3 * j], S.keys + i, 8); raw[3 * j + 2] = S.pos[i]; }
+                else __builtin_memcpy(&raw[3 * j], S.rec + 3 * i, 12);
+            }
+        }
+    }
+}
+template <int SRC>
+__device__ __forceinline__ void decode_tile(const part_src& S, int64_t t0, int64_t t_end, const uint32_t raw[PT_RAW], uint32_t w0[PT_PER],
+                                            uint32_t w1[PT_PER], uint32_t pay[PT_PER], bool ok[PT_PER]) {
+    if (SRC == SRC_DENSE) {
+#pragma unroll
+        for (int q = 0; q < PT_PER / 4; ++q) {
+            const int64_t p0 = t0 + ((int64_t)q * PT_THREADS + threadIdx.x) * 4;
+            uint64_t kk[4] = {SENT, SENT, SENT, SENT};
+            if (p0 < t_end) {
+                const uint64_t lo = (uint64_t)raw[6 * q] | ((uint64_t)raw[6 * q + 1] << 32), hi = (uint64_t)raw[6 * q + 2] | ((uint64_t)raw[6 * q + 3] << 32);
+                const uint64_t m = ((uint64_t)raw[6 * q + 4] | ((uint64_t)raw[6 * q + 5] << 32)) >> (int)(p0 & 31);
+                kmers4_window(S.A, p0, lo, hi, m, kk);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ok[4 * q + j] = kk[j] != SENT;
+                key_words(kk[j], S.k2, &w0[4 * q + j], &w1[4 * q + j]);
+                pay[4 * q + j] = (uint32_t)(p0 + j);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < PT_PER; ++j) {
+            const int64_t i = t0 + (int64_t)j * PT_THREADS + threadIdx.x;
+            ok[j] = i < t_end;
+            w0[j] = 0; w1[j] = 0; pay[j] = 0;
+            if (ok[j]) {
+                if (SRC == SRC_ARRAYS) { key_words((uint64_t)raw[3 * j] | ((uint64_t)raw[3 * j + 1] << 32), S.k2, &w0[j], &w1[j]); pay[j] = raw[3 * j + 2]; }
+                else { w0[j] = raw[3 * j]; w1[j] = raw[3 * j + 1]; pay[j] = raw[3 * j + 2]; }
             }
         }
     }
@@ -800,7 +867,7 @@ k_part_scatter(part_src S, int B1, int B2, int unit_tiles, int64_t n_units, cons
         const int64_t s0 = u * unit_tiles * PT_TILE, s1 = min(S.n, s0 + (int64_t)unit_tiles * PT_TILE);
         uint32_t bfirst = 0;
         if (LEVEL == 2) bfirst = S.rec[3 * s0] >> (32 - B1);
-        __syncthreads();
+        lds_sync();
         for (int b = threadIdx.x; b < nbins; b += PT_THREADS) {
             uint32_t off = 0;
             if (LEVEL == 1) off = Ts[(int64_t)b * n_units + u];
@@ -811,11 +878,19 @@ k_part_scatter(part_src S, int B1, int B2, int unit_tiles, int64_t n_units, cons
             }
             cursor[b] = off;
         }
+        // The raw words of tile t + 1 are requested while tile t is sorted; they (and, the memory pipeline being
+        // in order, the stores of tile t - 1) must have landed before tile t's stores are issued -- so the stores
+        // of one tile drain while the next is ranked and staged, instead of being waited for at its first load.
+        uint32_t raw[PT_RAW];
+#pragma unroll
+        for (int i = 0; i < PT_RAW; ++i) raw[i] = 0;
+        fetch_tile<SRC>(S, s0, s1, raw);
         for (int64_t t0 = s0; t0 < s1; t0 += PT_TILE) {
             for (int b = threadIdx.x; b < nbins; b += PT_THREADS) thist[b] = 0;
-            __syncthreads();
-            uint32_t w0[PT_PER], w1[PT_PER], pay[PT_PER], g4[PT_PER / 4 + 1], bin[PT_PER], rk[PT_PER]; bool ok[PT_PER];
-            load_tile<SRC>(S, t0, s1, w0, w1, pay, ok, g4);
+            lds_sync();
+            uint32_t w0[PT_PER], w1[PT_PER], pay[PT_PER], bin[PT_PER], rk[PT_PER]; bool ok[PT_PER];
+            decode_tile<SRC>(S, t0, s1, raw, w0, w1, pay, ok);
+            if (t0 + PT_TILE < s1) fetch_tile<SRC>(S, t0 + PT_TILE, s1, raw);
 #pragma unroll
             for (int j = 0; j < PT_PER; ++j) {
                 bin[j] = 0; rk[j] = 0;
@@ -824,7 +899,7 @@ k_part_scatter(part_src S, int B1, int B2, int unit_tiles, int64_t n_units, cons
                     rk[j] = atomicAdd(&thist[bin[j]], 1u);
                 }
             }
-            __syncthreads();
+            lds_sync();
             // exclusive scan of the tile histogram (nbins <= 4 096: four bins per thread)
             {
                 constexpr int BPT = PT_MAXBINS / PT_THREADS;
@@ -835,14 +910,16 @@ k_part_scatter(part_src S, int B1, int B2, int unit_tiles, int64_t n_units, cons
 #pragma unroll
                 for (int u = 0; u < BPT; ++u) { const int b = BPT * (int)threadIdx.x + u; if (b < nbins) tstart[b] = run; run += c[u]; }
             }
-            __syncthreads();
+            lds_sync();
 #pragma unroll
             for (int j = 0; j < PT_PER; ++j) if (ok[j]) {
                 const uint32_t slot = tstart[bin[j]] + rk[j];
                 s_w0[slot] = w0[j]; s_w1[slot] = w1[j]; s_pay[slot] = pay[j];
             }
-            __syncthreads();
+            lds_sync();
             const uint32_t n_tile = tstart[nbins - 1] + thist[nbins - 1];
+#pragma unroll
+            for (int i = 0; i < PT_RAW; ++i) asm volatile("" : "+v"(raw[i]));      // the prefetched words have arrived
             // one record per thread and trip, stored with ONE 12-byte (8-byte) instruction: consecutive threads
             // hold consecutive slots, so a wave writes each bin's segment of the tile as one contiguous run
             for (uint32_t slot = threadIdx.x; slot < n_tile; slot += PT_THREADS) {
@@ -858,9 +935,101 @@ k_part_scatter(part_src S, int B1, int B2, int unit_tiles, int64_t n_units, cons
                     __builtin_memcpy(o_rec + 3 * dst, v, 12);
                 }
             }
-            __syncthreads();
+            lds_sync();
             for (int b = threadIdx.x; b < nbins; b += PT_THREADS) cursor[b] += thist[b];
-            __syncthreads();
+            lds_sync();
+        }
+    }
+}
+
+// Level-1 scatter of the dense source with tiles of 32 768 positions.  The records are not staged: the LDS holds
+// the tile's packed bases (12 KiB) and, after the counting sort, only the PERMUTATION (a 16-bit local position
+// per output slot); the output loop computes each record's k-mer again from the bases in the LDS.  Four times
+// the tile of k_part_scatter in less LDS, so a bucket's segment of a tile is four times as long (partial-line
+// writes are what bounds this pass).
+constexpr int RT_TILE = 32768;
+constexpr int RT_PER = RT_TILE / PT_THREADS;
+__device__ __forceinline__ uint64_t kmer_key_lds(const kmer_args& A, const uint32_t* s_pk, uint32_t lp) {
+    const uint64_t kmask = (A.k == 32) ? ~0ULL : ((1ULL << (2 * A.k)) - 1);
+    const uint32_t wi = lp >> 4; const int sh = 2 * (int)(lp & 15);
+    const uint64_t lo = (uint64_t)s_pk[wi] | ((uint64_t)s_pk[wi + 1] << 32);
+    uint64_t x = sh ? ((lo >> sh) | ((uint64_t)s_pk[wi + 2] << (64 - sh))) : lo;
+    x &= kmask;
+    const uint64_t fwd = rev2(x) >> (64 - 2 * A.k);
+    const uint64_t rc = (~x) & kmask;
+    const uint64_t cano = fwd < rc ? fwd : rc;
+    return (cano * SCRAMBLE) & kmask;
+}
+__global__ void __launch_bounds__(PT_THREADS)
+k_part_scatter_dense(part_src S, int B1, int unit_tiles, int64_t n_units, const uint32_t* __restrict__ Ts, uint32_t* __restrict__ o_rec) {
+    __shared__ uint32_t s_pk[RT_TILE / 16 + 8], s_mk[RT_TILE / 32 + 4];
+    __shared__ uint16_t s_perm[RT_TILE];
+    __shared__ uint32_t thist[PT_MAXBINS], tstart[PT_MAXBINS], cursor[PT_MAXBINS];
+    __shared__ uint32_t s_wave[16];
+    const int nbins = 1 << B1;
+    const int64_t n_pk = (S.A.P >> 4) + 16, n_mk = (S.A.P >> 5) + 16;      // words the arrays hold (vg_genomes_finish: 16 of slack)
+    for (int64_t u = blockIdx.x; u < n_units; u += gridDim.x) {
+        const int64_t s0 = u * unit_tiles * RT_TILE, s1 = min(S.n, s0 + (int64_t)unit_tiles * RT_TILE);
+        lds_sync();
+        for (int b = threadIdx.x; b < nbins; b += PT_THREADS) cursor[b] = Ts[(int64_t)b * n_units + u];
+        for (int64_t t0 = s0; t0 < s1; t0 += RT_TILE) {
+            for (int i = threadIdx.x; i < RT_TILE / 16 + 4; i += PT_THREADS) { const int64_t w = (t0 >> 4) + i; s_pk[i] = w < n_pk ? S.A.packed[w] : 0u; }
+            for (int i = threadIdx.x; i < RT_TILE / 32 + 2; i += PT_THREADS) { const int64_t w = (t0 >> 5) + i; s_mk[i] = w < n_mk ? S.A.nmask[w] : 0xffffffffu; }
+            for (int b = threadIdx.x; b < nbins; b += PT_THREADS) thist[b] = 0;
+            lds_sync();
+            uint32_t br[RT_PER];                                  // bin | rank in bin << 12, or all ones
+#pragma unroll
+            for (int q = 0; q < RT_PER / 4; ++q) {
+                const uint32_t lp0 = ((uint32_t)q * PT_THREADS + threadIdx.x) * 4;
+                uint64_t kk[4] = {SENT, SENT, SENT, SENT};
+                if (t0 + lp0 < s1) {
+                    const uint32_t wi = lp0 >> 4;
+                    const uint64_t lo = (uint64_t)s_pk[wi] | ((uint64_t)s_pk[wi + 1] << 32), hi = (uint64_t)s_pk[wi + 2] | ((uint64_t)s_pk[wi + 3] << 32);
+                    const uint64_t m = ((uint64_t)s_mk[lp0 >> 5] | ((uint64_t)s_mk[(lp0 >> 5) + 1] << 32)) >> (lp0 & 31);
+                    kmers4_window(S.A, (int64_t)lp0, lo, hi, m, kk);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    br[4 * q + j] = 0xffffffffu;
+                    if (kk[j] != SENT) {
+                        const uint32_t bin = B1 ? (uint32_t)(kk[j] >> (S.k2 - B1)) : 0u;
+                        br[4 * q + j] = bin | (atomicAdd(&thist[bin], 1u) << 12);
+                    }
+                }
+            }
+            lds_sync();
+            {
+                constexpr int BPT = PT_MAXBINS / PT_THREADS;
+                uint32_t c[BPT], tot = 0;
+#pragma unroll
+                for (int v = 0; v < BPT; ++v) { const int b = BPT * (int)threadIdx.x + v; c[v] = b < nbins ? thist[b] : 0u; tot += c[v]; }
+                uint32_t run = block_scan_1024(tot, s_wave, nullptr);
+#pragma unroll
+                for (int v = 0; v < BPT; ++v) { const int b = BPT * (int)threadIdx.x + v; if (b < nbins) tstart[b] = run; run += c[v]; }
+            }
+            lds_sync();
+#pragma unroll
+            for (int q = 0; q < RT_PER / 4; ++q) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t v = br[4 * q + j];
+                    if (v != 0xffffffffu) s_perm[tstart[v & 0xfffu] + (v >> 12)] = (uint16_t)(((uint32_t)q * PT_THREADS + threadIdx.x) * 4 + j);
+                }
+            }
+            lds_sync();
+            const uint32_t n_tile = tstart[nbins - 1] + thist[nbins - 1];
+            for (uint32_t slot = threadIdx.x; slot < n_tile; slot += PT_THREADS) {
+                const uint32_t lp = s_perm[slot];
+                uint32_t v[3];
+                key_words(kmer_key_lds(S.A, s_pk, lp), S.k2, &v[0], &v[1]);
+                v[2] = (uint32_t)(t0 + lp);
+                const uint32_t b = B1 ? (v[0] >> (32 - B1)) : 0u;
+                const uint64_t dst = (uint64_t)cursor[b] + (slot - tstart[b]);
+                __builtin_memcpy(o_rec + 3 * dst, v, 12);
+            }
+            lds_sync();
+            for (int b = threadIdx.x; b < nbins; b += PT_THREADS) cursor[b] += thist[b];
+            lds_sync();
         }
     }
 }
@@ -911,9 +1080,9 @@ k_bucket_runs(const uint32_t* __restrict__ rec, int stride /* 3: (w0, w1, pay); 
         const int n = (int)(b1 - b0);
         if (n <= 1) continue;                                  // empty, or one singleton k-mer
         if (n > BK_CAP) { if (threadIdx.x == 0) atomicOr(overflow, 1u); continue; }
-        __syncthreads();
+        lds_sync();
         for (int b = threadIdx.x; b <= BK_SUB; b += BK_THREADS) cnt[b] = 0;
-        __syncthreads();
+        lds_sync();
         uint64_t key[BK_PER]; uint32_t pj[BK_PER]; uint32_t sb[BK_PER], ar[BK_PER];
 #pragma unroll
         for (int q = 0; q < BK_PER; ++q) {
@@ -929,7 +1098,7 @@ k_bucket_runs(const uint32_t* __restrict__ rec, int stride /* 3: (w0, w1, pay); 
         }
 #pragma unroll
         for (int q = 0; q < BK_PER; ++q) if (q * BK_THREADS + (int)threadIdx.x < n) ar[q] = atomicAdd(&cnt[sb[q]], 1u);
-        __syncthreads();
+        lds_sync();
         {   // exclusive scan of the sub-bin counters: BK_SUB / BK_THREADS per thread
             constexpr int CPT = BK_SUB / BK_THREADS;
             uint32_t c4[CPT], tot = 0;
@@ -939,7 +1108,7 @@ k_bucket_runs(const uint32_t* __restrict__ rec, int stride /* 3: (w0, w1, pay); 
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if (lane >= o) x += y; }
             if (lane == 63) s_wave[wv] = x;
-            __syncthreads();
+            lds_sync();
             uint32_t base = 0;
             for (int i = 0; i < wv; ++i) base += s_wave[i];
             uint32_t run = base + x - tot;
@@ -947,13 +1116,13 @@ k_bucket_runs(const uint32_t* __restrict__ rec, int stride /* 3: (w0, w1, pay); 
             for (int u = 0; u < CPT; ++u) { start[CPT * threadIdx.x + u] = run; run += c4[u]; }
             if (threadIdx.x == BK_THREADS - 1) start[BK_SUB] = run;
         }
-        __syncthreads();
+        lds_sync();
 #pragma unroll
         for (int q = 0; q < BK_PER; ++q) if (q * BK_THREADS + (int)threadIdx.x < n) {
             const uint32_t slot = start[sb[q]] + ar[q];
             sk[slot] = key[q]; if (!NARROW) sp[slot] = pj[q];
         }
-        __syncthreads();
+        lds_sync();
 #pragma unroll
         for (int q = 0; q < BK_PER; ++q) {
             if (q * BK_THREADS + (int)threadIdx.x >= n) continue;
@@ -1146,13 +1315,15 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
     int total_bits = 0; while ((n_src >> total_bits) > 1024 && total_bits < 22) ++total_bits;
     if ((n_src >> total_bits) > 1024) return false;
     const int levels = total_bits > 11 ? 2 : 1;
-    const int B2 = levels == 2 ? std::min(11, total_bits / 2) : 0;
+    static const char* b2_env = getenv("VG_B2");          // developer experiments: level-2 bits
+    const int B2 = levels == 2 ? (b2_env ? atoi(b2_env) : std::min(11, total_bits / 2)) : 0;
     const int B1 = total_bits - B2;
     const int nb1 = 1 << B1, nb2 = 1 << B2;
     const bool narrow = levels == 2 && 2 * k - total_bits <= 32;      // level-2 output: one key word instead of two
     part_src S; memset(&S, 0, sizeof S);
     S.A = A; S.keys = keys; S.pos = pos; S.n = n_src; S.k2 = 2 * k;
-    int st_tiles = (int)std::max<int64_t>(1, std::min<int64_t>(8, n_src / ((int64_t)PT_TILE * 2048)));
+    int st_tiles = (int)std::max<int64_t>(1, std::min<int64_t>(dense ? 16 : 8, n_src / ((int64_t)PT_TILE * 2048)));
+    if (dense && st_tiles >= 4) st_tiles &= ~3;             // whole 32 768-position tiles for k_part_scatter_dense
     const int64_t n_st = (n_src + (int64_t)st_tiles * PT_TILE - 1) / ((int64_t)st_tiles * PT_TILE);
     const size_t t1n = (size_t)nb1 * (size_t)n_st;
     dbuf<uint32_t> T1(t1n + 1), T1s(t1n + 1);
@@ -1176,7 +1347,10 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
         // descriptors are born after that: they take over the same block (48 GB less to allocate at 100 k genomes)
         a_rec.alloc(levels == 2 ? std::max(3 * (size_t)n1 + 8, 2 * (size_t)n_rows_info + (size_t)n1 + 16) : 3 * (size_t)n1 + 8);
         const int grid_s = (int)std::min<int64_t>(n_st, 256);
-        if (dense) hipLaunchKernelGGL((k_part_scatter<SRC_DENSE, 1>), dim3(grid_s), dim3(PT_THREADS), 0, s, S, B1, 0, st_tiles, n_st, (const uint32_t*)T1s.p,
+        static const bool old_scatter = [] { const char* e = getenv("VG_DENSE_SCATTER"); return e && !strcmp(e, "staged"); }();
+        if (dense && st_tiles % 4 == 0 && B1 <= 12 && !old_scatter)
+            hipLaunchKernelGGL(k_part_scatter_dense, dim3(grid_s), dim3(PT_THREADS), 0, s, S, B1, st_tiles / 4, n_st, (const uint32_t*)T1s.p, a_rec.p);
+        else if (dense) hipLaunchKernelGGL((k_part_scatter<SRC_DENSE, 1>), dim3(grid_s), dim3(PT_THREADS), 0, s, S, B1, 0, st_tiles, n_st, (const uint32_t*)T1s.p,
                                       (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint64_t*)nullptr, a_rec.p, -1);
         else hipLaunchKernelGGL((k_part_scatter<SRC_ARRAYS, 1>), dim3(grid_s), dim3(PT_THREADS), 0, s, S, B1, 0, st_tiles, n_st, (const uint32_t*)T1s.p,
                                 (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint64_t*)nullptr, a_rec.p, -1);
