@@ -823,59 +823,55 @@ k_part_count(part_src S, int B1, int st_tiles, int64_t n_st, uint32_t* __restric
     }
 }
 
-// level-2 histogram over the level-1 planes in chunks of ch_tiles tiles: joint digit (b1, b2); a chunk touches
-// at most two level-1 buckets (the host chooses the chunk size accordingly; *bad is set otherwise).
-// table entry of (b1, b2, chunk c): tb[b1] + b2 * nch[b1] + (c - cfirst[b1])
+// Level 2 works on chunks of ONE level-1 bucket: bucket b1's records [off1[b1], off1[b1 + 1]) are cut into
+// nch[b1] chunks of `chunk` records (the last one shorter); chunk c of the whole list belongs to bucket ch_b1[c]
+// and is its (c - cfirst[b1])-th.  Table entry of (b1, b2, chunk c): tb[b1] + b2 * nch[b1] + (c - cfirst[b1]).
+struct lvl2_tab {
+    const uint32_t* ch_b1; const uint32_t* cfirst; const uint32_t* nch; const uint32_t* off1; const uint64_t* tb;
+    uint32_t chunk;
+};
+__device__ __forceinline__ void lvl2_chunk(const lvl2_tab& L, int64_t c, uint32_t* b1, uint32_t* cl, int64_t* s0, int64_t* s1) {
+    *b1 = L.ch_b1[c]; *cl = (uint32_t)c - L.cfirst[*b1];
+    *s0 = (int64_t)L.off1[*b1] + (int64_t)*cl * L.chunk;
+    *s1 = min((int64_t)L.off1[*b1 + 1], *s0 + (int64_t)L.chunk);
+}
+
+// level-2 histogram of the next B2 key bits, one chunk per trip (only w0 of every record is read)
 __global__ void __launch_bounds__(PT_THREADS)
-k_part_count2(part_src S, int B1, int B2, int ch_tiles, int64_t n_ch, const uint32_t* __restrict__ cfirst, const uint32_t* __restrict__ nch,
-              const uint64_t* __restrict__ tb, uint32_t* __restrict__ T, unsigned int* __restrict__ bad) {
+k_part_count2(part_src S, int B1, int B2, int64_t n_ch, lvl2_tab L, uint32_t* __restrict__ T) {
     __shared__ uint32_t hist[PT_MAXBINS];
     const int nb2 = 1 << B2;
     for (int64_t c = blockIdx.x; c < n_ch; c += gridDim.x) {
-        for (int b = threadIdx.x; b < 2 * nb2; b += PT_THREADS) hist[b] = 0;
+        for (int b = threadIdx.x; b < nb2; b += PT_THREADS) hist[b] = 0;
         __syncthreads();
-        const int64_t s0 = c * ch_tiles * PT_TILE, s1 = min(S.n, s0 + (int64_t)ch_tiles * PT_TILE);
-        const uint32_t bfirst = S.rec[3 * s0] >> (32 - B1);
-        for (int64_t i = s0 + threadIdx.x; i < s1; i += PT_THREADS) {
-            const uint32_t w = S.rec[3 * i];
-            const uint32_t d = (w >> (32 - B1 - B2)) - (bfirst << B2);
-            if (d < (uint32_t)(2 * nb2)) atomicAdd(&hist[d], 1u); else atomicOr(bad, 1u);
-        }
+        uint32_t b1, cl; int64_t s0, s1;
+        lvl2_chunk(L, c, &b1, &cl, &s0, &s1);
+        for (int64_t i = s0 + threadIdx.x; i < s1; i += PT_THREADS)
+            atomicAdd(&hist[(S.rec[3 * i] >> (32 - B1 - B2)) & (uint32_t)(nb2 - 1)], 1u);
         __syncthreads();
-        for (int d = threadIdx.x; d < 2 * nb2; d += PT_THREADS) {
-            const uint32_t v = hist[d];
-            if (!v) continue;
-            const uint32_t b1 = bfirst + (uint32_t)(d >> B2), b2 = (uint32_t)(d & (nb2 - 1));
-            T[tb[b1] + (uint64_t)b2 * nch[b1] + (uint64_t)(c - cfirst[b1])] = v;
-        }
+        const uint64_t t0 = L.tb[b1] + cl; const uint32_t n = L.nch[b1];
+        for (int d = threadIdx.x; d < nb2; d += PT_THREADS) T[t0 + (uint64_t)d * n] = hist[d];
         __syncthreads();
     }
 }
 
 // scatter of one level: tiles are sorted by bin in the LDS and leave as contiguous segments.
-// LEVEL 1: bins = level-1 buckets, write offsets Ts[b * n_st + st].  LEVEL 2: bins = (b1 - bfirst, b2).
+// LEVEL 1: bins = level-1 buckets, write offsets Ts[b * n_st + st].  LEVEL 2: one chunk of one level-1 bucket, bins = b2.
 template <int SRC, int LEVEL>
 __global__ void __launch_bounds__(PT_THREADS)
-k_part_scatter(part_src S, int B1, int B2, int unit_tiles, int64_t n_units, const uint32_t* __restrict__ Ts,
-               const uint32_t* __restrict__ cfirst, const uint32_t* __restrict__ nch, const uint64_t* __restrict__ tb,
+k_part_scatter(part_src S, int B1, int B2, int unit_tiles, int64_t n_units, const uint32_t* __restrict__ Ts, lvl2_tab L,
                uint32_t* __restrict__ o_rec, int narrow_shift) {
     __shared__ uint32_t s_w0[PT_TILE], s_w1[PT_TILE], s_pay[PT_TILE];
     __shared__ uint32_t thist[PT_MAXBINS], tstart[PT_MAXBINS], cursor[PT_MAXBINS];
     __shared__ uint32_t s_wave[16];
-    const int nbins = LEVEL == 1 ? (1 << B1) : (2 << B2);
+    const int nbins = LEVEL == 1 ? (1 << B1) : (1 << B2);
     for (int64_t u = blockIdx.x; u < n_units; u += gridDim.x) {
-        const int64_t s0 = u * unit_tiles * PT_TILE, s1 = min(S.n, s0 + (int64_t)unit_tiles * PT_TILE);
-        uint32_t bfirst = 0;
-        if (LEVEL == 2) bfirst = S.rec[3 * s0] >> (32 - B1);
+        int64_t s0 = u * unit_tiles * PT_TILE, s1 = min(S.n, s0 + (int64_t)unit_tiles * PT_TILE);
+        uint32_t b1 = 0, cl = 0;
+        if (LEVEL == 2) lvl2_chunk(L, u, &b1, &cl, &s0, &s1);
         lds_sync();
         for (int b = threadIdx.x; b < nbins; b += PT_THREADS) {
-            uint32_t off = 0;
-            if (LEVEL == 1) off = Ts[(int64_t)b * n_units + u];
-            else {
-                const uint32_t b1 = bfirst + (uint32_t)(b >> B2), b2 = (uint32_t)(b & ((1 << B2) - 1));
-                if (b1 < (1u << B1) && nch[b1] && (uint64_t)u >= cfirst[b1] && (uint64_t)u < (uint64_t)cfirst[b1] + nch[b1])
-                    off = Ts[tb[b1] + (uint64_t)b2 * nch[b1] + ((uint64_t)u - cfirst[b1])];
-            }
+            const uint32_t off = LEVEL == 1 ? Ts[(int64_t)b * n_units + u] : Ts[L.tb[b1] + (uint64_t)b * L.nch[b1] + cl];
             cursor[b] = off;
         }
         // The raw words of tile t + 1 are requested while tile t is sorted; they (and, the memory pipeline being
@@ -895,7 +891,7 @@ k_part_scatter(part_src S, int B1, int B2, int unit_tiles, int64_t n_units, cons
             for (int j = 0; j < PT_PER; ++j) {
                 bin[j] = 0; rk[j] = 0;
                 if (ok[j]) {
-                    bin[j] = LEVEL == 1 ? (B1 ? (w0[j] >> (32 - B1)) : 0u) : ((w0[j] >> (32 - B1 - B2)) - (bfirst << B2));
+                    bin[j] = LEVEL == 1 ? (B1 ? (w0[j] >> (32 - B1)) : 0u) : ((w0[j] >> (32 - B1 - B2)) & (uint32_t)(nbins - 1));
                     rk[j] = atomicAdd(&thist[bin[j]], 1u);
                 }
             }
@@ -924,7 +920,7 @@ k_part_scatter(part_src S, int B1, int B2, int unit_tiles, int64_t n_units, cons
             // hold consecutive slots, so a wave writes each bin's segment of the tile as one contiguous run
             for (uint32_t slot = threadIdx.x; slot < n_tile; slot += PT_THREADS) {
                 const uint32_t w = s_w0[slot];
-                const uint32_t b = LEVEL == 1 ? (B1 ? (w >> (32 - B1)) : 0u) : ((w >> (32 - B1 - B2)) - (bfirst << B2));
+                const uint32_t b = LEVEL == 1 ? (B1 ? (w >> (32 - B1)) : 0u) : ((w >> (32 - B1 - B2)) & (uint32_t)(nbins - 1));
                 const uint64_t dst = (uint64_t)cursor[b] + (slot - tstart[b]);
                 if (narrow_shift >= 0) {
                     // the bucket fixes the top narrow_shift key bits and at most 32 remain: one word carries them
@@ -1026,6 +1022,74 @@ k_part_scatter_dense(part_src S, int B1, int unit_tiles, int64_t n_units, const 
                 const uint32_t b = B1 ? (v[0] >> (32 - B1)) : 0u;
                 const uint64_t dst = (uint64_t)cursor[b] + (slot - tstart[b]);
                 __builtin_memcpy(o_rec + 3 * dst, v, 12);
+            }
+            lds_sync();
+            for (int b = threadIdx.x; b < nbins; b += PT_THREADS) cursor[b] += thist[b];
+            lds_sync();
+        }
+    }
+}
+
+// Level-2 scatter for 8-byte output records (the bucket fixes the top narrow_shift key bits, <= 32 remain):
+// tiles of 16 384 records, staged in the LDS already narrowed.  The staged record no longer holds its bin, so
+// the output runs bin-major: eight lanes take one bin's slots (a bin's segment of the tile: 8 records = 64 bytes
+// on average), eight bins per wave and trip.
+constexpr int NT_TILE = 16384;
+constexpr int NT_PER = NT_TILE / PT_THREADS;
+constexpr int NT_MAXBINS = 2048;
+__global__ void __launch_bounds__(PT_THREADS)
+k_part_scatter2_narrow(part_src S, int B1, int B2, int64_t n_ch, const uint32_t* __restrict__ Ts, lvl2_tab L,
+                       uint32_t* __restrict__ o_rec, int narrow_shift) {
+    __shared__ uint2 s_rec[NT_TILE];
+    __shared__ uint32_t thist[NT_MAXBINS], tstart[NT_MAXBINS], cursor[NT_MAXBINS];
+    __shared__ uint32_t s_wave[16];
+    const int nbins = 1 << B2;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int64_t c = blockIdx.x; c < n_ch; c += gridDim.x) {
+        uint32_t b1, cl; int64_t s0, s1;
+        lvl2_chunk(L, c, &b1, &cl, &s0, &s1);
+        lds_sync();
+        for (int b = threadIdx.x; b < nbins; b += PT_THREADS) cursor[b] = Ts[L.tb[b1] + (uint64_t)b * L.nch[b1] + cl];
+        for (int64_t t0 = s0; t0 < s1; t0 += NT_TILE) {
+            for (int b = threadIdx.x; b < nbins; b += PT_THREADS) thist[b] = 0;
+            lds_sync();
+            uint32_t key[NT_PER], pay[NT_PER], br[NT_PER];      // br = bin | rank in bin << 11, or all ones
+#pragma unroll
+            for (int j = 0; j < NT_PER; ++j) {
+                const int64_t i = t0 + (int64_t)j * PT_THREADS + threadIdx.x;
+                br[j] = 0xffffffffu; key[j] = 0; pay[j] = 0;
+                if (i < s1) {
+                    uint32_t r[3]; __builtin_memcpy(r, S.rec + 3 * i, 12);
+                    key[j] = (uint32_t)(((((uint64_t)r[0] << 32) | r[1]) << narrow_shift) >> 32); pay[j] = r[2];
+                    br[j] = (r[0] >> (32 - B1 - B2)) & (uint32_t)(nbins - 1);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NT_PER; ++j) if (br[j] != 0xffffffffu) br[j] |= atomicAdd(&thist[br[j]], 1u) << 11;
+            lds_sync();
+            {
+                constexpr int BPT = NT_MAXBINS / PT_THREADS;
+                uint32_t cn[BPT], tot = 0;
+#pragma unroll
+                for (int v = 0; v < BPT; ++v) { const int b = BPT * (int)threadIdx.x + v; cn[v] = b < nbins ? thist[b] : 0u; tot += cn[v]; }
+                uint32_t run = block_scan_1024(tot, s_wave, nullptr);
+#pragma unroll
+                for (int v = 0; v < BPT; ++v) { const int b = BPT * (int)threadIdx.x + v; if (b < nbins) tstart[b] = run; run += cn[v]; }
+            }
+            lds_sync();
+#pragma unroll
+            for (int j = 0; j < NT_PER; ++j) if (br[j] != 0xffffffffu) s_rec[tstart[br[j] & 0x7ffu] + (br[j] >> 11)] = make_uint2(key[j], pay[j]);
+            lds_sync();
+            // bin-major output: wave w owns the bins [w * nbins / 16, (w + 1) * nbins / 16)
+            const int per_wave = (nbins + 15) >> 4;
+            for (int bb = wv * per_wave; bb < min(nbins, (wv + 1) * per_wave); bb += 8) {
+                const int b = bb + (lane >> 3);
+                const bool live = b < min(nbins, (wv + 1) * per_wave);
+                const uint32_t st = live ? tstart[b] : 0u, cnt = live ? thist[b] : 0u;
+                const uint64_t cur = live ? cursor[b] : 0ull;
+                for (uint32_t i = (uint32_t)(lane & 7); __any(i < cnt); i += 8) {
+                    if (i < cnt) { const uint2 v = s_rec[st + i]; __builtin_memcpy(o_rec + 2 * (cur + i), &v, 8); }
+                }
             }
             lds_sync();
             for (int b = threadIdx.x; b < nbins; b += PT_THREADS) cursor[b] += thist[b];
@@ -1351,9 +1415,9 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
         if (dense && st_tiles % 4 == 0 && B1 <= 12 && !old_scatter)
             hipLaunchKernelGGL(k_part_scatter_dense, dim3(grid_s), dim3(PT_THREADS), 0, s, S, B1, st_tiles / 4, n_st, (const uint32_t*)T1s.p, a_rec.p);
         else if (dense) hipLaunchKernelGGL((k_part_scatter<SRC_DENSE, 1>), dim3(grid_s), dim3(PT_THREADS), 0, s, S, B1, 0, st_tiles, n_st, (const uint32_t*)T1s.p,
-                                      (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint64_t*)nullptr, a_rec.p, -1);
+                                      lvl2_tab{}, a_rec.p, -1);
         else hipLaunchKernelGGL((k_part_scatter<SRC_ARRAYS, 1>), dim3(grid_s), dim3(PT_THREADS), 0, s, S, B1, 0, st_tiles, n_st, (const uint32_t*)T1s.p,
-                                (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint64_t*)nullptr, a_rec.p, -1);
+                                lvl2_tab{}, a_rec.p, -1);
     }
     const int64_t nbk = levels == 1 ? nb1 : (int64_t)nb1 * nb2;
     dbuf<uint32_t> boff((size_t)nbk + 1);
@@ -1367,44 +1431,43 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
         VG_HIP(hipMemcpy2DAsync(off1.data(), sizeof(uint32_t), T1s.p, (size_t)n_st * sizeof(uint32_t), sizeof(uint32_t), (size_t)nb1, hipMemcpyDeviceToHost, s));
         VG_HIP(hipStreamSynchronize(s));
         off1[(size_t)nb1] = n1;
-        uint32_t min_bucket = 0xffffffffu;
-        for (int b = 0; b < nb1; ++b) min_bucket = std::min(min_bucket, off1[(size_t)b + 1] - off1[(size_t)b]);
-        const int ch_tiles = (int)std::min<uint32_t>(8, min_bucket / PT_TILE);
-        if (ch_tiles < 1) return false;                       // a chunk could touch more than two level-1 buckets
-        const int64_t ST2 = (int64_t)ch_tiles * PT_TILE;
-        const int64_t n_ch = ((int64_t)n1 + ST2 - 1) / ST2;
-        std::vector<uint32_t> cfirst((size_t)nb1), nch((size_t)nb1); std::vector<uint64_t> tbv((size_t)nb1 + 1);
+        // level 2 runs on chunks of one level-1 bucket each (see lvl2_tab)
+        const uint32_t ST2 = 8 * PT_TILE;
+        std::vector<uint32_t> cfirst((size_t)nb1), nch((size_t)nb1), ch_b1; std::vector<uint64_t> tbv((size_t)nb1 + 1);
         uint64_t tot = 0;
         for (int b = 0; b < nb1; ++b) {
-            cfirst[(size_t)b] = (uint32_t)(off1[(size_t)b] / ST2);
-            nch[(size_t)b] = (uint32_t)((off1[(size_t)b + 1] - 1) / ST2 - cfirst[(size_t)b] + 1);
+            const uint32_t sz = off1[(size_t)b + 1] - off1[(size_t)b];
+            cfirst[(size_t)b] = (uint32_t)ch_b1.size();
+            nch[(size_t)b] = (sz + ST2 - 1) / ST2;
+            ch_b1.insert(ch_b1.end(), nch[(size_t)b], (uint32_t)b);
             tbv[(size_t)b] = tot; tot += (uint64_t)nch[(size_t)b] * nb2;
         }
         tbv[(size_t)nb1] = tot;
+        const int64_t n_ch = (int64_t)ch_b1.size();
         if (tot >= (1ULL << 31)) return false;
-        dbuf<uint32_t> d_off1((size_t)nb1 + 1), d_cfirst((size_t)nb1), d_nch((size_t)nb1); dbuf<uint64_t> d_tb((size_t)nb1 + 1);
+        dbuf<uint32_t> d_off1((size_t)nb1 + 1), d_cfirst((size_t)nb1), d_nch((size_t)nb1), d_chb1((size_t)std::max<int64_t>(1, n_ch)); dbuf<uint64_t> d_tb((size_t)nb1 + 1);
         d_off1.upload(off1.data(), off1.size(), s); d_cfirst.upload(cfirst.data(), cfirst.size(), s); d_nch.upload(nch.data(), nch.size(), s);
-        d_tb.upload(tbv.data(), tbv.size(), s);
-        dbuf<uint32_t> T2((size_t)tot + 1), T2s((size_t)tot + 1); dbuf<unsigned int> d_bad(1);
-        T2.zero(s); d_bad.zero(s);
+        d_tb.upload(tbv.data(), tbv.size(), s); if (n_ch) d_chb1.upload(ch_b1.data(), ch_b1.size(), s);
+        const lvl2_tab L2{ d_chb1.p, d_cfirst.p, d_nch.p, d_off1.p, d_tb.p, ST2 };
+        dbuf<uint32_t> T2((size_t)tot + 1), T2s((size_t)tot + 1);
+        VG_HIP(hipMemsetAsync(T2.p + tot, 0, sizeof(uint32_t), s));
         part_src S2; memset(&S2, 0, sizeof S2);
         S2.rec = a_rec.p; S2.n = (int64_t)n1; S2.k2 = 2 * k;
-        unsigned int bad = 0;
         {
             vg_prof_scope ps("kmer_partition2", (double)n1 * (4.0 + 12.0 + (narrow ? 8.0 : 12.0)));
-            hipLaunchKernelGGL(k_part_count2, dim3((int)std::min<int64_t>(n_ch, 512)), dim3(PT_THREADS), 0, s, S2, B1, B2, ch_tiles, n_ch,
-                               (const uint32_t*)d_cfirst.p, (const uint32_t*)d_nch.p, (const uint64_t*)d_tb.p, T2.p, d_bad.p);
+            hipLaunchKernelGGL(k_part_count2, dim3((int)std::min<int64_t>(n_ch, 512)), dim3(PT_THREADS), 0, s, S2, B1, B2, n_ch, L2, T2.p);
             size_t tb2 = 0;
             VG_HIP(rocprim::exclusive_scan(nullptr, tb2, T2.p, T2s.p, 0u, (size_t)tot + 1, rocprim::plus<uint32_t>(), s));
             dbuf<char> tmp2(tb2);
             VG_HIP(rocprim::exclusive_scan((void*)tmp2.p, tb2, T2.p, T2s.p, 0u, (size_t)tot + 1, rocprim::plus<uint32_t>(), s));
-            d_bad.download(&bad, 1, s);
             b_rec.alloc((narrow ? 2 : 3) * (size_t)n1 + 8);
-            VG_HIP(hipStreamSynchronize(s));
-            if (bad) return false;
-            hipLaunchKernelGGL((k_part_scatter<SRC_PLANES, 2>), dim3((int)std::min<int64_t>(n_ch, 256)), dim3(PT_THREADS), 0, s, S2, B1, B2, ch_tiles, n_ch,
-                               (const uint32_t*)T2s.p, (const uint32_t*)d_cfirst.p, (const uint32_t*)d_nch.p, (const uint64_t*)d_tb.p, b_rec.p,
-                               narrow ? total_bits : -1);
+            static const bool staged2 = [] { const char* e = getenv("VG_LEVEL2_SCATTER"); return e && !strcmp(e, "staged"); }();
+            if (narrow && B2 <= 11 && !staged2)
+                hipLaunchKernelGGL(k_part_scatter2_narrow, dim3((int)std::min<int64_t>(n_ch, 256)), dim3(PT_THREADS), 0, s, S2, B1, B2, n_ch,
+                                   (const uint32_t*)T2s.p, L2, b_rec.p, total_bits);
+            else
+                hipLaunchKernelGGL((k_part_scatter<SRC_PLANES, 2>), dim3((int)std::min<int64_t>(n_ch, 256)), dim3(PT_THREADS), 0, s, S2, B1, B2, 0, n_ch,
+                                   (const uint32_t*)T2s.p, L2, b_rec.p, narrow ? total_bits : -1);
         }
         hipLaunchKernelGGL(k_bucket_offsets, dim3(grid_for(nbk + 1)), dim3(256), 0, s, 2, B1, B2, n_st, (const uint32_t*)T1s.p, (const uint32_t*)d_off1.p,
                            (const uint32_t*)d_nch.p, (const uint64_t*)d_tb.p, (const uint32_t*)T2s.p, n1, boff.p);
