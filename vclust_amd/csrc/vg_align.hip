@@ -20,6 +20,7 @@
 // no MFMA, the levers are occupancy and L2 locality of the reference (tasks are grouped by
 // reference and dealt to workgroups XCD-aware).
 #include "vg_common.h"
+#include <rocprim/rocprim.hpp>
 #include <algorithm>
 #include <numeric>
 #include <cstring>
@@ -1193,6 +1194,45 @@ inline int grid_for(int64_t n, int block = 256, int max_blocks = 256 * 16) {
 }  // namespace
 
 static int64_t g_index_budget_bytes = 24LL << 30;
+// ---- task grouping on the device: the caller's (q, r) list is counted per reference, stably sorted on r
+// (rocPRIM radix sort of the 17..32-bit reference ids with the list position as value) and turned into the
+// device task records -- the host only sees the per-reference counts it plans the batches from.
+namespace {
+__global__ void __launch_bounds__(256)
+k_task_count(const vg_task* __restrict__ tasks, int64_t n_tasks, int n_genomes, const int64_t* __restrict__ len,
+             uint32_t* __restrict__ ref_cnt, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+             unsigned long long* __restrict__ sums /* [0] sum len[q], [1] sum len[r], [2] max len[q], [3] bad ids */) {
+    unsigned long long sq = 0, sr = 0, mq = 0, bad = 0;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_tasks; t += (int64_t)gridDim.x * blockDim.x) {
+        const vg_task tk = tasks[t];
+        keys[t] = tk.r; vals[t] = (uint32_t)t;
+        if (tk.q >= (uint32_t)n_genomes || tk.r >= (uint32_t)n_genomes) { bad = 1; continue; }
+        atomicAdd(&ref_cnt[tk.r], 1u);
+        const unsigned long long ql = (unsigned long long)len[tk.q];
+        sq += ql; sr += (unsigned long long)len[tk.r]; mq = ql > mq ? ql : mq;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        sq += __shfl_xor(sq, o); sr += __shfl_xor(sr, o); bad |= __shfl_xor(bad, o);
+        const unsigned long long m2 = __shfl_xor(mq, o); mq = m2 > mq ? m2 : mq;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (sq) atomicAdd(&sums[0], sq);
+        if (sr) atomicAdd(&sums[1], sr);
+        if (mq) atomicMax(&sums[2], mq);
+        if (bad) atomicOr(&sums[3], 1ULL);
+    }
+}
+__global__ void __launch_bounds__(256)
+k_task_records(const vg_task* __restrict__ tasks, const uint32_t* __restrict__ sorted_idx, int64_t n_tasks,
+               const uint32_t* __restrict__ ord /* genome -> ordinal among the references that have tasks */, task_dev* __restrict__ td) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_tasks; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t t = sorted_idx[i];
+        const vg_task tk = tasks[t];
+        td[i] = { tk.q, ord[tk.r], t, 0u };
+    }
+}
+}  // namespace
+
 static int64_t g_segment_task_limit = 32768;
 // VG_LZ_BUILD=lds: the scratch-based LDS build also for short references (tests compare the two)
 static const bool g_no_reg_build = [] { const char* e = getenv("VG_LZ_BUILD"); return e && strcmp(e, "lds") == 0; }();
@@ -1208,36 +1248,50 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
     vg_require_device();
     int rc = vg_genomes_to_device(g); if (rc) return rc;
     hipStream_t s = vg_stream();
+    vg_host_mark("vg_lz_align: enter");
     if (regions) { *regions = nullptr; if (n_regions) *n_regions = 0; }
     if (n_tasks == 0) return VG_OK;
     for (int i = 0; i < g->n; ++i) if (g->len[i] > (1 << 29)) throw vg_error(VG_EOVERFLOW, "genome longer than 2^29 bases");
     if (n_tasks >= (1LL << 32)) throw vg_error(VG_EOVERFLOW, "more than 2^32 - 1 ordered pairs in one call: split the task list");
 
-    // group tasks by reference: ONE stable counting sort writes the device task records of the whole call,
-    // (query, ordinal of the reference among the references that have tasks, position in the caller's list);
-    // ids are checked on the way.  (The GPU waits for this list: it is built once, not per batch.)
-    std::vector<task_dev> td((size_t)n_tasks);
+    // group tasks by reference ON THE DEVICE (k_task_count, a stable radix sort on the reference id, k_task_records):
+    // device task records (query, ordinal of the reference among the references that have tasks, position in
+    // the caller's list); the host gets the per-reference counts back and plans the batches from them.
+    std::vector<task_dev> td;                                 // host copy, fetched for --out-aln only
     std::vector<int64_t> ref_first((size_t)g->n + 1, 0);     // first sorted task of reference r
     std::vector<uint32_t> ref_ids;                            // references that have tasks, ascending
     int64_t q_max = 0; double q_sum = 0, bytes_alg_all = 0;
+    dbuf<task_dev> d_tasks((size_t)n_tasks);
     {
-        for (int64_t t = 0; t < n_tasks; ++t) {
-            if (tasks[t].q >= (uint32_t)g->n || tasks[t].r >= (uint32_t)g->n) throw vg_error(VG_EINVAL, "task id out of range");
-            ref_first[tasks[t].r + 1]++;
-        }
+        dbuf<vg_task> d_raw((size_t)n_tasks); d_raw.upload(tasks, (size_t)n_tasks, s);
+        dbuf<uint32_t> d_cnt((size_t)g->n), d_keys((size_t)n_tasks), d_vals((size_t)n_tasks), d_keys2((size_t)n_tasks), d_vals2((size_t)n_tasks);
+        dbuf<unsigned long long> d_sums(4);
+        d_cnt.zero(s); d_sums.zero(s);
+        hipLaunchKernelGGL(k_task_count, dim3(grid_for(n_tasks)), dim3(256), 0, s, (const vg_task*)d_raw.p, n_tasks, g->n, g->d_len.p, d_cnt.p,
+                           d_keys.p, d_vals.p, d_sums.p);
+        std::vector<uint32_t> cnt((size_t)g->n); unsigned long long sums[4];
+        d_cnt.download(cnt.data(), cnt.size(), s); d_sums.download(sums, 4, s);
+        int id_bits = 1; while ((1LL << id_bits) < g->n) ++id_bits;
+        size_t tmp_bytes = 0;
+        VG_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_keys.p, d_keys2.p, d_vals.p, d_vals2.p, (size_t)n_tasks, 0u, (unsigned)id_bits, s));
+        dbuf<char> tmp(tmp_bytes);
+        VG_HIP(rocprim::radix_sort_pairs((void*)tmp.p, tmp_bytes, d_keys.p, d_keys2.p, d_vals.p, d_vals2.p, (size_t)n_tasks, 0u, (unsigned)id_bits, s));
+        VG_HIP(hipStreamSynchronize(s));
+        if (sums[3]) throw vg_error(VG_EINVAL, "task id out of range");
         std::vector<uint32_t> ord((size_t)g->n, 0);
         for (int i = 0; i < g->n; ++i) {
-            if (ref_first[(size_t)i + 1]) { ord[(size_t)i] = (uint32_t)ref_ids.size(); ref_ids.push_back((uint32_t)i); }
-            ref_first[(size_t)i + 1] += ref_first[(size_t)i];
+            if (cnt[(size_t)i]) { ord[(size_t)i] = (uint32_t)ref_ids.size(); ref_ids.push_back((uint32_t)i); }
+            ref_first[(size_t)i + 1] = ref_first[(size_t)i] + cnt[(size_t)i];
         }
-        std::vector<int64_t> cur(ref_first.begin(), ref_first.end() - 1);
-        for (int64_t t = 0; t < n_tasks; ++t) {
-            const vg_task& tk = tasks[t];
-            td[(size_t)cur[tk.r]++] = { tk.q, ord[tk.r], (uint32_t)t, 0 };
-            const int64_t ql = g->len[tk.q];
-            q_max = std::max(q_max, ql); q_sum += (double)ql; bytes_alg_all += (double)(ql + g->len[tk.r]) / 4.0 + 20.0;
-        }
+        q_max = (int64_t)sums[2]; q_sum = (double)sums[0];
+        bytes_alg_all = ((double)sums[0] + (double)sums[1]) / 4.0 + 20.0 * (double)n_tasks;
+        dbuf<uint32_t> d_ord((size_t)g->n); d_ord.upload(ord.data(), ord.size(), s);
+        hipLaunchKernelGGL(k_task_records, dim3(grid_for(n_tasks)), dim3(256), 0, s, (const vg_task*)d_raw.p, (const uint32_t*)d_vals2.p, n_tasks,
+                           (const uint32_t*)d_ord.p, d_tasks.p);
+        if (regions) { td.resize((size_t)n_tasks); d_tasks.download(td.data(), td.size(), s); }
+        VG_HIP(hipStreamSynchronize(s));                      // the scratch buffers go out of scope
     }
+    vg_host_mark("lz: tasks grouped");
     const char* abl = getenv("VG_LZ_ABLATE");
     const lz_dev_params P{ p->mal, p->msl, p->mrd, p->mqd, p->reg, p->aw, p->am, p->ar, abl ? atoi(abl) : 0 };
     const int64_t stab_n = 1LL << (2 * p->msl);
@@ -1322,11 +1376,11 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
             B.scratch_words = (int64_t)B.nblk_build * B.stride * 3;
         }
     }
+    vg_host_mark("lz: batches planned");
     // ---- the task records and reference descriptors of the whole call go up once; one set of index buffers,
     // sized for the largest batch, is reused by every batch
-    dbuf<ref_desc> d_refs(std::max<size_t>(1, all_refs.size())); dbuf<task_dev> d_tasks((size_t)n_tasks);
+    dbuf<ref_desc> d_refs(std::max<size_t>(1, all_refs.size()));
     if (!all_refs.empty()) d_refs.upload(all_refs.data(), all_refs.size(), s);
-    d_tasks.upload(td.data(), td.size(), s);
     struct lz_slot { dbuf<uint32_t> rr_pool, mask_pool, stab_pool, sent_pool, scratch; dbuf<int> d_reg, d_small, d_large; dbuf<int64_t> d_lchunk; };
     lz_slot slot;
     {
@@ -1426,10 +1480,13 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
             }
         }
     }
+    vg_host_mark("lz: launched");
     VG_HIP(hipStreamSynchronize(s));
     VG_HIP(hipGetLastError());
+    vg_host_mark("lz: kernels done");
     d_stats.download(stats, (size_t)n_tasks, s);
     VG_HIP(hipStreamSynchronize(s));
+    vg_host_mark("lz: rows downloaded");
     if (want_regions) {
         vg_region* o = (vg_region*)malloc(sizeof(vg_region) * std::max<size_t>(1, h_regions.size()));
         if (!o) throw vg_error(VG_ENOMEM, "out of host memory");

@@ -107,6 +107,8 @@ void vg_length_order(const vg_genomes* g);        // fills g->len_order / g->len
 // fn(lo, hi, t) over [0, n) cut into contiguous chunks, one per thread (the library's host loops over
 // 10^5..10^6 pairs / tasks: a few threads are enough; an exception in a chunk is rethrown on the caller)
 int vg_host_threads();
+// developer aid: with VG_HOST_TRACE=1 prints the wall time since the previous mark (host-side phases of a call)
+void vg_host_mark(const char* what);
 template <class F> void vg_parallel_chunks(int64_t n, int n_thr, F fn);
 // append one genome given codes (0..3, >3 = N); used by the FASTA reader and vg_genomes_from_codes
 void vg_genomes_append(vg_genomes* g, const std::string& name, const uint8_t* codes, int64_t len, int n_parts);

@@ -1,5 +1,6 @@
 // vg_core.cpp — error channel, device selection, the library stream and HIP-event profiling.
 #include "vg_common.h"
+#include <chrono>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -59,6 +60,15 @@ hipStream_t vg_stream() {
     vg_require_device();
     if (!g_stream) VG_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
     return g_stream;
+}
+
+void vg_host_mark(const char* what) {
+    static const bool on = [] { const char* e = getenv("VG_HOST_TRACE"); return e && *e && *e != '0'; }();
+    if (!on) return;
+    static thread_local std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[vg host] %-28s +%.3f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
+    last = now;
 }
 
 int vg_host_threads() {

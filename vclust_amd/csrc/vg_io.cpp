@@ -5,6 +5,7 @@
 //   ani.tsv, ids.tsv    layout of example/output/ani{,.ids}.tsv  
 //   ani.aln.tsv         layout of example/output/ani.aln.tsv     
 #include "vg_common.h"
+#include <cmath>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -91,21 +92,32 @@ extern "C" int vg_filter_pairs(int k, int min_kmers, double min_ident, const int
                                const vg_pair_count* pairs, int64_t n_pairs, vg_pair_count** out, int64_t* n_out) {
     VG_API_BEGIN
     if (!set_sizes || (!pairs && n_pairs) || !out || !n_out) throw vg_error(VG_EINVAL, "vg_filter_pairs: null argument");
-    const int T = vg_host_threads();
-    std::vector<std::vector<vg_pair_count>> part((size_t)T);
-    vg_parallel_chunks(n_pairs, T, [&](int64_t lo, int64_t hi, int t) {
-        auto& keep = part[(size_t)t];
-        for (int64_t i = lo; i < hi; ++i) {
+    // ani >= min_ident  <=>  j = shared / min(|A|, |B|) >= J*, J* = E / (2 - E), E = exp((min_ident - 1) k): one
+    // division per pair instead of a logarithm.  A pair within 1e-9 (relative) of the threshold is decided by the
+    // formula itself, so the kept set is exactly the formula's.
+    vg_host_mark("filter_pairs: enter");
+    const double E = std::exp((min_ident - 1.0) * (double)k);
+    const double Jstar = E < 2.0 ? E / (2.0 - E) : INFINITY;
+    vg_pair_count* o = (vg_pair_count*)malloc(sizeof(vg_pair_count) * std::max<size_t>(1, (size_t)n_pairs));
+    if (!o) throw vg_error(VG_ENOMEM, "out of host memory");
+    size_t total = 0;
+    try {
+        for (int64_t i = 0; i < n_pairs; ++i) {
             const vg_pair_count& p = pairs[i];
             if ((int64_t)p.a >= n_genomes || (int64_t)p.b >= n_genomes) throw vg_error(VG_EINVAL, "pair id out of range");
             if ((int64_t)p.shared < min_kmers) continue;
-            if (vg_ani_shorter(p.shared, set_sizes[p.a], set_sizes[p.b], k) >= min_ident) keep.push_back(p);
+            const int64_t mn = std::min(set_sizes[p.a], set_sizes[p.b]);
+            bool keep_it;
+            if (mn <= 0 || p.shared == 0) keep_it = 0.0 >= min_ident;
+            else {
+                const double j = (double)p.shared / (double)mn;
+                if (std::isfinite(Jstar) && std::fabs(j - Jstar) > 1e-9 * Jstar) keep_it = j > Jstar;
+                else keep_it = vg_ani_shorter(p.shared, set_sizes[p.a], set_sizes[p.b], k) >= min_ident;
+            }
+            if (keep_it) o[total++] = p;
         }
-    });
-    size_t total = 0; for (auto& v : part) total += v.size();
-    vg_pair_count* o = (vg_pair_count*)malloc(sizeof(vg_pair_count) * std::max<size_t>(1, total));
-    if (!o) throw vg_error(VG_ENOMEM, "out of host memory");
-    { size_t w = 0; for (auto& v : part) { if (!v.empty()) memcpy(o + w, v.data(), sizeof(vg_pair_count) * v.size()); w += v.size(); } }
+    } catch (...) { free(o); throw; }
+    vg_host_mark("filter_pairs: done");
     struct { size_t n; size_t size() const { return n; } } keep{ total };
     *out = o; *n_out = (int64_t)keep.size();
     VG_API_END
@@ -233,51 +245,39 @@ extern "C" int vg_align_tasks(const vg_genomes* g, const vg_pair_count* pairs, i
                               vg_task** tasks, int64_t* n_tasks) {
     VG_API_BEGIN
     if (!g || (!pairs && n_pairs) || !tasks || !n_tasks) throw vg_error(VG_EINVAL, "vg_align_tasks: null argument");
+    vg_host_mark("align_tasks: enter");
     vg_length_order(g);
+    vg_host_mark("align_tasks: length order");
     const std::vector<int32_t>& order = g->len_order; const std::vector<int32_t>& rank = g->len_rank;
+    // couples sorted by (lo, hi) of the length ranks: one counting pass on lo, then every lo group (a genome's
+    // partners: a handful) is sorted on hi.  One thread: 10^5..10^6 couples are a few milliseconds of cache-
+    // resident work, less than starting helpers costs.
     struct rp { int32_t lo, hi; };
     std::vector<rp> v((size_t)n_pairs), tmp((size_t)n_pairs);
-    const int T = vg_host_threads();
-    // couples sorted by (lo, hi): one stable counting pass on lo (per-thread histograms), then every lo group
-    // (a genome's partners: a handful) is sorted on hi
-    std::vector<std::vector<int64_t>> hist((size_t)T, std::vector<int64_t>((size_t)g->n + 1, 0));
-    vg_parallel_chunks(n_pairs, T, [&](int64_t lo, int64_t hi, int t) {
-        auto& h = hist[(size_t)t];
-        for (int64_t i = lo; i < hi; ++i) {
-            if (pairs[i].a >= (uint32_t)g->n || pairs[i].b >= (uint32_t)g->n) throw vg_error(VG_EINVAL, "pair id out of range");
-            const int32_t x = rank[pairs[i].a], y = rank[pairs[i].b];
-            v[(size_t)i] = { std::min(x, y), std::max(x, y) };
-            h[(size_t)v[(size_t)i].lo]++;
-        }
-    });
     std::vector<int64_t> start((size_t)g->n + 1, 0);
-    {   // start[t][key] = global start of key + entries of the threads before t
-        int64_t run = 0;
-        for (int key = 0; key < g->n; ++key) {
-            start[(size_t)key] = run;
-            for (int t = 0; t < T; ++t) { const int64_t c = hist[(size_t)t][(size_t)key]; hist[(size_t)t][(size_t)key] = run; run += c; }
-        }
-        start[(size_t)g->n] = run;
+    for (int64_t i = 0; i < n_pairs; ++i) {
+        if (pairs[i].a >= (uint32_t)g->n || pairs[i].b >= (uint32_t)g->n) throw vg_error(VG_EINVAL, "pair id out of range");
+        const int32_t x = rank[pairs[i].a], y = rank[pairs[i].b];
+        v[(size_t)i] = { std::min(x, y), std::max(x, y) };
+        start[(size_t)v[(size_t)i].lo + 1]++;
     }
-    vg_parallel_chunks(n_pairs, T, [&](int64_t lo, int64_t hi, int t) {
-        auto& h = hist[(size_t)t];
-        for (int64_t i = lo; i < hi; ++i) tmp[(size_t)h[(size_t)v[(size_t)i].lo]++] = v[(size_t)i];
-    });
-    vg_parallel_chunks((int64_t)g->n, T, [&](int64_t lo, int64_t hi, int) {
-        for (int64_t key = lo; key < hi; ++key) {
-            const int64_t s0 = start[(size_t)key], s1 = start[(size_t)key + 1];
-            if (s1 - s0 > 1) std::sort(tmp.begin() + s0, tmp.begin() + s1, [](const rp& x, const rp& y) { return x.hi < y.hi; });
-        }
-    });
+    for (int key = 0; key < g->n; ++key) start[(size_t)key + 1] += start[(size_t)key];
+    {
+        std::vector<int64_t> cur(start.begin(), start.end() - 1);
+        for (int64_t i = 0; i < n_pairs; ++i) tmp[(size_t)cur[(size_t)v[(size_t)i].lo]++] = v[(size_t)i];
+    }
+    for (int key = 0; key < g->n; ++key) {
+        const int64_t s0 = start[(size_t)key], s1 = start[(size_t)key + 1];
+        if (s1 - s0 > 1) std::sort(tmp.begin() + s0, tmp.begin() + s1, [](const rp& x, const rp& y) { return x.hi < y.hi; });
+    }
     v.swap(tmp);
     vg_task* o = (vg_task*)malloc(sizeof(vg_task) * std::max<size_t>(1, 2 * v.size()));
     if (!o) throw vg_error(VG_ENOMEM, "out of host memory");
-    vg_parallel_chunks((int64_t)v.size(), T, [&](int64_t lo, int64_t hi, int) {
-        for (int64_t i = lo; i < hi; ++i) {
-            o[2 * i] = { (uint32_t)order[(size_t)v[(size_t)i].hi], (uint32_t)order[(size_t)v[(size_t)i].lo] };       // row (q = b, r = a)
-            o[2 * i + 1] = { (uint32_t)order[(size_t)v[(size_t)i].lo], (uint32_t)order[(size_t)v[(size_t)i].hi] };   // row (q = a, r = b)
-        }
-    });
+    for (size_t i = 0; i < v.size(); ++i) {
+        o[2 * i] = { (uint32_t)order[(size_t)v[i].hi], (uint32_t)order[(size_t)v[i].lo] };       // row (q = b, r = a)
+        o[2 * i + 1] = { (uint32_t)order[(size_t)v[i].lo], (uint32_t)order[(size_t)v[i].hi] };   // row (q = a, r = b)
+    }
+    vg_host_mark("align_tasks: done");
     *tasks = o; *n_tasks = (int64_t)(2 * v.size());
     VG_API_END
 }

@@ -1374,6 +1374,7 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
                                 const compact_map& cmap, int* d_kept, dbuf<uint32_t>& gen, dbuf<uint64_t>& rowinfo, dbuf<uint32_t>& arena,
                                 int64_t n_rows_info, int* d_dups, int64_t* n_valid_out) {
     hipStream_t s = vg_stream();
+    vg_host_mark("buckets: enter");
     if (g_index_path < 0) { const char* e = getenv("VG_INDEX_PATH"); g_index_path = (e && !strcmp(e, "radix")) ? 0 : 1; }
     if (!g_index_path || n_src < (1 << 16) || n_src >= (1LL << 32)) return false;
     int total_bits = 0; while ((n_src >> total_bits) > 1024 && total_bits < 22) ++total_bits;
@@ -1405,6 +1406,7 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
         VG_HIP(rocprim::exclusive_scan((void*)tmp.p, tb, T1.p, T1s.p, 0u, t1n + 1, rocprim::plus<uint32_t>(), s));
         VG_HIP(hipMemcpyAsync(&n1, T1s.p + t1n, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         VG_HIP(hipStreamSynchronize(s));
+        vg_host_mark("buckets: count+scan done");
         *n_valid_out = (int64_t)n1;
         if (n1 == 0) return true;
         // two levels: the level-1 records are dead once level 2 has scattered them, and the genome list + row
@@ -1431,6 +1433,7 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
         VG_HIP(hipMemcpy2DAsync(off1.data(), sizeof(uint32_t), T1s.p, (size_t)n_st * sizeof(uint32_t), sizeof(uint32_t), (size_t)nb1, hipMemcpyDeviceToHost, s));
         VG_HIP(hipStreamSynchronize(s));
         off1[(size_t)nb1] = n1;
+        vg_host_mark("buckets: level 1 done, off1");
         // level 2 runs on chunks of one level-1 bucket each (see lvl2_tab)
         const uint32_t ST2 = 8 * PT_TILE;
         std::vector<uint32_t> cfirst((size_t)nb1), nch((size_t)nb1), ch_b1; std::vector<uint64_t> tbv((size_t)nb1 + 1);
@@ -1448,6 +1451,7 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
         dbuf<uint32_t> d_off1((size_t)nb1 + 1), d_cfirst((size_t)nb1), d_nch((size_t)nb1), d_chb1((size_t)std::max<int64_t>(1, n_ch)); dbuf<uint64_t> d_tb((size_t)nb1 + 1);
         d_off1.upload(off1.data(), off1.size(), s); d_cfirst.upload(cfirst.data(), cfirst.size(), s); d_nch.upload(nch.data(), nch.size(), s);
         d_tb.upload(tbv.data(), tbv.size(), s); if (n_ch) d_chb1.upload(ch_b1.data(), ch_b1.size(), s);
+        vg_host_mark("buckets: level-2 tables");
         const lvl2_tab L2{ d_chb1.p, d_cfirst.p, d_nch.p, d_off1.p, d_tb.p, ST2 };
         dbuf<uint32_t> T2((size_t)tot + 1), T2s((size_t)tot + 1);
         VG_HIP(hipMemsetAsync(T2.p + tot, 0, sizeof(uint32_t), s));
@@ -1472,6 +1476,7 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
         hipLaunchKernelGGL(k_bucket_offsets, dim3(grid_for(nbk + 1)), dim3(256), 0, s, 2, B1, B2, n_st, (const uint32_t*)T1s.p, (const uint32_t*)d_off1.p,
                            (const uint32_t*)d_nch.p, (const uint64_t*)d_tb.p, (const uint32_t*)T2s.p, n1, boff.p);
         VG_HIP(hipStreamSynchronize(s));                       // the tables and level-1 planes go out of scope below
+        vg_host_mark("buckets: level 2 done");
         f_rec = b_rec.p; f_stride = narrow ? 2 : 3;
         arena = std::move(a_rec);
         rowinfo.view(reinterpret_cast<uint64_t*>(arena.p), (size_t)n_rows_info);
@@ -1531,6 +1536,7 @@ static void kmer_shared_pass(vg_genomes* g, int k, double fraction, int shard, i
             if (bucket_ok) si.kept.download(kept.data(), (size_t)n, s);
         }
         if (bucket_ok) { d_dups.download(dups.data(), (size_t)n, s); VG_HIP(hipStreamSynchronize(s)); }
+        vg_host_mark("index built");
     }
     if (!bucket_ok) {
     rowinfo.release(); gen.release(); arena.release();
@@ -1599,6 +1605,7 @@ static void kmer_shared_pass(vg_genomes* g, int k, double fraction, int shard, i
         host_pairs.resize(std::min<size_t>(EAGER, (size_t)cap));
         d_nover.download(&nover, 1, s); d_cursor.download(&produced, 1, s); d_out.download(host_pairs.data(), host_pairs.size(), s);
         VG_HIP(hipStreamSynchronize(s));
+        vg_host_mark("spgemm done");
         if (nover == 0 && produced <= host_pairs.size()) { host_pairs.resize((size_t)produced); break; }
         if (nover > 0) {
             // second try with the 64 KiB table for the rows that overflowed the small one
@@ -1648,6 +1655,7 @@ extern "C" int vg_kmer_shared(vg_genomes* g, int k, double fraction, int shard, 
     if (k < 8 || k > 31) throw vg_error(VG_EINVAL, "k out of range (8..31)");
     if (n_shards < 1 || shard < 0 || shard >= n_shards) throw vg_error(VG_EINVAL, "bad shard");
     if (!(fraction > 0.0) || fraction > 1.0) throw vg_error(VG_EINVAL, "fraction must be in (0,1]");
+    vg_host_mark("vg_kmer_shared: enter");
     vg_require_device();
     int rc = vg_genomes_to_device(g); if (rc) return rc;
     *pairs = nullptr; *n_pairs = 0;
@@ -1685,10 +1693,12 @@ extern "C" int vg_kmer_shared(vg_genomes* g, int k, double fraction, int shard, 
         }
         if (min_shared > 1) acc.erase(std::remove_if(acc.begin(), acc.end(), [&](const vg_pair_count& x) { return x.shared < min_shared; }), acc.end());
     }
+    vg_host_mark("pass done");
     vg_pair_count* outp = (vg_pair_count*)malloc(sizeof(vg_pair_count) * std::max<size_t>(1, acc.size()));
     if (!outp) throw vg_error(VG_ENOMEM, "out of host memory");
     if (!acc.empty()) memcpy(outp, acc.data(), sizeof(vg_pair_count) * acc.size());
     *pairs = outp; *n_pairs = (int64_t)acc.size();
+    vg_host_mark("vg_kmer_shared: return");
     VG_API_END
 }
 
