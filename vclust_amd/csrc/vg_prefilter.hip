@@ -17,9 +17,18 @@
 namespace {
 
 constexpr uint64_t SENT = ~0ULL;
-// k-mers are stored scrambled: key = (canonical * SCRAMBLE) mod 4^k, a bijection that spreads any
-// composition bias over the HIGH key bits, so that sorting on a high-bit prefix gives tiny groups
-constexpr uint64_t SCRAMBLE = 0x9E3779B97F4A7C15ULL;      // odd
+// k-mers are stored scrambled by a bijection of the 2k-bit canonical value that spreads any composition bias
+// over the HIGH key bits (the partition digits): one Feistel round on the two k-bit halves,
+//   (H, L) -> (H ^ top k bits of (L * SCRAMBLE32 mod 2^32), L)
+// -- one 32-bit multiply instead of the 64-bit one of key = canonical * odd mod 4^k (four quarter-rate
+// instructions per k-mer, three passes over every k-mer of the set).
+constexpr uint32_t SCRAMBLE32 = 0x9E3779B1u;
+__host__ __device__ __forceinline__ uint64_t scramble_key(uint64_t cano, int k) {
+    const uint32_t L = (uint32_t)cano & ((1u << k) - 1u);
+    const uint32_t H = (uint32_t)(cano >> k);
+    return ((uint64_t)(H ^ ((L * SCRAMBLE32) >> (32 - k))) << k) | L;
+}
+__host__ __device__ __forceinline__ uint64_t unscramble_key(uint64_t key, int k) { return scramble_key(key, k); }   // an involution
 constexpr uint32_t DUP_BIT = 0x80000000u;
 constexpr int RUNLEN_BITS = 24;
 constexpr uint64_t RUNLEN_MASK = (1ull << RUNLEN_BITS) - 1;
@@ -45,68 +54,65 @@ struct kmer_args {
 // end, contains N, or the k-mer is not kept by --kmers-fraction / belongs to another shard).  Every genome
 // is followed by at least one masked padding base, so "crosses the end" IS "contains a masked base": the
 // mask is the only validity test (no length / offset lookups behind the genome id).
-__device__ __forceinline__ uint64_t kmer_at(const kmer_args& A, int64_t p, uint32_t* genome) {
-    const uint64_t kmask = (A.k == 32) ? ~0ULL : ((1ULL << (2 * A.k)) - 1);
-    const uint32_t g = A.blk2g[p >> A.blk_shift];
-    *genome = g;
-    const int64_t mw = p >> 5; const int msh = (int)(p & 31);
-    const uint64_t m = (uint64_t)A.nmask[mw] | ((uint64_t)A.nmask[mw + 1] << 32);
-    if (((m >> msh) & ((1ULL << A.k) - 1)) != 0) return SENT;
-    const int64_t w = p >> 4; const int sh = 2 * (int)(p & 15);
-    const uint64_t lo = (uint64_t)A.packed[w] | ((uint64_t)A.packed[w + 1] << 32);
-    const uint64_t hi = (uint64_t)A.packed[w + 2] | ((uint64_t)A.packed[w + 3] << 32);
-    uint64_t x = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;   // first base in the low bits
-    x &= kmask;
-    const uint64_t fwd = rev2(x) >> (64 - 2 * A.k);             // first base most significant
-    const uint64_t rc = (~x) & kmask;                           // reverse complement, same convention
+//
+// The arithmetic is written on 32-bit halves: the 2k <= 62 bits of a k-mer are cut out of three sequence words
+// with two funnel shifts (v_alignbit_b32), reversed per dword, and scrambled with one 32-bit multiply.
+__device__ __forceinline__ uint32_t rev2_32(uint32_t y) {            // the 16 two-bit groups of y in reverse order
+    y = __brev(y);
+    return ((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1);
+}
+// x = the k-mer's 2k bits, first base in the low bits (xh:xl, already masked) -> scrambled canonical key or SENT
+__device__ __forceinline__ uint64_t canon_key(const kmer_args& A, uint32_t xl, uint32_t xh, uint32_t km_lo, uint32_t km_hi) {
+    const int k2 = 2 * A.k;
+    const uint64_t fwd = (((uint64_t)rev2_32(xl) << 32) | rev2_32(xh)) >> (64 - k2);     // first base most significant
+    const uint64_t rc = ((uint64_t)(~xh & km_hi) << 32) | (~xl & km_lo);                  // reverse complement, same convention
     const uint64_t cano = fwd < rc ? fwd : rc;
     if (A.use_frac && !(mix64(cano) < A.frac_thr)) return SENT;
-    const uint64_t key = (cano * SCRAMBLE) & kmask;             // bit 2k stays 0; SENT has it set
+    const uint64_t key = scramble_key(cano, A.k);               // bit 2k stays 0; SENT has it set
     if (A.n_shards > 1) {
         // shard = a cheap second multiplicative hash of the key's LOW half (one 32-bit multiply): it
-        // must not be a function of the high bits, which the radix sort relies on being uniform
+        // must not be a function of the high bits, which the partition relies on being uniform
         const uint32_t h2 = (uint32_t)key * 0x85ebca6bu;
         if ((uint32_t)(((uint64_t)h2 * A.n_shards) >> 32) != A.shard) return SENT;
     }
     return key;
 }
-
-// the four k-mers starting at padded positions p0 .. p0+3 (p0 a multiple of 4): one genome lookup,
-// one 128-bit sequence window and one 64-bit N window serve all four
-// (sequence window lo:hi = the 64 bases from the 16-base word that holds p0, m = the N mask bits from p0 on)
-__device__ __forceinline__ void kmers4_window(const kmer_args& A, int64_t p0, uint64_t lo, uint64_t hi, uint64_t m, uint64_t out[4]) {
-    const uint64_t kmask = (A.k == 32) ? ~0ULL : ((1ULL << (2 * A.k)) - 1);
-    const int sh = 2 * (int)(p0 & 15);                                // 0, 8, 16 or 24
-    const uint64_t nk = (1ULL << A.k) - 1;
+// the four k-mers starting at padded positions p0 .. p0+3 (p0 a multiple of 4) from w0..w2 = the 48 bases from
+// the 16-base word that holds p0 and m0, m1 = the N-mask words from the 32-base word that holds p0
+__device__ __forceinline__ void kmers4_words(const kmer_args& A, uint32_t p0_low, uint32_t w0, uint32_t w1, uint32_t w2,
+                                             uint32_t m0, uint32_t m1, uint64_t out[4]) {
+    const int k2 = 2 * A.k;                                               // 16 .. 62
+    const uint32_t sh = 2u * (p0_low & 15u), msh = p0_low & 31u;         // sh in {0, 8, 16, 24}, msh <= 28
+    const uint32_t nk = (1u << A.k) - 1u;
+    const uint32_t km_lo = k2 >= 32 ? 0xffffffffu : ((1u << k2) - 1u), km_hi = k2 > 32 ? ((1u << (k2 - 32)) - 1u) : 0u;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         uint64_t key = SENT;
-        if (((m >> j) & nk) == 0) {
-            const int s2 = sh + 2 * j;
-            uint64_t x = s2 ? ((lo >> s2) | (hi << (64 - s2))) : lo;
-            x &= kmask;
-            const uint64_t fwd = rev2(x) >> (64 - 2 * A.k);
-            const uint64_t rc = (~x) & kmask;
-            const uint64_t cano = fwd < rc ? fwd : rc;
-            if (!(A.use_frac && !(mix64(cano) < A.frac_thr))) {
-                key = (cano * SCRAMBLE) & kmask;
-                if (A.n_shards > 1) {
-                    const uint32_t h2 = (uint32_t)key * 0x85ebca6bu;
-                    if ((uint32_t)(((uint64_t)h2 * A.n_shards) >> 32) != A.shard) key = SENT;
-                }
-            }
+        if ((__builtin_amdgcn_alignbit(m1, m0, msh + j) & nk) == 0) {
+            const uint32_t s2 = sh + 2 * j;                               // <= 30
+            key = canon_key(A, __builtin_amdgcn_alignbit(w1, w0, s2) & km_lo, __builtin_amdgcn_alignbit(w2, w1, s2) & km_hi, km_lo, km_hi);
         }
         out[j] = key;
     }
 }
+__device__ __forceinline__ uint64_t kmer_at(const kmer_args& A, int64_t p, uint32_t* genome) {
+    *genome = A.blk2g[p >> A.blk_shift];
+    const int64_t mw = p >> 5; const uint32_t msh = (uint32_t)(p & 31);
+    const uint64_t m = ((uint64_t)A.nmask[mw] | ((uint64_t)A.nmask[mw + 1] << 32)) >> msh;
+    if ((m & ((1ULL << A.k) - 1)) != 0) return SENT;
+    const int k2 = 2 * A.k;
+    const uint32_t km_lo = k2 >= 32 ? 0xffffffffu : ((1u << k2) - 1u), km_hi = k2 > 32 ? ((1u << (k2 - 32)) - 1u) : 0u;
+    const int64_t w = p >> 4; const uint32_t sh = 2u * (uint32_t)(p & 15);
+    const uint32_t w0 = A.packed[w], w1 = A.packed[w + 1], w2 = A.packed[w + 2];
+    return canon_key(A, __builtin_amdgcn_alignbit(w1, w0, sh) & km_lo, __builtin_amdgcn_alignbit(w2, w1, sh) & km_hi, km_lo, km_hi);
+}
+
+// the four k-mers starting at padded positions p0 .. p0+3 (p0 a multiple of 4): one genome lookup,
+// one 96-bit sequence window and one 64-bit N window serve all four
 __device__ __forceinline__ void kmers4(const kmer_args& A, int64_t p0, uint64_t out[4], uint32_t* genome) {
     *genome = A.blk2g[p0 >> A.blk_shift];
-    const int64_t mw = p0 >> 5; const int msh = (int)(p0 & 31);
-    const uint64_t m = ((uint64_t)A.nmask[mw] | ((uint64_t)A.nmask[mw + 1] << 32)) >> msh;   // msh <= 28: 36+ bits left
-    const int64_t w = p0 >> 4;
-    const uint64_t lo = (uint64_t)A.packed[w] | ((uint64_t)A.packed[w + 1] << 32);
-    const uint64_t hi = (uint64_t)A.packed[w + 2] | ((uint64_t)A.packed[w + 3] << 32);
-    kmers4_window(A, p0, lo, hi, m, out);
+    const int64_t mw = p0 >> 5, w = p0 >> 4;
+    kmers4_words(A, (uint32_t)(p0 & 31), A.packed[w], A.packed[w + 1], A.packed[w + 2], A.nmask[mw], A.nmask[mw + 1], out);
 }
 
 // Dense form (all k-mers kept: one shard, fraction 1): four consecutive padded base positions per
@@ -762,9 +768,7 @@ __device__ __forceinline__ void decode_tile(const part_src& S, int64_t t0, int64
             const int64_t p0 = t0 + ((int64_t)q * PT_THREADS + threadIdx.x) * 4;
             uint64_t kk[4] = {SENT, SENT, SENT, SENT};
             if (p0 < t_end) {
-                const uint64_t lo = (uint64_t)raw[6 * q] | ((uint64_t)raw[6 * q + 1] << 32), hi = (uint64_t)raw[6 * q + 2] | ((uint64_t)raw[6 * q + 3] << 32);
-                const uint64_t m = ((uint64_t)raw[6 * q + 4] | ((uint64_t)raw[6 * q + 5] << 32)) >> (int)(p0 & 31);
-                kmers4_window(S.A, p0, lo, hi, m, kk);
+                kmers4_words(S.A, (uint32_t)(p0 & 31), raw[6 * q], raw[6 * q + 1], raw[6 * q + 2], raw[6 * q + 4], raw[6 * q + 5], kk);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -946,15 +950,14 @@ k_part_scatter(part_src S, int B1, int B2, int unit_tiles, int64_t n_units, cons
 constexpr int RT_TILE = 32768;
 constexpr int RT_PER = RT_TILE / PT_THREADS;
 __device__ __forceinline__ uint64_t kmer_key_lds(const kmer_args& A, const uint32_t* s_pk, uint32_t lp) {
-    const uint64_t kmask = (A.k == 32) ? ~0ULL : ((1ULL << (2 * A.k)) - 1);
-    const uint32_t wi = lp >> 4; const int sh = 2 * (int)(lp & 15);
-    const uint64_t lo = (uint64_t)s_pk[wi] | ((uint64_t)s_pk[wi + 1] << 32);
-    uint64_t x = sh ? ((lo >> sh) | ((uint64_t)s_pk[wi + 2] << (64 - sh))) : lo;
-    x &= kmask;
-    const uint64_t fwd = rev2(x) >> (64 - 2 * A.k);
-    const uint64_t rc = (~x) & kmask;
-    const uint64_t cano = fwd < rc ? fwd : rc;
-    return (cano * SCRAMBLE) & kmask;
+    const int k2 = 2 * A.k;
+    const uint32_t km_lo = k2 >= 32 ? 0xffffffffu : ((1u << k2) - 1u), km_hi = k2 > 32 ? ((1u << (k2 - 32)) - 1u) : 0u;
+    const uint32_t wi = lp >> 4, sh = 2u * (lp & 15u);
+    const uint32_t w0 = s_pk[wi], w1 = s_pk[wi + 1], w2 = s_pk[wi + 2];
+    const uint32_t xl = __builtin_amdgcn_alignbit(w1, w0, sh) & km_lo, xh = __builtin_amdgcn_alignbit(w2, w1, sh) & km_hi;
+    const uint64_t fwd = (((uint64_t)rev2_32(xl) << 32) | rev2_32(xh)) >> (64 - k2);
+    const uint64_t rc = ((uint64_t)(~xh & km_hi) << 32) | (~xl & km_lo);
+    return scramble_key(fwd < rc ? fwd : rc, A.k);
 }
 __global__ void __launch_bounds__(PT_THREADS)
 k_part_scatter_dense(part_src S, int B1, int unit_tiles, int64_t n_units, const uint32_t* __restrict__ Ts, uint32_t* __restrict__ o_rec) {
@@ -980,9 +983,7 @@ k_part_scatter_dense(part_src S, int B1, int unit_tiles, int64_t n_units, const 
                 uint64_t kk[4] = {SENT, SENT, SENT, SENT};
                 if (t0 + lp0 < s1) {
                     const uint32_t wi = lp0 >> 4;
-                    const uint64_t lo = (uint64_t)s_pk[wi] | ((uint64_t)s_pk[wi + 1] << 32), hi = (uint64_t)s_pk[wi + 2] | ((uint64_t)s_pk[wi + 3] << 32);
-                    const uint64_t m = ((uint64_t)s_mk[lp0 >> 5] | ((uint64_t)s_mk[(lp0 >> 5) + 1] << 32)) >> (lp0 & 31);
-                    kmers4_window(S.A, (int64_t)lp0, lo, hi, m, kk);
+                    kmers4_words(S.A, lp0 & 31u, s_pk[wi], s_pk[wi + 1], s_pk[wi + 2], s_mk[lp0 >> 5], s_mk[(lp0 >> 5) + 1], kk);
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -1728,11 +1729,8 @@ extern "C" int vg_kmer_set(vg_genomes* g, int idx, int k, double fraction, uint6
         VG_HIP(hipStreamSynchronize(s));
         lo = c[0]; hi = c[1];
     }
-    uint64_t inv = SCRAMBLE;                                   // inverse of SCRAMBLE mod 2^64 (Newton)
-    for (int it = 0; it < 6; ++it) inv *= 2 - SCRAMBLE * inv;
-    const uint64_t kmask = (1ULL << (2 * k)) - 1;
     for (size_t i = 0; i < keys.size(); ++i)
-        if ((int64_t)pos[i] >= lo && (int64_t)pos[i] < hi) mine.push_back((keys[i] * inv) & kmask);
+        if ((int64_t)pos[i] >= lo && (int64_t)pos[i] < hi) mine.push_back(unscramble_key(keys[i], k));
     std::sort(mine.begin(), mine.end());
     mine.erase(std::unique(mine.begin(), mine.end()), mine.end());
     uint64_t* o = (uint64_t*)malloc(sizeof(uint64_t) * std::max<size_t>(1, mine.size()));
