@@ -792,7 +792,8 @@ __device__ __forceinline__ void decode_tile(const part_src& S, int64_t t0, int64
 }
 
 // level-1 histogram: one super-tile (st_tiles tiles) per trip; T[b * n_st + st] = elements of bucket b.
-// The dense source also counts the kept k-mers per genome (set sizes) on the way.
+// The dense source also counts the kept k-mers per genome (set sizes) on the way.  The raw words of the next
+// tile are requested before the current one is counted (one workgroup per CU: nothing else hides the latency).
 template <int SRC>
 __global__ void __launch_bounds__(PT_THREADS)
 k_part_count(part_src S, int B1, int st_tiles, int64_t n_st, uint32_t* __restrict__ T, int* __restrict__ kept_per_genome) {
@@ -803,21 +804,37 @@ k_part_count(part_src S, int B1, int st_tiles, int64_t n_st, uint32_t* __restric
         for (int b = threadIdx.x; b < nb; b += PT_THREADS) hist[b] = 0;
         __syncthreads();
         const int64_t s0 = st * st_tiles * PT_TILE, s1 = min(S.n, s0 + (int64_t)st_tiles * PT_TILE);
+        uint32_t raw[PT_RAW], gq[PT_PER / 4];
+#pragma unroll
+        for (int i = 0; i < PT_RAW; ++i) raw[i] = 0;
+        auto fetch_genomes = [&](int64_t t0) {
+#pragma unroll
+            for (int q = 0; q < PT_PER / 4; ++q) {
+                const int64_t p0 = t0 + ((int64_t)q * PT_THREADS + threadIdx.x) * 4;
+                gq[q] = (SRC == SRC_DENSE && kept_per_genome && p0 < s1) ? S.A.blk2g[p0 >> S.A.blk_shift] : 0u;
+            }
+        };
+        fetch_tile<SRC>(S, s0, s1, raw); fetch_genomes(s0);
         for (int64_t t0 = s0; t0 < s1; t0 += PT_TILE) {
-            uint32_t w0[PT_PER], w1[PT_PER], pay[PT_PER], g4[PT_PER / 4 + 1]; bool ok[PT_PER];
-            load_tile<SRC>(S, t0, s1, w0, w1, pay, ok, g4);
+            uint32_t w0[PT_PER], w1[PT_PER], pay[PT_PER], g4[PT_PER / 4]; bool ok[PT_PER];
+            decode_tile<SRC>(S, t0, s1, raw, w0, w1, pay, ok);
+#pragma unroll
+            for (int q = 0; q < PT_PER / 4; ++q) g4[q] = gq[q];
+            if (t0 + PT_TILE < s1) { fetch_tile<SRC>(S, t0 + PT_TILE, s1, raw); fetch_genomes(t0 + PT_TILE); }
 #pragma unroll
             for (int j = 0; j < PT_PER; ++j) if (ok[j]) atomicAdd(&hist[B1 ? (w0[j] >> (32 - B1)) : 0u], 1u);
             if (SRC == SRC_DENSE && kept_per_genome) {
 #pragma unroll
                 for (int q = 0; q < PT_PER / 4; ++q) {
-                    const int mine = (int)ok[4 * q] + (int)ok[4 * q + 1] + (int)ok[4 * q + 2] + (int)ok[4 * q + 3];
                     const uint32_t g = g4[q]; const uint32_t g0 = __shfl(g, 0);
                     if (__all(g == g0)) {
-                        int tot = mine;
-                        for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+                        // the wave's 256 positions lie in one genome: four ballots count its kept k-mers
+                        const int tot = __popcll(__ballot(ok[4 * q])) + __popcll(__ballot(ok[4 * q + 1])) + __popcll(__ballot(ok[4 * q + 2])) + __popcll(__ballot(ok[4 * q + 3]));
                         if (lane == 0 && tot) atomicAdd(&kept_per_genome[g0], tot);
-                    } else if (mine) atomicAdd(&kept_per_genome[g], mine);
+                    } else {
+                        const int mine = (int)ok[4 * q] + (int)ok[4 * q + 1] + (int)ok[4 * q + 2] + (int)ok[4 * q + 3];
+                        if (mine) atomicAdd(&kept_per_genome[g], mine);
+                    }
                 }
             }
         }
@@ -850,8 +867,14 @@ k_part_count2(part_src S, int B1, int B2, int64_t n_ch, lvl2_tab L, uint32_t* __
         __syncthreads();
         uint32_t b1, cl; int64_t s0, s1;
         lvl2_chunk(L, c, &b1, &cl, &s0, &s1);
-        for (int64_t i = s0 + threadIdx.x; i < s1; i += PT_THREADS)
-            atomicAdd(&hist[(S.rec[3 * i] >> (32 - B1 - B2)) & (uint32_t)(nb2 - 1)], 1u);
+        // eight independent loads per thread and trip (one workgroup per CU: the loop is latency bound otherwise)
+        for (int64_t i0 = s0 + threadIdx.x; i0 < s1; i0 += 8 * PT_THREADS) {
+            uint32_t w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int64_t i = i0 + (int64_t)u * PT_THREADS; w[u] = i < s1 ? S.rec[3 * i] : 0u; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (i0 + (int64_t)u * PT_THREADS < s1) atomicAdd(&hist[(w[u] >> (32 - B1 - B2)) & (uint32_t)(nb2 - 1)], 1u);
+        }
         __syncthreads();
         const uint64_t t0 = L.tb[b1] + cl; const uint32_t n = L.nch[b1];
         for (int d = threadIdx.x; d < nb2; d += PT_THREADS) T[t0 + (uint64_t)d * n] = hist[d];
