@@ -844,46 +844,76 @@ k_part_count(part_src S, int B1, int st_tiles, int64_t n_st, uint32_t* __restric
     }
 }
 
-// Level 2 works on chunks of ONE level-1 bucket: bucket b1's records [off1[b1], off1[b1 + 1]) are cut into
-// nch[b1] chunks of `chunk` records (the last one shorter); chunk c of the whole list belongs to bucket ch_b1[c]
-// and is its (c - cfirst[b1])-th.  Table entry of (b1, b2, chunk c): tb[b1] + b2 * nch[b1] + (c - cfirst[b1]).
+// Level 2 works on UNITS: the records of one level-1 bucket that came from u_st consecutive super-tiles (about
+// 65 536 of them).  A unit's range is read straight off the scanned level-1 table, so the host builds no chunk
+// lists and level 2 follows level 1 without a round trip.  Table entry of (b1, b2, unit U):
+// (b1 * 2^B2 + b2) * n_u + U -- bucket-major, so the scanned entries of U = 0 are the final bucket offsets.
+//
+// SHORT records (dense source, 2k - B1 + 25 <= 64): level 1 writes 8 bytes instead of 12,
+//   rec = (key bits below the level-1 digit) << 25 | (position mod 2^25);
+// the missing high position bits are those of the 2^25-position group the record came from, and a unit spans at
+// most four groups whose boundaries are again entries of the level-1 table.
+constexpr int SR_POS_BITS = 25;
 struct lvl2_tab {
-    const uint32_t* ch_b1; const uint32_t* cfirst; const uint32_t* nch; const uint32_t* off1; const uint64_t* tb;
-    uint32_t chunk;
+    const uint32_t* T1s; int64_t n_st;      // scanned level-1 table [bucket][super-tile] (+ the total at the end)
+    int u_st, n_u;                          // super-tiles per unit, units per level-1 bucket
+    int g_st;                               // SHORT: super-tiles per position group (0: a unit lies inside one group)
+    int st_shift;                           // SHORT: log2(positions per super-tile)
+    int kr;                                 // SHORT: key bits kept in a record = 2k - B1
 };
-__device__ __forceinline__ void lvl2_chunk(const lvl2_tab& L, int64_t c, uint32_t* b1, uint32_t* cl, int64_t* s0, int64_t* s1) {
-    *b1 = L.ch_b1[c]; *cl = (uint32_t)c - L.cfirst[*b1];
-    *s0 = (int64_t)L.off1[*b1] + (int64_t)*cl * L.chunk;
-    *s1 = min((int64_t)L.off1[*b1 + 1], *s0 + (int64_t)L.chunk);
+__device__ __forceinline__ void lvl2_unit(const lvl2_tab& L, int64_t u, uint32_t* b1, uint32_t* U, int64_t* r0, int64_t* r1) {
+    *b1 = (uint32_t)(u / L.n_u); *U = (uint32_t)(u % L.n_u);
+    const int64_t row = (int64_t)*b1 * L.n_st, st0 = (int64_t)*U * L.u_st, st1 = st0 + L.u_st;
+    *r0 = L.T1s[row + st0];
+    *r1 = L.T1s[row + (st1 < L.n_st ? st1 : L.n_st)];
+}
+// SHORT: position base of the unit's first group and the record indices at which its 2nd..4th group start
+__device__ __forceinline__ void lvl2_groups(const lvl2_tab& L, uint32_t b1, uint32_t U, int64_t r1, uint32_t* base, uint32_t gb[3]) {
+    const int64_t st0 = (int64_t)U * L.u_st;
+    *base = (uint32_t)(((uint64_t)st0 << L.st_shift) >> SR_POS_BITS << SR_POS_BITS);
+    const int64_t row = (int64_t)b1 * L.n_st;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int64_t stg = st0 + (int64_t)(j + 1) * L.g_st;
+        gb[j] = (L.g_st > 0 && stg < st0 + L.u_st && stg < L.n_st) ? L.T1s[row + stg] : (uint32_t)r1;
+    }
 }
 
-// level-2 histogram of the next B2 key bits, one chunk per trip (only w0 of every record is read)
+// level-2 histogram of the next B2 key bits, one unit per trip
+template <bool SHORT>
 __global__ void __launch_bounds__(PT_THREADS)
-k_part_count2(part_src S, int B1, int B2, int64_t n_ch, lvl2_tab L, uint32_t* __restrict__ T) {
+k_part_count2(const uint32_t* __restrict__ rec, int B1, int B2, int64_t n_units, lvl2_tab L, uint32_t* __restrict__ T) {
     __shared__ uint32_t hist[PT_MAXBINS];
     const int nb2 = 1 << B2;
-    for (int64_t c = blockIdx.x; c < n_ch; c += gridDim.x) {
+    for (int64_t u = blockIdx.x; u < n_units; u += gridDim.x) {
         for (int b = threadIdx.x; b < nb2; b += PT_THREADS) hist[b] = 0;
         __syncthreads();
-        uint32_t b1, cl; int64_t s0, s1;
-        lvl2_chunk(L, c, &b1, &cl, &s0, &s1);
+        uint32_t b1, U; int64_t s0, s1;
+        lvl2_unit(L, u, &b1, &U, &s0, &s1);
         // eight independent loads per thread and trip (one workgroup per CU: the loop is latency bound otherwise)
         for (int64_t i0 = s0 + threadIdx.x; i0 < s1; i0 += 8 * PT_THREADS) {
-            uint32_t w[8];
+            uint32_t d[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const int64_t i = i0 + (int64_t)u * PT_THREADS; w[u] = i < s1 ? S.rec[3 * i] : 0u; }
+            for (int v = 0; v < 8; ++v) {
+                const int64_t i = i0 + (int64_t)v * PT_THREADS;
+                d[v] = 0;
+                if (i < s1) {
+                    if (SHORT) { uint64_t r; __builtin_memcpy(&r, rec + 2 * i, 8); d[v] = (uint32_t)(r >> (SR_POS_BITS + L.kr - B2)); }
+                    else d[v] = rec[3 * i] >> (32 - B1 - B2);
+                }
+            }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) if (i0 + (int64_t)u * PT_THREADS < s1) atomicAdd(&hist[(w[u] >> (32 - B1 - B2)) & (uint32_t)(nb2 - 1)], 1u);
+            for (int v = 0; v < 8; ++v) if (i0 + (int64_t)v * PT_THREADS < s1) atomicAdd(&hist[d[v] & (uint32_t)(nb2 - 1)], 1u);
         }
         __syncthreads();
-        const uint64_t t0 = L.tb[b1] + cl; const uint32_t n = L.nch[b1];
-        for (int d = threadIdx.x; d < nb2; d += PT_THREADS) T[t0 + (uint64_t)d * n] = hist[d];
+        const uint64_t t0 = (uint64_t)b1 * nb2 * L.n_u + U;
+        for (int d = threadIdx.x; d < nb2; d += PT_THREADS) T[t0 + (uint64_t)d * L.n_u] = hist[d];
         __syncthreads();
     }
 }
 
 // scatter of one level: tiles are sorted by bin in the LDS and leave as contiguous segments.
-// LEVEL 1: bins = level-1 buckets, write offsets Ts[b * n_st + st].  LEVEL 2: one chunk of one level-1 bucket, bins = b2.
+// LEVEL 1: bins = level-1 buckets, write offsets Ts[b * n_st + st].  LEVEL 2: one unit of one level-1 bucket, bins = b2.
 template <int SRC, int LEVEL>
 __global__ void __launch_bounds__(PT_THREADS)
 k_part_scatter(part_src S, int B1, int B2, int unit_tiles, int64_t n_units, const uint32_t* __restrict__ Ts, lvl2_tab L,
@@ -895,10 +925,10 @@ k_part_scatter(part_src S, int B1, int B2, int unit_tiles, int64_t n_units, cons
     for (int64_t u = blockIdx.x; u < n_units; u += gridDim.x) {
         int64_t s0 = u * unit_tiles * PT_TILE, s1 = min(S.n, s0 + (int64_t)unit_tiles * PT_TILE);
         uint32_t b1 = 0, cl = 0;
-        if (LEVEL == 2) lvl2_chunk(L, u, &b1, &cl, &s0, &s1);
+        if (LEVEL == 2) lvl2_unit(L, u, &b1, &cl, &s0, &s1);
         lds_sync();
         for (int b = threadIdx.x; b < nbins; b += PT_THREADS) {
-            const uint32_t off = LEVEL == 1 ? Ts[(int64_t)b * n_units + u] : Ts[L.tb[b1] + (uint64_t)b * L.nch[b1] + cl];
+            const uint32_t off = LEVEL == 1 ? Ts[(int64_t)b * n_units + u] : Ts[((uint64_t)b1 * nbins + b) * L.n_u + cl];
             cursor[b] = off;
         }
         // The raw words of tile t + 1 are requested while tile t is sorted; they (and, the memory pipeline being
@@ -983,7 +1013,8 @@ __device__ __forceinline__ uint64_t kmer_key_lds(const kmer_args& A, const uint3
     return scramble_key(fwd < rc ? fwd : rc, A.k);
 }
 __global__ void __launch_bounds__(PT_THREADS)
-k_part_scatter_dense(part_src S, int B1, int unit_tiles, int64_t n_units, const uint32_t* __restrict__ Ts, uint32_t* __restrict__ o_rec) {
+k_part_scatter_dense(part_src S, int B1, int unit_tiles, int64_t n_units, const uint32_t* __restrict__ Ts, uint32_t* __restrict__ o_rec,
+                     int short_kr /* > 0: SHORT 8-byte records keeping this many key bits */) {
     __shared__ uint32_t s_pk[RT_TILE / 16 + 8], s_mk[RT_TILE / 32 + 4];
     __shared__ uint16_t s_perm[RT_TILE];
     __shared__ uint32_t thist[PT_MAXBINS], tstart[PT_MAXBINS], cursor[PT_MAXBINS];
@@ -1040,12 +1071,16 @@ k_part_scatter_dense(part_src S, int B1, int unit_tiles, int64_t n_units, const 
             const uint32_t n_tile = tstart[nbins - 1] + thist[nbins - 1];
             for (uint32_t slot = threadIdx.x; slot < n_tile; slot += PT_THREADS) {
                 const uint32_t lp = s_perm[slot];
+                const uint64_t key = kmer_key_lds(S.A, s_pk, lp);
                 uint32_t v[3];
-                key_words(kmer_key_lds(S.A, s_pk, lp), S.k2, &v[0], &v[1]);
+                key_words(key, S.k2, &v[0], &v[1]);
                 v[2] = (uint32_t)(t0 + lp);
                 const uint32_t b = B1 ? (v[0] >> (32 - B1)) : 0u;
                 const uint64_t dst = (uint64_t)cursor[b] + (slot - tstart[b]);
-                __builtin_memcpy(o_rec + 3 * dst, v, 12);
+                if (short_kr > 0) {
+                    const uint64_t r = ((key & ((1ULL << short_kr) - 1)) << SR_POS_BITS) | (uint64_t)(v[2] & ((1u << SR_POS_BITS) - 1u));
+                    __builtin_memcpy(o_rec + 2 * dst, &r, 8);
+                } else __builtin_memcpy(o_rec + 3 * dst, v, 12);
             }
             lds_sync();
             for (int b = threadIdx.x; b < nbins; b += PT_THREADS) cursor[b] += thist[b];
@@ -1061,19 +1096,22 @@ k_part_scatter_dense(part_src S, int B1, int unit_tiles, int64_t n_units, const 
 constexpr int NT_TILE = 16384;
 constexpr int NT_PER = NT_TILE / PT_THREADS;
 constexpr int NT_MAXBINS = 2048;
+template <bool SHORT>
 __global__ void __launch_bounds__(PT_THREADS)
-k_part_scatter2_narrow(part_src S, int B1, int B2, int64_t n_ch, const uint32_t* __restrict__ Ts, lvl2_tab L,
+k_part_scatter2_narrow(const uint32_t* __restrict__ rec, int B1, int B2, int64_t n_units, const uint32_t* __restrict__ Ts, lvl2_tab L,
                        uint32_t* __restrict__ o_rec, int narrow_shift) {
     __shared__ uint2 s_rec[NT_TILE];
     __shared__ uint32_t thist[NT_MAXBINS], tstart[NT_MAXBINS], cursor[NT_MAXBINS];
     __shared__ uint32_t s_wave[16];
     const int nbins = 1 << B2;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int64_t c = blockIdx.x; c < n_ch; c += gridDim.x) {
-        uint32_t b1, cl; int64_t s0, s1;
-        lvl2_chunk(L, c, &b1, &cl, &s0, &s1);
+    for (int64_t u = blockIdx.x; u < n_units; u += gridDim.x) {
+        uint32_t b1, U; int64_t s0, s1;
+        lvl2_unit(L, u, &b1, &U, &s0, &s1);
+        uint32_t gbase = 0, gb[3] = {0, 0, 0};
+        if (SHORT) lvl2_groups(L, b1, U, s1, &gbase, gb);
         lds_sync();
-        for (int b = threadIdx.x; b < nbins; b += PT_THREADS) cursor[b] = Ts[L.tb[b1] + (uint64_t)b * L.nch[b1] + cl];
+        for (int b = threadIdx.x; b < nbins; b += PT_THREADS) cursor[b] = Ts[((uint64_t)b1 * nbins + b) * L.n_u + U];
         for (int64_t t0 = s0; t0 < s1; t0 += NT_TILE) {
             for (int b = threadIdx.x; b < nbins; b += PT_THREADS) thist[b] = 0;
             lds_sync();
@@ -1083,9 +1121,18 @@ k_part_scatter2_narrow(part_src S, int B1, int B2, int64_t n_ch, const uint32_t*
                 const int64_t i = t0 + (int64_t)j * PT_THREADS + threadIdx.x;
                 br[j] = 0xffffffffu; key[j] = 0; pay[j] = 0;
                 if (i < s1) {
-                    uint32_t r[3]; __builtin_memcpy(r, S.rec + 3 * i, 12);
-                    key[j] = (uint32_t)(((((uint64_t)r[0] << 32) | r[1]) << narrow_shift) >> 32); pay[j] = r[2];
-                    br[j] = (r[0] >> (32 - B1 - B2)) & (uint32_t)(nbins - 1);
+                    if (SHORT) {
+                        uint64_t r; __builtin_memcpy(&r, rec + 2 * i, 8);
+                        const uint32_t ui = (uint32_t)i;
+                        const uint32_t gsel = (uint32_t)(ui >= gb[0]) + (uint32_t)(ui >= gb[1]) + (uint32_t)(ui >= gb[2]);
+                        key[j] = (uint32_t)(r >> SR_POS_BITS) << (32 - (L.kr - B2));
+                        pay[j] = gbase + (gsel << SR_POS_BITS) + ((uint32_t)r & ((1u << SR_POS_BITS) - 1u));
+                        br[j] = (uint32_t)(r >> (SR_POS_BITS + L.kr - B2)) & (uint32_t)(nbins - 1);
+                    } else {
+                        uint32_t r[3]; __builtin_memcpy(r, rec + 3 * i, 12);
+                        key[j] = (uint32_t)(((((uint64_t)r[0] << 32) | r[1]) << narrow_shift) >> 32); pay[j] = r[2];
+                        br[j] = (r[0] >> (32 - B1 - B2)) & (uint32_t)(nbins - 1);
+                    }
                 }
             }
 #pragma unroll
@@ -1123,20 +1170,10 @@ k_part_scatter2_narrow(part_src S, int B1, int B2, int64_t n_ch, const uint32_t*
 }
 
 // start offset of every final bucket (nbk + 1 entries) from the scanned tables
-__global__ void k_bucket_offsets(int levels, int B1, int B2, int64_t n_st, const uint32_t* __restrict__ T1s, const uint32_t* __restrict__ off1,
-                                 const uint32_t* __restrict__ nch, const uint64_t* __restrict__ tb, const uint32_t* __restrict__ T2s,
+__global__ void k_bucket_offsets(int levels, int64_t nbk, int64_t n_st, const uint32_t* __restrict__ T1s, int n_u, const uint32_t* __restrict__ T2s,
                                  uint32_t n_total, uint32_t* __restrict__ boff) {
-    const int64_t nbk = levels == 1 ? (1LL << B1) : (1LL << (B1 + B2));
-    for (int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; d <= nbk; d += (int64_t)gridDim.x * blockDim.x) {
-        uint32_t v;
-        if (d == nbk) v = n_total;
-        else if (levels == 1) v = T1s[d * n_st];
-        else {
-            const uint32_t b1 = (uint32_t)(d >> B2), b2 = (uint32_t)(d & ((1 << B2) - 1));
-            v = nch[b1] ? T2s[tb[b1] + (uint64_t)b2 * nch[b1]] : off1[b1];
-        }
-        boff[d] = v;
-    }
+    for (int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; d <= nbk; d += (int64_t)gridDim.x * blockDim.x)
+        boff[d] = d == nbk ? n_total : (levels == 1 ? T1s[d * n_st] : T2s[d * n_u]);
 }
 
 // One workgroup per bucket.  The bucket's keys agree on their top `pbits` bits and are uniform below them, so a
@@ -1418,8 +1455,27 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
     dbuf<uint32_t> T1(t1n + 1), T1s(t1n + 1);
     dbuf<uint32_t> a_rec, b_rec;
     uint32_t n1 = 0;
+    // level-2 units and (dense source, k <= 25 at 2^11 buckets) short level-1 records, see lvl2_tab
+    lvl2_tab L2; memset(&L2, 0, sizeof L2);
+    const int64_t st_pos = (int64_t)st_tiles * PT_TILE;
+    L2.T1s = T1s.p; L2.n_st = n_st;
+    L2.u_st = (int)std::max<int64_t>(1, std::min<int64_t>(n_st, (65536LL * nb1) / st_pos));
+    L2.n_u = (int)((n_st + L2.u_st - 1) / L2.u_st);
+    L2.kr = 2 * k - B1;
+    { int sh = 0; while ((1LL << sh) < st_pos) ++sh; L2.st_shift = sh; }
+    static const bool long_rec = [] { const char* e = getenv("VG_LEVEL1_RECORDS"); return e && !strcmp(e, "long"); }();
+    static const bool old_scatter = [] { const char* e = getenv("VG_DENSE_SCATTER"); return e && !strcmp(e, "staged"); }();
+    const bool tile32k = dense && st_tiles % 4 == 0 && B1 <= 12 && !old_scatter;          // k_part_scatter_dense applies
+    bool short_rec = levels == 2 && tile32k && narrow && B2 <= 11 && L2.kr + SR_POS_BITS <= 64 && L2.kr - B2 >= 1 &&
+                     (st_pos & (st_pos - 1)) == 0 && st_pos <= (1LL << SR_POS_BITS) && !long_rec;
+    if (short_rec) {
+        const int64_t g_st = (1LL << SR_POS_BITS) / st_pos;                       // super-tiles per position group
+        if (L2.u_st <= g_st) L2.g_st = (g_st % L2.u_st == 0) ? 0 : -1;            // a unit inside one group
+        else L2.g_st = (L2.u_st % g_st == 0 && L2.u_st / g_st <= 4) ? (int)g_st : -1;
+        if (L2.g_st < 0) { short_rec = false; L2.g_st = 0; }
+    }
     {
-        vg_prof_scope ps("kmer_partition", (double)n_src * (dense ? 2 * 3.0 / 8.0 : 8.0 + 12.0) + (double)n_src * 12.0);
+        vg_prof_scope ps("kmer_partition", (double)n_src * (dense ? 2 * 3.0 / 8.0 : 8.0 + 12.0) + (double)n_src * (short_rec ? 8.0 : 12.0));
         VG_HIP(hipMemsetAsync(T1.p + t1n, 0, sizeof(uint32_t), s));
         const int grid_c = (int)std::min<int64_t>(n_st, 512);
         if (dense) hipLaunchKernelGGL(k_part_count<SRC_DENSE>, dim3(grid_c), dim3(PT_THREADS), 0, s, S, B1, st_tiles, n_st, T1.p, d_kept);
@@ -1435,11 +1491,11 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
         if (n1 == 0) return true;
         // two levels: the level-1 records are dead once level 2 has scattered them, and the genome list + row
         // descriptors are born after that: they take over the same block (48 GB less to allocate at 100 k genomes)
-        a_rec.alloc(levels == 2 ? std::max(3 * (size_t)n1 + 8, 2 * (size_t)n_rows_info + (size_t)n1 + 16) : 3 * (size_t)n1 + 8);
+        a_rec.alloc(levels == 2 ? std::max((short_rec ? 2 : 3) * (size_t)n1 + 8, 2 * (size_t)n_rows_info + (size_t)n1 + 16) : 3 * (size_t)n1 + 8);
         const int grid_s = (int)std::min<int64_t>(n_st, 256);
-        static const bool old_scatter = [] { const char* e = getenv("VG_DENSE_SCATTER"); return e && !strcmp(e, "staged"); }();
-        if (dense && st_tiles % 4 == 0 && B1 <= 12 && !old_scatter)
-            hipLaunchKernelGGL(k_part_scatter_dense, dim3(grid_s), dim3(PT_THREADS), 0, s, S, B1, st_tiles / 4, n_st, (const uint32_t*)T1s.p, a_rec.p);
+        if (tile32k)
+            hipLaunchKernelGGL(k_part_scatter_dense, dim3(grid_s), dim3(PT_THREADS), 0, s, S, B1, st_tiles / 4, n_st, (const uint32_t*)T1s.p, a_rec.p,
+                               short_rec ? L2.kr : 0);
         else if (dense) hipLaunchKernelGGL((k_part_scatter<SRC_DENSE, 1>), dim3(grid_s), dim3(PT_THREADS), 0, s, S, B1, 0, st_tiles, n_st, (const uint32_t*)T1s.p,
                                       lvl2_tab{}, a_rec.p, -1);
         else hipLaunchKernelGGL((k_part_scatter<SRC_ARRAYS, 1>), dim3(grid_s), dim3(PT_THREADS), 0, s, S, B1, 0, st_tiles, n_st, (const uint32_t*)T1s.p,
@@ -1449,57 +1505,41 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
     dbuf<uint32_t> boff((size_t)nbk + 1);
     const uint32_t* f_rec = a_rec.p; int f_stride = 3;
     if (levels == 1) {
-        hipLaunchKernelGGL(k_bucket_offsets, dim3(grid_for(nbk + 1)), dim3(256), 0, s, 1, B1, 0, n_st, (const uint32_t*)T1s.p, (const uint32_t*)nullptr,
-                           (const uint32_t*)nullptr, (const uint64_t*)nullptr, (const uint32_t*)nullptr, n1, boff.p);
+        hipLaunchKernelGGL(k_bucket_offsets, dim3(grid_for(nbk + 1)), dim3(256), 0, s, 1, nbk, n_st, (const uint32_t*)T1s.p, 0, (const uint32_t*)nullptr, n1, boff.p);
     } else {
-        // level-1 bucket bounds -> chunking of level 2
-        std::vector<uint32_t> off1((size_t)nb1 + 1);
-        VG_HIP(hipMemcpy2DAsync(off1.data(), sizeof(uint32_t), T1s.p, (size_t)n_st * sizeof(uint32_t), sizeof(uint32_t), (size_t)nb1, hipMemcpyDeviceToHost, s));
-        VG_HIP(hipStreamSynchronize(s));
-        off1[(size_t)nb1] = n1;
-        vg_host_mark("buckets: level 1 done, off1");
-        // level 2 runs on chunks of one level-1 bucket each (see lvl2_tab)
-        const uint32_t ST2 = 8 * PT_TILE;
-        std::vector<uint32_t> cfirst((size_t)nb1), nch((size_t)nb1), ch_b1; std::vector<uint64_t> tbv((size_t)nb1 + 1);
-        uint64_t tot = 0;
-        for (int b = 0; b < nb1; ++b) {
-            const uint32_t sz = off1[(size_t)b + 1] - off1[(size_t)b];
-            cfirst[(size_t)b] = (uint32_t)ch_b1.size();
-            nch[(size_t)b] = (sz + ST2 - 1) / ST2;
-            ch_b1.insert(ch_b1.end(), nch[(size_t)b], (uint32_t)b);
-            tbv[(size_t)b] = tot; tot += (uint64_t)nch[(size_t)b] * nb2;
-        }
-        tbv[(size_t)nb1] = tot;
-        const int64_t n_ch = (int64_t)ch_b1.size();
-        if (tot >= (1ULL << 31)) return false;
-        dbuf<uint32_t> d_off1((size_t)nb1 + 1), d_cfirst((size_t)nb1), d_nch((size_t)nb1), d_chb1((size_t)std::max<int64_t>(1, n_ch)); dbuf<uint64_t> d_tb((size_t)nb1 + 1);
-        d_off1.upload(off1.data(), off1.size(), s); d_cfirst.upload(cfirst.data(), cfirst.size(), s); d_nch.upload(nch.data(), nch.size(), s);
-        d_tb.upload(tbv.data(), tbv.size(), s); if (n_ch) d_chb1.upload(ch_b1.data(), ch_b1.size(), s);
-        vg_host_mark("buckets: level-2 tables");
-        const lvl2_tab L2{ d_chb1.p, d_cfirst.p, d_nch.p, d_off1.p, d_tb.p, ST2 };
-        dbuf<uint32_t> T2((size_t)tot + 1), T2s((size_t)tot + 1);
-        VG_HIP(hipMemsetAsync(T2.p + tot, 0, sizeof(uint32_t), s));
-        part_src S2; memset(&S2, 0, sizeof S2);
-        S2.rec = a_rec.p; S2.n = (int64_t)n1; S2.k2 = 2 * k;
+        // level 2 on units of u_st super-tiles of one level-1 bucket (see lvl2_tab): everything it needs is in the
+        // scanned level-1 table, so it is launched right behind level 1
+        const int64_t n_units = (int64_t)nb1 * L2.n_u;
+        const size_t t2n = (size_t)nb1 * (size_t)nb2 * (size_t)L2.n_u;
+        dbuf<uint32_t> T2(t2n + 1), T2s(t2n + 1);
+        VG_HIP(hipMemsetAsync(T2.p + t2n, 0, sizeof(uint32_t), s));
         {
-            vg_prof_scope ps("kmer_partition2", (double)n1 * (4.0 + 12.0 + (narrow ? 8.0 : 12.0)));
-            hipLaunchKernelGGL(k_part_count2, dim3((int)std::min<int64_t>(n_ch, 512)), dim3(PT_THREADS), 0, s, S2, B1, B2, n_ch, L2, T2.p);
+            vg_prof_scope ps("kmer_partition2", (double)n1 * (4.0 + (short_rec ? 8.0 : 12.0) + (narrow ? 8.0 : 12.0)));
+            const int grid_c2 = (int)std::min<int64_t>(n_units, 512);
+            if (short_rec) hipLaunchKernelGGL(k_part_count2<true>, dim3(grid_c2), dim3(PT_THREADS), 0, s, (const uint32_t*)a_rec.p, B1, B2, n_units, L2, T2.p);
+            else hipLaunchKernelGGL(k_part_count2<false>, dim3(grid_c2), dim3(PT_THREADS), 0, s, (const uint32_t*)a_rec.p, B1, B2, n_units, L2, T2.p);
             size_t tb2 = 0;
-            VG_HIP(rocprim::exclusive_scan(nullptr, tb2, T2.p, T2s.p, 0u, (size_t)tot + 1, rocprim::plus<uint32_t>(), s));
+            VG_HIP(rocprim::exclusive_scan(nullptr, tb2, T2.p, T2s.p, 0u, t2n + 1, rocprim::plus<uint32_t>(), s));
             dbuf<char> tmp2(tb2);
-            VG_HIP(rocprim::exclusive_scan((void*)tmp2.p, tb2, T2.p, T2s.p, 0u, (size_t)tot + 1, rocprim::plus<uint32_t>(), s));
+            VG_HIP(rocprim::exclusive_scan((void*)tmp2.p, tb2, T2.p, T2s.p, 0u, t2n + 1, rocprim::plus<uint32_t>(), s));
             b_rec.alloc((narrow ? 2 : 3) * (size_t)n1 + 8);
             static const bool staged2 = [] { const char* e = getenv("VG_LEVEL2_SCATTER"); return e && !strcmp(e, "staged"); }();
-            if (narrow && B2 <= 11 && !staged2)
-                hipLaunchKernelGGL(k_part_scatter2_narrow, dim3((int)std::min<int64_t>(n_ch, 256)), dim3(PT_THREADS), 0, s, S2, B1, B2, n_ch,
+            const int grid_s2 = (int)std::min<int64_t>(n_units, 256);
+            if (short_rec)
+                hipLaunchKernelGGL(k_part_scatter2_narrow<true>, dim3(grid_s2), dim3(PT_THREADS), 0, s, (const uint32_t*)a_rec.p, B1, B2, n_units,
                                    (const uint32_t*)T2s.p, L2, b_rec.p, total_bits);
-            else
-                hipLaunchKernelGGL((k_part_scatter<SRC_PLANES, 2>), dim3((int)std::min<int64_t>(n_ch, 256)), dim3(PT_THREADS), 0, s, S2, B1, B2, 0, n_ch,
+            else if (narrow && B2 <= 11 && !staged2)
+                hipLaunchKernelGGL(k_part_scatter2_narrow<false>, dim3(grid_s2), dim3(PT_THREADS), 0, s, (const uint32_t*)a_rec.p, B1, B2, n_units,
+                                   (const uint32_t*)T2s.p, L2, b_rec.p, total_bits);
+            else {
+                part_src S2; memset(&S2, 0, sizeof S2);
+                S2.rec = a_rec.p; S2.n = (int64_t)n1; S2.k2 = 2 * k;
+                hipLaunchKernelGGL((k_part_scatter<SRC_PLANES, 2>), dim3(grid_s2), dim3(PT_THREADS), 0, s, S2, B1, B2, 0, n_units,
                                    (const uint32_t*)T2s.p, L2, b_rec.p, narrow ? total_bits : -1);
+            }
         }
-        hipLaunchKernelGGL(k_bucket_offsets, dim3(grid_for(nbk + 1)), dim3(256), 0, s, 2, B1, B2, n_st, (const uint32_t*)T1s.p, (const uint32_t*)d_off1.p,
-                           (const uint32_t*)d_nch.p, (const uint64_t*)d_tb.p, (const uint32_t*)T2s.p, n1, boff.p);
-        VG_HIP(hipStreamSynchronize(s));                       // the tables and level-1 planes go out of scope below
+        hipLaunchKernelGGL(k_bucket_offsets, dim3(grid_for(nbk + 1)), dim3(256), 0, s, 2, nbk, n_st, (const uint32_t*)T1s.p, L2.n_u, (const uint32_t*)T2s.p, n1, boff.p);
+        VG_HIP(hipStreamSynchronize(s));                       // the tables and level-1 records go out of scope below
         vg_host_mark("buckets: level 2 done");
         f_rec = b_rec.p; f_stride = narrow ? 2 : 3;
         arena = std::move(a_rec);
