@@ -151,3 +151,20 @@ def test_bucket_pipeline_key_widths(k):
         for p in pr:
             acc[(int(p['a']), int(p['b']))] = acc.get((int(p['a']), int(p['b'])), 0) + int(p['shared'])
     assert list(tot) == list(osizes) and acc == opairs
+
+
+def test_bucket_pipeline_large_buckets():
+    """200 near-identical genomes: every k-mer is shared by ~200 of them, so some final buckets exceed the 1 536
+    entries of the ordinary bucket kernel; the stage is repeated with the 6 144-entry variant (still the own
+    pipeline, no radix sort) and the counts equal the oracle's."""
+    codes, offsets, names = synth.make_families(1, 200, length=40000, seed=5)
+    gs = api.GenomeSet.from_codes(codes, offsets, names)
+    osizes, opairs = orc.shared_all(codes, offsets, k=25)
+    api.profile_enable(True); api.profile_reset()
+    sizes, pairs = gs.kmer_shared(k=25)
+    prof = api.profile_get()
+    api.profile_enable(False)
+    scopes = {e['name']: e for e in prof}
+    assert 'radix_sort_pairs' not in scopes and scopes['bucket_sort_runs']['launches'] == 2
+    assert list(sizes) == list(osizes)
+    assert {(int(p['a']), int(p['b'])): int(p['shared']) for p in pairs} == opairs

@@ -1182,50 +1182,50 @@ __global__ void k_bucket_offsets(int levels, int64_t nbk, int64_t n_st, const ui
 // comparing with the few members.  From the same loop it learns its run: start in the fully sorted list,
 // length, its place in position order, and the entry in front of it (duplicate test).  Output exactly as
 // k_group_runs: gen[] at the final place, one row descriptor scattered; the sorted keys are never written.
-constexpr int BK_SUBBITS = 9;
-constexpr int BK_SUB = 1 << BK_SUBBITS;
 constexpr int BK_PER = BK_CAP / BK_THREADS;
 constexpr int BK_MAXBIN = 768;           // a sub-bin beyond this (one k-mer occurring hundreds of times) takes the general path
 // NARROW: 8-byte records (key bits below the bucket's in one word, position): an entry is ONE u64 `key << 32 | pos`
 // in the LDS, so the ranking loop reads a single word per sub-bin member and every relation it needs (smaller
 // key, equal key, equal key at a smaller position, the predecessor in the run) is a compare of that word.
-template <bool NARROW>
-__global__ void __launch_bounds__(BK_THREADS)
+// THREADS x BK_PER = the largest bucket taken; SUBBITS: digit of the LDS counting sort (sub-bins of ~2 entries)
+template <bool NARROW, int THREADS, int SUBBITS>
+__global__ void __launch_bounds__(THREADS)
 k_bucket_runs(const uint32_t* __restrict__ rec, int stride /* 3: (w0, w1, pay); 2: (key bits below the bucket's, pay) */,
               const uint32_t* __restrict__ boff, int64_t n_buckets, int pbits, const uint32_t* __restrict__ blk2g, int blk_shift,
               uint32_t* __restrict__ gen, uint64_t* __restrict__ rowinfo, compact_map M, int* __restrict__ dup_per_genome,
               unsigned int* __restrict__ overflow) {
-    __shared__ uint64_t sk[BK_CAP];                  // NARROW: key << 32 | pos; else (w0 << 32) | w1 -- in sub-bin order
-    __shared__ uint32_t sp[NARROW ? 1 : BK_CAP];
+    constexpr int BK_SUB = 1 << SUBBITS, CAP = THREADS * BK_PER;
+    __shared__ uint64_t sk[CAP];                  // NARROW: key << 32 | pos; else (w0 << 32) | w1 -- in sub-bin order
+    __shared__ uint32_t sp[NARROW ? 1 : CAP];
     __shared__ uint32_t cnt[BK_SUB + 1], start[BK_SUB + 1];
-    __shared__ uint32_t s_wave[BK_THREADS / 64];
+    __shared__ uint32_t s_wave[THREADS / 64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int64_t bk = blockIdx.x; bk < n_buckets; bk += gridDim.x) {
         const uint32_t b0 = boff[bk], b1 = boff[bk + 1];
         const int n = (int)(b1 - b0);
         if (n <= 1) continue;                                  // empty, or one singleton k-mer
-        if (n > BK_CAP) { if (threadIdx.x == 0) atomicOr(overflow, 1u); continue; }
+        if (n > CAP) { if (threadIdx.x == 0) atomicOr(overflow, 1u); continue; }
         lds_sync();
-        for (int b = threadIdx.x; b <= BK_SUB; b += BK_THREADS) cnt[b] = 0;
+        for (int b = threadIdx.x; b <= BK_SUB; b += THREADS) cnt[b] = 0;
         lds_sync();
         uint64_t key[BK_PER]; uint32_t pj[BK_PER]; uint32_t sb[BK_PER], ar[BK_PER];
 #pragma unroll
         for (int q = 0; q < BK_PER; ++q) {
-            const int j = q * BK_THREADS + threadIdx.x;
+            const int j = q * THREADS + threadIdx.x;
             sb[q] = 0; ar[q] = 0; key[q] = 0; pj[q] = 0;
             if (j < n) {
                 const uint32_t* r = rec + (uint64_t)(b0 + j) * stride;
                 const uint32_t a = r[0], c = (!NARROW && stride == 3) ? r[1] : 0u;
                 pj[q] = r[stride - 1];
                 key[q] = NARROW ? (((uint64_t)a << 32) | pj[q]) : (((uint64_t)a << 32) | c);
-                sb[q] = NARROW ? (a >> (32 - BK_SUBBITS)) : (uint32_t)((key[q] << pbits) >> (64 - BK_SUBBITS));
+                sb[q] = NARROW ? (a >> (32 - SUBBITS)) : (uint32_t)((key[q] << pbits) >> (64 - SUBBITS));
             }
         }
 #pragma unroll
-        for (int q = 0; q < BK_PER; ++q) if (q * BK_THREADS + (int)threadIdx.x < n) ar[q] = atomicAdd(&cnt[sb[q]], 1u);
+        for (int q = 0; q < BK_PER; ++q) if (q * THREADS + (int)threadIdx.x < n) ar[q] = atomicAdd(&cnt[sb[q]], 1u);
         lds_sync();
-        {   // exclusive scan of the sub-bin counters: BK_SUB / BK_THREADS per thread
-            constexpr int CPT = BK_SUB / BK_THREADS;
+        {   // exclusive scan of the sub-bin counters: BK_SUB / THREADS per thread
+            constexpr int CPT = BK_SUB / THREADS;
             uint32_t c4[CPT], tot = 0;
 #pragma unroll
             for (int u = 0; u < CPT; ++u) { c4[u] = cnt[CPT * threadIdx.x + u]; tot += c4[u]; }
@@ -1239,18 +1239,18 @@ k_bucket_runs(const uint32_t* __restrict__ rec, int stride /* 3: (w0, w1, pay); 
             uint32_t run = base + x - tot;
 #pragma unroll
             for (int u = 0; u < CPT; ++u) { start[CPT * threadIdx.x + u] = run; run += c4[u]; }
-            if (threadIdx.x == BK_THREADS - 1) start[BK_SUB] = run;
+            if (threadIdx.x == THREADS - 1) start[BK_SUB] = run;
         }
         lds_sync();
 #pragma unroll
-        for (int q = 0; q < BK_PER; ++q) if (q * BK_THREADS + (int)threadIdx.x < n) {
+        for (int q = 0; q < BK_PER; ++q) if (q * THREADS + (int)threadIdx.x < n) {
             const uint32_t slot = start[sb[q]] + ar[q];
             sk[slot] = key[q]; if (!NARROW) sp[slot] = pj[q];
         }
         lds_sync();
 #pragma unroll
         for (int q = 0; q < BK_PER; ++q) {
-            if (q * BK_THREADS + (int)threadIdx.x >= n) continue;
+            if (q * THREADS + (int)threadIdx.x >= n) continue;
             const uint32_t s0 = start[sb[q]], s1 = start[sb[q] + 1];
             if (s1 - s0 < 2) continue;                           // alone in its sub-bin: a singleton k-mer
             if (s1 - s0 > BK_MAXBIN) { atomicOr(overflow, 1u); continue; }
@@ -1438,8 +1438,11 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
     vg_host_mark("buckets: enter");
     if (g_index_path < 0) { const char* e = getenv("VG_INDEX_PATH"); g_index_path = (e && !strcmp(e, "radix")) ? 0 : 1; }
     if (!g_index_path || n_src < (1 << 16) || n_src >= (1LL << 32)) return false;
+    static const int tb_env = [] { const char* e = getenv("VG_TOTAL_BITS"); return e ? atoi(e) : 0; }();     // developer experiments
     int total_bits = 0; while ((n_src >> total_bits) > 1024 && total_bits < 22) ++total_bits;
-    if ((n_src >> total_bits) > 1024) return false;
+    if (tb_env > 0 && tb_env < total_bits) total_bits = tb_env;
+    const bool big_buckets = (n_src >> total_bits) > 1024;
+    if ((n_src >> total_bits) > 4096) return false;
     const int levels = total_bits > 11 ? 2 : 1;
     static const char* b2_env = getenv("VG_B2");          // developer experiments: level-2 bits
     const int B2 = levels == 2 ? (b2_env ? atoi(b2_env) : std::min(11, total_bits / 2)) : 0;
@@ -1548,18 +1551,31 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
     }
     if (gen.n < (size_t)n1 + 4) gen.alloc((size_t)n1 + 4);
     if (rowinfo.n < (size_t)n_rows_info) rowinfo.alloc((size_t)n_rows_info);      // (one level: nothing to take over)
-    VG_HIP(hipMemsetAsync(rowinfo.p, 0, (size_t)n_rows_info * sizeof(uint64_t), s));
-    dbuf<unsigned int> d_over(1); d_over.zero(s);
+    dbuf<unsigned int> d_over(1);
     unsigned int over = 0;
-    {
+    // ordinary buckets (mean <= 1 024): 256 threads, 9-bit sub-bins.  When one of them exceeds the 1 536 entries that
+    // variant takes (k-mers shared by dozens of genomes), the stage is repeated with the 1 024-thread variant
+    // (6 144 entries, 11-bit sub-bins) before the call is handed to the general path.
+    auto run_buckets = [&](bool big) {
+        VG_HIP(hipMemsetAsync(rowinfo.p, 0, (size_t)n_rows_info * sizeof(uint64_t), s));
+        d_over.zero(s);
         vg_prof_scope ps("bucket_sort_runs", (double)n1 * ((narrow ? 8 : 12) + 4 + 8));
-        if (narrow) hipLaunchKernelGGL(k_bucket_runs<true>, dim3((int)std::min<int64_t>(nbk, 256 * 16)), dim3(BK_THREADS), 0, s, f_rec, f_stride, (const uint32_t*)boff.p, nbk,
-                                       0, (const uint32_t*)g->d_blk2g.p, g->align_shift, gen.p, rowinfo.p, cmap, d_dups, d_over.p);
-        else hipLaunchKernelGGL(k_bucket_runs<false>, dim3((int)std::min<int64_t>(nbk, 256 * 16)), dim3(BK_THREADS), 0, s, f_rec, f_stride, (const uint32_t*)boff.p, nbk,
-                                total_bits, (const uint32_t*)g->d_blk2g.p, g->align_shift, gen.p, rowinfo.p, cmap, d_dups, d_over.p);
+        const int grid_b = (int)std::min<int64_t>(nbk, 256 * 16);
+        const int pb = narrow ? 0 : total_bits;
+#define VG_BUCKET_LAUNCH(NARROW_, THREADS_, SUBBITS_) \
+        hipLaunchKernelGGL((k_bucket_runs<NARROW_, THREADS_, SUBBITS_>), dim3(grid_b), dim3(THREADS_), 0, s, f_rec, f_stride, (const uint32_t*)boff.p, nbk, \
+                           pb, (const uint32_t*)g->d_blk2g.p, g->align_shift, gen.p, rowinfo.p, cmap, d_dups, d_over.p)
+        if (big) { if (narrow) VG_BUCKET_LAUNCH(true, 1024, 11); else VG_BUCKET_LAUNCH(false, 1024, 11); }
+        else { if (narrow) VG_BUCKET_LAUNCH(true, BK_THREADS, 9); else VG_BUCKET_LAUNCH(false, BK_THREADS, 9); }
+#undef VG_BUCKET_LAUNCH
+        d_over.download(&over, 1, s);
+        VG_HIP(hipStreamSynchronize(s));
+    };
+    run_buckets(big_buckets);
+    if (over && !big_buckets) {
+        VG_HIP(hipMemsetAsync(d_dups, 0, (size_t)g->n * sizeof(int), s));      // the duplicates counted by the first attempt
+        run_buckets(true);
     }
-    d_over.download(&over, 1, s);
-    VG_HIP(hipStreamSynchronize(s));
     return over == 0;
 }
 
