@@ -531,7 +531,10 @@ k_spgemm(const uint64_t* __restrict__ rowinfo, const uint32_t* __restrict__ gen,
     __shared__ uint32_t hc[HT_SIZE];
     __shared__ uint64_t lq[LQ_CAP];
     __shared__ uint32_t s_used, s_lq, s_fail;
-    const int row = blockIdx.x;
+    // XCD-aware dealing (workgroup b runs on XCD b % 8): consecutive rows -- neighbouring genomes, which share
+    // their k-mers' genome lists when they are related -- go to ONE XCD, so the lists are re-read from its L2
+    const int per_xcd = (int)gridDim.x / 8;                    // the grid is a multiple of 8 workgroups
+    const int row = (int)(blockIdx.x % 8) * per_xcd + (int)(blockIdx.x / 8);
     if (row >= n_rows) return;
     const uint32_t a = row_list ? row_list[row] : (uint32_t)row;
     for (int i = threadIdx.x; i < HT_SIZE; i += blockDim.x) { hk[i] = HT_EMPTY; hc[i] = 0; }
@@ -1676,7 +1679,7 @@ static void kmer_shared_pass(vg_genomes* g, int k, double fraction, int shard, i
         d_cursor.zero(s); d_nover.zero(s);
         {
             vg_prof_scope ps("spgemm_rows", (double)n_rows_info * 8.0);
-            hipLaunchKernelGGL(k_spgemm<11>, dim3(n), dim3(256), 0, s, rowinfo.p, gen.p, big_runs.p, n_big, g->d_base_off.p, g->d_len.p, wbase, n,
+            hipLaunchKernelGGL(k_spgemm<11>, dim3((n + 7) / 8 * 8), dim3(256), 0, s, rowinfo.p, gen.p, big_runs.p, n_big, g->d_base_off.p, g->d_len.p, wbase, n,
                                min_shared, (const uint32_t*)nullptr, n, d_out.p, d_cursor.p, cap, d_over.p, d_nover.p);
         }
         // one round trip in the common case: overflow count, pair count and the first pairs together
@@ -1694,7 +1697,7 @@ static void kmer_shared_pass(vg_genomes* g, int k, double fraction, int shard, i
             d_nover.zero(s);
             {
                 vg_prof_scope ps("spgemm_rows_wide", 0);
-                hipLaunchKernelGGL(k_spgemm<13>, dim3(nover), dim3(256), 0, s, rowinfo.p, gen.p, big_runs.p, n_big, g->d_base_off.p, g->d_len.p, wbase, n,
+                hipLaunchKernelGGL(k_spgemm<13>, dim3((nover + 7) / 8 * 8), dim3(256), 0, s, rowinfo.p, gen.p, big_runs.p, n_big, g->d_base_off.p, g->d_len.p, wbase, n,
                                    min_shared, (const uint32_t*)d_rows2.p, (int)nover, d_out.p, d_cursor.p, cap, d_over2.p, d_nover.p);
             }
             VG_HIP(hipMemcpyAsync(d_over.p, d_over2.p, sizeof(uint32_t) * nover, hipMemcpyDeviceToDevice, s));
