@@ -30,8 +30,9 @@ __host__ __device__ __forceinline__ uint64_t scramble_key(uint64_t cano, int k) 
 }
 __host__ __device__ __forceinline__ uint64_t unscramble_key(uint64_t key, int k) { return scramble_key(key, k); }   // an involution
 constexpr uint32_t DUP_BIT = 0x80000000u;
-constexpr int RUNLEN_BITS = 24;
-constexpr uint64_t RUNLEN_MASK = (1ull << RUNLEN_BITS) - 1;
+// Row pointers: one u32 per base position (dense) or kept k-mer (compact): 0 = nothing to do, else 1 + the start
+// of the k-mer's run in gen[].  The run is ascending in genome id and contains the position's own genome, so a
+// walk from the start needs no length: it ends at the first genome >= a.
 
 __device__ __forceinline__ uint64_t mix64(uint64_t x) {
     x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33;
@@ -328,9 +329,8 @@ __device__ __forceinline__ int64_t run_upper(const uint64_t* __restrict__ keys, 
 
 __global__ void __launch_bounds__(256)
 k_runs(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos, const uint32_t* __restrict__ blk2g, int blk_shift,
-       int64_t n, uint32_t* __restrict__ gen, uint64_t* __restrict__ rowinfo,
-       compact_map M, int* __restrict__ dup_per_genome,
-       uint64_t* __restrict__ big_runs, unsigned int* __restrict__ n_big, unsigned int big_cap) {
+       int64_t n, uint32_t* __restrict__ gen, uint32_t* __restrict__ rowinfo,
+       compact_map M, int* __restrict__ dup_per_genome) {
     // four consecutive entries per thread: their keys, positions and genomes are fetched with
     // independent loads first (the kernel is bound by load latency, not by bandwidth)
     const int64_t n4 = (n + 3) >> 2;
@@ -354,15 +354,8 @@ k_runs(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos, cons
             gen[i] = g | (dup ? DUP_BIT : 0u);
             if (dup) { atomicAdd(&dup_per_genome[g], 1); continue; }
             if (!has_prev && !has_next) continue;               // singleton k-mer: no partner possible
-            const int64_t rs = has_prev ? run_lower(keys, i, key) : i;
-            const int64_t re = has_next ? run_upper(keys, n, i, key) : i + 1;
-            uint64_t rl = (uint64_t)(re - rs);
-            if (rl >= RUNLEN_MASK) {
-                if (i == rs) { unsigned int o = atomicAdd(n_big, 1u); if (o < big_cap) { big_runs[2 * o] = (uint64_t)rs; big_runs[2 * o + 1] = rl; } }
-                rl = RUNLEN_MASK;
-            }
             if (!has_prev) continue;                            // the run's smallest genome: no partner b < a
-            rowinfo[p] = ((uint64_t)rs << RUNLEN_BITS) | rl;            // p = base position (dense) or compact index
+            rowinfo[p] = (uint32_t)run_lower(keys, i, key) + 1u;        // p = base position (dense) or compact index
         }
     }
 }
@@ -377,7 +370,7 @@ k_runs(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos, cons
 // conserved genes) is queued for k_long_groups.
 __global__ void __launch_bounds__(256)
 k_group_runs(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos, const uint32_t* __restrict__ blk2g, int blk_shift,
-             int64_t n, int low_bit, uint32_t* __restrict__ gen, uint64_t* __restrict__ rowinfo,
+             int64_t n, int low_bit, uint32_t* __restrict__ gen, uint32_t* __restrict__ rowinfo,
              compact_map M, int* __restrict__ dup_per_genome, int64_t* __restrict__ long_list, unsigned int* __restrict__ n_long,
              unsigned int long_cap) {
     __shared__ uint64_t sk[GS_TILE + GS_HALO + 1];
@@ -440,7 +433,7 @@ k_group_runs(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos
             if (dup) { atomicAdd(&dup_per_genome[g], 1); continue; }
             if (eq_before == 0) continue;                                // the run's smallest genome: no partner b < a
             const uint32_t p = sp[j];
-            rowinfo[p] = ((uint64_t)rs << RUNLEN_BITS) | rl;            // p = base position (dense) or compact index
+            rowinfo[p] = (uint32_t)rs + 1u;                             // p = base position (dense) or compact index
         }
     }
 }
@@ -451,9 +444,8 @@ k_group_runs(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos
 // a long group need a real sort: *need_full_sort sends the call to the general path.
 __global__ void __launch_bounds__(256)
 k_long_groups(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos, const uint32_t* __restrict__ blk2g, int blk_shift,
-              int64_t n, int low_bit, const int64_t* __restrict__ long_list, uint32_t* __restrict__ gen, uint64_t* __restrict__ rowinfo,
-              compact_map M, int* __restrict__ dup_per_genome, uint64_t* __restrict__ big_runs, unsigned int* __restrict__ n_big,
-              unsigned int big_cap, unsigned int* __restrict__ need_full_sort) {
+              int64_t n, int low_bit, const int64_t* __restrict__ long_list, uint32_t* __restrict__ gen, uint32_t* __restrict__ rowinfo,
+              compact_map M, int* __restrict__ dup_per_genome, unsigned int* __restrict__ need_full_sort) {
     __shared__ int64_t s_end;
     const int64_t gs = long_list[blockIdx.x];
     const uint64_t key0 = keys[gs]; const uint64_t pre = key0 >> low_bit;
@@ -472,11 +464,6 @@ k_long_groups(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ po
     }
     if (!__syncthreads_and(same)) { if (threadIdx.x == 0) atomicOr(need_full_sort, 1u); return; }
     const int64_t ge = s_end;
-    uint64_t rl = (uint64_t)(ge - gs);
-    if (rl >= RUNLEN_MASK) {
-        if (threadIdx.x == 0) { const unsigned int o = atomicAdd(n_big, 1u); if (o < big_cap) { big_runs[2 * o] = (uint64_t)gs; big_runs[2 * o + 1] = rl; } }
-        rl = RUNLEN_MASK;
-    }
     for (int64_t i = gs + threadIdx.x; i < ge; i += blockDim.x) {
         const uint32_t p = pos[i];
         const uint32_t g = M.cblk ? genome_of_compact(M, p) : blk2g[p >> blk_shift];
@@ -484,7 +471,7 @@ k_long_groups(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ po
         if (i > gs) { const uint32_t pp = pos[i - 1]; dup = (M.cblk ? genome_of_compact(M, pp) : blk2g[pp >> blk_shift]) == g; }
         gen[i] = g | (dup ? DUP_BIT : 0u);
         if (dup || i == gs) { if (dup) atomicAdd(&dup_per_genome[g], 1); continue; }   // (the run's smallest genome has no partner b < a)
-        rowinfo[p] = ((uint64_t)gs << RUNLEN_BITS) | rl;
+        rowinfo[p] = (uint32_t)gs + 1u;
     }
 }
 
@@ -497,10 +484,6 @@ constexpr uint32_t HT_EMPTY = 0xffffffffu;
 constexpr int LONG_RUN = 48;           // runs longer than this are walked by the whole workgroup
 constexpr int LQ_CAP = 512;
 
-__device__ __forceinline__ uint32_t big_run_len(const uint64_t* __restrict__ big_runs, unsigned int n_big, uint32_t rs) {
-    for (unsigned int i = 0; i < n_big; ++i) if (big_runs[2 * i] == rs) return (uint32_t)big_runs[2 * i + 1];
-    return 0;
-}
 
 template <int HT_BITS>
 __device__ __forceinline__ bool ht_add(uint32_t* hk, uint32_t* hc, uint32_t b, uint32_t* n_used) {
@@ -521,7 +504,7 @@ __device__ __forceinline__ bool ht_add(uint32_t* hk, uint32_t* hc, uint32_t b, u
 
 template <int HT_BITS>
 __global__ void __launch_bounds__(256)
-k_spgemm(const uint64_t* __restrict__ rowinfo, const uint32_t* __restrict__ gen, const uint64_t* __restrict__ big_runs, unsigned int n_big,
+k_spgemm(const uint32_t* __restrict__ rowinfo, const uint32_t* __restrict__ gen, uint64_t n_gen,
          const int64_t* __restrict__ base_off, const int64_t* __restrict__ len, const uint32_t* __restrict__ wave_base,
          int n_genomes, uint32_t min_emit, const uint32_t* __restrict__ row_list, int n_rows,
          vg_pair_count* __restrict__ out, unsigned long long* __restrict__ out_cursor,
@@ -529,8 +512,8 @@ k_spgemm(const uint64_t* __restrict__ rowinfo, const uint32_t* __restrict__ gen,
     constexpr int HT_SIZE = 1 << HT_BITS;
     __shared__ uint32_t hk[HT_SIZE];
     __shared__ uint32_t hc[HT_SIZE];
-    __shared__ uint64_t lq[LQ_CAP];
-    __shared__ uint32_t s_used, s_lq, s_fail;
+    __shared__ uint32_t lq[LQ_CAP];
+    __shared__ uint32_t s_used, s_lq, s_fail, s_first;
     // XCD-aware dealing (workgroup b runs on XCD b % 8): consecutive rows -- neighbouring genomes, which share
     // their k-mers' genome lists when they are related -- go to ONE XCD, so the lists are re-read from its L2
     const int per_xcd = (int)gridDim.x / 8;                    // the grid is a multiple of 8 workgroups
@@ -543,37 +526,42 @@ k_spgemm(const uint64_t* __restrict__ rowinfo, const uint32_t* __restrict__ gen,
     // row a = its base positions (dense) or its kept k-mers (compact index space)
     const int64_t p0 = wave_base ? (int64_t)wave_base[base_off[a] >> 6] : base_off[a];
     const int64_t L = wave_base ? (int64_t)wave_base[base_off[a + 1] >> 6] - p0 : len[a];
-    constexpr int ROWS_PER_TRIP = 4;              // independent row-descriptor loads per thread and trip
+    constexpr int ROWS_PER_TRIP = 4;              // independent row-pointer loads per thread and trip
     for (int64_t base = 0; base < L; base += (int64_t)blockDim.x * ROWS_PER_TRIP) {
-        uint64_t rr4[ROWS_PER_TRIP];
+        uint32_t rr4[ROWS_PER_TRIP];
 #pragma unroll
         for (int u = 0; u < ROWS_PER_TRIP; ++u) {
             const int64_t i = base + (int64_t)u * blockDim.x + threadIdx.x;
-            rr4[u] = (i < L) ? rowinfo[p0 + i] : 0;
+            rr4[u] = (i < L) ? rowinfo[p0 + i] : 0u;
         }
 #pragma unroll
         for (int u = 0; u < ROWS_PER_TRIP; ++u) {
-            const uint64_t r = rr4[u];
-            if (!r) continue;
-            uint32_t rl = (uint32_t)(r & RUNLEN_MASK); const uint32_t rs = (uint32_t)(r >> RUNLEN_BITS);
-            if (rl < 2) continue;
-            if (rl > LONG_RUN) {
-                const uint32_t slot = atomicAdd(&s_lq, 1u);
-                if (slot < LQ_CAP) { lq[slot] = r; continue; }
-            }
-            if (rl == RUNLEN_MASK) rl = big_run_len(big_runs, n_big, rs);
-            // the genome list of the run, four entries per memory round trip; ascending, so the
-            // first genome >= a ends the walk
+            if (!rr4[u]) continue;
+            const uint32_t rs = rr4[u] - 1u;
+            // the genome list of the run, four entries per memory round trip; ascending, and genome a itself is
+            // in it: the first genome >= a ends the walk (entries past the run are never reached)
             bool done = false;
-            for (uint32_t e = 0; e < rl && !done; e += 4) {
+            uint32_t e = 0;
+            for (; e < (uint32_t)LONG_RUN && !done; e += 4) {
                 uint32_t g4[4];
-                __builtin_memcpy(g4, gen + (size_t)rs + e, 16);            // one 16-byte load; entries past the run are ignored (4 slack entries)
+                __builtin_memcpy(g4, gen + (size_t)rs + e, 16);            // one 16-byte load (the list carries 4 slack entries)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    if (e + j >= rl || done) continue;
+                    if (done) continue;
                     const uint32_t g = g4[j];
                     if (g & DUP_BIT) continue;
                     if (g >= a) { done = true; continue; }
+                    if (!ht_add<HT_BITS>(hk, hc, g, &s_used)) s_fail = 1;
+                }
+            }
+            if (!done) {
+                // a long run: the rest is walked by the whole workgroup (queue full: this thread goes on alone)
+                const uint32_t slot = atomicAdd(&s_lq, 1u);
+                if (slot < LQ_CAP) lq[slot] = rs + e;
+                else for (uint64_t x = (uint64_t)rs + e; x < n_gen; ++x) {
+                    const uint32_t g = gen[x];
+                    if (g & DUP_BIT) continue;
+                    if (g >= a) break;
                     if (!ht_add<HT_BITS>(hk, hc, g, &s_used)) s_fail = 1;
                 }
             }
@@ -581,15 +569,21 @@ k_spgemm(const uint64_t* __restrict__ rowinfo, const uint32_t* __restrict__ gen,
         // drain the long-run queue cooperatively when it fills up
         __syncthreads();
         if (s_lq >= LQ_CAP / 2 || base + (int64_t)blockDim.x * ROWS_PER_TRIP >= L) {
-            uint32_t nq = s_lq < LQ_CAP ? s_lq : LQ_CAP;
+            const uint32_t nq = s_lq < LQ_CAP ? s_lq : LQ_CAP;
             for (uint32_t qi = 0; qi < nq; ++qi) {
-                uint64_t rr = lq[qi];
-                uint32_t rl = (uint32_t)(rr & RUNLEN_MASK); uint32_t rs = (uint32_t)(rr >> RUNLEN_BITS);
-                if (rl == RUNLEN_MASK) rl = big_run_len(big_runs, n_big, rs);
-                for (uint32_t e = threadIdx.x; e < rl; e += blockDim.x) {
-                    uint32_t g = gen[rs + e];
-                    if ((g & DUP_BIT) || g >= a) continue;
-                    if (!ht_add<HT_BITS>(hk, hc, g, &s_used)) s_fail = 1;
+                for (uint64_t c0 = lq[qi]; ; c0 += blockDim.x) {
+                    // one chunk of the list: everything in front of the first genome >= a counts
+                    if (threadIdx.x == 0) s_first = 0xffffffffu;
+                    __syncthreads();
+                    const uint64_t x = c0 + threadIdx.x;
+                    const uint32_t g = x < n_gen ? gen[x] : 0u;
+                    const bool stop = x >= n_gen || (!(g & DUP_BIT) && g >= a);
+                    if (stop) atomicMin(&s_first, (uint32_t)threadIdx.x);
+                    __syncthreads();
+                    const uint32_t f = s_first;
+                    if (threadIdx.x < f && !(g & DUP_BIT)) { if (!ht_add<HT_BITS>(hk, hc, g, &s_used)) s_fail = 1; }
+                    __syncthreads();
+                    if (f != 0xffffffffu) break;
                 }
             }
             __syncthreads();
@@ -615,7 +609,7 @@ k_spgemm(const uint64_t* __restrict__ rowinfo, const uint32_t* __restrict__ gen,
 // dense fallback for rows whose partner set does not fit the LDS table: one workgroup per
 // overflowing row, counters in a private global array of n_genomes entries
 __global__ void __launch_bounds__(256)
-k_spgemm_dense(const uint64_t* __restrict__ rowinfo, const uint32_t* __restrict__ gen, const uint64_t* __restrict__ big_runs, unsigned int n_big,
+k_spgemm_dense(const uint32_t* __restrict__ rowinfo, const uint32_t* __restrict__ gen, uint64_t n_gen,
                const int64_t* __restrict__ base_off, const int64_t* __restrict__ len, const uint32_t* __restrict__ wave_base,
                int n_genomes, uint32_t min_emit, const uint32_t* __restrict__ rows, uint32_t* __restrict__ dense /* gridDim.x * n_genomes, zeroed */,
                vg_pair_count* __restrict__ out, unsigned long long* __restrict__ out_cursor, unsigned long long out_cap) {
@@ -624,13 +618,10 @@ k_spgemm_dense(const uint64_t* __restrict__ rowinfo, const uint32_t* __restrict_
     const int64_t p0 = wave_base ? (int64_t)wave_base[base_off[a] >> 6] : base_off[a];
     const int64_t L = wave_base ? (int64_t)wave_base[base_off[a + 1] >> 6] - p0 : len[a];
     for (int64_t i = threadIdx.x; i < L; i += blockDim.x) {
-        uint64_t r = rowinfo[p0 + i];
+        const uint32_t r = rowinfo[p0 + i];
         if (!r) continue;
-        uint32_t rl = (uint32_t)(r & RUNLEN_MASK); uint32_t rs = (uint32_t)(r >> RUNLEN_BITS);
-        if (rl == RUNLEN_MASK) rl = big_run_len(big_runs, n_big, rs);
-        if (rl < 2) continue;
-        for (uint32_t e = 0; e < rl; ++e) {
-            uint32_t g = gen[rs + e];
+        for (uint64_t x = (uint64_t)r - 1; x < n_gen; ++x) {
+            const uint32_t g = gen[x];
             if (g & DUP_BIT) continue;
             if (g >= a) break;
             atomicAdd(&cnt[g], 1u);
@@ -1195,7 +1186,7 @@ template <bool NARROW, int THREADS, int SUBBITS>
 __global__ void __launch_bounds__(THREADS)
 k_bucket_runs(const uint32_t* __restrict__ rec, int stride /* 3: (w0, w1, pay); 2: (key bits below the bucket's, pay) */,
               const uint32_t* __restrict__ boff, int64_t n_buckets, int pbits, const uint32_t* __restrict__ blk2g, int blk_shift,
-              uint32_t* __restrict__ gen, uint64_t* __restrict__ rowinfo, compact_map M, int* __restrict__ dup_per_genome,
+              uint32_t* __restrict__ gen, uint32_t* __restrict__ rowinfo, compact_map M, int* __restrict__ dup_per_genome,
               unsigned int* __restrict__ overflow) {
     constexpr int BK_SUB = 1 << SUBBITS, CAP = THREADS * BK_PER;
     __shared__ uint64_t sk[CAP];                  // NARROW: key << 32 | pos; else (w0 << 32) | w1 -- in sub-bin order
@@ -1292,7 +1283,7 @@ k_bucket_runs(const uint32_t* __restrict__ rec, int stride /* 3: (w0, w1, pay); 
             gen[rs + before] = g | (dup ? DUP_BIT : 0u);
             if (dup) { atomicAdd(&dup_per_genome[g], 1); continue; }
             if (before == 0) continue;                           // the run's smallest genome: no partner b < a
-            rowinfo[pq] = ((uint64_t)rs << RUNLEN_BITS) | eq;
+            rowinfo[pq] = rs + 1u;
         }
     }
 }
@@ -1435,7 +1426,7 @@ static void run_extract_sort(vg_genomes* g, int k, double fraction, int shard, i
 // input does not suit it (tiny, skewed, a bucket beyond the LDS): the caller takes the general path.
 static int g_index_path = -1;      // -1 = not read yet; 0 = radix (rocPRIM) path forced; 1 = buckets
 static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_args& A, const uint64_t* keys, const uint32_t* pos, int64_t n_src,
-                                const compact_map& cmap, int* d_kept, dbuf<uint32_t>& gen, dbuf<uint64_t>& rowinfo, dbuf<uint32_t>& arena,
+                                const compact_map& cmap, int* d_kept, dbuf<uint32_t>& gen, dbuf<uint32_t>& rowinfo, dbuf<uint32_t>& arena,
                                 int64_t n_rows_info, int* d_dups, int64_t* n_valid_out) {
     hipStream_t s = vg_stream();
     vg_host_mark("buckets: enter");
@@ -1497,7 +1488,7 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
         if (n1 == 0) return true;
         // two levels: the level-1 records are dead once level 2 has scattered them, and the genome list + row
         // descriptors are born after that: they take over the same block (48 GB less to allocate at 100 k genomes)
-        a_rec.alloc(levels == 2 ? std::max((short_rec ? 2 : 3) * (size_t)n1 + 8, 2 * (size_t)n_rows_info + (size_t)n1 + 16) : 3 * (size_t)n1 + 8);
+        a_rec.alloc(levels == 2 ? std::max((short_rec ? 2 : 3) * (size_t)n1 + 8, (size_t)n_rows_info + (size_t)n1 + 16) : 3 * (size_t)n1 + 8);
         const int grid_s = (int)std::min<int64_t>(n_st, 256);
         if (tile32k)
             hipLaunchKernelGGL(k_part_scatter_dense, dim3(grid_s), dim3(PT_THREADS), 0, s, S, B1, st_tiles / 4, n_st, (const uint32_t*)T1s.p, a_rec.p,
@@ -1549,8 +1540,8 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
         vg_host_mark("buckets: level 2 done");
         f_rec = b_rec.p; f_stride = narrow ? 2 : 3;
         arena = std::move(a_rec);
-        rowinfo.view(reinterpret_cast<uint64_t*>(arena.p), (size_t)n_rows_info);
-        gen.view(arena.p + 2 * (size_t)n_rows_info, (size_t)n1 + 4);
+        rowinfo.view(arena.p, (size_t)n_rows_info);
+        gen.view(arena.p + (((size_t)n_rows_info + 3) & ~(size_t)3), (size_t)n1 + 4);
     }
     if (gen.n < (size_t)n1 + 4) gen.alloc((size_t)n1 + 4);
     if (rowinfo.n < (size_t)n_rows_info) rowinfo.alloc((size_t)n_rows_info);      // (one level: nothing to take over)
@@ -1560,7 +1551,7 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
     // variant takes (k-mers shared by dozens of genomes), the stage is repeated with the 1 024-thread variant
     // (6 144 entries, 11-bit sub-bins) before the call is handed to the general path.
     auto run_buckets = [&](bool big) {
-        VG_HIP(hipMemsetAsync(rowinfo.p, 0, (size_t)n_rows_info * sizeof(uint64_t), s));
+        VG_HIP(hipMemsetAsync(rowinfo.p, 0, (size_t)n_rows_info * sizeof(uint32_t), s));
         d_over.zero(s);
         vg_prof_scope ps("bucket_sort_runs", (double)n1 * ((narrow ? 8 : 12) + 4 + 8));
         const int grid_b = (int)std::min<int64_t>(nbk, 256 * 16);
@@ -1592,11 +1583,8 @@ static void kmer_shared_pass(vg_genomes* g, int k, double fraction, int shard, i
     const bool dense_src = !(fraction < 1.0) && n_shards == 1;
     int64_t nv = 0, n_rows_info = 0;
     dbuf<uint32_t> arena;                            // owner of rowinfo / gen when they are windows of one block
-    dbuf<uint64_t> rowinfo; dbuf<uint32_t> gen;
+    dbuf<uint32_t> rowinfo; dbuf<uint32_t> gen;
     dbuf<int> d_dups((size_t)n); d_dups.zero(s);
-    constexpr unsigned int BIG_CAP = 4096;
-    dbuf<uint64_t> big_runs(2 * BIG_CAP); dbuf<unsigned int> d_nbig(1); d_nbig.zero(s);
-    unsigned int n_big = 0;
     std::vector<int> kept((size_t)n), dups((size_t)n);
     // ---- the bucket pipeline first (own MSD partition + LDS sort); the general radix path when it declines
     bool bucket_ok = false;
@@ -1629,8 +1617,9 @@ static void kmer_shared_pass(vg_genomes* g, int k, double fraction, int shard, i
     nv = si.n_valid;
     n_rows_info = si.compact ? std::max<int64_t>(nv, 1) : P;      // row descriptors: per kept k-mer or per base
     // row descriptors and genome list live in the sort's input buffers (32 + 16 GB less at 100 k genomes)
-    rowinfo = si.spare64.n >= (size_t)n_rows_info ? std::move(si.spare64) : dbuf<uint64_t>((size_t)n_rows_info);
-    VG_HIP(hipMemsetAsync(rowinfo.p, 0, (size_t)n_rows_info * sizeof(uint64_t), s));
+    if (2 * si.spare64.n >= (size_t)n_rows_info) rowinfo.view(reinterpret_cast<uint32_t*>(si.spare64.p), (size_t)n_rows_info);
+    else rowinfo.alloc((size_t)n_rows_info);
+    VG_HIP(hipMemsetAsync(rowinfo.p, 0, (size_t)n_rows_info * sizeof(uint32_t), s));
     const compact_map cmap{ si.compact ? si.goff.p : nullptr, si.compact ? si.cblk.p : nullptr };
     gen = si.spare32.n >= (size_t)std::max<int64_t>(nv, 1) + 4 ? std::move(si.spare32) : dbuf<uint32_t>((size_t)std::max<int64_t>(nv, 1) + 4);
     constexpr unsigned int LONG_CAP = 1u << 16;
@@ -1647,27 +1636,26 @@ static void kmer_shared_pass(vg_genomes* g, int k, double fraction, int shard, i
         {
             vg_prof_scope ps("index_long_runs", 0);
             hipLaunchKernelGGL(k_long_groups, dim3(n_long), dim3(256), 0, s, si.keys.p, si.pos.p, g->d_blk2g.p, g->align_shift, nv, si.low_bit,
-                               long_list.p, gen.p, rowinfo.p, cmap, d_dups.p, big_runs.p, d_nbig.p, BIG_CAP, d_full.p);
+                               long_list.p, gen.p, rowinfo.p, cmap, d_dups.p, d_full.p);
         }
-        d_full.download(&need_full, 1, s); d_nbig.download(&n_big, 1, s); d_dups.download(dups.data(), (size_t)n, s);
+        d_full.download(&need_full, 1, s); d_dups.download(dups.data(), (size_t)n, s);
         VG_HIP(hipStreamSynchronize(s));
     }
     if (need_full || n_long > LONG_CAP) {
         // several frequent k-mers share a prefix group (or too many long groups): sort on all bits, general run pass
-        rowinfo.zero(s); d_dups.zero(s); d_nbig.zero(s);
+        rowinfo.zero(s); d_dups.zero(s);
         finish_sort(si, k);
         {
             vg_prof_scope ps("index_runs_general", (double)nv * (8 + 4 + 4 + 8));
             hipLaunchKernelGGL(k_runs, dim3(grid_for((nv + 3) / 4)), dim3(256), 0, s, si.keys.p, si.pos.p, g->d_blk2g.p, g->align_shift, nv,
-                               gen.p, rowinfo.p, cmap, d_dups.p, big_runs.p, d_nbig.p, BIG_CAP);
+                               gen.p, rowinfo.p, cmap, d_dups.p);
         }
-        d_nbig.download(&n_big, 1, s); d_dups.download(dups.data(), (size_t)n, s);
+        d_dups.download(dups.data(), (size_t)n, s);
         VG_HIP(hipStreamSynchronize(s));
     }
     }
     const bool compact_rows = !dense_src;
     const uint32_t* wbase = compact_rows ? si.wave_base.p : nullptr;
-    if (n_big > BIG_CAP) throw vg_error(VG_EOVERFLOW, "too many k-mers shared by >= 2^24 entries");
     for (int i = 0; i < n; ++i) set_sizes[i] = (int64_t)kept[i] - dups[i];
     si.keys.release();
     // SpGEMM with a growing output buffer
@@ -1678,8 +1666,8 @@ static void kmer_shared_pass(vg_genomes* g, int k, double fraction, int shard, i
         dbuf<vg_pair_count> d_out((size_t)cap);
         d_cursor.zero(s); d_nover.zero(s);
         {
-            vg_prof_scope ps("spgemm_rows", (double)n_rows_info * 8.0);
-            hipLaunchKernelGGL(k_spgemm<11>, dim3((n + 7) / 8 * 8), dim3(256), 0, s, rowinfo.p, gen.p, big_runs.p, n_big, g->d_base_off.p, g->d_len.p, wbase, n,
+            vg_prof_scope ps("spgemm_rows", (double)n_rows_info * 4.0);
+            hipLaunchKernelGGL(k_spgemm<11>, dim3((n + 7) / 8 * 8), dim3(256), 0, s, rowinfo.p, gen.p, (uint64_t)gen.n, g->d_base_off.p, g->d_len.p, wbase, n,
                                min_shared, (const uint32_t*)nullptr, n, d_out.p, d_cursor.p, cap, d_over.p, d_nover.p);
         }
         // one round trip in the common case: overflow count, pair count and the first pairs together
@@ -1697,7 +1685,7 @@ static void kmer_shared_pass(vg_genomes* g, int k, double fraction, int shard, i
             d_nover.zero(s);
             {
                 vg_prof_scope ps("spgemm_rows_wide", 0);
-                hipLaunchKernelGGL(k_spgemm<13>, dim3((nover + 7) / 8 * 8), dim3(256), 0, s, rowinfo.p, gen.p, big_runs.p, n_big, g->d_base_off.p, g->d_len.p, wbase, n,
+                hipLaunchKernelGGL(k_spgemm<13>, dim3((nover + 7) / 8 * 8), dim3(256), 0, s, rowinfo.p, gen.p, (uint64_t)gen.n, g->d_base_off.p, g->d_len.p, wbase, n,
                                    min_shared, (const uint32_t*)d_rows2.p, (int)nover, d_out.p, d_cursor.p, cap, d_over2.p, d_nover.p);
             }
             VG_HIP(hipMemcpyAsync(d_over.p, d_over2.p, sizeof(uint32_t) * nover, hipMemcpyDeviceToDevice, s));
@@ -1714,7 +1702,7 @@ static void kmer_shared_pass(vg_genomes* g, int k, double fraction, int shard, i
                 dense.zero(s);
                 d_rows.upload(rows.data() + o, nb, s);
                 vg_prof_scope ps("spgemm_dense_rows", 0);
-                hipLaunchKernelGGL(k_spgemm_dense, dim3(nb), dim3(256), 0, s, rowinfo.p, gen.p, big_runs.p, n_big, g->d_base_off.p,
+                hipLaunchKernelGGL(k_spgemm_dense, dim3(nb), dim3(256), 0, s, rowinfo.p, gen.p, (uint64_t)gen.n, g->d_base_off.p,
                                    g->d_len.p, wbase, n, min_shared, d_rows.p, dense.p, d_out.p, d_cursor.p, cap);
                 VG_HIP(hipStreamSynchronize(s));
             }
