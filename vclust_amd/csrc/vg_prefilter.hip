@@ -785,7 +785,7 @@ __device__ __forceinline__ void decode_tile(const part_src& S, int64_t t0, int64
     }
 }
 
-// level-1 histogram: one super-tile (st_tiles tiles) per trip; T[b * n_st + st] = elements of bucket b.
+// level-1 histogram: one super-tile (st_tiles tiles) per trip; T[st * 2^B1 + b] = elements of bucket b.
 // The dense source also counts the kept k-mers per genome (set sizes) on the way.  The raw words of the next
 // tile are requested before the current one is counted (one workgroup per CU: nothing else hides the latency).
 template <int SRC>
@@ -833,15 +833,15 @@ k_part_count(part_src S, int B1, int st_tiles, int64_t n_st, uint32_t* __restric
             }
         }
         __syncthreads();
-        for (int b = threadIdx.x; b < nb; b += PT_THREADS) T[(int64_t)b * n_st + st] = hist[b];
+        for (int b = threadIdx.x; b < nb; b += PT_THREADS) T[st * nb + b] = hist[b];      // [super-tile][bucket]: one contiguous row
         __syncthreads();
     }
 }
 
 // Level 2 works on UNITS: the records of one level-1 bucket that came from u_st consecutive super-tiles (about
 // 65 536 of them).  A unit's range is read straight off the scanned level-1 table, so the host builds no chunk
-// lists and level 2 follows level 1 without a round trip.  Table entry of (b1, b2, unit U):
-// (b1 * 2^B2 + b2) * n_u + U -- bucket-major, so the scanned entries of U = 0 are the final bucket offsets.
+// lists and level 2 follows level 1 without a round trip.  Table entry of (b1, unit U, b2):
+// (b1 * n_u + U) * 2^B2 + b2 -- a unit's counters are one contiguous row; k_scan_units makes them write offsets.
 //
 // SHORT records (dense source, 2k - B1 + 25 <= 64): level 1 writes 8 bytes instead of 12,
 //   rec = (key bits below the level-1 digit) << 25 | (position mod 2^25);
@@ -849,7 +849,8 @@ k_part_count(part_src S, int B1, int st_tiles, int64_t n_st, uint32_t* __restric
 // most four groups whose boundaries are again entries of the level-1 table.
 constexpr int SR_POS_BITS = 25;
 struct lvl2_tab {
-    const uint32_t* T1s; int64_t n_st;      // scanned level-1 table [bucket][super-tile] (+ the total at the end)
+    const uint32_t* T1s; int64_t n_st;      // level-1 write offsets [super-tile][bucket] (k_scan_columns)
+    const uint32_t* off1; int nb1;          // start of every level-1 bucket (+ the total)
     int u_st, n_u;                          // super-tiles per unit, units per level-1 bucket
     int g_st;                               // SHORT: super-tiles per position group (0: a unit lies inside one group)
     int st_shift;                           // SHORT: log2(positions per super-tile)
@@ -857,19 +858,18 @@ struct lvl2_tab {
 };
 __device__ __forceinline__ void lvl2_unit(const lvl2_tab& L, int64_t u, uint32_t* b1, uint32_t* U, int64_t* r0, int64_t* r1) {
     *b1 = (uint32_t)(u / L.n_u); *U = (uint32_t)(u % L.n_u);
-    const int64_t row = (int64_t)*b1 * L.n_st, st0 = (int64_t)*U * L.u_st, st1 = st0 + L.u_st;
-    *r0 = L.T1s[row + st0];
-    *r1 = L.T1s[row + (st1 < L.n_st ? st1 : L.n_st)];
+    const int64_t st0 = (int64_t)*U * L.u_st, st1 = st0 + L.u_st;
+    *r0 = L.T1s[st0 * L.nb1 + *b1];
+    *r1 = st1 < L.n_st ? L.T1s[st1 * L.nb1 + *b1] : L.off1[*b1 + 1];
 }
 // SHORT: position base of the unit's first group and the record indices at which its 2nd..4th group start
 __device__ __forceinline__ void lvl2_groups(const lvl2_tab& L, uint32_t b1, uint32_t U, int64_t r1, uint32_t* base, uint32_t gb[3]) {
     const int64_t st0 = (int64_t)U * L.u_st;
     *base = (uint32_t)(((uint64_t)st0 << L.st_shift) >> SR_POS_BITS << SR_POS_BITS);
-    const int64_t row = (int64_t)b1 * L.n_st;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const int64_t stg = st0 + (int64_t)(j + 1) * L.g_st;
-        gb[j] = (L.g_st > 0 && stg < st0 + L.u_st && stg < L.n_st) ? L.T1s[row + stg] : (uint32_t)r1;
+        gb[j] = (L.g_st > 0 && stg < st0 + L.u_st && stg < L.n_st) ? L.T1s[stg * L.nb1 + b1] : (uint32_t)r1;
     }
 }
 
@@ -900,8 +900,8 @@ k_part_count2(const uint32_t* __restrict__ rec, int B1, int B2, int64_t n_units,
             for (int v = 0; v < 8; ++v) if (i0 + (int64_t)v * PT_THREADS < s1) atomicAdd(&hist[d[v] & (uint32_t)(nb2 - 1)], 1u);
         }
         __syncthreads();
-        const uint64_t t0 = (uint64_t)b1 * nb2 * L.n_u + U;
-        for (int d = threadIdx.x; d < nb2; d += PT_THREADS) T[t0 + (uint64_t)d * L.n_u] = hist[d];
+        const uint64_t t0 = ((uint64_t)b1 * L.n_u + U) * nb2;                     // [bucket][unit][b2]: one contiguous row
+        for (int d = threadIdx.x; d < nb2; d += PT_THREADS) T[t0 + d] = hist[d];
         __syncthreads();
     }
 }
@@ -922,7 +922,7 @@ k_part_scatter(part_src S, int B1, int B2, int unit_tiles, int64_t n_units, cons
         if (LEVEL == 2) lvl2_unit(L, u, &b1, &cl, &s0, &s1);
         lds_sync();
         for (int b = threadIdx.x; b < nbins; b += PT_THREADS) {
-            const uint32_t off = LEVEL == 1 ? Ts[(int64_t)b * n_units + u] : Ts[((uint64_t)b1 * nbins + b) * L.n_u + cl];
+            const uint32_t off = LEVEL == 1 ? Ts[u * nbins + b] : Ts[((uint64_t)b1 * L.n_u + cl) * nbins + b];
             cursor[b] = off;
         }
         // The raw words of tile t + 1 are requested while tile t is sorted; they (and, the memory pipeline being
@@ -1018,7 +1018,7 @@ k_part_scatter_dense(part_src S, int B1, int unit_tiles, int64_t n_units, const 
     for (int64_t u = blockIdx.x; u < n_units; u += gridDim.x) {
         const int64_t s0 = u * unit_tiles * RT_TILE, s1 = min(S.n, s0 + (int64_t)unit_tiles * RT_TILE);
         lds_sync();
-        for (int b = threadIdx.x; b < nbins; b += PT_THREADS) cursor[b] = Ts[(int64_t)b * n_units + u];
+        for (int b = threadIdx.x; b < nbins; b += PT_THREADS) cursor[b] = Ts[u * nbins + b];
         for (int64_t t0 = s0; t0 < s1; t0 += RT_TILE) {
             for (int i = threadIdx.x; i < RT_TILE / 16 + 4; i += PT_THREADS) { const int64_t w = (t0 >> 4) + i; s_pk[i] = w < n_pk ? S.A.packed[w] : 0u; }
             for (int i = threadIdx.x; i < RT_TILE / 32 + 2; i += PT_THREADS) { const int64_t w = (t0 >> 5) + i; s_mk[i] = w < n_mk ? S.A.nmask[w] : 0xffffffffu; }
@@ -1105,7 +1105,7 @@ k_part_scatter2_narrow(const uint32_t* __restrict__ rec, int B1, int B2, int64_t
         uint32_t gbase = 0, gb[3] = {0, 0, 0};
         if (SHORT) lvl2_groups(L, b1, U, s1, &gbase, gb);
         lds_sync();
-        for (int b = threadIdx.x; b < nbins; b += PT_THREADS) cursor[b] = Ts[((uint64_t)b1 * nbins + b) * L.n_u + U];
+        for (int b = threadIdx.x; b < nbins; b += PT_THREADS) cursor[b] = Ts[((uint64_t)b1 * L.n_u + U) * nbins + b];
         for (int64_t t0 = s0; t0 < s1; t0 += NT_TILE) {
             for (int b = threadIdx.x; b < nbins; b += PT_THREADS) thist[b] = 0;
             lds_sync();
@@ -1163,11 +1163,84 @@ k_part_scatter2_narrow(const uint32_t* __restrict__ rec, int B1, int B2, int64_t
     }
 }
 
-// start offset of every final bucket (nbk + 1 entries) from the scanned tables
-__global__ void k_bucket_offsets(int levels, int64_t nbk, int64_t n_st, const uint32_t* __restrict__ T1s, int n_u, const uint32_t* __restrict__ T2s,
-                                 uint32_t n_total, uint32_t* __restrict__ boff) {
-    for (int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; d <= nbk; d += (int64_t)gridDim.x * blockDim.x)
-        boff[d] = d == nbk ? n_total : (levels == 1 ? T1s[d * n_st] : T2s[d * n_u]);
+// ---- the tables' prefix sums.  A table is [row][column] = [super-tile][bucket] (level 1) or, per level-1 bucket,
+// [unit][b2] (level 2); the records are laid out column-major (bucket after bucket, inside a bucket row after
+// row), so the write offset of (row r, column c) is
+//     start(c) + sum of T[r'][c] over r' < r,      start(c) = sum of the totals of the columns < c.
+// Rows are contiguous, so all passes read and write whole lines (a one-dimensional scan needs the transposed
+// layout: every histogram row a 2^B-way strided write, every cursor load a strided read).
+// Level 1 (tens of thousands of rows): column sums per slab of rows, one workgroup scans the slab sums and the
+// column totals, the slabs are then rewritten in place.
+constexpr int SC_SLAB = 128;          // rows per slab
+__global__ void __launch_bounds__(PT_THREADS)
+k_scan_columns_a(const uint32_t* __restrict__ T, int64_t n_rows, int n_cols, uint32_t* __restrict__ S) {
+    const int64_t r0 = (int64_t)blockIdx.x * SC_SLAB, r1 = min(n_rows, r0 + SC_SLAB);
+    for (int c = threadIdx.x; c < n_cols; c += PT_THREADS) {
+        uint32_t sum = 0;
+        for (int64_t r = r0; r < r1; ++r) sum += T[r * n_cols + c];
+        S[(int64_t)blockIdx.x * n_cols + c] = sum;
+    }
+}
+__global__ void __launch_bounds__(PT_THREADS)
+k_scan_columns_b(uint32_t* __restrict__ S, int n_slabs, int n_cols /* <= 4 096 */, uint32_t* __restrict__ start /* n_cols + 1 */) {
+    __shared__ uint32_t s_wave[16];
+    constexpr int CPT = PT_MAXBINS / PT_THREADS;
+    uint32_t tot[CPT], sum = 0;
+#pragma unroll
+    for (int v = 0; v < CPT; ++v) {
+        const int c = CPT * (int)threadIdx.x + v;
+        tot[v] = 0;
+        if (c < n_cols) for (int sl = 0; sl < n_slabs; ++sl) tot[v] += S[(int64_t)sl * n_cols + c];
+        sum += tot[v];
+    }
+    uint32_t total = 0;
+    uint32_t run = block_scan_1024(sum, s_wave, &total);
+#pragma unroll
+    for (int v = 0; v < CPT; ++v) {
+        const int c = CPT * (int)threadIdx.x + v;
+        if (c >= n_cols) continue;
+        start[c] = run;
+        uint32_t acc = run;
+        for (int sl = 0; sl < n_slabs; ++sl) { const uint32_t t = S[(int64_t)sl * n_cols + c]; S[(int64_t)sl * n_cols + c] = acc; acc += t; }
+        run += tot[v];
+    }
+    if (threadIdx.x == 0) start[n_cols] = total;
+}
+__global__ void __launch_bounds__(PT_THREADS)
+k_scan_columns_c(uint32_t* __restrict__ T, int64_t n_rows, int n_cols, const uint32_t* __restrict__ S) {
+    const int64_t r0 = (int64_t)blockIdx.x * SC_SLAB, r1 = min(n_rows, r0 + SC_SLAB);
+    for (int c = threadIdx.x; c < n_cols; c += PT_THREADS) {
+        uint32_t acc = S[(int64_t)blockIdx.x * n_cols + c];
+        for (int64_t r = r0; r < r1; ++r) { const uint32_t t = T[r * n_cols + c]; T[r * n_cols + c] = acc; acc += t; }
+    }
+}
+// Level 2: one workgroup per level-1 bucket scans its [unit][b2] table in place (a few dozen rows); the offsets
+// start at the bucket's own start, and the starts of its final buckets go to boff.
+__global__ void __launch_bounds__(PT_THREADS)
+k_scan_units(uint32_t* __restrict__ T, int n_u, int nb2 /* <= 4 096 */, const uint32_t* __restrict__ off1, int nb1, uint32_t* __restrict__ boff) {
+    __shared__ uint32_t s_wave[16];
+    constexpr int CPT = PT_MAXBINS / PT_THREADS;
+    const int b1 = blockIdx.x;
+    uint32_t* tab = T + (size_t)b1 * n_u * nb2;
+    uint32_t tot[CPT], sum = 0;
+#pragma unroll
+    for (int v = 0; v < CPT; ++v) {
+        const int c = CPT * (int)threadIdx.x + v;
+        tot[v] = 0;
+        if (c < nb2) for (int u = 0; u < n_u; ++u) tot[v] += tab[(size_t)u * nb2 + c];
+        sum += tot[v];
+    }
+    uint32_t run = off1[b1] + block_scan_1024(sum, s_wave, nullptr);
+#pragma unroll
+    for (int v = 0; v < CPT; ++v) {
+        const int c = CPT * (int)threadIdx.x + v;
+        if (c >= nb2) continue;
+        boff[(size_t)b1 * nb2 + c] = run;
+        uint32_t acc = run;
+        for (int u = 0; u < n_u; ++u) { const uint32_t t = tab[(size_t)u * nb2 + c]; tab[(size_t)u * nb2 + c] = acc; acc += t; }
+        run += tot[v];
+    }
+    if (b1 == nb1 - 1 && threadIdx.x == 0) boff[(size_t)nb1 * nb2] = off1[nb1];
 }
 
 // One workgroup per bucket.  The bucket's keys agree on their top `pbits` bits and are uniform below them, so a
@@ -1449,13 +1522,15 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
     if (dense && st_tiles >= 4) st_tiles &= ~3;             // whole 32 768-position tiles for k_part_scatter_dense
     const int64_t n_st = (n_src + (int64_t)st_tiles * PT_TILE - 1) / ((int64_t)st_tiles * PT_TILE);
     const size_t t1n = (size_t)nb1 * (size_t)n_st;
-    dbuf<uint32_t> T1(t1n + 1), T1s(t1n + 1);
+    dbuf<uint32_t> T1s(t1n + 1);                              // counts [super-tile][bucket], scanned in place
+    const int n_slabs = (int)((n_st + SC_SLAB - 1) / SC_SLAB);
+    dbuf<uint32_t> slab((size_t)n_slabs * nb1), d_off1((size_t)nb1 + 1);
     dbuf<uint32_t> a_rec, b_rec;
     uint32_t n1 = 0;
     // level-2 units and (dense source, k <= 25 at 2^11 buckets) short level-1 records, see lvl2_tab
     lvl2_tab L2; memset(&L2, 0, sizeof L2);
     const int64_t st_pos = (int64_t)st_tiles * PT_TILE;
-    L2.T1s = T1s.p; L2.n_st = n_st;
+    L2.T1s = T1s.p; L2.n_st = n_st; L2.off1 = d_off1.p; L2.nb1 = nb1;
     L2.u_st = (int)std::max<int64_t>(1, std::min<int64_t>(n_st, (65536LL * nb1) / st_pos));
     L2.n_u = (int)((n_st + L2.u_st - 1) / L2.u_st);
     L2.kr = 2 * k - B1;
@@ -1473,15 +1548,14 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
     }
     {
         vg_prof_scope ps("kmer_partition", (double)n_src * (dense ? 2 * 3.0 / 8.0 : 8.0 + 12.0) + (double)n_src * (short_rec ? 8.0 : 12.0));
-        VG_HIP(hipMemsetAsync(T1.p + t1n, 0, sizeof(uint32_t), s));
         const int grid_c = (int)std::min<int64_t>(n_st, 512);
-        if (dense) hipLaunchKernelGGL(k_part_count<SRC_DENSE>, dim3(grid_c), dim3(PT_THREADS), 0, s, S, B1, st_tiles, n_st, T1.p, d_kept);
-        else hipLaunchKernelGGL(k_part_count<SRC_ARRAYS>, dim3(grid_c), dim3(PT_THREADS), 0, s, S, B1, st_tiles, n_st, T1.p, (int*)nullptr);
-        size_t tb = 0;
-        VG_HIP(rocprim::exclusive_scan(nullptr, tb, T1.p, T1s.p, 0u, t1n + 1, rocprim::plus<uint32_t>(), s));
-        dbuf<char> tmp(tb);
-        VG_HIP(rocprim::exclusive_scan((void*)tmp.p, tb, T1.p, T1s.p, 0u, t1n + 1, rocprim::plus<uint32_t>(), s));
-        VG_HIP(hipMemcpyAsync(&n1, T1s.p + t1n, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        if (dense) hipLaunchKernelGGL(k_part_count<SRC_DENSE>, dim3(grid_c), dim3(PT_THREADS), 0, s, S, B1, st_tiles, n_st, T1s.p, d_kept);
+        else hipLaunchKernelGGL(k_part_count<SRC_ARRAYS>, dim3(grid_c), dim3(PT_THREADS), 0, s, S, B1, st_tiles, n_st, T1s.p, (int*)nullptr);
+        // counts -> write offsets, in place (see k_scan_columns_*)
+        hipLaunchKernelGGL(k_scan_columns_a, dim3(n_slabs), dim3(PT_THREADS), 0, s, (const uint32_t*)T1s.p, n_st, nb1, slab.p);
+        hipLaunchKernelGGL(k_scan_columns_b, dim3(1), dim3(PT_THREADS), 0, s, slab.p, n_slabs, nb1, d_off1.p);
+        hipLaunchKernelGGL(k_scan_columns_c, dim3(n_slabs), dim3(PT_THREADS), 0, s, T1s.p, n_st, nb1, (const uint32_t*)slab.p);
+        VG_HIP(hipMemcpyAsync(&n1, d_off1.p + nb1, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         VG_HIP(hipStreamSynchronize(s));
         vg_host_mark("buckets: count+scan done");
         *n_valid_out = (int64_t)n1;
@@ -1502,23 +1576,19 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
     dbuf<uint32_t> boff((size_t)nbk + 1);
     const uint32_t* f_rec = a_rec.p; int f_stride = 3;
     if (levels == 1) {
-        hipLaunchKernelGGL(k_bucket_offsets, dim3(grid_for(nbk + 1)), dim3(256), 0, s, 1, nbk, n_st, (const uint32_t*)T1s.p, 0, (const uint32_t*)nullptr, n1, boff.p);
+        VG_HIP(hipMemcpyAsync(boff.p, d_off1.p, ((size_t)nb1 + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));     // the level-1 buckets are the final ones
     } else {
         // level 2 on units of u_st super-tiles of one level-1 bucket (see lvl2_tab): everything it needs is in the
         // scanned level-1 table, so it is launched right behind level 1
         const int64_t n_units = (int64_t)nb1 * L2.n_u;
         const size_t t2n = (size_t)nb1 * (size_t)nb2 * (size_t)L2.n_u;
-        dbuf<uint32_t> T2(t2n + 1), T2s(t2n + 1);
-        VG_HIP(hipMemsetAsync(T2.p + t2n, 0, sizeof(uint32_t), s));
+        dbuf<uint32_t> T2s(t2n);                              // counts [bucket][unit][b2], scanned in place
         {
             vg_prof_scope ps("kmer_partition2", (double)n1 * (4.0 + (short_rec ? 8.0 : 12.0) + (narrow ? 8.0 : 12.0)));
             const int grid_c2 = (int)std::min<int64_t>(n_units, 512);
-            if (short_rec) hipLaunchKernelGGL(k_part_count2<true>, dim3(grid_c2), dim3(PT_THREADS), 0, s, (const uint32_t*)a_rec.p, B1, B2, n_units, L2, T2.p);
-            else hipLaunchKernelGGL(k_part_count2<false>, dim3(grid_c2), dim3(PT_THREADS), 0, s, (const uint32_t*)a_rec.p, B1, B2, n_units, L2, T2.p);
-            size_t tb2 = 0;
-            VG_HIP(rocprim::exclusive_scan(nullptr, tb2, T2.p, T2s.p, 0u, t2n + 1, rocprim::plus<uint32_t>(), s));
-            dbuf<char> tmp2(tb2);
-            VG_HIP(rocprim::exclusive_scan((void*)tmp2.p, tb2, T2.p, T2s.p, 0u, t2n + 1, rocprim::plus<uint32_t>(), s));
+            if (short_rec) hipLaunchKernelGGL(k_part_count2<true>, dim3(grid_c2), dim3(PT_THREADS), 0, s, (const uint32_t*)a_rec.p, B1, B2, n_units, L2, T2s.p);
+            else hipLaunchKernelGGL(k_part_count2<false>, dim3(grid_c2), dim3(PT_THREADS), 0, s, (const uint32_t*)a_rec.p, B1, B2, n_units, L2, T2s.p);
+            hipLaunchKernelGGL(k_scan_units, dim3(nb1), dim3(PT_THREADS), 0, s, T2s.p, L2.n_u, nb2, (const uint32_t*)d_off1.p, nb1, boff.p);
             b_rec.alloc((narrow ? 2 : 3) * (size_t)n1 + 8);
             static const bool staged2 = [] { const char* e = getenv("VG_LEVEL2_SCATTER"); return e && !strcmp(e, "staged"); }();
             const int grid_s2 = (int)std::min<int64_t>(n_units, 256);
@@ -1535,7 +1605,6 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
                                    (const uint32_t*)T2s.p, L2, b_rec.p, narrow ? total_bits : -1);
             }
         }
-        hipLaunchKernelGGL(k_bucket_offsets, dim3(grid_for(nbk + 1)), dim3(256), 0, s, 2, nbk, n_st, (const uint32_t*)T1s.p, L2.n_u, (const uint32_t*)T2s.p, n1, boff.p);
         VG_HIP(hipStreamSynchronize(s));                       // the tables and level-1 records go out of scope below
         vg_host_mark("buckets: level 2 done");
         f_rec = b_rec.p; f_stride = narrow ? 2 : 3;
