@@ -133,7 +133,7 @@ def test_many_regions_per_task(tmp_path):
 def test_bucket_pipeline_key_widths(k):
     """The own index pipeline at the ends of the k range with two partition levels: k = 15 (30 key bits: the
     narrow 8-byte level-2 records with few bits left) and k = 30 (60 key bits: the wide 12-byte records),
-    2 000 genomes x 8 kb; sizes and counts equal the oracle's, dense and as four shards (compact source)."""
+    2 000 genomes x 8 kb; sizes and counts equal the oracle's, dense and as four / eight shards (both shard sources)."""
     codes, offsets, names = synth.make_families(200, 10, length=8000, seed=23)
     gs = api.GenomeSet.from_codes(codes, offsets, names)
     osizes, opairs = orc.shared_all(codes, offsets, k=k)
@@ -144,13 +144,14 @@ def test_bucket_pipeline_key_widths(k):
     assert 'kmer_partition2' in scopes and 'bucket_sort_runs' in scopes and 'radix_sort_pairs' not in scopes
     assert list(sizes) == list(osizes)
     assert {(int(p['a']), int(p['b'])): int(p['shared']) for p in pairs} == opairs
-    tot = np.zeros(len(gs), dtype=np.int64); acc = {}
-    for sh in range(4):
-        sz, pr = gs.kmer_shared(k=k, shard=sh, n_shards=4)
-        tot += sz
-        for p in pr:
-            acc[(int(p['a']), int(p['b']))] = acc.get((int(p['a']), int(p['b'])), 0) + int(p['shared'])
-    assert list(tot) == list(osizes) and acc == opairs
+    for n_shards in (4, 8):           # four shards: dense source with the shard filter; eight: compact source
+        tot = np.zeros(len(gs), dtype=np.int64); acc = {}
+        for sh in range(n_shards):
+            sz, pr = gs.kmer_shared(k=k, shard=sh, n_shards=n_shards)
+            tot += sz
+            for p in pr:
+                acc[(int(p['a']), int(p['b']))] = acc.get((int(p['a']), int(p['b'])), 0) + int(p['shared'])
+        assert list(tot) == list(osizes) and acc == opairs
 
 
 def test_bucket_pipeline_large_buckets():

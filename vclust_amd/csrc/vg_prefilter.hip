@@ -1506,13 +1506,16 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
     if (g_index_path < 0) { const char* e = getenv("VG_INDEX_PATH"); g_index_path = (e && !strcmp(e, "radix")) ? 0 : 1; }
     if (!g_index_path || n_src < (1 << 16) || n_src >= (1LL << 32)) return false;
     static const int tb_env = [] { const char* e = getenv("VG_TOTAL_BITS"); return e ? atoi(e) : 0; }();     // developer experiments
-    int total_bits = 0; while ((n_src >> total_bits) > 1024 && total_bits < 22) ++total_bits;
+    const int64_t n_expect = dense ? n_src / std::max<uint32_t>(1u, A.n_shards) : n_src;       // elements the partition will hold
+    int total_bits = 0; while ((n_expect >> total_bits) > 1024 && total_bits < 22) ++total_bits;
     if (tb_env > 0 && tb_env < total_bits) total_bits = tb_env;
-    const bool big_buckets = (n_src >> total_bits) > 1024;
-    if ((n_src >> total_bits) > 4096) return false;
+    const bool big_buckets = (n_expect >> total_bits) > 1024;
+    if ((n_expect >> total_bits) > 4096) return false;
     const int levels = total_bits > 11 ? 2 : 1;
     static const char* b2_env = getenv("VG_B2");          // developer experiments: level-2 bits
-    const int B2 = levels == 2 ? (b2_env ? atoi(b2_env) : std::min(11, total_bits / 2)) : 0;
+    // level 1 takes 11 bits whenever there are two levels: its segment length does not depend on the digit (tiles of
+    // 32 768), level 2's grows as its digit shrinks, and 2k - 11 key bits fit the short records up to k = 25
+    const int B2 = levels == 2 ? (b2_env ? atoi(b2_env) : total_bits - 11) : 0;
     const int B1 = total_bits - B2;
     const int nb1 = 1 << B1, nb2 = 1 << B2;
     const bool narrow = levels == 2 && 2 * k - total_bits <= 32;      // level-2 output: one key word instead of two
@@ -1649,7 +1652,14 @@ static void kmer_shared_pass(vg_genomes* g, int k, double fraction, int shard, i
     const int n = g->n;
     sorted_index si;
     const int64_t P = g->padded_total();
-    const bool dense_src = !(fraction < 1.0) && n_shards == 1;
+    // Up to four k-mer range shards of a set below 2^32 padded bases run on the dense source too: every rank scans
+    // the bases and keeps its own k-mers (the other shards' are SENT inside canon_key) -- 85 vs 106 ms per rank at
+    // two shards of 100 k genomes.  With more shards the two full-length passes and the per-position row pointers
+    // cost more than materialising the kept k-mers first (compact source: 40 vs 46 ms at eight shards); that source
+    // also serves --kmers-fraction and sets beyond 2^32.  VG_SHARD_SOURCE=dense|compact forces one.
+    static const int shard_src = [] { const char* e = getenv("VG_SHARD_SOURCE"); return !e ? 0 : !strcmp(e, "compact") ? 1 : !strcmp(e, "dense") ? 2 : 0; }();
+    const bool dense_shards = shard_src == 2 || (shard_src == 0 && n_shards <= 4);
+    const bool dense_src = !(fraction < 1.0) && (n_shards == 1 || (dense_shards && P < (1LL << 32)));
     int64_t nv = 0, n_rows_info = 0;
     dbuf<uint32_t> arena;                            // owner of rowinfo / gen when they are windows of one block
     dbuf<uint32_t> rowinfo; dbuf<uint32_t> gen;
@@ -1659,7 +1669,8 @@ static void kmer_shared_pass(vg_genomes* g, int k, double fraction, int shard, i
     bool bucket_ok = false;
     {
         dbuf<int> kept_b((size_t)n); kept_b.zero(s);
-        kmer_args A{ g->d_packed.p, g->d_nmask.p, g->d_blk2g.p, g->d_base_off.p, g->d_len.p, P, k, 0, ~0ULL, 0u, 1u, g->align_shift };
+        kmer_args A{ g->d_packed.p, g->d_nmask.p, g->d_blk2g.p, g->d_base_off.p, g->d_len.p, P, k, 0, ~0ULL,
+                     dense_src ? (uint32_t)shard : 0u, dense_src ? (uint32_t)n_shards : 1u, g->align_shift };
         if (dense_src) {
             if (P < (1LL << 32)) {
                 n_rows_info = P;
@@ -1723,7 +1734,7 @@ static void kmer_shared_pass(vg_genomes* g, int k, double fraction, int shard, i
         VG_HIP(hipStreamSynchronize(s));
     }
     }
-    const bool compact_rows = !dense_src;
+    const bool compact_rows = bucket_ok ? !dense_src : si.compact;
     const uint32_t* wbase = compact_rows ? si.wave_base.p : nullptr;
     for (int i = 0; i < n; ++i) set_sizes[i] = (int64_t)kept[i] - dups[i];
     si.keys.release();
