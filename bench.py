@@ -37,12 +37,13 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # profile scope (vg_profile_*) -> (kernel as rocprofv3 names it, stage of SURVEY 8(d) whose algorithmic bytes it is priced on)
 SCOPES = {
     'kmer_extract': ('k_kmer_extract', 'extract'),
-    'kmer_partition': ('k_part_scatter', 'index'),
+    'kmer_partition': ('k_part_scatter_dense', 'index'),
+    'kmer_partition2': ('k_part_scatter2_narrow', 'index'),
     'radix_sort_pairs': ('rocprim::onesweep_iteration', 'index'),
     'index_runs': ('k_group_runs', 'index'),
     'bucket_sort_runs': ('k_bucket_runs', 'index'),
     'spgemm_rows': ('k_spgemm', 'join'),
-    'lz_build_index': ('k_build_index_lds', 'align'),
+    'lz_build_index': ('k_build_index_reg', 'align'),
     'lz_parse': ('k_lz_parse', 'align'),
 }
 
