@@ -640,18 +640,25 @@ k_spgemm_dense(const uint32_t* __restrict__ rowinfo, const uint32_t* __restrict_
 // ------------------------------------------------------------------ K1b + K2a, bucket pipeline
 // The inverted index without a general radix sort (this replaces rocprim::radix_sort_pairs + k_group_runs on
 // the hot path).  Keys are scrambled, so their top bits are uniform: one or two MSD partition levels
-// (<= 2^11 and <= 2^10 ways) cut the k-mers into buckets of ~2 000 that are sorted inside the LDS, where the
-// runs of equal k-mers are found and (genome list, row descriptors) written exactly as k_group_runs does.
-//   level 1   k_part_count<SRC>    per super-tile histogram of the top B1 key bits -> table T1[b][st]
-//             exclusive scan of T1 (bucket-major = output order: the scanned entries ARE the write offsets)
-//             k_part_scatter<SRC>  k-mers computed a second time straight from the packed bases (no key array,
-//                                  no iota), tiles of 8 192 sorted by bucket in the LDS, written out as
-//                                  contiguous segments (write combining) in three u32 planes: w0 = top 32
-//                                  key bits, w1 = the rest, pay = base position
-//   level 2   the same on the level-1 planes in chunks, joint digit (b1, b2); only w0 is read for counting
-//   buckets   k_bucket_runs        LDS sort by (w0, w1, pay), runs, duplicates, gen[] and row descriptors
-// No global atomics, deterministic output.  A bucket that does not fit the LDS (a k-mer present thousands of
-// times) or an input too small / too skewed for the chunking sends the call to the general path.
+// (2^11 ways, then up to 2^11) cut the k-mers into buckets of ~1 000 that are sorted inside the LDS, where the
+// runs of equal k-mers are found and (genome list, row pointers) written exactly as k_group_runs does.
+//   level 1   k_part_count<SRC>      per super-tile histogram of the top B1 key bits -> one row of T1[st][b]
+//             k_scan_columns_a/b/c   T1 -> write offsets in place (column-major record order), bucket starts
+//             k_part_scatter_dense   dense source: tiles of 32 768 positions, the k-mers computed again from
+//                                    the packed bases held in the LDS, sorted there as a PERMUTATION only and
+//                                    computed a third time at output; one contiguous run per (tile, bucket);
+//                                    8-byte records when 2k - 11 + 25 <= 64 (lvl2_tab), else 12-byte (w0, w1, pay)
+//             k_part_scatter<SRC,1>  other sources (kept k-mers of a fraction / shard; small inputs): tiles of
+//                                    8 192 records staged in the LDS
+//   level 2   units = the records of ONE level-1 bucket from u_st super-tiles (~65 536), bounds read off T1
+//             k_part_count2          histogram of the next B2 bits -> one row of T2[b1][unit][b2]
+//             k_scan_units           per level-1 bucket: T2 -> write offsets in place + the final bucket starts
+//             k_part_scatter2_narrow tiles of 16 384 records narrowed to 8 bytes (<= 32 key bits left), bin-major
+//                                    output; k_part_scatter<SRC_PLANES,2> for wider keys
+//   buckets   k_bucket_runs          LDS counting sort on the next 9 (11) bits, in-bin ranking, runs, duplicates,
+//                                    gen[] and row pointers; 1 536-entry buckets, 6 144 on a second attempt
+// No global atomics, no host round trip between the levels, deterministic output.  A bucket that does not fit the
+// LDS (a k-mer present many hundreds of times) or an input too small sends the call to the general path.
 constexpr int PT_THREADS = 1024;
 constexpr int PT_TILE = 8192;            // elements staged per trip: 96 KiB of LDS + bins
 constexpr int PT_PER = PT_TILE / PT_THREADS;
