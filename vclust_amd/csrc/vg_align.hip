@@ -881,8 +881,11 @@ struct seg_rec { int i_ev, ev_pos; uint32_t VM, VA, VN; };     // VN: bit 31 = o
 #define PARSE_ARG_NAMES tasks, n_tasks, refs, packed, nmask, base_off, glen, g_has_n, rr_pool, mask_pool, \
     stab_pool, sent_pool, P, stats, regions, region_off
 
-template <int S, bool DEV>
+// FAST: the default LZ-ANI parameters and a set without N as compile-time constants (shift counts, loop bounds
+// and the mask paths fold away); the host launches it when both hold.
+template <int S, bool DEV, bool FAST = false>
 __device__ __forceinline__ void lz_parse_body(PARSE_ARGS) {
+    if (FAST) { P.mal = 11; P.msl = 7; P.mrd = 40; P.mqd = 40; P.reg = 35; P.aw = 15; P.am = 7; P.ar = 3; P.ablate = 0; }
     const int ABL = DEV ? P.ablate : 0;           // developer timing knobs: compiled out of the production kernels
     __shared__ seg_rec s_log[S > 1 ? S * SEG_LOG_CAP : 1];
     __shared__ int s_cnt[4], s_sync_v[4], s_sync_idx[4];
@@ -895,10 +898,11 @@ __device__ __forceinline__ void lz_parse_body(PARSE_ARGS) {
     const int64_t t = (S == 1) ? vblk * 4 + w : vblk;
     if (t >= n_tasks) return;                        // S > 1: the whole workgroup leaves together
     const task_dev tk = tasks[t];
-    const ref_desc rd = refs[tk.r_slot];
+    ref_desc rd = refs[tk.r_slot];
+    if (FAST) { rd.tag_bits = 8; rd.has_n = 0; }
     pair_ctx c;
     const int64_t qb = base_off[tk.q];
-    c.qpk = packed + (qb >> 4); c.qmk = nmask + (qb >> 5); c.qlen = (int)glen[tk.q]; c.q_has_n = g_has_n[tk.q];
+    c.qpk = packed + (qb >> 4); c.qmk = nmask + (qb >> 5); c.qlen = (int)glen[tk.q]; c.q_has_n = FAST ? 0 : g_has_n[tk.q];
     c.rpk = rr_pool + rd.rr_w; c.rmk = mask_pool + rd.mask_w; c.n_rr = rd.n_rr; c.L = rd.L; c.r_has_n = rd.has_n;
     const uint32_t* stab = stab_pool + rd.stab; const uint32_t* sent = sent_pool + rd.sent;
     const uint64_t smask = (1ULL << (2 * P.msl)) - 1;
@@ -1179,12 +1183,13 @@ __device__ __forceinline__ void lz_parse_body(PARSE_ARGS) {
 
 // The parse is bound by dependent memory round trips, so resident waves are throughput: the
 // register budget is capped for the occupancy named in each kernel (waves per SIMD).
-#define PARSE_KERNEL(NAME, S, DEV, WAVES) \
+#define PARSE_KERNEL(NAME, S, DEV, WAVES, FAST) \
     __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) NAME(PARSE_ARGS) { \
-        lz_parse_body<S, DEV>(PARSE_ARG_NAMES); }
-PARSE_KERNEL(k_lz_parse, 1, false, 8)
-PARSE_KERNEL(k_lz_parse_seg, 4, false, 8)
-PARSE_KERNEL(k_lz_parse_dev, 1, true, 3)
+        lz_parse_body<S, DEV, FAST>(PARSE_ARG_NAMES); }
+PARSE_KERNEL(k_lz_parse, 1, false, 8, false)
+PARSE_KERNEL(k_lz_parse_fast, 1, false, 8, true)
+PARSE_KERNEL(k_lz_parse_seg, 4, false, 8, false)
+PARSE_KERNEL(k_lz_parse_dev, 1, true, 3, false)
 
 inline int grid_for(int64_t n, int block = 256, int max_blocks = 256 * 16) {
     int64_t b = (n + block - 1) / block; if (b < 1) b = 1;
@@ -1295,6 +1300,10 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
     const char* abl = getenv("VG_LZ_ABLATE");
     const lz_dev_params P{ p->mal, p->msl, p->mrd, p->mqd, p->reg, p->aw, p->am, p->ar, abl ? atoi(abl) : 0 };
     const int64_t stab_n = 1LL << (2 * p->msl);
+    // default parameters on a set without N: the kernel with those as compile-time constants (VG_LZ_KERNEL=general: never)
+    static const bool no_fast = [] { const char* e = getenv("VG_LZ_KERNEL"); return e && !strcmp(e, "general"); }();
+    bool fast_params = !no_fast && !abl && p->mal == 11 && p->msl == 7 && p->mrd == 40 && p->mqd == 40 && p->reg == 35 && p->aw == 15 && p->am == 7 && p->ar == 3;
+    for (int i = 0; fast_params && i < g->n; ++i) if (g->has_n[(size_t)i] || g->len[(size_t)i] >= (1 << 22)) fast_params = false;   // (tag: 8 bits beside <= 24 position bits)
 
     dbuf<vg_pair_stat> d_stats((size_t)n_tasks);
     const bool want_regions = regions != nullptr;
@@ -1447,6 +1456,10 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
                 const int64_t nblk = ((nt + 3) / 4 + 7) / 8 * 8;
                 if (P.ablate) {
                     hipLaunchKernelGGL(k_lz_parse_dev, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p + B.pos, nt, d_refs.p, g->d_packed.p, g->d_nmask.p,
+                                   g->d_base_off.p, g->d_len.p, g->d_has_n.p, L.rr_pool.p, L.mask_pool.p, L.stab_pool.p,
+                                   L.sent_pool.p, P, d_stats.p, (vg_region*)nullptr, no_off);
+                } else if (fast_params) {
+                    hipLaunchKernelGGL(k_lz_parse_fast, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p + B.pos, nt, d_refs.p, g->d_packed.p, g->d_nmask.p,
                                    g->d_base_off.p, g->d_len.p, g->d_has_n.p, L.rr_pool.p, L.mask_pool.p, L.stab_pool.p,
                                    L.sent_pool.p, P, d_stats.p, (vg_region*)nullptr, no_off);
                 } else {
