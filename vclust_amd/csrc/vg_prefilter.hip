@@ -795,9 +795,11 @@ __device__ __forceinline__ void decode_tile(const part_src& S, int64_t t0, int64
 // level-1 histogram: one super-tile (st_tiles tiles) per trip; T[st * 2^B1 + b] = elements of bucket b.
 // The dense source also counts the kept k-mers per genome (set sizes) on the way.  The raw words of the next
 // tile are requested before the current one is counted (one workgroup per CU: nothing else hides the latency).
-template <int SRC>
+// KC > 0: k = KC, all k-mers kept, one shard -- as compile-time constants (the default k = 25 of a whole set)
+template <int SRC, int KC = 0>
 __global__ void __launch_bounds__(PT_THREADS)
 k_part_count(part_src S, int B1, int st_tiles, int64_t n_st, uint32_t* __restrict__ T, int* __restrict__ kept_per_genome) {
+    if (KC > 0) { S.A.k = KC; S.k2 = 2 * KC; S.A.use_frac = 0; S.A.n_shards = 1; }
     __shared__ uint32_t hist[PT_MAXBINS];
     const int nb = 1 << B1;
     const int lane = threadIdx.x & 63;
@@ -1013,9 +1015,11 @@ __device__ __forceinline__ uint64_t kmer_key_lds(const kmer_args& A, const uint3
     const uint64_t rc = ((uint64_t)(~xh & km_hi) << 32) | (~xl & km_lo);
     return scramble_key(fwd < rc ? fwd : rc, A.k);
 }
+template <int KC>
 __global__ void __launch_bounds__(PT_THREADS)
 k_part_scatter_dense(part_src S, int B1, int unit_tiles, int64_t n_units, const uint32_t* __restrict__ Ts, uint32_t* __restrict__ o_rec,
                      int short_kr /* > 0: SHORT 8-byte records keeping this many key bits */) {
+    if (KC > 0) { S.A.k = KC; S.k2 = 2 * KC; S.A.use_frac = 0; S.A.n_shards = 1; }
     __shared__ uint32_t s_pk[RT_TILE / 16 + 8], s_mk[RT_TILE / 32 + 4];
     __shared__ uint16_t s_perm[RT_TILE];
     __shared__ uint32_t thist[PT_MAXBINS], tstart[PT_MAXBINS], cursor[PT_MAXBINS];
@@ -1559,7 +1563,9 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
     {
         vg_prof_scope ps("kmer_partition", (double)n_src * (dense ? 2 * 3.0 / 8.0 : 8.0 + 12.0) + (double)n_src * (short_rec ? 8.0 : 12.0));
         const int grid_c = (int)std::min<int64_t>(n_st, 512);
-        if (dense) hipLaunchKernelGGL(k_part_count<SRC_DENSE>, dim3(grid_c), dim3(PT_THREADS), 0, s, S, B1, st_tiles, n_st, T1s.p, d_kept);
+        const bool k25 = dense && k == 25 && !A.use_frac && A.n_shards == 1;          // the default: kernels with k as a constant
+        if (k25) hipLaunchKernelGGL((k_part_count<SRC_DENSE, 25>), dim3(grid_c), dim3(PT_THREADS), 0, s, S, B1, st_tiles, n_st, T1s.p, d_kept);
+        else if (dense) hipLaunchKernelGGL(k_part_count<SRC_DENSE>, dim3(grid_c), dim3(PT_THREADS), 0, s, S, B1, st_tiles, n_st, T1s.p, d_kept);
         else hipLaunchKernelGGL(k_part_count<SRC_ARRAYS>, dim3(grid_c), dim3(PT_THREADS), 0, s, S, B1, st_tiles, n_st, T1s.p, (int*)nullptr);
         // counts -> write offsets, in place (see k_scan_columns_*)
         hipLaunchKernelGGL(k_scan_columns_a, dim3(n_slabs), dim3(PT_THREADS), 0, s, (const uint32_t*)T1s.p, n_st, nb1, slab.p);
@@ -1575,8 +1581,10 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
         a_rec.alloc(levels == 2 ? std::max((short_rec ? 2 : 3) * (size_t)n1 + 8, (size_t)n_rows_info + (size_t)n1 + 16) : 3 * (size_t)n1 + 8);
         const int grid_s = (int)std::min<int64_t>(n_st, 256);
         if (tile32k)
-            hipLaunchKernelGGL(k_part_scatter_dense, dim3(grid_s), dim3(PT_THREADS), 0, s, S, B1, st_tiles / 4, n_st, (const uint32_t*)T1s.p, a_rec.p,
-                               short_rec ? L2.kr : 0);
+            if (k25) hipLaunchKernelGGL(k_part_scatter_dense<25>, dim3(grid_s), dim3(PT_THREADS), 0, s, S, B1, st_tiles / 4, n_st, (const uint32_t*)T1s.p, a_rec.p,
+                                        short_rec ? L2.kr : 0);
+            else hipLaunchKernelGGL(k_part_scatter_dense<0>, dim3(grid_s), dim3(PT_THREADS), 0, s, S, B1, st_tiles / 4, n_st, (const uint32_t*)T1s.p, a_rec.p,
+                                    short_rec ? L2.kr : 0);
         else if (dense) hipLaunchKernelGGL((k_part_scatter<SRC_DENSE, 1>), dim3(grid_s), dim3(PT_THREADS), 0, s, S, B1, 0, st_tiles, n_st, (const uint32_t*)T1s.p,
                                       lvl2_tab{}, a_rec.p, -1);
         else hipLaunchKernelGGL((k_part_scatter<SRC_ARRAYS, 1>), dim3(grid_s), dim3(PT_THREADS), 0, s, S, B1, 0, st_tiles, n_st, (const uint32_t*)T1s.p,
