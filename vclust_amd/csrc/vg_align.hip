@@ -705,16 +705,18 @@ k_build_index_reg(const ref_desc* __restrict__ refs, const int* __restrict__ slo
             const int p0 = 4 * (tid + 1024 * it);
             reg[it][0] = reg[it][1] = reg[it][2] = reg[it][3] = 0xffffffffu;
             if (p0 < n4) {
-                const int wi = p0 >> 4; const int sh = 2 * (p0 & 15);
-                const uint64_t lo = (uint64_t)s_rr[wi] | ((uint64_t)s_rr[wi + 1] << 32);
-                const uint64_t hi = (uint64_t)s_rr[wi + 2] | ((uint64_t)s_rr[wi + 3] << 32);
-                const uint64_t ml = ((uint64_t)s_mk[p0 >> 5] | ((uint64_t)s_mk[(p0 >> 5) + 1] << 32)) >> (p0 & 31);
+                // the msl + tag bases of a position are <= 32 bits: one funnel shift over two words serves each of the
+                // four positions (p0 is a multiple of 4: their bit offsets 2 * (p0 & 15) + 2 j stay below 32)
+                const int wi = p0 >> 4; const uint32_t sh = 2u * (uint32_t)(p0 & 15);
+                const uint32_t w0 = s_rr[wi], w1 = s_rr[wi + 1];
+                const uint32_t m0 = s_mk[p0 >> 5], m1 = s_mk[(p0 >> 5) + 1];
+                const uint32_t tagmask = rd.tag_bits ? ((1u << rd.tag_bits) - 1u) : 0u;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int p = p0 + j; const int s2 = sh + 2 * j;
-                    if (p + msl <= rd.n_rr && ((ml >> j) & ((1ULL << msl) - 1)) == 0) {
-                        const uint64_t x = s2 ? ((lo >> s2) | (hi << (64 - s2))) : lo;
-                        const uint32_t bt = (uint32_t)(x & smask) | (seed_tag(x, msl, rd.tag_bits) << 18);
+                    const int p = p0 + j;
+                    if (p + msl <= rd.n_rr && (__builtin_amdgcn_alignbit(m1, m0, (uint32_t)(p0 & 31) + j) & ((1u << msl) - 1u)) == 0) {
+                        const uint32_t x = __builtin_amdgcn_alignbit(w1, w0, sh + 2 * j);
+                        const uint32_t bt = (x & (uint32_t)smask) | (((x >> (2 * msl)) & tagmask) << 18);
                         atomicAdd(&tab[bt & 0x3ffffu], 1u);
                         reg[it][j] = bt;
                     }
