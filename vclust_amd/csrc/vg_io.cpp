@@ -268,7 +268,14 @@ extern "C" int vg_align_tasks(const vg_genomes* g, const vg_pair_count* pairs, i
     }
     for (int key = 0; key < g->n; ++key) {
         const int64_t s0 = start[(size_t)key], s1 = start[(size_t)key + 1];
-        if (s1 - s0 > 1) std::sort(tmp.begin() + s0, tmp.begin() + s1, [](const rp& x, const rp& y) { return x.hi < y.hi; });
+        if (s1 - s0 <= 1) continue;
+        if (s1 - s0 <= 24) {                                   // a genome's partners are a handful: insertion sort in place
+            for (int64_t a = s0 + 1; a < s1; ++a) {
+                const rp x = tmp[(size_t)a]; int64_t b = a;
+                while (b > s0 && tmp[(size_t)b - 1].hi > x.hi) { tmp[(size_t)b] = tmp[(size_t)b - 1]; --b; }
+                tmp[(size_t)b] = x;
+            }
+        } else std::sort(tmp.begin() + s0, tmp.begin() + s1, [](const rp& x, const rp& y) { return x.hi < y.hi; });
     }
     v.swap(tmp);
     vg_task* o = (vg_task*)malloc(sizeof(vg_task) * std::max<size_t>(1, 2 * v.size()));
