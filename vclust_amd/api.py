@@ -36,17 +36,31 @@ def set_device(idx):
     check(_lib.load().vg_set_device(int(idx)))
 
 
+class _LibOwned:
+    """Releases a library-owned buffer (vg_free) when the numpy array that views it is collected."""
+    __slots__ = ('_ptr', '_free')
+
+    def __init__(self, ptr, free):
+        self._ptr, self._free = ptr, free
+
+    def __del__(self):
+        try:
+            self._free(self._ptr)
+        except Exception:
+            pass
+
+
 def _take(ptr, n, dtype):
-    """Copy a library-owned array into numpy and release it."""
+    """A library-owned array as a numpy array WITHOUT a copy: the array views the buffer, which is handed back to
+    the library (vg_free) when the last view of it is gone."""
     lib = _lib.load()
     if n <= 0:
         if ptr:
             lib.vg_free(C.cast(ptr, C.c_void_p))
         return np.zeros(0, dtype=dtype)
     buf = (C.c_char * (n * dtype.itemsize)).from_address(C.addressof(ptr.contents))
-    out = np.frombuffer(buf, dtype=dtype, count=n).copy()
-    lib.vg_free(C.cast(ptr, C.c_void_p))
-    return out
+    buf._owner = _LibOwned(C.cast(ptr, C.c_void_p), lib.vg_free)      # lives exactly as long as the buffer object
+    return np.frombuffer(buf, dtype=dtype, count=n)
 
 
 class GenomeSet:
