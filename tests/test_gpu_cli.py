@@ -125,6 +125,36 @@ def test_workflow_equals_oracle_files(tmp_path):
     assert filecmp.cmp(flt, oflt, shallow=False) and filecmp.cmp(ani, oani, shallow=False)
 
 
+def test_kernel_variants_write_the_same_files(tmp_path):
+    """The specialised kernels against the general ones they replace, through the CLI on a 7 000-genome set (280 M
+    positions: 18 partition bits) without N and with the default parameters, so that the default run takes
+    k_lz_parse_fast, the register index build, the 8-byte level-1 records, the 32 768-position tiles and the narrow
+    level-2 scatter: switching each of them off must not change a byte."""
+    import filecmp
+    import os
+    sys.path.insert(0, str(ROOT))
+    from vclust_amd import synth
+    codes, offsets, names = synth.make_families(700, 10, length=40000, seed=31)
+    fa = tmp_path / 'set.fna'
+    synth.write_fasta(fa, codes, offsets, names)
+
+    def go(tag, **env):
+        flt, ani = tmp_path / f'{tag}.flt', tmp_path / f'{tag}.tsv'
+        e = dict(os.environ, **env)
+        for args in (('prefilter', '-i', fa, '-o', flt, '-v', '0'), ('align', '-i', fa, '-o', ani, '--filter', flt, '--outfmt', 'complete', '-v', '0')):
+            p = subprocess.run([sys.executable, str(VCLUST), *map(str, args)], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+            assert p.returncode == 0, p.stderr[-2000:]
+        return flt, ani
+
+    base = go('default')
+    assert sum(1 for _ in open(base[1])) > 50000
+    for tag, env in (('general_parse', dict(VG_LZ_KERNEL='general')), ('lds_build', dict(VG_LZ_BUILD='lds')),
+                     ('long_records', dict(VG_LEVEL1_RECORDS='long')), ('staged', dict(VG_DENSE_SCATTER='staged', VG_LEVEL2_SCATTER='staged')),
+                     ('radix', dict(VG_INDEX_PATH='radix'))):
+        other = go(tag, **env)
+        assert filecmp.cmp(base[0], other[0], shallow=False) and filecmp.cmp(base[1], other[1], shallow=False), tag
+
+
 def _torchrun(nproc, *cmd):
     import os
     import socket
