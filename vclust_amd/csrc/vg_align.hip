@@ -401,23 +401,42 @@ constexpr int LDS_TAB = 16384;      // bucket table: anchors use B <= 14 bits, s
 constexpr int LDS_STAGE = 22016;    // staged entries per window (tab + stage + scan scratch fill the 160 KiB of a CU)
 constexpr int TOP_BITS = 9;         // big references: entries are first dealt into 2^TOP_BITS bins
 constexpr int BIG_RR = 131072;      // RR symbols from which the linear (binned) build is used
-__device__ __forceinline__ void lds_scan_exclusive(uint32_t* tab, int n, uint32_t* part) {
-    // blockDim.x == 1024: each thread owns ceil(n/1024) consecutive entries
-    const int per = (n + 1023) / 1024;
-    const int i0 = threadIdx.x * per;
-    uint32_t s = 0;
-    for (int j = 0; j < per; ++j) if (i0 + j < n) s += tab[i0 + j];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        uint32_t add = threadIdx.x >= (unsigned)o ? part[threadIdx.x - o] : 0;
-        __syncthreads();
-        part[threadIdx.x] += add;
-        __syncthreads();
+// workgroup barrier that waits for this wave's LDS traffic only: global stores stay in flight
+__device__ __forceinline__ void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// inclusive scan over the 64 lanes of a wave with DPP adds (row shifts, then the two row broadcasts): six
+// dependent VALU instructions instead of six LDS-crossbar round trips
+__device__ __forceinline__ uint32_t wave_scan_inclusive(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);     // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);     // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);     // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);     // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);    // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);    // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+// exclusive scan of tab[0, n) by 1024 threads (16 waves, each a contiguous slice, 64 consecutive entries per
+// trip: no bank conflicts); returns the total.  wtot: 16 words of scratch.
+__device__ __forceinline__ uint32_t lds_scan_exclusive_waves(uint32_t* tab, int n, uint32_t* wtot) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int per_wave = (((n + 15) >> 4) + 63) & ~63;
+    uint32_t carry = 0;
+    for (int r = 0; r < per_wave; r += 64) {
+        const int i = w * per_wave + r + lane;
+        const uint32_t v = i < n ? tab[i] : 0u;
+        const uint32_t inc = wave_scan_inclusive(v);
+        if (i < n) tab[i] = carry + inc - v;
+        carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
     }
-    uint32_t run = part[threadIdx.x] - s;
-    for (int j = 0; j < per; ++j) if (i0 + j < n) { uint32_t v = tab[i0 + j]; tab[i0 + j] = run; run += v; }
-    __syncthreads();
+    if (lane == 0) wtot[w] = carry;
+    lds_sync();
+    uint32_t off = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { const uint32_t t = wtot[k]; if (k < w) off += t; total += t; }
+    for (int r = 0; r < per_wave; r += 64) { const int i = w * per_wave + r + lane; if (i < n) tab[i] += off; }
+    lds_sync();
+    return total;
 }
 
 __global__ void __launch_bounds__(1024)
@@ -460,7 +479,7 @@ k_build_index_lds(const ref_desc* __restrict__ refs, const int* __restrict__ slo
             const int tsh = nbits > TOP_BITS ? nbits - TOP_BITS : 0;             // bucket -> top-level bin
             const int n_cnt = big ? (1 << (nbits - tsh)) : (1 << nbits);
             for (int i = threadIdx.x; i < n_cnt; i += blockDim.x) tab[i] = 0;
-            __syncthreads();
+            lds_sync();
             const int n4 = (rd.n_rr + 3) & ~3;
             for (int p0 = 4 * threadIdx.x; p0 < n4; p0 += 4 * blockDim.x) {
                 const int wi = p0 >> 4; const int sh = 2 * (p0 & 15);
@@ -484,9 +503,7 @@ k_build_index_lds(const ref_desc* __restrict__ refs, const int* __restrict__ slo
             __threadfence_block();
             __syncthreads();
             if (!big) {
-                lds_scan_exclusive(tab, n_cnt, part);              // tab[b] = first slot of bucket b
-                const uint32_t total = part[1023];                 // inclusive sum of all thread partials
-                __syncthreads();
+                const uint32_t total = lds_scan_exclusive_waves(tab, n_cnt, part);     // tab[b] = first slot of bucket b
                 // fill, one window of whole buckets holding <= LDS_STAGE entries at a time.  Buckets at or
                 // beyond the window start are still untouched, so end(b) = tab[b + 1] (or the total).
                 // Every window re-reads the scratch: fine for a handful of windows (< BIG_RR symbols).
@@ -495,18 +512,18 @@ k_build_index_lds(const ref_desc* __restrict__ refs, const int* __restrict__ slo
                 while (w_lo < nb) {
                     const uint32_t base = tab[w_lo];
                     if (threadIdx.x == 0) s_whi = w_lo + 1;
-                    __syncthreads();
+                    lds_sync();
                     int best = w_lo + 1;
                     for (int b2 = w_lo + threadIdx.x; b2 < nb; b2 += blockDim.x) {
                         const uint32_t e2 = (b2 + 1 < nb) ? tab[b2 + 1] : total;
                         if (e2 - base <= (uint32_t)LDS_STAGE) best = b2 + 1; else break;     // ends ascend
                     }
                     atomicMax(&s_whi, best);
-                    __syncthreads();
+                    lds_sync();
                     const int w_hi = s_whi;
                     const uint32_t e_lo = (w_lo + 1 < nb) ? tab[w_lo + 1] : total;
                     const bool direct = (e_lo - base > (uint32_t)LDS_STAGE);   // one bucket larger than the stage
-                    __syncthreads();
+                    lds_sync();
                     // four independent 16-byte loads per thread and trip: the loop is latency bound
                     for (int pb = 4 * threadIdx.x; pb < n4; pb += 16 * blockDim.x) {
                         uint4 v[4];
@@ -530,27 +547,25 @@ k_build_index_lds(const ref_desc* __restrict__ refs, const int* __restrict__ slo
                             }
                         }
                     }
-                    __syncthreads();
+                    lds_sync();
                     if (!direct) {
                         const uint32_t cnt = tab[w_hi - 1] - base;   // cursor of the last bucket == its end
                         for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) gent[base + i] = stage[i];
                     }
-                    __syncthreads();
+                    lds_sync();
                     w_lo = w_hi;
                 }
                 for (int i = threadIdx.x; i < nb; i += blockDim.x) gtab[i] = tab[i];   // END of every bucket
-                __syncthreads();
+                lds_sync();
                 continue;
             }
             // ---- big references: a scratch re-read per window would be quadratic, so the entries are first
             // dealt into 512 top-level bins (contiguous bucket ranges) in a second scratch; a window is then
             // a contiguous slice of that list and every pass is linear in the reference.
             const int n_bins = n_cnt;
-            lds_scan_exclusive(tab, n_bins, part);
-            const uint32_t total = part[1023];
-            __syncthreads();
+            const uint32_t total = lds_scan_exclusive_waves(tab, n_bins, part);
             for (int i = threadIdx.x; i <= n_bins; i += blockDim.x) { s_bstart[i] = i < n_bins ? tab[i] : total; }
-            __syncthreads();
+            lds_sync();
             for (int pb = 4 * threadIdx.x; pb < n4; pb += 16 * blockDim.x) {
                 uint4 v[4];
 #pragma unroll
@@ -581,26 +596,26 @@ k_build_index_lds(const ref_desc* __restrict__ refs, const int* __restrict__ slo
                     while (hi < n_bins && s_bstart[hi + 1] - s_bstart[w_lo] <= (uint32_t)LDS_STAGE && (hi + 1 - w_lo) * per_bin <= LDS_TAB) ++hi;
                     s_whi = hi;
                 }
-                __syncthreads();
+                lds_sync();
                 const int w_hi = s_whi;
                 const uint32_t base = s_bstart[w_lo], cnt = s_bstart[w_hi] - base;
                 const int nbw = (w_hi - w_lo) * per_bin; const uint32_t b_lo = (uint32_t)w_lo << tsh;
                 const bool direct = cnt > (uint32_t)LDS_STAGE;     // a single bin larger than the stage
                 for (int i = threadIdx.x; i < nbw; i += blockDim.x) tab[i] = 0;
-                __syncthreads();
+                lds_sync();
                 for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) atomicAdd(&tab[(binned[base + i].x & 0x3ffffu) - b_lo], 1u);
-                __syncthreads();
-                lds_scan_exclusive(tab, nbw, part);
+                lds_sync();
+                lds_scan_exclusive_waves(tab, nbw, part);
                 for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
                     const uint2 e = binned[base + i];
                     const uint32_t ent = e.y | ((e.x >> 18) << rd.pos_bits);
                     const uint32_t slot = atomicAdd(&tab[(e.x & 0x3ffffu) - b_lo], 1u);
                     if (direct) gent[base + slot] = ent; else stage[slot] = ent;
                 }
-                __syncthreads();
+                lds_sync();
                 if (!direct) for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) gent[base + i] = stage[i];
                 for (int i = threadIdx.x; i < nbw; i += blockDim.x) gtab[b_lo + i] = base + tab[i];       // END of every bucket
-                __syncthreads();
+                lds_sync();
                 w_lo = w_hi;
             }
         }
@@ -623,44 +638,6 @@ constexpr int REG_LDS_WORDS = LDS_TAB + REG_GEN_WORDS + REG_RR_WORDS + REG_MK_WO
 constexpr int REG_STAGE = REG_LDS_WORDS / 1024 * 1024;  // entries per staging window: the whole LDS block
 constexpr int REG_STAGE0 = (REG_LDS_WORDS - LDS_TAB) / 1024 * 1024;   // slots staged while the table is still live
 constexpr int REG_SLOT_BITS = 17;                       // slot < n_rr < 2^17; tag (<= 14 bits) above it
-
-// workgroup barrier that waits for this wave's LDS traffic only: global stores stay in flight
-__device__ __forceinline__ void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// inclusive scan over the 64 lanes of a wave with DPP adds (row shifts, then the two row broadcasts): six
-// dependent VALU instructions instead of six LDS-crossbar round trips
-__device__ __forceinline__ uint32_t wave_scan_inclusive(uint32_t v) {
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);     // row_shr:1
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);     // row_shr:2
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);     // row_shr:4
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);     // row_shr:8
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);    // row_bcast:15 into rows 1 and 3
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);    // row_bcast:31 into rows 2 and 3
-    return v;
-}
-
-// exclusive scan of tab[0, n) by 1024 threads (16 waves, each a contiguous slice, 64 consecutive entries per
-// trip: no bank conflicts); returns the total.  wtot: 16 words of scratch.
-__device__ __forceinline__ uint32_t lds_scan_exclusive_waves(uint32_t* tab, int n, uint32_t* wtot) {
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int per_wave = (((n + 15) >> 4) + 63) & ~63;
-    uint32_t carry = 0;
-    for (int r = 0; r < per_wave; r += 64) {
-        const int i = w * per_wave + r + lane;
-        const uint32_t v = i < n ? tab[i] : 0u;
-        const uint32_t inc = wave_scan_inclusive(v);
-        if (i < n) tab[i] = carry + inc - v;
-        carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-    }
-    if (lane == 0) wtot[w] = carry;
-    lds_sync();
-    uint32_t off = 0, total = 0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) { const uint32_t t = wtot[k]; if (k < w) off += t; total += t; }
-    for (int r = 0; r < per_wave; r += 64) { const int i = w * per_wave + r + lane; if (i < n) tab[i] += off; }
-    lds_sync();
-    return total;
-}
 
 __global__ void __launch_bounds__(1024)
 k_build_index_reg(const ref_desc* __restrict__ refs, const int* __restrict__ slot_list, int n_list,
