@@ -249,35 +249,20 @@ extern "C" int vg_align_tasks(const vg_genomes* g, const vg_pair_count* pairs, i
     vg_length_order(g);
     vg_host_mark("align_tasks: length order");
     const std::vector<int32_t>& order = g->len_order; const std::vector<int32_t>& rank = g->len_rank;
-    // couples sorted by (lo, hi) of the length ranks: one counting pass on lo, then every lo group (a genome's
-    // partners: a handful) is sorted on hi.  One thread: 10^5..10^6 couples are a few milliseconds of cache-
-    // resident work, less than starting helpers costs.
+    // couples sorted by (lo, hi) of the length ranks: two stable counting passes, on hi and then on lo (LSD order).
+    // One thread: 10^5..10^6 couples are a few milliseconds of cache-resident work, less than starting helpers costs.
     struct rp { int32_t lo, hi; };
     std::vector<rp> v((size_t)n_pairs), tmp((size_t)n_pairs);
-    std::vector<int64_t> start((size_t)g->n + 1, 0);
+    std::vector<int64_t> at_lo((size_t)g->n + 1, 0), at_hi((size_t)g->n + 1, 0);
     for (int64_t i = 0; i < n_pairs; ++i) {
         if (pairs[i].a >= (uint32_t)g->n || pairs[i].b >= (uint32_t)g->n) throw vg_error(VG_EINVAL, "pair id out of range");
         const int32_t x = rank[pairs[i].a], y = rank[pairs[i].b];
         v[(size_t)i] = { std::min(x, y), std::max(x, y) };
-        start[(size_t)v[(size_t)i].lo + 1]++;
+        at_lo[(size_t)v[(size_t)i].lo + 1]++; at_hi[(size_t)v[(size_t)i].hi + 1]++;
     }
-    for (int key = 0; key < g->n; ++key) start[(size_t)key + 1] += start[(size_t)key];
-    {
-        std::vector<int64_t> cur(start.begin(), start.end() - 1);
-        for (int64_t i = 0; i < n_pairs; ++i) tmp[(size_t)cur[(size_t)v[(size_t)i].lo]++] = v[(size_t)i];
-    }
-    for (int key = 0; key < g->n; ++key) {
-        const int64_t s0 = start[(size_t)key], s1 = start[(size_t)key + 1];
-        if (s1 - s0 <= 1) continue;
-        if (s1 - s0 <= 24) {                                   // a genome's partners are a handful: insertion sort in place
-            for (int64_t a = s0 + 1; a < s1; ++a) {
-                const rp x = tmp[(size_t)a]; int64_t b = a;
-                while (b > s0 && tmp[(size_t)b - 1].hi > x.hi) { tmp[(size_t)b] = tmp[(size_t)b - 1]; --b; }
-                tmp[(size_t)b] = x;
-            }
-        } else std::sort(tmp.begin() + s0, tmp.begin() + s1, [](const rp& x, const rp& y) { return x.hi < y.hi; });
-    }
-    v.swap(tmp);
+    for (int key = 0; key < g->n; ++key) { at_lo[(size_t)key + 1] += at_lo[(size_t)key]; at_hi[(size_t)key + 1] += at_hi[(size_t)key]; }
+    for (int64_t i = 0; i < n_pairs; ++i) tmp[(size_t)at_hi[(size_t)v[(size_t)i].hi]++] = v[(size_t)i];
+    for (int64_t i = 0; i < n_pairs; ++i) v[(size_t)at_lo[(size_t)tmp[(size_t)i].lo]++] = tmp[(size_t)i];
     vg_task* o = (vg_task*)malloc(sizeof(vg_task) * std::max<size_t>(1, 2 * v.size()));
     if (!o) throw vg_error(VG_ENOMEM, "out of host memory");
     for (size_t i = 0; i < v.size(); ++i) {
