@@ -307,3 +307,37 @@ def test_shards_on_low_complexity_sequence():
         api.profile_enable(False)
     assert list(tot) == list(osizes) and acc == opairs
     assert 'kmer_emit_recompute' in scopes and 'kmer_emit' in scopes, scopes
+
+
+def test_genomes_ending_on_a_block_boundary():
+    """Genomes whose length is an exact multiple of every block size the layout may choose (64 .. 4 096): a
+    k-mer window that ran from the end of one genome into the start of the next would be a false k-mer -- the
+    sequence joined across the boundary is planted in a third genome, which must share nothing with the first
+    two beyond what the oracle counts.  (Every genome is followed by at least one masked padding base.)"""
+    rng = np.random.default_rng(77)
+    a = rng.integers(0, 4, 8192).astype(np.uint8)
+    b = rng.integers(0, 4, 4096).astype(np.uint8)
+    c = rng.integers(0, 4, 8192).astype(np.uint8)
+    c[1000:1060] = np.concatenate([a[-30:], b[:30]])          # the junction a|b, inside c
+    d = np.concatenate([b[-40:], c[:40], rng.integers(0, 4, 4016).astype(np.uint8)])     # the junction b|c, inside d (4 096 long)
+    seqs = [a, b, c, d]
+    codes = np.concatenate(seqs)
+    offsets = np.concatenate([[0], np.cumsum([len(x) for x in seqs])]).astype(np.int64)
+    gs = api.GenomeSet.from_codes(codes, offsets)
+    for k in (15, 25, 30):
+        _check_prefilter(codes, offsets, gs, k)
+    # the same through the dense bucket pipeline: many copies so that the set is large enough for it
+    reps = 12
+    seqs2 = []
+    for r in range(reps):
+        for x in seqs:
+            y = x.copy(); y[(17 * r) % len(y)] ^= 1
+            seqs2.append(y)
+    codes2 = np.concatenate(seqs2)
+    offsets2 = np.concatenate([[0], np.cumsum([len(x) for x in seqs2])]).astype(np.int64)
+    gs2 = api.GenomeSet.from_codes(codes2, offsets2)
+    api.profile_enable(True); api.profile_reset()
+    _check_prefilter(codes2, offsets2, gs2, 25)
+    scopes = {e['name'] for e in api.profile_get()}
+    api.profile_enable(False)
+    assert 'bucket_sort_runs' in scopes
