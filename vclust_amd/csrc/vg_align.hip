@@ -1168,6 +1168,7 @@ __device__ __forceinline__ void lz_parse_body(PARSE_ARGS) {
 PARSE_KERNEL(k_lz_parse, 1, false, 8, false)
 PARSE_KERNEL(k_lz_parse_fast, 1, false, 8, true)
 PARSE_KERNEL(k_lz_parse_seg, 4, false, 8, false)
+PARSE_KERNEL(k_lz_parse_seg_fast, 4, false, 8, true)
 PARSE_KERNEL(k_lz_parse_dev, 1, true, 3, false)
 
 inline int grid_for(int64_t n, int block = 256, int max_blocks = 256 * 16) {
@@ -1428,7 +1429,10 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
             const unsigned long long* no_off = nullptr;
             if (segments && P.ablate == 0 && nt < (1LL << 31)) {
                 const int64_t nblk = (nt + 7) / 8 * 8;
-                hipLaunchKernelGGL(k_lz_parse_seg, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p + B.pos, nt, d_refs.p, g->d_packed.p, g->d_nmask.p,
+                if (fast_params) hipLaunchKernelGGL(k_lz_parse_seg_fast, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p + B.pos, nt, d_refs.p, g->d_packed.p, g->d_nmask.p,
+                                   g->d_base_off.p, g->d_len.p, g->d_has_n.p, L.rr_pool.p, L.mask_pool.p, L.stab_pool.p,
+                                   L.sent_pool.p, P, d_stats.p, (vg_region*)nullptr, no_off);
+                else hipLaunchKernelGGL(k_lz_parse_seg, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p + B.pos, nt, d_refs.p, g->d_packed.p, g->d_nmask.p,
                                    g->d_base_off.p, g->d_len.p, g->d_has_n.p, L.rr_pool.p, L.mask_pool.p, L.stab_pool.p,
                                    L.sent_pool.p, P, d_stats.p, (vg_region*)nullptr, no_off);
             } else {
