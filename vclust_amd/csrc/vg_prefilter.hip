@@ -1336,19 +1336,19 @@ k_bucket_runs(const uint32_t* __restrict__ rec, int stride /* 3: (w0, w1, pay); 
             uint32_t lt = 0, eq = 0, before = 0; uint32_t prev_pay = 0; bool has_prev = false;
             if (NARROW) {
                 const uint32_t kh = (uint32_t)(kq >> 32);
-                uint64_t best = 0;                               // largest entry of the same k-mer below this one
+                uint32_t best = 0;                               // largest position of the same k-mer below this one (+ 1)
 #pragma unroll 4
                 for (uint32_t t = s0; t < s1; ++t) {
                     const uint64_t vt = sk[t];
-                    const uint32_t th = (uint32_t)(vt >> 32);
+                    const uint32_t th = (uint32_t)(vt >> 32), pt = (uint32_t)vt;
                     lt += th < kh;
                     const bool same = th == kh;
                     eq += same;
-                    const bool below = same && vt < kq;
+                    const bool below = same && pt < pq;          // same key: the order of the entries is that of the positions
                     before += below;
-                    if (below && vt >= best) { best = vt; has_prev = true; }
+                    best = max(best, below ? pt + 1u : 0u);
                 }
-                prev_pay = (uint32_t)best;
+                has_prev = before > 0; prev_pay = best - 1u;
             } else {
                 for (uint32_t t = s0; t < s1; ++t) {
                     const uint64_t kt = sk[t];
