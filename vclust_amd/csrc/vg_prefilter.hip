@@ -6,7 +6,7 @@
 //
 // All kernels are HBM-streaming integer kernels (no MFMA): per padded base position the
 // pipeline reads 3 bits of sequence, writes/reads one u64 key per sort pass and one u64
-// row descriptor for the SpGEMM; the only random traffic is the read of the short genome
+// row pointer for the SpGEMM; the only random traffic is the read of the short genome
 // lists of shared k-mers.
 #include "vg_common.h"
 #include <rocprim/rocprim.hpp>
@@ -305,11 +305,11 @@ constexpr int GS_TILE = 1024;       // list entries owned by a workgroup per tri
 constexpr int GS_HALO = 256;        // staged beyond the tile so that groups starting inside it are complete
 
 // ------------------------------------------------------------------ K2a: runs of the inverted index
-// One pass over the sorted (k-mer, position) list: every entry finds the boundaries of its run
-// of equal k-mers by galloping over its neighbours (runs are short; the neighbours are in
-// cache), flags duplicates (same k-mer, same genome), records its genome (the CSC side of the
-// SpGEMM) and, for k-mers shared by >= 2 entries, scatters one row descriptor
-// (run start, run length) to its base position (the CSR side).  Singletons write nothing.
+// One pass over the sorted (k-mer, position) list: every entry finds the start of its run of equal k-mers
+// by galloping over its neighbours (runs are short; the neighbours are in cache), flags duplicates (same
+// k-mer, same genome), records its genome (the CSC side of the SpGEMM) and, for k-mers shared by >= 2
+// entries, scatters one row pointer (1 + run start) to its base position (the CSR side).  Singletons write
+// nothing.
 __device__ __forceinline__ int64_t run_lower(const uint64_t* __restrict__ keys, int64_t i, uint64_t key) {
     int64_t lo = i;                                   // invariant: keys[lo] == key
     int64_t step = 1;
@@ -318,13 +318,6 @@ __device__ __forceinline__ int64_t run_lower(const uint64_t* __restrict__ keys, 
     int64_t a = lo - step < -1 ? -1 : lo - step;      // keys[a] != key (or a == -1)
     while (lo - a > 1) { int64_t m = (a + lo) >> 1; if (keys[m] == key) lo = m; else a = m; }
     return lo;
-}
-__device__ __forceinline__ int64_t run_upper(const uint64_t* __restrict__ keys, int64_t n, int64_t i, uint64_t key) {
-    int64_t hi = i; int64_t step = 1;
-    while (hi + step < n && keys[hi + step] == key) { hi += step; step <<= 1; }
-    int64_t b = hi + step > n ? n : hi + step;        // keys[b] != key (or b == n)
-    while (b - hi > 1) { int64_t m = (hi + b) >> 1; if (keys[m] == key) hi = m; else b = m; }
-    return hi + 1;                                    // exclusive end
 }
 
 __global__ void __launch_bounds__(256)
@@ -365,7 +358,7 @@ k_runs(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos, cons
 // its group by the full key (stable) and, from the same two scans, knows the run of its own k-mer:
 // where it starts in the fully sorted list, how long it is, and whether the entry in front of it
 // in that order belongs to the same genome (duplicate).  It writes its genome to its final place
-// and scatters the row descriptor; the sorted keys themselves are never written.  A group that
+// and scatters the row pointer; the sorted keys themselves are never written.  A group that
 // does not fit the staged window (a k-mer that occurs hundreds of times: low-complexity sequence,
 // conserved genes) is queued for k_long_groups.
 __global__ void __launch_bounds__(256)
@@ -440,7 +433,7 @@ k_group_runs(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos
 
 // A queued group: one workgroup walks it.  If it is a single k-mer (the usual case: one long run),
 // start and length of the run are the group's, the order is already final, and every entry gets
-// its genome / duplicate flag / row descriptor in parallel.  Several k-mers sharing the prefix of
+// its genome / duplicate flag / row pointer in parallel.  Several k-mers sharing the prefix of
 // a long group need a real sort: *need_full_sort sends the call to the general path.
 __global__ void __launch_bounds__(256)
 k_long_groups(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos, const uint32_t* __restrict__ blk2g, int blk_shift,
@@ -1259,7 +1252,7 @@ k_scan_units(uint32_t* __restrict__ T, int n_u, int nb2 /* <= 4 096 */, const ui
 // or two runs of equal k-mers, contiguous in the LDS; every entry then ranks itself inside its sub-bin by
 // comparing with the few members.  From the same loop it learns its run: start in the fully sorted list,
 // length, its place in position order, and the entry in front of it (duplicate test).  Output exactly as
-// k_group_runs: gen[] at the final place, one row descriptor scattered; the sorted keys are never written.
+// k_group_runs: gen[] at the final place, one row pointer scattered; the sorted keys are never written.
 constexpr int BK_PER = BK_CAP / BK_THREADS;
 constexpr int BK_MAXBIN = 768;           // a sub-bin beyond this (one k-mer occurring hundreds of times) takes the general path
 // NARROW: 8-byte records (key bits below the bucket's in one word, position): an entry is ONE u64 `key << 32 | pos`
@@ -1710,8 +1703,8 @@ static void kmer_shared_pass(vg_genomes* g, int k, double fraction, int shard, i
     si = sorted_index();
     run_extract_sort(g, k, fraction, shard, n_shards, si, false);
     nv = si.n_valid;
-    n_rows_info = si.compact ? std::max<int64_t>(nv, 1) : P;      // row descriptors: per kept k-mer or per base
-    // row descriptors and genome list live in the sort's input buffers (32 + 16 GB less at 100 k genomes)
+    n_rows_info = si.compact ? std::max<int64_t>(nv, 1) : P;      // row pointers: per kept k-mer or per base
+    // row pointers and genome list live in the sort's input buffers (16 + 16 GB less at 100 k genomes)
     if (2 * si.spare64.n >= (size_t)n_rows_info) rowinfo.view(reinterpret_cast<uint32_t*>(si.spare64.p), (size_t)n_rows_info);
     else rowinfo.alloc((size_t)n_rows_info);
     VG_HIP(hipMemsetAsync(rowinfo.p, 0, (size_t)n_rows_info * sizeof(uint32_t), s));
