@@ -481,24 +481,37 @@ k_build_index_lds(const ref_desc* __restrict__ refs, const int* __restrict__ slo
             for (int i = threadIdx.x; i < n_cnt; i += blockDim.x) tab[i] = 0;
             lds_sync();
             const int n4 = (rd.n_rr + 3) & ~3;
-            for (int p0 = 4 * threadIdx.x; p0 < n4; p0 += 4 * blockDim.x) {
-                const int wi = p0 >> 4; const int sh = 2 * (p0 & 15);
-                const uint64_t lo = (uint64_t)pk[wi] | ((uint64_t)pk[wi + 1] << 32);
-                const uint64_t hi = (uint64_t)pk[wi + 2] | ((uint64_t)pk[wi + 3] << 32);
-                const uint64_t ml = ((uint64_t)mk[p0 >> 5] | ((uint64_t)mk[(p0 >> 5) + 1] << 32)) >> (p0 & 31);
-                uint32_t out[4];
+            // (the msl + tag bases of a position are <= 32 bits: one funnel shift over two words serves each of four
+            // consecutive positions; the loads of four trips are issued together)
+            const uint32_t tagmask = rd.tag_bits ? ((1u << rd.tag_bits) - 1u) : 0u;
+            for (int pb = 4 * threadIdx.x; pb < n4; pb += 16 * blockDim.x) {
+                uint32_t w0[4], w1[4], m0[4], m1[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int p = p0 + j; const int s2 = sh + 2 * j;            // bit offset inside (hi:lo), <= 36
-                    uint32_t bt = 0xffffffffu;
-                    if (p + w <= rd.n_rr && ((ml >> j) & ((1ULL << w) - 1)) == 0) {
-                        const uint64_t x = s2 ? ((lo >> s2) | (hi << (64 - s2))) : lo;
-                        bt = (uint32_t)(x & smask) | (seed_tag(x, msl, rd.tag_bits) << 18);
-                        atomicAdd(&tab[(bt & 0x3ffffu) >> (big ? tsh : 0)], 1u);
-                    }
-                    out[j] = bt;
+                for (int u = 0; u < 4; ++u) {
+                    const int p0 = pb + u * 4 * (int)blockDim.x;
+                    const bool in = p0 < n4;
+                    w0[u] = in ? pk[p0 >> 4] : 0u; w1[u] = in ? pk[(p0 >> 4) + 1] : 0u;
+                    m0[u] = in ? mk[p0 >> 5] : ~0u; m1[u] = in ? mk[(p0 >> 5) + 1] : ~0u;
                 }
-                *reinterpret_cast<uint4*>(&scratch[p0]) = make_uint4(out[0], out[1], out[2], out[3]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int p0 = pb + u * 4 * (int)blockDim.x;
+                    if (p0 >= n4) continue;
+                    const uint32_t sh = 2u * (uint32_t)(p0 & 15);
+                    uint32_t out[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int p = p0 + j;
+                        uint32_t bt = 0xffffffffu;
+                        if (p + w <= rd.n_rr && (__builtin_amdgcn_alignbit(m1[u], m0[u], (uint32_t)(p0 & 31) + j) & ((1u << w) - 1u)) == 0) {
+                            const uint32_t x = __builtin_amdgcn_alignbit(w1[u], w0[u], sh + 2 * j);
+                            bt = (x & (uint32_t)smask) | (((x >> (2 * msl)) & tagmask) << 18);
+                            atomicAdd(&tab[(bt & 0x3ffffu) >> (big ? tsh : 0)], 1u);
+                        }
+                        out[j] = bt;
+                    }
+                    *reinterpret_cast<uint4*>(&scratch[p0]) = make_uint4(out[0], out[1], out[2], out[3]);
+                }
             }
             __threadfence_block();
             __syncthreads();
@@ -603,14 +616,29 @@ k_build_index_lds(const ref_desc* __restrict__ refs, const int* __restrict__ slo
                 const bool direct = cnt > (uint32_t)LDS_STAGE;     // a single bin larger than the stage
                 for (int i = threadIdx.x; i < nbw; i += blockDim.x) tab[i] = 0;
                 lds_sync();
-                for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) atomicAdd(&tab[(binned[base + i].x & 0x3ffffu) - b_lo], 1u);
+                // (four independent loads per thread and trip in both passes over the window: one workgroup per CU,
+                // nothing else hides the latency of a load per trip)
+                for (uint32_t i0 = threadIdx.x; i0 < cnt; i0 += 4 * blockDim.x) {
+                    uint32_t bx[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + u * blockDim.x; bx[u] = i < cnt ? binned[base + i].x : 0xffffffffu; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) if (i0 + u * blockDim.x < cnt) atomicAdd(&tab[(bx[u] & 0x3ffffu) - b_lo], 1u);
+                }
                 lds_sync();
                 lds_scan_exclusive_waves(tab, nbw, part);
-                for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
-                    const uint2 e = binned[base + i];
-                    const uint32_t ent = e.y | ((e.x >> 18) << rd.pos_bits);
-                    const uint32_t slot = atomicAdd(&tab[(e.x & 0x3ffffu) - b_lo], 1u);
-                    if (direct) gent[base + slot] = ent; else stage[slot] = ent;
+                for (uint32_t i0 = threadIdx.x; i0 < cnt; i0 += 4 * blockDim.x) {
+                    uint2 e4[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + u * blockDim.x; e4[u] = i < cnt ? binned[base + i] : make_uint2(0u, 0u); }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (i0 + u * blockDim.x >= cnt) continue;
+                        const uint2 e = e4[u];
+                        const uint32_t ent = e.y | ((e.x >> 18) << rd.pos_bits);
+                        const uint32_t slot = atomicAdd(&tab[(e.x & 0x3ffffu) - b_lo], 1u);
+                        if (direct) gent[base + slot] = ent; else stage[slot] = ent;
+                    }
                 }
                 lds_sync();
                 if (!direct) for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) gent[base + i] = stage[i];
