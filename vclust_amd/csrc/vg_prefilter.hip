@@ -886,17 +886,33 @@ k_part_count2(const uint32_t* __restrict__ rec, int B1, int B2, int64_t n_units,
         __syncthreads();
         uint32_t b1, U; int64_t s0, s1;
         lvl2_unit(L, u, &b1, &U, &s0, &s1);
+        if (SHORT) {
+            // 8-byte records, two per 16-byte load (from an even record index), four loads per thread and trip
+            const int sh = SR_POS_BITS + L.kr - B2;
+            for (int64_t i0 = (s0 & ~(int64_t)1) + 2 * (int64_t)threadIdx.x; i0 < s1; i0 += 8 * PT_THREADS) {
+                uint4 r[4];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int64_t i = i0 + (int64_t)v * 2 * PT_THREADS;
+                    r[v] = make_uint4(0u, 0u, 0u, 0u);
+                    if (i + 1 < s1 && i >= s0) __builtin_memcpy(&r[v], rec + 2 * i, 16);
+                    else { if (i >= s0 && i < s1) __builtin_memcpy(&r[v].x, rec + 2 * i, 8); if (i + 1 >= s0 && i + 1 < s1) __builtin_memcpy(&r[v].z, rec + 2 * (i + 1), 8); }
+                }
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int64_t i = i0 + (int64_t)v * 2 * PT_THREADS;
+                    if (i >= s0 && i < s1) atomicAdd(&hist[(uint32_t)((((uint64_t)r[v].y << 32) | r[v].x) >> sh) & (uint32_t)(nb2 - 1)], 1u);
+                    if (i + 1 >= s0 && i + 1 < s1) atomicAdd(&hist[(uint32_t)((((uint64_t)r[v].w << 32) | r[v].z) >> sh) & (uint32_t)(nb2 - 1)], 1u);
+                }
+            }
+        } else
         // eight independent loads per thread and trip (one workgroup per CU: the loop is latency bound otherwise)
         for (int64_t i0 = s0 + threadIdx.x; i0 < s1; i0 += 8 * PT_THREADS) {
             uint32_t d[8];
 #pragma unroll
             for (int v = 0; v < 8; ++v) {
                 const int64_t i = i0 + (int64_t)v * PT_THREADS;
-                d[v] = 0;
-                if (i < s1) {
-                    if (SHORT) { uint64_t r; __builtin_memcpy(&r, rec + 2 * i, 8); d[v] = (uint32_t)(r >> (SR_POS_BITS + L.kr - B2)); }
-                    else d[v] = rec[3 * i] >> (32 - B1 - B2);
-                }
+                d[v] = i < s1 ? rec[3 * i] >> (32 - B1 - B2) : 0u;
             }
 #pragma unroll
             for (int v = 0; v < 8; ++v) if (i0 + (int64_t)v * PT_THREADS < s1) atomicAdd(&hist[d[v] & (uint32_t)(nb2 - 1)], 1u);
