@@ -1130,19 +1130,40 @@ k_part_scatter2_narrow(const uint32_t* __restrict__ rec, int B1, int B2, int64_t
             for (int b = threadIdx.x; b < nbins; b += PT_THREADS) thist[b] = 0;
             lds_sync();
             uint32_t key[NT_PER], pay[NT_PER], br[NT_PER];      // br = bin | rank in bin << 11, or all ones
+            if (SHORT) {
+                // two 8-byte records per 16-byte load: element 2 p and 2 p + 1 of the thread are the records
+                // t0 + 2 (p * 1024 + t) and the next one
+                uint4 rr[NT_PER / 2];
 #pragma unroll
-            for (int j = 0; j < NT_PER; ++j) {
-                const int64_t i = t0 + (int64_t)j * PT_THREADS + threadIdx.x;
-                br[j] = 0xffffffffu; key[j] = 0; pay[j] = 0;
-                if (i < s1) {
-                    if (SHORT) {
-                        uint64_t r; __builtin_memcpy(&r, rec + 2 * i, 8);
-                        const uint32_t ui = (uint32_t)i;
-                        const uint32_t gsel = (uint32_t)(ui >= gb[0]) + (uint32_t)(ui >= gb[1]) + (uint32_t)(ui >= gb[2]);
-                        key[j] = (uint32_t)(r >> SR_POS_BITS) << (32 - (L.kr - B2));
-                        pay[j] = gbase + (gsel << SR_POS_BITS) + ((uint32_t)r & ((1u << SR_POS_BITS) - 1u));
-                        br[j] = (uint32_t)(r >> (SR_POS_BITS + L.kr - B2)) & (uint32_t)(nbins - 1);
-                    } else {
+                for (int p = 0; p < NT_PER / 2; ++p) {
+                    const int64_t i = t0 + 2 * ((int64_t)p * PT_THREADS + threadIdx.x);
+                    rr[p] = make_uint4(0u, 0u, 0u, 0u);
+                    if (i + 1 < s1) __builtin_memcpy(&rr[p], rec + 2 * i, 16);
+                    else if (i < s1) __builtin_memcpy(&rr[p].x, rec + 2 * i, 8);
+                }
+#pragma unroll
+                for (int p = 0; p < NT_PER / 2; ++p) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int j = 2 * p + h;
+                        const int64_t i = t0 + 2 * ((int64_t)p * PT_THREADS + threadIdx.x) + h;
+                        br[j] = 0xffffffffu; key[j] = 0; pay[j] = 0;
+                        if (i < s1) {
+                            const uint64_t r = h ? (((uint64_t)rr[p].w << 32) | rr[p].z) : (((uint64_t)rr[p].y << 32) | rr[p].x);
+                            const uint32_t ui = (uint32_t)i;
+                            const uint32_t gsel = (uint32_t)(ui >= gb[0]) + (uint32_t)(ui >= gb[1]) + (uint32_t)(ui >= gb[2]);
+                            key[j] = (uint32_t)(r >> SR_POS_BITS) << (32 - (L.kr - B2));
+                            pay[j] = gbase + (gsel << SR_POS_BITS) + ((uint32_t)r & ((1u << SR_POS_BITS) - 1u));
+                            br[j] = (uint32_t)(r >> (SR_POS_BITS + L.kr - B2)) & (uint32_t)(nbins - 1);
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NT_PER; ++j) {
+                    const int64_t i = t0 + (int64_t)j * PT_THREADS + threadIdx.x;
+                    br[j] = 0xffffffffu; key[j] = 0; pay[j] = 0;
+                    if (i < s1) {
                         uint32_t r[3]; __builtin_memcpy(r, rec + 3 * i, 12);
                         key[j] = (uint32_t)(((((uint64_t)r[0] << 32) | r[1]) << narrow_shift) >> 32); pay[j] = r[2];
                         br[j] = (r[0] >> (32 - B1 - B2)) & (uint32_t)(nbins - 1);
@@ -1296,20 +1317,41 @@ k_bucket_runs(const uint32_t* __restrict__ rec, int stride /* 3: (w0, w1, pay); 
         for (int b = threadIdx.x; b <= BK_SUB; b += THREADS) cnt[b] = 0;
         lds_sync();
         uint64_t key[BK_PER]; uint32_t pj[BK_PER]; uint32_t sb[BK_PER], ar[BK_PER];
+        if (NARROW) {
+            // two 8-byte records per 16-byte load: entries 2 p and 2 p + 1 of the thread are the records 2 (p * THREADS + t), + 1
+            static_assert(BK_PER % 2 == 0, "pairs of records per thread");
 #pragma unroll
-        for (int q = 0; q < BK_PER; ++q) {
-            const int j = q * THREADS + threadIdx.x;
-            sb[q] = 0; ar[q] = 0; key[q] = 0; pj[q] = 0;
-            if (j < n) {
-                const uint32_t* r = rec + (uint64_t)(b0 + j) * stride;
-                const uint32_t a = r[0], c = (!NARROW && stride == 3) ? r[1] : 0u;
-                pj[q] = r[stride - 1];
-                key[q] = NARROW ? (((uint64_t)a << 32) | pj[q]) : (((uint64_t)a << 32) | c);
-                sb[q] = NARROW ? (a >> (32 - SUBBITS)) : (uint32_t)((key[q] << pbits) >> (64 - SUBBITS));
+            for (int p = 0; p < BK_PER / 2; ++p) {
+                const int j = 2 * (p * THREADS + (int)threadIdx.x);
+                uint4 rr = make_uint4(0u, 0u, 0u, 0u);
+                if (j + 1 < n) __builtin_memcpy(&rr, rec + 2 * (uint64_t)(b0 + j), 16);
+                else if (j < n) __builtin_memcpy(&rr.x, rec + 2 * (uint64_t)(b0 + j), 8);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int q = 2 * p + h;
+                    const uint32_t a = h ? rr.z : rr.x, pay = h ? rr.w : rr.y;
+                    sb[q] = 0; ar[q] = 0; key[q] = 0; pj[q] = 0;
+                    if (j + h < n) { pj[q] = pay; key[q] = ((uint64_t)a << 32) | pay; sb[q] = a >> (32 - SUBBITS); }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < BK_PER; ++q) {
+                const int j = q * THREADS + threadIdx.x;
+                sb[q] = 0; ar[q] = 0; key[q] = 0; pj[q] = 0;
+                if (j < n) {
+                    const uint32_t* r = rec + (uint64_t)(b0 + j) * stride;
+                    const uint32_t a = r[0], c = stride == 3 ? r[1] : 0u;
+                    pj[q] = r[stride - 1];
+                    key[q] = ((uint64_t)a << 32) | c;
+                    sb[q] = (uint32_t)((key[q] << pbits) >> (64 - SUBBITS));
+                }
             }
         }
+        // (entry q of the thread: record q * THREADS + t, or with pairs 2 ((q / 2) * THREADS + t) + q % 2)
+        auto rec_of = [&](int q) -> int { return NARROW ? 2 * ((q >> 1) * THREADS + (int)threadIdx.x) + (q & 1) : q * THREADS + (int)threadIdx.x; };
 #pragma unroll
-        for (int q = 0; q < BK_PER; ++q) if (q * THREADS + (int)threadIdx.x < n) ar[q] = atomicAdd(&cnt[sb[q]], 1u);
+        for (int q = 0; q < BK_PER; ++q) if (rec_of(q) < n) ar[q] = atomicAdd(&cnt[sb[q]], 1u);
         lds_sync();
         {   // exclusive scan of the sub-bin counters: BK_SUB / THREADS per thread
             constexpr int CPT = BK_SUB / THREADS;
@@ -1330,14 +1372,14 @@ k_bucket_runs(const uint32_t* __restrict__ rec, int stride /* 3: (w0, w1, pay); 
         }
         lds_sync();
 #pragma unroll
-        for (int q = 0; q < BK_PER; ++q) if (q * THREADS + (int)threadIdx.x < n) {
+        for (int q = 0; q < BK_PER; ++q) if (rec_of(q) < n) {
             const uint32_t slot = start[sb[q]] + ar[q];
             sk[slot] = key[q]; if (!NARROW) sp[slot] = pj[q];
         }
         lds_sync();
 #pragma unroll
         for (int q = 0; q < BK_PER; ++q) {
-            if (q * THREADS + (int)threadIdx.x >= n) continue;
+            if (rec_of(q) >= n) continue;
             const uint32_t s0 = start[sb[q]], s1 = start[sb[q] + 1];
             if (s1 - s0 < 2) continue;                           // alone in its sub-bin: a singleton k-mer
             if (s1 - s0 > BK_MAXBIN) { atomicOr(overflow, 1u); continue; }
