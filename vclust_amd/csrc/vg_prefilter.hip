@@ -1039,11 +1039,25 @@ k_part_scatter_dense(part_src S, int B1, int unit_tiles, int64_t n_units, const 
         const int64_t s0 = u * unit_tiles * RT_TILE, s1 = min(S.n, s0 + (int64_t)unit_tiles * RT_TILE);
         lds_sync();
         for (int b = threadIdx.x; b < nbins; b += PT_THREADS) cursor[b] = Ts[u * nbins + b];
+        // the tile's packed bases and mask: three + two words per thread, requested one tile ahead (the barriers of
+        // this kernel wait for LDS traffic only, so the loads travel while the current tile is sorted)
+        constexpr int NPK = (RT_TILE / 16 + 4 + PT_THREADS - 1) / PT_THREADS, NMK = (RT_TILE / 32 + 2 + PT_THREADS - 1) / PT_THREADS;
+        uint32_t pf_pk[NPK], pf_mk[NMK];
+        auto fetch_bases = [&](int64_t t0) {
+#pragma unroll
+            for (int v = 0; v < NPK; ++v) { const int i = v * PT_THREADS + (int)threadIdx.x; const int64_t w = (t0 >> 4) + i; pf_pk[v] = (i < RT_TILE / 16 + 4 && w < n_pk) ? S.A.packed[w] : 0u; }
+#pragma unroll
+            for (int v = 0; v < NMK; ++v) { const int i = v * PT_THREADS + (int)threadIdx.x; const int64_t w = (t0 >> 5) + i; pf_mk[v] = (i < RT_TILE / 32 + 2 && w < n_mk) ? S.A.nmask[w] : 0xffffffffu; }
+        };
+        fetch_bases(s0);
         for (int64_t t0 = s0; t0 < s1; t0 += RT_TILE) {
-            for (int i = threadIdx.x; i < RT_TILE / 16 + 4; i += PT_THREADS) { const int64_t w = (t0 >> 4) + i; s_pk[i] = w < n_pk ? S.A.packed[w] : 0u; }
-            for (int i = threadIdx.x; i < RT_TILE / 32 + 2; i += PT_THREADS) { const int64_t w = (t0 >> 5) + i; s_mk[i] = w < n_mk ? S.A.nmask[w] : 0xffffffffu; }
+#pragma unroll
+            for (int v = 0; v < NPK; ++v) { const int i = v * PT_THREADS + (int)threadIdx.x; if (i < RT_TILE / 16 + 4) s_pk[i] = pf_pk[v]; }
+#pragma unroll
+            for (int v = 0; v < NMK; ++v) { const int i = v * PT_THREADS + (int)threadIdx.x; if (i < RT_TILE / 32 + 2) s_mk[i] = pf_mk[v]; }
             for (int b = threadIdx.x; b < nbins; b += PT_THREADS) thist[b] = 0;
             lds_sync();
+            if (t0 + RT_TILE < s1) fetch_bases(t0 + RT_TILE);
             uint32_t br[RT_PER];                                  // bin | rank in bin << 12, or all ones
 #pragma unroll
             for (int q = 0; q < RT_PER / 4; ++q) {
