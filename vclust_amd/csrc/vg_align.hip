@@ -975,8 +975,10 @@ __device__ __forceinline__ void lz_parse_body(PARSE_ARGS) {
             const uint32_t posmask = (rd.pos_bits >= 32) ? 0xffffffffu : ((1u << rd.pos_bits) - 1u);
             const uint32_t qtag = rd.tag_bits ? (uint32_t)((xq >> (2 * P.msl)) & ((1u << rd.tag_bits) - 1u)) : 0u;
             if ((do_a || do_s) && q_ok_s) {
+                // bucket bounds = two neighbouring table words: one 8-byte load
                 const uint32_t b = (uint32_t)(xq & smask);
-                s_u = b ? stab[b - 1] : 0u; s_e = stab[b];
+                uint2 bb; __builtin_memcpy(&bb, stab + (b ? b - 1 : 0u), 8);
+                s_u = b ? bb.x : 0u; s_e = b ? bb.y : bb.x;
             }
             const int pred0 = pred - lit;                        // reference end of the previous match
             const bool pred_rc = pred0 > c.L;                    // strand of the prediction
