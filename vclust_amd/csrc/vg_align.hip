@@ -753,11 +753,15 @@ k_build_index_reg(const ref_desc* __restrict__ refs, const int* __restrict__ slo
             }
         }
         lds_sync();
-        for (int i = tid; i < nb; i += 1024) gtab[i] = tab[i];
-        {
-            const uint32_t cnt0 = min((uint32_t)REG_STAGE0, total);
-            for (uint32_t i = tid; i < cnt0; i += 1024) gent[i] = stage0[i];
-        }
+        // (copies out of the LDS: four words per lane and store)
+        auto copy_out = [&](uint32_t* dst, const uint32_t* src, uint32_t n) {
+            for (uint32_t i = 4u * (uint32_t)tid; i < n; i += 4096u) {
+                if (i + 4 <= n) { const uint4 v = make_uint4(src[i], src[i + 1], src[i + 2], src[i + 3]); __builtin_memcpy(dst + i, &v, 16); }
+                else for (uint32_t j = i; j < n; ++j) dst[j] = src[j];
+            }
+        };
+        copy_out(gtab, tab, (uint32_t)nb);
+        copy_out(gent, stage0, min((uint32_t)REG_STAGE0, total));
         lds_sync();
         for (uint32_t base = REG_STAGE0; base < total; base += REG_STAGE) {
             uint32_t t4 = 4u * (uint32_t)tid;
@@ -775,8 +779,7 @@ k_build_index_reg(const ref_desc* __restrict__ refs, const int* __restrict__ slo
                 __builtin_amdgcn_sched_barrier(0);
             }
             lds_sync();
-            const uint32_t cnt = min((uint32_t)REG_STAGE, total - base);
-            for (uint32_t i = tid; i < cnt; i += 1024) gent[base + i] = stage[i];
+            copy_out(gent + base, stage, min((uint32_t)REG_STAGE, total - base));
             lds_sync();
         }
     }
