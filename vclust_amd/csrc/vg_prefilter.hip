@@ -1319,6 +1319,7 @@ k_bucket_runs(const uint32_t* __restrict__ rec, int stride /* 3: (w0, w1, pay); 
     constexpr int BK_SUB = 1 << SUBBITS, CAP = THREADS * BK_PER;
     __shared__ uint64_t sk[CAP];                  // NARROW: key << 32 | pos; else (w0 << 32) | w1 -- in sub-bin order
     __shared__ uint32_t sp[NARROW ? 1 : CAP];
+    __shared__ uint32_t sgen[CAP];                  // gen[] of the bucket in final order: leaves as one contiguous copy
     __shared__ uint32_t cnt[BK_SUB + 1], start[BK_SUB + 1];
     __shared__ uint32_t s_wave[THREADS / 64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1429,10 +1430,16 @@ k_bucket_runs(const uint32_t* __restrict__ rec, int stride /* 3: (w0, w1, pay); 
             const uint32_t g = M.cblk ? genome_of_compact(M, pq) : blk2g[pq >> blk_shift];
             const bool dup = has_prev && (M.cblk ? genome_of_compact(M, prev_pay) : blk2g[prev_pay >> blk_shift]) == g;
             const uint32_t rs = b0 + s0 + lt;                    // first entry of this k-mer's run in the sorted list
-            gen[rs + before] = g | (dup ? DUP_BIT : 0u);
+            sgen[s0 + lt + before] = g | (dup ? DUP_BIT : 0u);
             if (dup) { atomicAdd(&dup_per_genome[g], 1); continue; }
             if (before == 0) continue;                           // the run's smallest genome: no partner b < a
             rowinfo[pq] = rs + 1u;
+        }
+        lds_sync();
+        // (the slots of singleton k-mers carry whatever the LDS held: nobody reads them)
+        for (uint32_t i = 4u * threadIdx.x; i < (uint32_t)n; i += 4u * THREADS) {
+            if (i + 4 <= (uint32_t)n) { const uint4 v = make_uint4(sgen[i], sgen[i + 1], sgen[i + 2], sgen[i + 3]); __builtin_memcpy(gen + b0 + i, &v, 16); }
+            else for (uint32_t j = i; j < (uint32_t)n; ++j) gen[b0 + j] = sgen[j];
         }
     }
 }
