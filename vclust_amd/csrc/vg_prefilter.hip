@@ -519,7 +519,7 @@ k_spgemm(const uint32_t* __restrict__ rowinfo, const uint32_t* __restrict__ gen,
     // row a = its base positions (dense) or its kept k-mers (compact index space)
     const int64_t p0 = wave_base ? (int64_t)wave_base[base_off[a] >> 6] : base_off[a];
     const int64_t L = wave_base ? (int64_t)wave_base[base_off[a + 1] >> 6] - p0 : len[a];
-    constexpr int ROWS_PER_TRIP = 4;              // independent row-pointer loads per thread and trip
+    constexpr int ROWS_PER_TRIP = 16;             // independent row-pointer loads per thread and trip
     for (int64_t base = 0; base < L; base += (int64_t)blockDim.x * ROWS_PER_TRIP) {
         uint32_t rr4[ROWS_PER_TRIP];
 #pragma unroll
