@@ -6,7 +6,7 @@
  * .gitmodules:4-6) is absent from the checkout, so this file restates the published
  * LZ-ANI algorithm and was fitted, rule by rule, to the 5 693 golden regions of
  * example/output/ani.aln.tsv (see DESIGN.md "LZ parse rules" for the evidence per rule).  Status: all 5 693
- * regions reproduced with every integer, one surplus region (tests/test_oracle_golden.py):
+ * regions reproduced with every integer, none surplus; ani.tsv byte-identical (tests/test_oracle_golden.py):
  *
  *   R1  reference = forward strand | N ... | reverse complement (query is never reversed); the separator is
  *       mrd + mqd + 1 symbols, so nothing ever reaches across the strands.
@@ -15,7 +15,8 @@
  *   R3  with a prediction alive: first a SEED, an exact match >= msl whose reference position p satisfies
  *       pred0 <= p and p - pred < mrd (pred0 = reference end of the previous match, pred = pred0 + literals
  *       skipped); longest wins, ties -> closest to the prediction, then smallest position.  An anchor is
- *       taken instead only if it is longer than the seed by at least msl; it continues the region when it
+ *       taken instead only if it is longer than the seed by at least msl (msl - 1 against a WEAK seed, one
+ *       shorter than a third of the literal run in front of it); it continues the region when it
  *       lies within +-mrd of the prediction, otherwise it closes the region and opens a new one.
  *   R4  after every match an approximate extension walks the diagonal while the last aw symbols hold <= am
  *       mismatches and is cut back to the end of the last run of >= ar matches.
@@ -69,6 +70,7 @@ void vo_lz_default_variant(vo_lz_variant* v) {
     v->rend_mode = 6;                /* R9 */
     v->trace = 0;
     v->anchor_margin = -1;           /* R2: -1 = msl - 1 */
+    v->weak_seed_ratio = 3;          /* R3: a seed shorter than lit / 3 gives one symbol of the margin away */
 }
 
 static inline uint64_t mix64(uint64_t x) {
@@ -232,6 +234,7 @@ int vo_lz_parse(const vo_ref_index* ix, const uint8_t* qry, int64_t qn,
 #define CLOSE_REGION() do { if (in_region) { \
         cur.n_mismatch = (cur.qend - cur.qstart + 1) - cur.n_match; \
         int keep = v->reg_on_span ? (cur.qend - cur.qstart + 1 >= p->reg) : (cur.n_match >= p->reg); \
+        if (v->trace) fprintf(stderr, "REGION %s qs=%d qe=%d nm=%d\n", keep ? "KEPT" : "DROP", cur.qstart + 1, cur.qend + 1, cur.n_match); \
         if (keep) { rpush(&regs, cur); kept_end = cur.qend + 1; } in_region = 0; } } while (0)
 
     while (i < lim) {
@@ -282,7 +285,11 @@ int vo_lz_parse(const vo_ref_index* ix, const uint8_t* qry, int64_t qn,
             case 0: take_anchor = 0; break;
             case 1: take_anchor = (s_len == 0 && a_len > 0); break;
             case 2: take_anchor = (a_len > 0); break;
-            default: take_anchor = (a_len > 0) && (s_len == 0 || a_len > s_len + margin); break;
+            default: {
+                /* R3: a far anchor needs msl more symbols than the seed; one less when the seed is WEAK,
+                 * i.e. shorter than a third of the literal run it would bridge */
+                int64_t mg = margin - ((v->weak_seed_ratio > 0 && lit > v->weak_seed_ratio * s_len) ? 1 : 0);
+                take_anchor = (a_len > 0) && (s_len == 0 || a_len > s_len + mg); break; }
             }
             if (take_anchor) {
                 best_len = a_len; best_pos = a_pos;
@@ -292,6 +299,7 @@ int vo_lz_parse(const vo_ref_index* ix, const uint8_t* qry, int64_t qn,
         }
 
         if (best_len > 0) {
+            if (v->trace && s_len > 0 && a_len > 0) fprintf(stderr, "BOTH i=%lld s_len=%lld s_pos=%lld a_len=%lld a_pos=%lld pred=%lld lit=%lld\n", (long long)i + 1, (long long)s_len, (long long)s_pos, (long long)a_len, (long long)a_pos, (long long)pred, (long long)lit);
             if (v->trace) fprintf(stderr, "i=%lld %s pos=%lld len=%lld pred=%lld lit=%lld\n", (long long)i + 1,
                                   is_close ? "CLOSE" : "DIST", (long long)best_pos, (long long)best_len,
                                   (long long)pred, (long long)lit);
@@ -354,6 +362,7 @@ int vo_lz_parse(const vo_ref_index* ix, const uint8_t* qry, int64_t qn,
                 i += e; pred += e;
             }
             cur.qend = (int32_t)(i - 1);
+            if (v->trace) fprintf(stderr, "  ext=%lld e_mm=%lld nmatch=%d qs=%d qe=%d\n", (long long)e, (long long)e_mm, cur.n_match, cur.qstart + 1, cur.qend + 1);
             if (is_close && v->rend_mode >= 3) {
                 /* virtual reference end: every query symbol moves it except those matched on the new
                  * diagonal (suffix of the gap, the match itself, matches of its extension) */

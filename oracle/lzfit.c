@@ -22,14 +22,18 @@ int main(int argc, char** argv) {
 #define K(name) if (!strcmp(k, #name)) v.name = val;
         K(sep_len) K(anchor_while_predicting) K(bwd_bound_kept) K(bwd_exact_first) K(seed_window)
         K(seed_back) K(seed_fwd) K(seed_choice) K(lit_reset_ge) K(gap_mode) K(fwd_after_close)
-        K(loop_le) K(anchor_tie) K(reg_on_span) K(rend_mode) K(trace) K(anchor_margin)
+        K(loop_le) K(anchor_tie) K(reg_on_span) K(rend_mode) K(trace) K(anchor_margin) K(weak_seed_ratio)
 #undef K
         if (!strcmp(k, "q")) only_q = eq + 1;
         if (!strcmp(k, "r")) only_r = eq + 1;
-        if (!strcmp(k, "mal")) p.mal = val; if (!strcmp(k, "msl")) p.msl = val;
-        if (!strcmp(k, "mrd")) p.mrd = val; if (!strcmp(k, "mqd")) p.mqd = val;
-        if (!strcmp(k, "reg")) p.reg = val; if (!strcmp(k, "aw")) p.aw = val;
-        if (!strcmp(k, "am")) p.am = val; if (!strcmp(k, "ar")) p.ar = val;
+        if (!strcmp(k, "mal")) p.mal = val;
+        if (!strcmp(k, "msl")) p.msl = val;
+        if (!strcmp(k, "mrd")) p.mrd = val;
+        if (!strcmp(k, "mqd")) p.mqd = val;
+        if (!strcmp(k, "reg")) p.reg = val;
+        if (!strcmp(k, "aw")) p.aw = val;
+        if (!strcmp(k, "am")) p.am = val;
+        if (!strcmp(k, "ar")) p.ar = val;
     }
     printf("query\treference\tpident\talnlen\tqstart\tqend\trstart\trend\tnt_match\tnt_mismatch\n");
     for (int r = 0; r < gs.n; ++r) {

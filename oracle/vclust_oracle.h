@@ -91,6 +91,7 @@ typedef struct {
     int rend_mode;               /* 0 true end, 1 max with chained ends, 2 also max with the gap end on the old diagonal */
     int trace;
     int anchor_margin;           /* anchor_while_predicting 3: a far anchor beats a seed when longer by more than this */
+    int weak_seed_ratio;         /* the margin drops by one when lit > ratio * seed length (0 = never) */
 } vo_lz_variant;
 
 typedef struct {

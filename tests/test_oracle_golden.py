@@ -104,9 +104,6 @@ def test_row_order_and_layout(oracle_align, golden_dir):
     assert [r[10] for r in g] == [r[10] for r in m]          # len_ratio
 
 
-KNOWN_SURPLUS = {(('NC_010807.alt3', 'NC_025457'), (45, 17179, 17223, 4793, 4751, 29, 16))}
-
-
 def _load_regions(p):
     d = collections.defaultdict(list)
     for r in read_tsv(p)[1:]:
@@ -114,26 +111,20 @@ def _load_regions(p):
     return d
 
 
-def test_lz_parse_reproduces_every_golden_region(oracle_align, golden_dir):
-    """example/output/ani.aln.tsv:1-5694: every one of the 5 693 regions of the reference is reproduced
-    with all seven integers and pident.  The restatement finds ONE region the reference does not report
-    (KNOWN_SURPLUS): that is the whole residual."""
+def test_lz_parse_identical_to_golden_regions(oracle_align, golden_dir):
+    """example/output/ani.aln.tsv:1-5694: STRICT identity -- the multiset of regions (all seven integers and
+    pident) per ordered pair equals the reference's: 5 693 of 5 693, nothing missing, nothing surplus."""
     g = _load_regions(golden_dir / 'output' / 'ani.aln.tsv'); m = _load_regions(oracle_align / 'ani.aln.tsv')
     assert sum(len(v) for v in g.values()) == 5693
-    missing = [(k, x) for k, regs in g.items() for x in regs if x not in set(m.get(k, []))]
-    assert missing == []
-    surplus = {(k, x[:7]) for k, regs in m.items() for x in regs if x not in set(g.get(k, []))}
-    assert surplus == KNOWN_SURPLUS
+    assert sum(len(v) for v in m.values()) == 5693
+    assert set(g) == set(m)
+    for k in g:
+        assert sorted(g[k]) == sorted(m[k]), k
 
 
 def test_ani_rows_identical_to_golden(oracle_align, golden_dir):
-    """example/output/ani.tsv:1-133: rows are byte-identical except the two rows of the pair that holds
-    the surplus region (its num_alns / sums enter both directions' tani)."""
-    g = (golden_dir / 'output' / 'ani.tsv').read_text().splitlines()
-    m = (oracle_align / 'ani.tsv').read_text().splitlines()
-    assert len(g) == len(m) == 133 and g[0] == m[0]
-    diff = [a.split('\t')[2:4] for a, b in zip(g, m) if a != b]
-    assert sorted(diff) == [['NC_010807.alt3', 'NC_025457'], ['NC_025457', 'NC_010807.alt3']]
+    """example/output/ani.tsv:1-133: the file is byte-identical to the reference's (132 rows + header)."""
+    assert (golden_dir / 'output' / 'ani.tsv').read_bytes() == (oracle_align / 'ani.tsv').read_bytes()
 
 
 def test_tani_within_reference_test_tolerance(oracle_align):
@@ -151,7 +142,7 @@ def test_tani_within_reference_test_tolerance(oracle_align):
 def test_tani_close_to_golden(oracle_align, golden_dir):
     g = read_tsv(golden_dir / 'output' / 'ani.tsv')[1:]; m = read_tsv(oracle_align / 'ani.tsv')[1:]
     worst = max(abs(float(a[4]) - float(b[4])) for a, b in zip(g, m))
-    assert worst < 0.0006, worst      # the one surplus region: 29 matches in 85 kb
+    assert worst == 0.0, worst
 
 
 def test_identical_and_shuffled_genome(example):

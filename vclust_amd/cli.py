@@ -375,8 +375,8 @@ def handle_info(args, parser, logger):
         ok = False
     lines += ['', 'Parity with the reference (golden example of refresh-bio/vclust, DESIGN.md section 2):',
               '   fltr.txt, ani.ids.tsv            byte-identical',
-              '   ani.aln.tsv                      5693 / 5693 regions identical (+ 1 surplus region)',
-              '   ani.tsv                          130 / 132 rows byte-identical (one pair: num_alns +1, tANI +-2e-4)']
+              '   ani.aln.tsv                      5693 / 5693 regions identical, none surplus',
+              '   ani.tsv                          132 / 132 rows byte-identical']
     lines += ['', 'CPU tools (optional):']
     for name, path in (('Clusty', BIN_CLUSTY), ('mfasta', BIN_MFASTA)):
         lines.append(f'   {name:<20} {"found" if path.exists() else "not installed"} ({path})')

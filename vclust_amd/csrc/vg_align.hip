@@ -1049,7 +1049,8 @@ __device__ __forceinline__ void lz_parse_body(PARSE_ARGS) {
                 if (best_len == 32) best_len = match_len_lane(c, qi, best_pos, 1 << 30);
                 if (sbest_len == 32) sbest_len = match_len_lane(c, qi, sbest_pos, 1 << 30);
             }
-            if (best_len > 0 && (sbest_len == 0 || best_len >= sbest_len + P.msl)) {
+            // (one symbol less when the seed is weak: shorter than a third of the literal run it would bridge)
+            if (best_len > 0 && (sbest_len == 0 || best_len >= sbest_len + P.msl - ((lit + lane > 3 * sbest_len) ? 1 : 0))) {
                 const int d = best_pos - pred_l;
                 hit_close = alive_l && ((best_pos > c.L) == pred_rc) && d >= -P.mrd && d <= P.mrd;
             } else if (sbest_len > 0) { best_len = sbest_len; best_pos = sbest_pos; hit_close = true; }

@@ -1315,21 +1315,28 @@ __global__ void __launch_bounds__(THREADS)
 k_bucket_runs(const uint32_t* __restrict__ rec, int stride /* 3: (w0, w1, pay); 2: (key bits below the bucket's, pay) */,
               const uint32_t* __restrict__ boff, int64_t n_buckets, int pbits, const uint32_t* __restrict__ blk2g, int blk_shift,
               uint32_t* __restrict__ gen, uint32_t* __restrict__ rowinfo, compact_map M, int* __restrict__ dup_per_genome,
-              unsigned int* __restrict__ overflow) {
+              const uint32_t* __restrict__ bucket_list /* null: all buckets; else the n_buckets listed ones */,
+              uint32_t* __restrict__ over_list, unsigned int* __restrict__ n_over) {
     constexpr int BK_SUB = 1 << SUBBITS, CAP = THREADS * BK_PER;
+    __shared__ uint32_t s_big;
     __shared__ uint64_t sk[CAP];                  // NARROW: key << 32 | pos; else (w0 << 32) | w1 -- in sub-bin order
     __shared__ uint32_t sp[NARROW ? 1 : CAP];
     __shared__ uint32_t sgen[CAP];                  // gen[] of the bucket in final order: leaves as one contiguous copy
     __shared__ uint32_t cnt[BK_SUB + 1], start[BK_SUB + 1];
     __shared__ uint32_t s_wave[THREADS / 64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int64_t bk = blockIdx.x; bk < n_buckets; bk += gridDim.x) {
+    for (int64_t it = blockIdx.x; it < n_buckets; it += gridDim.x) {
+        const int64_t bk = bucket_list ? (int64_t)bucket_list[it] : it;
         const uint32_t b0 = boff[bk], b1 = boff[bk + 1];
-        const int n = (int)(b1 - b0);
-        if (n <= 1) continue;                                  // empty, or one singleton k-mer
-        if (n > CAP) { if (threadIdx.x == 0) atomicOr(overflow, 1u); continue; }
+        const uint32_t n_u = b1 - b0;
+        if (n_u <= 1) continue;                                // empty, or one singleton k-mer
+        // a bucket this variant does not take is queued (for the larger variant, then for k_bucket_big): nothing
+        // of it has been written when it is handed on
+        if (n_u > (uint32_t)CAP) { if (threadIdx.x == 0) over_list[atomicAdd(n_over, 1u)] = (uint32_t)bk; continue; }
+        const int n = (int)n_u;
         lds_sync();
         for (int b = threadIdx.x; b <= BK_SUB; b += THREADS) cnt[b] = 0;
+        if (threadIdx.x == 0) s_big = 0;
         lds_sync();
         uint64_t key[BK_PER]; uint32_t pj[BK_PER]; uint32_t sb[BK_PER], ar[BK_PER];
         if (NARROW) {
@@ -1372,7 +1379,7 @@ k_bucket_runs(const uint32_t* __restrict__ rec, int stride /* 3: (w0, w1, pay); 
             constexpr int CPT = BK_SUB / THREADS;
             uint32_t c4[CPT], tot = 0;
 #pragma unroll
-            for (int u = 0; u < CPT; ++u) { c4[u] = cnt[CPT * threadIdx.x + u]; tot += c4[u]; }
+            for (int u = 0; u < CPT; ++u) { c4[u] = cnt[CPT * threadIdx.x + u]; tot += c4[u]; if (c4[u] > (uint32_t)BK_MAXBIN) s_big = 1; }
             uint32_t x = tot;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if (lane >= o) x += y; }
@@ -1386,6 +1393,8 @@ k_bucket_runs(const uint32_t* __restrict__ rec, int stride /* 3: (w0, w1, pay); 
             if (threadIdx.x == THREADS - 1) start[BK_SUB] = run;
         }
         lds_sync();
+        // a sub-bin beyond BK_MAXBIN (one k-mer occurring hundreds of times): the in-bin ranking is quadratic
+        if (s_big) { if (threadIdx.x == 0) over_list[atomicAdd(n_over, 1u)] = (uint32_t)bk; continue; }
 #pragma unroll
         for (int q = 0; q < BK_PER; ++q) if (rec_of(q) < n) {
             const uint32_t slot = start[sb[q]] + ar[q];
@@ -1397,7 +1406,6 @@ k_bucket_runs(const uint32_t* __restrict__ rec, int stride /* 3: (w0, w1, pay); 
             if (rec_of(q) >= n) continue;
             const uint32_t s0 = start[sb[q]], s1 = start[sb[q] + 1];
             if (s1 - s0 < 2) continue;                           // alone in its sub-bin: a singleton k-mer
-            if (s1 - s0 > BK_MAXBIN) { atomicOr(overflow, 1u); continue; }
             const uint64_t kq = key[q]; const uint32_t pq = pj[q];
             uint32_t lt = 0, eq = 0, before = 0; uint32_t prev_pay = 0; bool has_prev = false;
             if (NARROW) {
