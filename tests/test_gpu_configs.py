@@ -156,8 +156,8 @@ def test_bucket_pipeline_key_widths(k):
 
 def test_bucket_pipeline_large_buckets():
     """200 near-identical genomes: every k-mer is shared by ~200 of them, so some final buckets exceed the 1 536
-    entries of the ordinary bucket kernel; the stage is repeated with the 6 144-entry variant (still the own
-    pipeline, no radix sort) and the counts equal the oracle's."""
+    entries of the ordinary bucket kernel; exactly those are queued for the 6 144-entry variant (still the own
+    pipeline, no radix sort, nothing redone) and the counts equal the oracle's."""
     codes, offsets, names = synth.make_families(1, 200, length=40000, seed=5)
     gs = api.GenomeSet.from_codes(codes, offsets, names)
     osizes, opairs = orc.shared_all(codes, offsets, k=25)
@@ -166,6 +166,89 @@ def test_bucket_pipeline_large_buckets():
     prof = api.profile_get()
     api.profile_enable(False)
     scopes = {e['name']: e for e in prof}
-    assert 'radix_sort_pairs' not in scopes and scopes['bucket_sort_runs']['launches'] == 2
+    assert 'radix_sort_pairs' not in scopes and scopes['bucket_sort_runs']['launches'] == 1
+    assert scopes['bucket_sort_runs_wide']['launches'] == 1 and 'bucket_big' not in scopes
     assert list(sizes) == list(osizes)
     assert {(int(p['a']), int(p['b'])): int(p['shared']) for p in pairs} == opairs
+
+
+def _real_shaped_set(n_contigs, n_block, n_polya, seed, block_len=300, polya_len=120):
+    """log-uniform contigs (the contigs-1M generator) of which n_block carry one shared block (a conserved gene:
+    a k-mer present in n_block genomes) and n_polya a poly-A run (one k-mer, many times per genome)."""
+    codes, offsets, names, _ = synth.make_workload('contigs-1M', n_contigs)
+    codes = codes.copy()
+    rng = np.random.default_rng(seed)
+    block = rng.integers(0, 4, block_len).astype(np.uint8)
+    lens = np.diff(offsets)
+    ok = np.flatnonzero(lens > 2 * (block_len + polya_len))
+    for g in rng.choice(ok, n_block, replace=False):
+        p = int(offsets[g]) + int(rng.integers(0, lens[g] - block_len))
+        codes[p:p + block_len] = block
+    for g in rng.choice(ok, n_polya, replace=False):
+        p = int(offsets[g]) + int(rng.integers(0, lens[g] - polya_len))
+        codes[p:p + polya_len] = 0
+    return codes, offsets, names
+
+
+def test_high_multiplicity_kmers_stay_in_the_own_pipeline():
+    """Real-shaped data: 6 000 contigs of which 1 500 share a 300-bp block and 800 carry a
+    120-base poly-A run.  The buckets holding those k-mers exceed both LDS variants and are finished by
+    k_bucket_big; the call never falls back to the rocPRIM radix sort, and sizes and counts equal the oracle's."""
+    codes, offsets, names = _real_shaped_set(6000, 1500, 800, seed=9)
+    gs = api.GenomeSet.from_codes(codes, offsets, names)
+    osizes, opairs = orc.shared_all(codes, offsets, k=25)
+    api.profile_enable(True); api.profile_reset()
+    sizes, pairs = gs.kmer_shared(k=25)
+    scopes = {e['name']: e for e in api.profile_get()}
+    api.profile_enable(False)
+    assert 'radix_sort_pairs' not in scopes and 'radix_sort_full' not in scopes and 'bucket_big' in scopes
+    assert list(sizes) == list(osizes)
+    assert {(int(p['a']), int(p['b'])): int(p['shared']) for p in pairs} == opairs
+    # the same through k-mer range shards (compact source) and a fraction
+    tot = np.zeros(len(gs), dtype=np.int64); acc = {}
+    for sh in range(8):
+        sz, pr = gs.kmer_shared(k=25, shard=sh, n_shards=8)
+        tot += sz
+        for p in pr:
+            acc[(int(p['a']), int(p['b']))] = acc.get((int(p['a']), int(p['b'])), 0) + int(p['shared'])
+    assert list(tot) == list(osizes) and acc == opairs
+
+
+def test_high_multiplicity_index_time_at_100k_contigs():
+    """100 000 contigs, 5 000 sharing a 300-bp block and 2 000 with a poly-A run: the index stage (everything up to
+    the SpGEMM) stays within 1.3x of the same set without them, no radix sort; the pairs are exactly the family
+    pairs plus the pairs of block carriers (and the poly-A pairs that reach min-kmers)."""
+    base, offsets, names, _ = synth.make_workload('contigs-1M', 100000)
+
+    def run(codes):
+        gs = api.GenomeSet.from_codes(codes, offsets, names)
+        gs.kmer_shared(k=25, min_shared=30)            # warm-up (allocator)
+        api.profile_enable(True); api.profile_reset()
+        sizes, pairs = gs.kmer_shared(k=25, min_shared=30)
+        prof = {e['name']: e for e in api.profile_get()}
+        api.profile_enable(False)
+        idx_ms = sum(e['total_ms'] for n, e in prof.items() if n.startswith(('kmer_partition', 'bucket_')))
+        return sizes, pairs, prof, idx_ms
+    s0, p0, prof0, t0 = run(base)
+    codes, _, _ = _real_shaped_set(100000, 5000, 2000, seed=10)
+    s1, p1, prof1, t1 = run(codes)
+    assert 'radix_sort_pairs' not in prof1 and 'bucket_big' in prof1
+    assert t1 <= 1.3 * t0, (t0, t1)
+    assert len(p1) >= len(p0) + 5000 * 4999 // 2 * 0.99
+
+
+def test_set_without_any_kmer():
+    """>= 65 536 padded bases and not one valid k-mer (every record shorter than k, or all N): the
+    bucket pipeline returns empty outputs the SpGEMM can read (no null row pointers)."""
+    n = 1200
+    lens = np.full(n, 20, dtype=np.int64); lens[::2] = 24
+    offsets = np.concatenate([[0], np.cumsum(lens)])
+    codes = np.random.default_rng(1).integers(0, 4, int(offsets[-1])).astype(np.uint8)
+    gs = api.GenomeSet.from_codes(codes, offsets, ['s%d' % i for i in range(n)])
+    sizes, pairs = gs.kmer_shared(k=25)
+    assert not np.any(sizes) and len(pairs) == 0
+    codes = np.full(80000, 4, dtype=np.uint8)
+    offsets = np.array([0, 30000, 80000])
+    gs = api.GenomeSet.from_codes(codes, offsets, ['n1', 'n2'])
+    sizes, pairs = gs.kmer_shared(k=25)
+    assert not np.any(sizes) and len(pairs) == 0

@@ -1452,6 +1452,167 @@ k_bucket_runs(const uint32_t* __restrict__ rec, int stride /* 3: (w0, w1, pay); 
     }
 }
 
+// ---- buckets beyond the LDS variants (a k-mer present in thousands of genomes, poly-A runs, conserved genes):
+// one 1 024-thread workgroup sorts the bucket in global scratch -- a stable LSD radix sort on (key, position), eight
+// bits per pass, passes whose digit is constant skipped -- and then writes runs, duplicates, gen[] and row pointers
+// from the sorted order.  Duplicates (the same k-mer again in the same genome) are squeezed OUT of the genome list:
+// the non-duplicates of a run are written first, so a walk over a poly-A run of 100 000 entries in 2 000 genomes
+// touches 2 000 entries, not 100 000 (the tail of the run's slots is never read: walks end at their own genome).
+// Scratch per entry: two (u64 key, u32 position) copies; the dead copy of the last pass holds the two scan arrays.
+constexpr int BB_THREADS = 1024;
+constexpr int BB_DIGITS = 12;            // 4 bytes of position, then 8 bytes of key
+__device__ __forceinline__ uint32_t bb_scan_incl_add(uint32_t v, uint32_t* s_w, uint32_t* carry) {
+    // inclusive prefix sum over the workgroup, plus *carry (sum of the chunks before); returns with *carry advanced
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if (lane >= o) x += y; }
+    if (lane == 63) s_w[wv] = x;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < BB_THREADS / 64; ++i) { const uint32_t t = s_w[i]; if (i < wv) base += t; tot += t; }
+    const uint32_t r = *carry + base + x;
+    __syncthreads();
+    if (threadIdx.x == 0) *carry += tot;
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ uint32_t bb_scan_incl_max(uint32_t v, uint32_t* s_w, uint32_t* carry) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if (lane >= o) x = max(x, y); }
+    if (lane == 63) s_w[wv] = x;
+    __syncthreads();
+    uint32_t base = *carry, tot = *carry;
+#pragma unroll
+    for (int i = 0; i < BB_THREADS / 64; ++i) { const uint32_t t = s_w[i]; if (i < wv) base = max(base, t); tot = max(tot, t); }
+    const uint32_t r = max(base, x);
+    __syncthreads();
+    if (threadIdx.x == 0) *carry = tot;
+    __syncthreads();
+    return r;
+}
+__global__ void __launch_bounds__(BB_THREADS)
+k_bucket_big(const uint32_t* __restrict__ rec, int stride, const uint32_t* __restrict__ boff, const uint32_t* __restrict__ list,
+             const uint64_t* __restrict__ soff /* scratch offset of every listed bucket, in entries */, int pbits,
+             uint64_t* __restrict__ kA, uint32_t* __restrict__ pA, uint64_t* __restrict__ kB, uint32_t* __restrict__ pB,
+             const uint32_t* __restrict__ blk2g, int blk_shift, uint32_t* __restrict__ gen, uint32_t* __restrict__ rowinfo,
+             compact_map M, int* __restrict__ dup_per_genome) {
+    __shared__ uint32_t hist[BB_DIGITS][256];
+    __shared__ uint32_t gbase[256];
+    __shared__ uint32_t wcnt[BB_THREADS / 64][256];
+    __shared__ uint32_t s_w[BB_THREADS / 64];
+    __shared__ uint32_t s_carry_a, s_carry_b;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t bk = list[blockIdx.x];
+    const uint32_t b0 = boff[bk];
+    const uint32_t n = boff[bk + 1] - b0;
+    uint64_t* k0 = kA + soff[blockIdx.x]; uint32_t* p0 = pA + soff[blockIdx.x];
+    uint64_t* k1 = kB + soff[blockIdx.x]; uint32_t* p1 = pB + soff[blockIdx.x];
+    for (int i = threadIdx.x; i < BB_DIGITS * 256; i += BB_THREADS) (&hist[0][0])[i] = 0;
+    __syncthreads();
+    // copy in + all twelve digit histograms (a histogram does not depend on the order of the entries)
+    for (uint32_t i = threadIdx.x; i < n; i += BB_THREADS) {
+        const uint32_t* r = rec + (uint64_t)(b0 + i) * stride;
+        uint64_t key; uint32_t pos;
+        if (stride == 2) { key = r[0]; pos = r[1]; }
+        else { key = ((((uint64_t)r[0] << 32) | r[1]) << pbits) >> pbits; pos = r[2]; }
+        k0[i] = key; p0[i] = pos;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) atomicAdd(&hist[d][(pos >> (8 * d)) & 255u], 1u);
+#pragma unroll
+        for (int d = 0; d < 8; ++d) atomicAdd(&hist[4 + d][(uint32_t)(key >> (8 * d)) & 255u], 1u);
+    }
+    __syncthreads();
+    for (int d = 0; d < BB_DIGITS; ++d) {
+        // a digit that is the same in every entry needs no pass
+        bool trivial = false;
+        if (threadIdx.x < 256 && hist[d][threadIdx.x] == n) trivial = true;
+        if (__syncthreads_or(trivial)) continue;
+        if (threadIdx.x < 64) {          // exclusive scan of the 256 counters by one wave, four per lane
+            uint32_t c[4], tot = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { c[u] = hist[d][4 * lane + u]; tot += c[u]; }
+            uint32_t x = tot;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if (lane >= o) x += y; }
+            uint32_t run = x - tot;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { gbase[4 * lane + u] = run; run += c[u]; }
+        }
+        __syncthreads();
+        for (uint32_t c0 = 0; c0 < n; c0 += BB_THREADS) {
+            const uint32_t i = c0 + threadIdx.x;
+            const bool in = i < n;
+            uint64_t key = 0; uint32_t pos = 0;
+            if (in) { key = k0[i]; pos = p0[i]; }
+            const uint32_t dg = in ? (d < 4 ? (pos >> (8 * d)) & 255u : (uint32_t)(key >> (8 * (d - 4))) & 255u) : 256u;
+            // lanes of the wave holding the same digit (stable: rank = equal lanes below)
+            unsigned long long same = __ballot(in);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) { const unsigned long long bal = __ballot((dg >> b) & 1u); same &= ((dg >> b) & 1u) ? bal : ~bal; }
+            const uint32_t rank = (uint32_t)__popcll(same & ((1ULL << lane) - 1ULL));
+            for (int j = threadIdx.x; j < (BB_THREADS / 64) * 256; j += BB_THREADS) (&wcnt[0][0])[j] = 0;
+            __syncthreads();
+            if (in && rank == 0) wcnt[wv][dg] = (uint32_t)__popcll(same);
+            __syncthreads();
+            uint32_t before = 0;
+            if (in) for (int w2 = 0; w2 < wv; ++w2) before += wcnt[w2][dg];
+            const uint32_t dst = in ? gbase[dg] + before + rank : 0u;
+            __syncthreads();
+            if (threadIdx.x < 256) { uint32_t t = 0; for (int w2 = 0; w2 < BB_THREADS / 64; ++w2) t += wcnt[w2][threadIdx.x]; gbase[threadIdx.x] += t; }
+            if (in) { k1[dst] = key; p1[dst] = pos; }
+            __syncthreads();
+        }
+        { uint64_t* tk = k0; k0 = k1; k1 = tk; uint32_t* tp = p0; p0 = p1; p1 = tp; }
+        __threadfence_block();
+        __syncthreads();
+    }
+    // (k0, p0) = the bucket in (key, position) order.  Pass 1: head flags, duplicates; inclusive scans of
+    // "not a duplicate" (S) and of the run start (RS) go to the dead copy
+    uint32_t* S = reinterpret_cast<uint32_t*>(k1);        // 2 u32 per entry
+    if (threadIdx.x == 0) { s_carry_a = 0; s_carry_b = 0; }
+    __syncthreads();
+    for (uint32_t c0 = 0; c0 < n; c0 += BB_THREADS) {
+        const uint32_t i = c0 + threadIdx.x;
+        uint32_t nd = 0, hd = 0;
+        if (i < n) {
+            const uint64_t key = k0[i]; const uint32_t pos = p0[i];
+            const bool head = i == 0 || k0[i - 1] != key;
+            bool dup = false;
+            if (!head) {
+                const uint32_t g = M.cblk ? genome_of_compact(M, pos) : blk2g[pos >> blk_shift];
+                const uint32_t pp = p0[i - 1];
+                dup = (M.cblk ? genome_of_compact(M, pp) : blk2g[pp >> blk_shift]) == g;
+            }
+            nd = dup ? 0u : 1u; hd = head ? i : 0u;
+        }
+        const uint32_t s_incl = bb_scan_incl_add(nd, s_w, &s_carry_a);
+        const uint32_t rs = bb_scan_incl_max(hd, s_w, &s_carry_b);
+        if (i < n) { S[2 * (uint64_t)i] = s_incl | (nd ? 0u : 0x80000000u); S[2 * (uint64_t)i + 1] = rs; }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // Pass 2: outputs
+    for (uint32_t i = threadIdx.x; i < n; i += BB_THREADS) {
+        const uint32_t sv = S[2 * (uint64_t)i], rs = S[2 * (uint64_t)i + 1];
+        const uint32_t pos = p0[i];
+        const uint32_t g = M.cblk ? genome_of_compact(M, pos) : blk2g[pos >> blk_shift];
+        if (sv & 0x80000000u) { atomicAdd(&dup_per_genome[g], 1); continue; }
+        const uint32_t base = rs ? (S[2 * (uint64_t)(rs - 1)] & 0x7fffffffu) : 0u;
+        const uint32_t rank = (sv & 0x7fffffffu) - 1u - base;       // among the run's non-duplicates
+        // (a singleton k-mer writes its own slot: nobody reads it)
+        gen[(uint64_t)b0 + rs + rank] = g;
+        if (rank > 0) rowinfo[pos] = b0 + rs + 1u;
+    }
+}
+
+__global__ void k_bucket_sizes(const uint32_t* __restrict__ boff, const uint32_t* __restrict__ list, int64_t n, uint32_t* __restrict__ sizes) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) sizes[i] = boff[list[i] + 1] - boff[list[i]];
+}
+
 inline int grid_for(int64_t n, int block = 256, int max_blocks = 256 * 16) {
     int64_t b = (n + block - 1) / block;
     if (b < 1) b = 1;
@@ -1655,7 +1816,11 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
         VG_HIP(hipStreamSynchronize(s));
         vg_host_mark("buckets: count+scan done");
         *n_valid_out = (int64_t)n1;
-        if (n1 == 0) return true;
+        if (n1 == 0) {
+            // no valid k-mer at all (every record shorter than k, or all N): empty outputs the SpGEMM can read
+            rowinfo.alloc((size_t)n_rows_info); rowinfo.zero(s); gen.alloc(4); gen.zero(s);
+            return true;
+        }
         // two levels: the level-1 records are dead once level 2 has scattered them, and the genome list + row
         // descriptors are born after that: they take over the same block (48 GB less to allocate at 100 k genomes)
         a_rec.alloc(levels == 2 ? std::max((short_rec ? 2 : 3) * (size_t)n1 + 8, (size_t)n_rows_info + (size_t)n1 + 16) : 3 * (size_t)n1 + 8);
@@ -1712,32 +1877,57 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
     }
     if (gen.n < (size_t)n1 + 4) gen.alloc((size_t)n1 + 4);
     if (rowinfo.n < (size_t)n_rows_info) rowinfo.alloc((size_t)n_rows_info);      // (one level: nothing to take over)
-    dbuf<unsigned int> d_over(1);
-    unsigned int over = 0;
-    // ordinary buckets (mean <= 1 024): 256 threads, 9-bit sub-bins.  When one of them exceeds the 1 536 entries that
-    // variant takes (k-mers shared by dozens of genomes), the stage is repeated with the 1 024-thread variant
-    // (6 144 entries, 11-bit sub-bins) before the call is handed to the general path.
-    auto run_buckets = [&](bool big) {
-        VG_HIP(hipMemsetAsync(rowinfo.p, 0, (size_t)n_rows_info * sizeof(uint32_t), s));
-        d_over.zero(s);
+    // ordinary buckets (mean <= 1 024): 256 threads, 9-bit sub-bins.  A bucket beyond the 1 536 entries that variant
+    // takes (k-mers shared by dozens of genomes) is queued for the 1 024-thread variant (6 144 entries, 11-bit
+    // sub-bins); what that one cannot take either (a k-mer occurring many hundreds of times) goes to k_bucket_big.
+    // Every bucket is finished by exactly one of the three: nothing is redone, nothing leaves the own pipeline.
+    dbuf<unsigned int> d_nover(2); d_nover.zero(s);
+    dbuf<uint32_t> over1((size_t)nbk), over2;
+    VG_HIP(hipMemsetAsync(rowinfo.p, 0, (size_t)n_rows_info * sizeof(uint32_t), s));
+    const int pb = narrow ? 0 : total_bits;
+    unsigned int n_over[2] = {0, 0};
+#define VG_BUCKET_LAUNCH(NARROW_, THREADS_, SUBBITS_, GRID_, COUNT_, LIST_, OVER_, NOVER_) \
+    hipLaunchKernelGGL((k_bucket_runs<NARROW_, THREADS_, SUBBITS_>), dim3(GRID_), dim3(THREADS_), 0, s, f_rec, f_stride, (const uint32_t*)boff.p, (int64_t)(COUNT_), \
+                       pb, (const uint32_t*)g->d_blk2g.p, g->align_shift, gen.p, rowinfo.p, cmap, d_dups, (const uint32_t*)(LIST_), (OVER_), (NOVER_))
+    {
         vg_prof_scope ps("bucket_sort_runs", (double)n1 * ((narrow ? 8 : 12) + 4 + 8));
         const int grid_b = (int)std::min<int64_t>(nbk, 256 * 16);
-        const int pb = narrow ? 0 : total_bits;
-#define VG_BUCKET_LAUNCH(NARROW_, THREADS_, SUBBITS_) \
-        hipLaunchKernelGGL((k_bucket_runs<NARROW_, THREADS_, SUBBITS_>), dim3(grid_b), dim3(THREADS_), 0, s, f_rec, f_stride, (const uint32_t*)boff.p, nbk, \
-                           pb, (const uint32_t*)g->d_blk2g.p, g->align_shift, gen.p, rowinfo.p, cmap, d_dups, d_over.p)
-        if (big) { if (narrow) VG_BUCKET_LAUNCH(true, 1024, 11); else VG_BUCKET_LAUNCH(false, 1024, 11); }
-        else { if (narrow) VG_BUCKET_LAUNCH(true, BK_THREADS, 9); else VG_BUCKET_LAUNCH(false, BK_THREADS, 9); }
-#undef VG_BUCKET_LAUNCH
-        d_over.download(&over, 1, s);
+        if (big_buckets) { if (narrow) VG_BUCKET_LAUNCH(true, 1024, 11, grid_b, nbk, nullptr, over1.p, d_nover.p); else VG_BUCKET_LAUNCH(false, 1024, 11, grid_b, nbk, nullptr, over1.p, d_nover.p); }
+        else { if (narrow) VG_BUCKET_LAUNCH(true, BK_THREADS, 9, grid_b, nbk, nullptr, over1.p, d_nover.p); else VG_BUCKET_LAUNCH(false, BK_THREADS, 9, grid_b, nbk, nullptr, over1.p, d_nover.p); }
+        d_nover.download(n_over, 2, s);
         VG_HIP(hipStreamSynchronize(s));
-    };
-    run_buckets(big_buckets);
-    if (over && !big_buckets) {
-        VG_HIP(hipMemsetAsync(d_dups, 0, (size_t)g->n * sizeof(int), s));      // the duplicates counted by the first attempt
-        run_buckets(true);
     }
-    return over == 0;
+    const uint32_t* big_list = over1.p; unsigned int n_big = n_over[0];
+    if (n_big > 0 && !big_buckets) {
+        over2.alloc((size_t)n_big);
+        vg_prof_scope ps("bucket_sort_runs_wide", 0);
+        const int grid_b = (int)std::min<int64_t>(n_big, 256 * 16);
+        if (narrow) VG_BUCKET_LAUNCH(true, 1024, 11, grid_b, n_big, over1.p, over2.p, d_nover.p + 1); else VG_BUCKET_LAUNCH(false, 1024, 11, grid_b, n_big, over1.p, over2.p, d_nover.p + 1);
+        d_nover.download(n_over, 2, s);
+        VG_HIP(hipStreamSynchronize(s));
+        big_list = over2.p; n_big = n_over[1];
+    }
+#undef VG_BUCKET_LAUNCH
+    if (n_big > 0) {
+        // sizes of the queued buckets -> scratch offsets (the host adds them up)
+        dbuf<uint32_t> d_sz(n_big); std::vector<uint32_t> sz(n_big);
+        hipLaunchKernelGGL(k_bucket_sizes, dim3(grid_for(n_big)), dim3(256), 0, s, (const uint32_t*)boff.p, big_list, (int64_t)n_big, d_sz.p);
+        d_sz.download(sz.data(), n_big, s);
+        VG_HIP(hipStreamSynchronize(s));
+        std::vector<uint64_t> so(n_big); uint64_t tot = 0;
+        for (unsigned int i = 0; i < n_big; ++i) { so[i] = tot; tot += ((uint64_t)sz[i] + 3) & ~3ULL; }
+        dbuf<uint64_t> d_so(n_big);
+        d_so.upload(so.data(), n_big, s);
+        const uint32_t* d_lst_p = big_list;
+        dbuf<uint64_t> kA((size_t)tot + 4), kB((size_t)tot + 4); dbuf<uint32_t> pA((size_t)tot + 4), pB((size_t)tot + 4);
+        {
+            vg_prof_scope ps("bucket_big", (double)tot * 12.0 * 2.0);
+            hipLaunchKernelGGL(k_bucket_big, dim3(n_big), dim3(BB_THREADS), 0, s, f_rec, f_stride, (const uint32_t*)boff.p, d_lst_p,
+                               (const uint64_t*)d_so.p, pb, kA.p, pA.p, kB.p, pB.p, (const uint32_t*)g->d_blk2g.p, g->align_shift, gen.p, rowinfo.p, cmap, d_dups);
+        }
+        VG_HIP(hipStreamSynchronize(s));
+    }
+    return true;
 }
 
 // one pass over the k-mers of one shard: per-genome set sizes and (a, b, shared) of every pair
