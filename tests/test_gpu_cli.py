@@ -210,7 +210,47 @@ def test_rccl_two_ranks_when_two_gpus_are_visible():
 
 def test_rccl_collectives_one_rank():
     """The sharded C-ABI entry points through the built-in RCCL communicator (ncclCommInitRank / ncclAllGather
-    of the real librccl) with world size 1 (the test box has one GPU): results equal the plain calls."""
+    of the real librccl) with world size 1 (the test box has one GPU) and VG_DIST_FORCE=1, so that every exchange
+    really runs ncclAllGather (nranks = 1) and every merge kernel runs: results equal the plain calls."""
     p = subprocess.run([sys.executable, str(ROOT / 'tools' / 'rccl_one_rank.py')], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                        text=True, timeout=600)
     assert p.returncode == 0 and 'rccl ok: world 1' in p.stdout, (p.stdout[-500:], p.stderr[-1500:])
+
+
+def test_forced_exchanges_with_a_callback_communicator():
+    """VG_DIST_FORCE=1 with a one-rank callback communicator (the all-gather copies send to recv): the nomination /
+    union / count-sum protocol of vg_kmer_shared_sharded and the row / region gathers of vg_lz_align_sharded run in
+    this process and reproduce the plain calls, for min_shared = 1 and above."""
+    code = r"""
+import os, sys, ctypes as C
+os.environ['VG_DIST_FORCE'] = '1'
+sys.path.insert(0, %r)
+import numpy as np
+from vclust_amd import api, synth, _lib, distributed as D
+lib = _lib.load()
+calls = []
+def ag(ctx, send, recv, nbytes, on_device):
+    calls.append((int(nbytes), int(on_device)))
+    if on_device:
+        tmp = np.empty(max(int(nbytes), 1), dtype=np.uint8)
+        _lib.hip_copy(tmp.ctypes.data, send, nbytes, to_host=True); _lib.hip_copy(recv, tmp.ctypes.data, nbytes, to_host=False)
+    else:
+        C.memmove(recv, send, int(nbytes))
+    return 0
+cb = _lib.ALLGATHER_FN(ag)
+h = C.c_void_p(); _lib.check(lib.vg_comm_create(0, 1, C.cast(cb, C.c_void_p), None, C.byref(h)))
+comm = D.Comm(h, lib, keep=cb)
+codes, offsets, names = synth.make_families(8, 5, length=7000, seed=12)
+gs = api.GenomeSet.from_codes(codes, offsets, names)
+for ms in (1, 20, 200):
+    s0, p0 = gs.kmer_shared(k=25, min_shared=ms); s1, p1 = D.prefilter_counts(gs, comm, 25, 1.0, min_shared=ms)
+    o0 = np.lexsort((p0['b'], p0['a'])); o1 = np.lexsort((p1['b'], p1['a']))
+    assert np.array_equal(s0, s1) and np.array_equal(p0[o0], p1[o1]), ms
+assert any(d for _, d in calls)                      # device-to-device exchanges happened
+tasks = gs.align_tasks(gs.filter_pairs(s1, p1))
+st0, rg0 = gs.lz_align(tasks, want_regions=True); st1, rg1 = D.align_rows(gs, tasks, comm, None, True)
+assert np.array_equal(st0, st1) and len(rg0) == len(rg1)
+print('forced ok', len(calls))
+""" % str(ROOT)
+    p = subprocess.run([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0 and 'forced ok' in p.stdout, (p.stdout[-500:], p.stderr[-1500:])

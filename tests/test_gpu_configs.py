@@ -252,3 +252,50 @@ def test_set_without_any_kmer():
     gs = api.GenomeSet.from_codes(codes, offsets, ['n1', 'n2'])
     sizes, pairs = gs.kmer_shared(k=25)
     assert not np.any(sizes) and len(pairs) == 0
+
+
+@pytest.mark.slow
+def test_config4_contigs_1M_full_size():
+    """BASELINE configs[4] AT ITS SIZE: 1 000 000 contigs (25 Gbp, log-uniform 2-100 kb, families geometric(0.2) <= 20),
+    --min-kmers 30 (reference large.yml:65-72) on ONE MI355X.  25 G positions exceed the 32-bit row numbering of one
+    pass, so the prefilter runs its automatic k-mer sub-shard loop (7 passes over the bases, partial counts summed on
+    the device).  Size-independent properties + an oracle sample:
+      * every candidate pair lies inside one family, shared >= 30, and their number is within 10 % of the family pairs
+      * a second run returns bit-identical arrays (prefilter and align rows)
+      * set sizes and shared counts of sampled genomes / pairs equal the oracle's k-mer sets
+      * LZ rows of sampled tasks equal the oracle's; row invariants hold for all 7 M rows
+      * the dereplication cut (--out-ani 0.95 --out-qcov 0.85) keeps a non-trivial subset."""
+    codes, offsets, names, _ = synth.make_workload('contigs-1M', 1000000)
+    assert len(names) == 1000000 and offsets[-1] > 24e9
+    fam = np.array([int(n.split('_')[0][3:]) for n in names])
+    gs = api.GenomeSet.from_codes(codes, offsets, names)
+    sizes, pairs = gs.kmer_shared(k=25, min_shared=30)
+    cand = gs.filter_pairs(sizes, pairs, k=25, min_kmers=30, min_ident=0.7)
+    assert np.all(fam[cand['a']] == fam[cand['b']]) and np.all(cand['shared'] >= 30)
+    n_expected = sum(c * (c - 1) // 2 for c in np.bincount(fam))
+    assert 0.9 * n_expected <= len(cand) <= n_expected
+    tasks = gs.align_tasks(cand)
+    stats = gs.lz_align(tasks)
+    lens = gs.lengths()
+    assert len(stats) == 2 * len(cand)
+    assert np.all(stats['n_match'] <= stats['aln_len']) and np.all(stats['aln_len'] <= lens[tasks['q']])
+    # determinism
+    sizes2, pairs2 = gs.kmer_shared(k=25, min_shared=30)
+    assert np.array_equal(sizes, sizes2)
+    o1 = np.lexsort((pairs['b'], pairs['a'])); o2 = np.lexsort((pairs2['b'], pairs2['a']))
+    assert np.array_equal(pairs[o1], pairs2[o2])
+    assert np.array_equal(stats, gs.lz_align(tasks))
+    # oracle sample: k-mer sets of 40 pairs, LZ rows of 24 tasks
+    rng = np.random.default_rng(4)
+    for i in rng.choice(len(cand), 40, replace=False):
+        a, b = int(cand[i]['a']), int(cand[i]['b'])
+        ka = orc.kmer_set(codes[offsets[a]:offsets[a + 1]], 25); kb = orc.kmer_set(codes[offsets[b]:offsets[b + 1]], 25)
+        assert len(ka) == sizes[a] and len(kb) == sizes[b]
+        assert len(np.intersect1d(ka, kb, assume_unique=True)) == int(cand[i]['shared']), (a, b)
+    for i in rng.choice(len(tasks), 24, replace=False):
+        q, r = int(tasks[i]['q']), int(tasks[i]['r'])
+        assert orc.lz_pair_stat(codes[offsets[q]:offsets[q + 1]], codes[offsets[r]:offsets[r + 1]]) == tuple(int(x) for x in stats[i]), (q, r)
+    # the dereplication flags of large.yml:65-72 on the rows
+    ani = stats['n_match'] / np.maximum(stats['aln_len'], 1); qcov = stats['aln_len'] / lens[tasks['q']]
+    kept = np.count_nonzero((ani >= 0.95) & (qcov >= 0.85))
+    assert 0 < kept < len(stats)

@@ -1,7 +1,9 @@
 """RCCL smoke test of the built-in communicator (vg_comm_rccl_create): the sharded C-ABI entry points on the
-real RCCL with the ranks torchrun gives it (world size 1 on a one-GPU box) must reproduce the plain
-single-process results."""
+real RCCL with the ranks torchrun gives it must reproduce the plain single-process results.  With one rank (a
+one-GPU box) VG_DIST_FORCE=1 keeps every exchange and merge on the path: ncclAllGather with nranks = 1, the staging
+through HBM, the nomination / union / count-sum protocol of the prefilter and the row / region gathers of align."""
 import os, sys, pathlib
+os.environ.setdefault('VG_DIST_FORCE', '1')
 os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29533')
 os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1'); os.environ.setdefault('LOCAL_RANK', '0')
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
@@ -25,6 +27,10 @@ gs = api.GenomeSet.from_codes(codes, offsets, names)
 s0, p0 = gs.kmer_shared(k=25, min_shared=1)
 s1, p1 = D.prefilter_counts(gs, comm, 25, 1.0)
 assert np.array_equal(s0, s1)
+s20, p20 = gs.kmer_shared(k=25, min_shared=20)
+s21, p21 = D.prefilter_counts(gs, comm, 25, 1.0, min_shared=20)
+o0 = np.lexsort((p20['b'], p20['a'])); o1 = np.lexsort((p21['b'], p21['a']))
+assert np.array_equal(s20, s21) and np.array_equal(p20[o0], p21[o1]) and len(p21) > 0
 k0 = np.sort((p0['a'].astype(np.int64) << 32) | p0['b']); k1 = np.sort((p1['a'].astype(np.int64) << 32) | p1['b'])
 assert np.array_equal(k0, k1) and int(p0['shared'].sum()) == int(p1['shared'].sum())
 cand = gs.filter_pairs(s1, p1)

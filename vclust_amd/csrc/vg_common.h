@@ -103,6 +103,10 @@ struct vg_genomes {
 };
 void vg_length_order(const vg_genomes* g);        // fills g->len_order / g->len_rank on first use
 
+// one k-mer range shard of vg_kmer_shared with the (a, b, shared) records left in HBM (vg_prefilter.hip; used by vg_dist.hip)
+void vg_kmer_shared_device(vg_genomes* g, int k, double fraction, int shard, int n_shards, uint32_t min_shared,
+                           int64_t* set_sizes, dbuf<vg_pair_count>& pairs, int64_t* n_pairs);
+
 // ---------------------------------------------------------------- host threads
 // fn(lo, hi, t) over [0, n) cut into contiguous chunks, one per thread (the library's host loops over
 // 10^5..10^6 pairs / tasks: a few threads are enough; an exception in a chunk is rethrown on the caller)

@@ -78,11 +78,13 @@ int vg_host_threads() {
 
 // ---------------------------------------------------------------- caching device allocator
 namespace {
+struct block_info { size_t size; int device; };
 std::mutex g_alloc_mu;
-std::multimap<size_t, void*> g_free_blocks;          // size -> block
-std::map<void*, size_t> g_block_size;                // every live or cached block
-size_t g_cached_bytes = 0;
+std::multimap<size_t, void*> g_free_blocks;          // size -> block (blocks of the current device only)
+std::map<void*, block_info> g_block_size;            // every live or cached block and the device that owns it
+size_t g_cached_bytes = 0, g_live_bytes = 0;
 constexpr size_t ALLOC_GRAN = 1 << 12;
+const bool g_alloc_trace = [] { const char* e = getenv("VG_ALLOC_TRACE"); return e && *e && *e != '0'; }();
 }
 
 void* vg_dev_alloc(size_t bytes) {
@@ -92,28 +94,37 @@ void* vg_dev_alloc(size_t bytes) {
         std::lock_guard<std::mutex> lk(g_alloc_mu);
         auto it = g_free_blocks.lower_bound(want);
         if (it != g_free_blocks.end() && it->first <= want + want / 4 + (1 << 20)) {
-            void* p = it->second; g_cached_bytes -= it->first; g_free_blocks.erase(it);
+            void* p = it->second; g_cached_bytes -= it->first; g_live_bytes += it->first; g_free_blocks.erase(it);
             return p;
         }
     }
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, want);
     if (e != hipSuccess) {
+        (void)hipGetLastError();                      // the failure is handled here: do not leave it as the sticky "last error"
+        if (g_alloc_trace) fprintf(stderr, "[vg alloc] hipMalloc(%.1f MB) failed: trimming %.1f GB of cached blocks (live %.1f GB)\n", want / 1048576.0, g_cached_bytes / 1073741824.0, g_live_bytes / 1073741824.0);
         vg_dev_trim();                                // give cached blocks back and retry once
         e = hipMalloc(&p, want);
-        if (e != hipSuccess) throw vg_error(VG_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+        if (e != hipSuccess) { (void)hipGetLastError(); throw vg_error(VG_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)); }
     }
     std::lock_guard<std::mutex> lk(g_alloc_mu);
-    g_block_size[p] = want;
+    g_block_size[p] = { want, g_device };
+    g_live_bytes += want;
+    if (g_alloc_trace && want >= (64u << 20)) fprintf(stderr, "[vg alloc] hipMalloc %.1f MB (live %.1f GB, cached %.1f GB)\n", want / 1048576.0, g_live_bytes / 1073741824.0, g_cached_bytes / 1073741824.0);
     return p;
 }
 
 void vg_dev_free(void* p) {
     if (!p) return;
-    std::lock_guard<std::mutex> lk(g_alloc_mu);
+    std::unique_lock<std::mutex> lk(g_alloc_mu);
     auto it = g_block_size.find(p);
-    if (it == g_block_size.end()) { (void)hipFree(p); return; }
-    g_free_blocks.emplace(it->second, p); g_cached_bytes += it->second;
+    if (it == g_block_size.end()) { lk.unlock(); (void)hipFree(p); return; }
+    g_live_bytes -= it->second.size;
+    if (it->second.device != g_device) {
+        // a block of another device (a genome set freed after vg_set_device): it must not be handed out here
+        g_block_size.erase(it); lk.unlock(); (void)hipFree(p); return;
+    }
+    g_free_blocks.emplace(it->second.size, p); g_cached_bytes += it->second.size;
 }
 
 void vg_dev_trim() {

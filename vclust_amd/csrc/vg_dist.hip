@@ -4,20 +4,27 @@
 // over the GPUs of one node with a gather of result rows over RCCL/xGMI.  The path shards without any
 // collective inside the kernels:
 //   prefilter  rank r handles the k-mers whose shard hash falls into range r of `world` (vg_kmer_shared's
-//              shard/n_shards): per-genome set sizes and per-pair shared counts of the shards ADD UP.  The
-//              partial (a, b, count) records -- set sizes ride along as diagonal records (g, g, size) -- travel in
-//              ONE padded all-gather (plus a one-word count exchange) and are summed on the device (radix sort
-//              + segmented reduction).  Thresholds can only be applied to the SUM, so they follow the merge.
+//              shard/n_shards): per-genome set sizes and per-pair shared counts of the shards ADD UP.  What travels
+//              is bounded by the RESULT, not by the partial lists: a pair whose total reaches min_shared has at least
+//              ceil(min_shared / world) shared k-mers on SOME rank, so (1) every rank nominates the pairs it holds
+//              that many of (keys only), (2) the union of the nominations is formed on every rank, (3) every rank
+//              reports its count for each pair of the union (0 if it has none) and the counts are summed.  Pairs that
+//              share one or two k-mers per range -- the bulk of the partial lists on real data -- never leave their
+//              GPU.  Everything stays in HBM: all-gathers are device to device, sort / unique / lookup are kernels.
 //   align      the task list is cut into `world` contiguous reference-id ranges with about equal task counts --
 //              a pure function of the list, so no communication -- each rank indexes 1/world of the references
 //              and the 12-byte rows come back in one all-gather of known sizes (regions: one more, variable).
 // The exchange itself is a vg_comm: either callbacks supplied by the host application (MPI, torch.distributed
 // over gloo for CPU tests, ...) or the built-in RCCL communicator (vg_comm_rccl_create: ncclAllGather on the
-// library's stream; librccl is loaded on first use so that hosts without it still load this library).
-// Failures are agreed on before every exchange (one status word per rank), so a rank that fails makes every rank
-// return the error instead of leaving the others inside a collective.
+// library's stream; librccl is loaded on first use so that hosts without it still load this library; the entry
+// points are typed by <rccl/rccl.h>, so a signature drift is a compile error here, not a crash on the 8-GPU box).
+// Failures are agreed on before every exchange (one status word per rank): every compute section between two
+// exchanges runs under a guard whose status feeds the next agreement, so a rank that fails -- in its shard, in an
+// allocation, in a sort -- makes every rank return the error instead of leaving the others inside a collective.
+// VG_DIST_FORCE=1 (tests): a world of one still goes through the exchanges and merges (RCCL accepts nranks = 1).
 #include "vg_common.h"
 #include <rocprim/rocprim.hpp>
+#include <rccl/rccl.h>
 #include <dlfcn.h>
 #include <algorithm>
 #include <cstring>
@@ -26,41 +33,53 @@
 // ------------------------------------------------------------------ communicator
 struct vg_comm {
     int rank = 0, world = 1;
+    bool force = false;                                          // VG_DIST_FORCE: exchanges also at world == 1
     vg_allgather_fn allgather = nullptr; void* ctx = nullptr;   // callback form
     // built-in RCCL form
-    void* nccl_lib = nullptr; void* nccl_comm = nullptr;
-    int (*p_allgather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
-    int (*p_destroy)(void*) = nullptr;
+    void* nccl_lib = nullptr; ncclComm_t nccl_comm = nullptr;
+    decltype(&ncclAllGather) p_allgather = nullptr;
+    decltype(&ncclCommDestroy) p_destroy = nullptr;
+    // HBM staging of host gathers over RCCL: reserved inside guarded sections, so that an allocation failure is
+    // agreed on like any other instead of striking between an agreement and its exchange
+    mutable dbuf<char> st_send, st_recv;
+    bool exchanges() const { return world > 1 || (force && (allgather || p_allgather)); }
 };
 
 namespace {
 void check(int rc) { if (rc != VG_OK) throw vg_error(rc, vg_last_error()); }
+bool env_force() { const char* e = getenv("VG_DIST_FORCE"); return e && *e && *e != '0'; }
 
+void reserve_staging(const vg_comm* c, int64_t bytes) {
+    if (!c->p_allgather) return;
+    const size_t need = (size_t)std::max<int64_t>(bytes, 64);
+    if (c->st_send.n < need) c->st_send.alloc(need + need / 4);
+    if (c->st_recv.n < need * c->world) c->st_recv.alloc((need + need / 4) * c->world);
+}
 // all ranks contribute `bytes` bytes of HOST memory; recv = world * bytes in rank order
 void gather_host(const vg_comm* c, const void* send, void* recv, int64_t bytes) {
-    if (c->world == 1) { memcpy(recv, send, (size_t)bytes); return; }
+    if (!c->exchanges()) { memcpy(recv, send, (size_t)bytes); return; }
     if (c->allgather) {
         if (c->allgather(c->ctx, send, recv, bytes, 0) != 0) throw vg_error(VG_EIO, "vg_comm: allgather callback failed");
         return;
     }
     // RCCL moves device memory: stage through HBM
     hipStream_t s = vg_stream();
-    dbuf<char> d_send((size_t)std::max<int64_t>(bytes, 1)), d_recv((size_t)std::max<int64_t>(bytes, 1) * c->world);
-    d_send.upload((const char*)send, (size_t)bytes, s);
-    if (c->p_allgather(d_send.p, d_recv.p, (size_t)bytes, /*ncclChar*/ 0, c->nccl_comm, s) != 0) throw vg_error(VG_EIO, "ncclAllGather failed");
-    d_recv.download((char*)recv, (size_t)bytes * c->world, s);
+    reserve_staging(c, bytes);
+    VG_HIP(hipMemcpyAsync(c->st_send.p, send, (size_t)bytes, hipMemcpyHostToDevice, s));
+    if (c->p_allgather(c->st_send.p, c->st_recv.p, (size_t)bytes, ncclChar, c->nccl_comm, s) != ncclSuccess) throw vg_error(VG_EIO, "ncclAllGather failed");
+    VG_HIP(hipMemcpyAsync(recv, c->st_recv.p, (size_t)bytes * c->world, hipMemcpyDeviceToHost, s));
     VG_HIP(hipStreamSynchronize(s));
 }
 // the same for DEVICE memory (buffers of the current device)
 void gather_device(const vg_comm* c, const void* send, void* recv, int64_t bytes) {
     hipStream_t s = vg_stream();
-    if (c->world == 1) { VG_HIP(hipMemcpyAsync(recv, send, (size_t)bytes, hipMemcpyDeviceToDevice, s)); return; }
+    if (!c->exchanges()) { VG_HIP(hipMemcpyAsync(recv, send, (size_t)bytes, hipMemcpyDeviceToDevice, s)); return; }
     if (c->allgather) {
         VG_HIP(hipStreamSynchronize(s));                          // the callback runs on the application's own stream
         if (c->allgather(c->ctx, send, recv, bytes, 1) != 0) throw vg_error(VG_EIO, "vg_comm: allgather callback failed");
         return;
     }
-    if (c->p_allgather(send, recv, (size_t)bytes, 0, c->nccl_comm, s) != 0) throw vg_error(VG_EIO, "ncclAllGather failed");
+    if (c->p_allgather(send, recv, (size_t)bytes, ncclChar, c->nccl_comm, s) != ncclSuccess) throw vg_error(VG_EIO, "ncclAllGather failed");
 }
 // every rank learns whether any rank failed: throws the first failure on all of them
 void agree(const vg_comm* c, int my_rc, const char* what) {
@@ -69,15 +88,54 @@ void agree(const vg_comm* c, int my_rc, const char* what) {
     for (int r = 0; r < c->world; ++r) if (all[(size_t)r] != 0)
         throw vg_error(all[(size_t)r], std::string(what) + ": rank " + std::to_string(r) + " failed" + (r == c->rank ? std::string(": ") + vg_last_error() : std::string()));
 }
+// a compute section between two exchanges: its failure becomes this rank's status word of the next agreement
+template <class F> void guarded(const vg_comm* c, const char* what, F fn) {
+    int rc = VG_OK;
+    try { fn(); }
+    catch (const vg_error& e) { vg_set_error("%s", e.what()); rc = e.code; }
+    catch (const std::bad_alloc&) { vg_set_error("out of host memory"); rc = VG_ENOMEM; }
+    catch (const std::exception& e) { vg_set_error("%s", e.what()); rc = VG_EINVAL; }
+    agree(c, rc, what);
+}
 
-struct rec_t { uint64_t key; uint64_t val; };
-__global__ void k_split_rec(const rec_t* __restrict__ rec, const int64_t* __restrict__ valid_prefix, int world, int64_t pad, int64_t n_out,
-                            uint64_t* __restrict__ keys, uint64_t* __restrict__ vals) {
-    // gathered layout: world blocks of `pad` records, the first cnt[r] of block r are real; valid_prefix[r] = real records before block r
+inline int dgrid(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 4096)); }
+// keys of the pairs this rank nominates (count >= thr), compacted through a cursor (their order is irrelevant: they are sorted next)
+__global__ void k_nominate(const vg_pair_count* __restrict__ rec, int64_t n, uint32_t thr, uint64_t* __restrict__ keys, unsigned long long* __restrict__ cursor) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const vg_pair_count r = rec[i];
+        if (r.shared >= thr) keys[atomicAdd(cursor, 1ULL)] = ((uint64_t)r.a << 32) | r.b;
+    }
+}
+__global__ void k_local_keys(const vg_pair_count* __restrict__ rec, int64_t n, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const vg_pair_count r = rec[i]; keys[i] = ((uint64_t)r.a << 32) | r.b; vals[i] = r.shared;
+    }
+}
+// gathered layout: world blocks of `pad` keys, the first cnt[r] of block r are real -> one dense array
+__global__ void k_squeeze_keys(const uint64_t* __restrict__ all, const int64_t* __restrict__ prefix, int world, int64_t pad, uint64_t* __restrict__ out) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)world * pad; i += (int64_t)gridDim.x * blockDim.x) {
         const int r = (int)(i / pad); const int64_t j = i - (int64_t)r * pad;
-        const int64_t cnt = valid_prefix[r + 1] - valid_prefix[r];
-        if (j < cnt) { const rec_t x = rec[i]; keys[valid_prefix[r] + j] = x.key; vals[valid_prefix[r] + j] = x.val; }
+        if (j < prefix[r + 1] - prefix[r]) out[prefix[r] + j] = all[i];
+    }
+}
+// this rank's count of every pair of the union (binary search in its sorted keys)
+__global__ void k_lookup_counts(const uint64_t* __restrict__ uni, int64_t nu, const uint64_t* __restrict__ lk, const uint32_t* __restrict__ lv, int64_t nl,
+                                uint32_t* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nu; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t key = uni[i];
+        int64_t lo = 0, hi = nl;
+        while (lo < hi) { const int64_t m = (lo + hi) >> 1; if (lk[m] < key) lo = m + 1; else hi = m; }
+        out[i] = (lo < nl && lk[lo] == key) ? lv[lo] : 0u;
+    }
+}
+__global__ void k_sum_counts(const uint64_t* __restrict__ uni, int64_t nu, const uint32_t* __restrict__ cnt /* world x nu */, int world, uint32_t min_shared,
+                             vg_pair_count* __restrict__ out, unsigned long long* __restrict__ cursor) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nu; i += (int64_t)gridDim.x * blockDim.x) {
+        uint64_t t = 0;
+        for (int r = 0; r < world; ++r) t += cnt[(int64_t)r * nu + i];
+        if (t < min_shared) continue;
+        const unsigned long long o = atomicAdd(cursor, 1ULL);
+        out[o].a = (uint32_t)(uni[i] >> 32); out[o].b = (uint32_t)uni[i]; out[o].shared = (uint32_t)t;
     }
 }
 }  // namespace
@@ -85,7 +143,7 @@ __global__ void k_split_rec(const rec_t* __restrict__ rec, const int64_t* __rest
 extern "C" int vg_comm_create(int rank, int world, vg_allgather_fn allgather, void* ctx, vg_comm** out) {
     VG_API_BEGIN
     if (!out || world < 1 || rank < 0 || rank >= world || (world > 1 && !allgather)) throw vg_error(VG_EINVAL, "vg_comm_create: bad arguments");
-    vg_comm* c = new vg_comm; c->rank = rank; c->world = world; c->allgather = allgather; c->ctx = ctx;
+    vg_comm* c = new vg_comm; c->rank = rank; c->world = world; c->allgather = allgather; c->ctx = ctx; c->force = env_force();
     *out = c;
     VG_API_END
 }
@@ -97,27 +155,31 @@ static void* load_rccl() {
 
 extern "C" int vg_rccl_unique_id(void* out, int64_t bytes) {
     VG_API_BEGIN
-    if (!out || bytes < 128) throw vg_error(VG_EINVAL, "vg_rccl_unique_id: needs a 128-byte buffer");
+    static_assert(sizeof(ncclUniqueId) == 128, "the C ABI hands the RCCL unique id around as 128 bytes");
+    if (!out || bytes < (int64_t)sizeof(ncclUniqueId)) throw vg_error(VG_EINVAL, "vg_rccl_unique_id: needs a 128-byte buffer");
     void* h = load_rccl();
-    auto get = (int (*)(void*))dlsym(h, "ncclGetUniqueId");
+    auto get = (decltype(&ncclGetUniqueId))dlsym(h, "ncclGetUniqueId");
     if (!get) throw vg_error(VG_EIO, "librccl has no ncclGetUniqueId");
-    if (get(out) != 0) throw vg_error(VG_EIO, "ncclGetUniqueId failed");
+    ncclUniqueId id;
+    if (get(&id) != ncclSuccess) throw vg_error(VG_EIO, "ncclGetUniqueId failed");
+    memcpy(out, &id, sizeof id);
     VG_API_END
 }
 
 extern "C" int vg_comm_rccl_create(int rank, int world, const void* unique_id, int64_t id_bytes, vg_comm** out) {
     VG_API_BEGIN
-    if (!out || !unique_id || id_bytes < 128 || world < 1 || rank < 0 || rank >= world) throw vg_error(VG_EINVAL, "vg_comm_rccl_create: bad arguments");
+    if (!out || !unique_id || id_bytes < (int64_t)sizeof(ncclUniqueId) || world < 1 || rank < 0 || rank >= world) throw vg_error(VG_EINVAL, "vg_comm_rccl_create: bad arguments");
     vg_require_device();
     void* h = load_rccl();
-    struct id128 { char b[128]; } id; memcpy(id.b, unique_id, 128);
-    auto init = (int (*)(void**, int, id128, int))dlsym(h, "ncclCommInitRank");
-    auto ag = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(h, "ncclAllGather");
-    auto destroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
+    ncclUniqueId id; memcpy(&id, unique_id, sizeof id);
+    auto init = (decltype(&ncclCommInitRank))dlsym(h, "ncclCommInitRank");
+    auto ag = (decltype(&ncclAllGather))dlsym(h, "ncclAllGather");
+    auto destroy = (decltype(&ncclCommDestroy))dlsym(h, "ncclCommDestroy");
     if (!init || !ag || !destroy) throw vg_error(VG_EIO, "librccl lacks ncclCommInitRank / ncclAllGather / ncclCommDestroy");
-    void* comm = nullptr;
-    if (init(&comm, world, id, rank) != 0) throw vg_error(VG_EIO, "ncclCommInitRank failed");
-    vg_comm* c = new vg_comm; c->rank = rank; c->world = world; c->nccl_lib = h; c->nccl_comm = comm; c->p_allgather = ag; c->p_destroy = destroy;
+    ncclComm_t comm = nullptr;
+    if (init(&comm, world, id, rank) != ncclSuccess) throw vg_error(VG_EIO, "ncclCommInitRank failed");
+    vg_comm* c = new vg_comm; c->rank = rank; c->world = world; c->nccl_lib = h; c->nccl_comm = comm; c->p_allgather = ag; c->p_destroy = destroy; c->force = env_force();
+    reserve_staging(c, 1 << 16);                    // status words and counts never allocate
     *out = c;
     VG_API_END
 }
@@ -125,6 +187,7 @@ extern "C" int vg_comm_rccl_create(int rank, int world, const void* unique_id, i
 extern "C" void vg_comm_free(vg_comm* c) {
     if (!c) return;
     if (c->nccl_comm && c->p_destroy) { (void)hipDeviceSynchronize(); (void)c->p_destroy(c->nccl_comm); }
+    c->st_send.release(); c->st_recv.release();
     delete c;
 }
 extern "C" int vg_comm_rank(const vg_comm* c) { return c ? c->rank : 0; }
@@ -168,52 +231,86 @@ extern "C" int vg_kmer_shared_sharded(vg_genomes* g, int k, double fraction, uin
     if (!g || !c || !set_sizes || !pairs || !n_pairs) throw vg_error(VG_EINVAL, "vg_kmer_shared_sharded: null argument");
     *pairs = nullptr; *n_pairs = 0;
     const int n = vg_genomes_count(g);
-    if (c->world == 1) { check(vg_kmer_shared(g, k, fraction, 0, 1, min_shared, set_sizes, pairs, n_pairs)); return VG_OK; }
-    // this rank's shard of the k-mer range: partial sizes and partial counts (every pair with >= 1 shared k-mer here)
-    std::vector<int64_t> part_sizes((size_t)std::max(n, 1), 0);
-    vg_pair_count* loc = nullptr; int64_t n_loc = 0;
-    int rc = vg_kmer_shared(g, k, fraction, c->rank, c->world, 1u, part_sizes.data(), &loc, &n_loc);
-    struct guard { void* p; ~guard() { if (p) vg_free(p); } } gl{ loc };
-    agree(c, rc, "prefilter shard");
-    // records: (a << 32 | b, count) and the diagonal (g << 32 | g, size)
-    const int64_t n_rec = n_loc + n;
-    std::vector<rec_t> rec((size_t)std::max<int64_t>(n_rec, 1));
-    for (int64_t i = 0; i < n_loc; ++i) rec[(size_t)i] = { ((uint64_t)loc[i].a << 32) | loc[i].b, loc[i].shared };
-    for (int i = 0; i < n; ++i) rec[(size_t)(n_loc + i)] = { ((uint64_t)i << 32) | (uint64_t)i, (uint64_t)part_sizes[(size_t)i] };
-    std::vector<int64_t> cnt((size_t)c->world, 0);
-    gather_host(c, &n_rec, cnt.data(), sizeof(int64_t));
-    int64_t pad = 1, total = 0; std::vector<int64_t> prefix((size_t)c->world + 1, 0);
-    for (int r = 0; r < c->world; ++r) { pad = std::max(pad, cnt[(size_t)r]); prefix[(size_t)r + 1] = prefix[(size_t)r] + cnt[(size_t)r]; }
-    total = prefix[(size_t)c->world];
+    if (!c->exchanges()) { check(vg_kmer_shared(g, k, fraction, 0, 1, min_shared, set_sizes, pairs, n_pairs)); return VG_OK; }
+    const int W = c->world;
+    if (min_shared < 1) min_shared = 1;
     hipStream_t s = vg_stream();
-    dbuf<rec_t> d_send((size_t)pad), d_all((size_t)pad * c->world);
-    d_send.zero(s);
-    if (n_rec) d_send.upload(rec.data(), (size_t)n_rec, s);
-    gather_device(c, d_send.p, d_all.p, pad * (int64_t)sizeof(rec_t));
-    // sum the partial records on the device: sort by key, reduce by key
-    dbuf<int64_t> d_prefix((size_t)c->world + 1); d_prefix.upload(prefix.data(), prefix.size(), s);
-    const size_t nt = (size_t)std::max<int64_t>(total, 1);
-    dbuf<uint64_t> keys(nt), vals(nt), keys2(nt), vals2(nt), ukeys(nt), usums(nt); dbuf<unsigned long long> d_nu(1);
-    hipLaunchKernelGGL(k_split_rec, dim3(1024), dim3(256), 0, s, d_all.p, (const int64_t*)d_prefix.p, c->world, pad, total, keys.p, vals.p);
-    size_t tb = 0, tb2 = 0;
-    VG_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys.p, keys2.p, vals.p, vals2.p, (size_t)total, 0u, 64u, s));
-    VG_HIP(rocprim::reduce_by_key(nullptr, tb2, keys2.p, vals2.p, (size_t)total, ukeys.p, usums.p, d_nu.p, rocprim::plus<uint64_t>(), rocprim::equal_to<uint64_t>(), s));
-    dbuf<char> tmp(std::max(tb, tb2));
-    VG_HIP(rocprim::radix_sort_pairs((void*)tmp.p, tb, keys.p, keys2.p, vals.p, vals2.p, (size_t)total, 0u, 64u, s));
-    VG_HIP(rocprim::reduce_by_key((void*)tmp.p, tb2, keys2.p, vals2.p, (size_t)total, ukeys.p, usums.p, d_nu.p, rocprim::plus<uint64_t>(), rocprim::equal_to<uint64_t>(), s));
-    unsigned long long nu = 0; d_nu.download(&nu, 1, s); VG_HIP(hipStreamSynchronize(s));
-    std::vector<uint64_t> hk((size_t)nu), hv((size_t)nu);
-    if (nu) { ukeys.download(hk.data(), (size_t)nu, s); usums.download(hv.data(), (size_t)nu, s); VG_HIP(hipStreamSynchronize(s)); }
-    for (int i = 0; i < n; ++i) set_sizes[i] = 0;
-    vg_pair_count* out = (vg_pair_count*)malloc(sizeof(vg_pair_count) * std::max<size_t>(1, (size_t)nu));
-    if (!out) throw vg_error(VG_ENOMEM, "out of host memory");
-    int64_t m = 0;
-    for (size_t i = 0; i < (size_t)nu; ++i) {
-        const uint32_t a = (uint32_t)(hk[i] >> 32), b = (uint32_t)hk[i];
-        if (a == b) { if ((int)a < n) set_sizes[a] = (int64_t)hv[i]; }
-        else if (hv[i] >= min_shared) { out[m].a = a; out[m].b = b; out[m].shared = (uint32_t)hv[i]; ++m; }
+    // ---- this rank's shard of the k-mer range: partial sizes (host) and partial counts (left in HBM)
+    std::vector<int64_t> part_sizes((size_t)std::max(n, 1), 0);
+    dbuf<vg_pair_count> d_loc; int64_t n_loc = 0;
+    dbuf<uint64_t> d_nom, lk, lk2; dbuf<uint32_t> lv, lv2; dbuf<unsigned long long> d_cur(1);
+    unsigned long long n_nom = 0;
+    const uint32_t thr = (min_shared + (uint32_t)W - 1) / (uint32_t)W;        // pigeonhole: some rank holds >= ceil(T / W) of a pair that reaches T
+    guarded(c, "prefilter shard", [&] {
+        vg_kmer_shared_device(g, k, fraction, c->rank, W, 1u, part_sizes.data(), d_loc, &n_loc);
+        // nominations, and this rank's records sorted by key for the lookups of step 3
+        d_nom.alloc((size_t)std::max<int64_t>(n_loc, 1)); d_cur.zero(s);
+        lk.alloc((size_t)std::max<int64_t>(n_loc, 1)); lk2.alloc(lk.n); lv.alloc(lk.n); lv2.alloc(lk.n);
+        if (n_loc) {
+            hipLaunchKernelGGL(k_nominate, dim3(dgrid(n_loc)), dim3(256), 0, s, (const vg_pair_count*)d_loc.p, n_loc, thr, d_nom.p, d_cur.p);
+            hipLaunchKernelGGL(k_local_keys, dim3(dgrid(n_loc)), dim3(256), 0, s, (const vg_pair_count*)d_loc.p, n_loc, lk.p, lv.p);
+            size_t tb = 0;
+            VG_HIP(rocprim::radix_sort_pairs(nullptr, tb, lk.p, lk2.p, lv.p, lv2.p, (size_t)n_loc, 0u, 64u, s));
+            dbuf<char> tmp(tb);
+            VG_HIP(rocprim::radix_sort_pairs((void*)tmp.p, tb, lk.p, lk2.p, lv.p, lv2.p, (size_t)n_loc, 0u, 64u, s));
+        }
+        d_cur.download(&n_nom, 1, s);
+        VG_HIP(hipStreamSynchronize(s));
+        d_loc.release();
+        reserve_staging(c, (int64_t)sizeof(int64_t) * std::max(n, 1));
+    });
+    // ---- set sizes add up (n words per rank)
+    {
+        std::vector<int64_t> all_sizes((size_t)std::max(n, 1) * W, 0);
+        gather_host(c, part_sizes.data(), all_sizes.data(), (int64_t)sizeof(int64_t) * std::max(n, 1));
+        for (int i = 0; i < n; ++i) { int64_t t = 0; for (int r = 0; r < W; ++r) t += all_sizes[(size_t)r * std::max(n, 1) + i]; set_sizes[i] = t; }
     }
-    *pairs = out; *n_pairs = m;
+    // ---- 1: nominations travel (keys only), 2: their union
+    std::vector<int64_t> cnt((size_t)W, 0), prefix((size_t)W + 1, 0);
+    const int64_t my_nom = (int64_t)n_nom;
+    gather_host(c, &my_nom, cnt.data(), sizeof(int64_t));
+    int64_t pad = 1; for (int r = 0; r < W; ++r) { pad = std::max(pad, cnt[(size_t)r]); prefix[(size_t)r + 1] = prefix[(size_t)r] + cnt[(size_t)r]; }
+    const int64_t total = prefix[(size_t)W];
+    dbuf<uint64_t> d_send, d_all, d_uni; dbuf<uint32_t> d_cnt, d_cnt_all; unsigned long long nu = 0;
+    guarded(c, "prefilter nominations", [&] {
+        d_send.alloc((size_t)pad); d_all.alloc((size_t)pad * W); d_send.zero(s);
+        if (my_nom) VG_HIP(hipMemcpyAsync(d_send.p, d_nom.p, sizeof(uint64_t) * (size_t)my_nom, hipMemcpyDeviceToDevice, s));
+    });
+    gather_device(c, d_send.p, d_all.p, pad * (int64_t)sizeof(uint64_t));
+    guarded(c, "prefilter union", [&] {
+        const size_t nt = (size_t)std::max<int64_t>(total, 1);
+        dbuf<uint64_t> keys(nt), keys2(nt); dbuf<int64_t> d_prefix((size_t)W + 1); dbuf<unsigned long long> d_nu(1);
+        d_prefix.upload(prefix.data(), prefix.size(), s);
+        d_uni.alloc(nt);
+        if (total) {
+            hipLaunchKernelGGL(k_squeeze_keys, dim3(dgrid(pad * W)), dim3(256), 0, s, (const uint64_t*)d_all.p, (const int64_t*)d_prefix.p, W, pad, keys.p);
+            size_t tb = 0, tb2 = 0;
+            VG_HIP(rocprim::radix_sort_keys(nullptr, tb, keys.p, keys2.p, (size_t)total, 0u, 64u, s));
+            VG_HIP(rocprim::unique(nullptr, tb2, keys2.p, d_uni.p, d_nu.p, (size_t)total, rocprim::equal_to<uint64_t>(), s));
+            dbuf<char> tmp(std::max(tb, tb2));
+            VG_HIP(rocprim::radix_sort_keys((void*)tmp.p, tb, keys.p, keys2.p, (size_t)total, 0u, 64u, s));
+            VG_HIP(rocprim::unique((void*)tmp.p, tb2, keys2.p, d_uni.p, d_nu.p, (size_t)total, rocprim::equal_to<uint64_t>(), s));
+            d_nu.download(&nu, 1, s); VG_HIP(hipStreamSynchronize(s));
+        }
+        // ---- 3: this rank's count of every pair of the union (the union is the same on every rank)
+        d_cnt.alloc((size_t)std::max<unsigned long long>(nu, 1)); d_cnt_all.alloc(d_cnt.n * W);
+        if (nu) hipLaunchKernelGGL(k_lookup_counts, dim3(dgrid((int64_t)nu)), dim3(256), 0, s, (const uint64_t*)d_uni.p, (int64_t)nu, (const uint64_t*)lk2.p,
+                                   (const uint32_t*)lv2.p, n_loc, d_cnt.p);
+    });
+    if (nu) gather_device(c, d_cnt.p, d_cnt_all.p, (int64_t)nu * (int64_t)sizeof(uint32_t));
+    vg_pair_count* out = nullptr; unsigned long long n_out = 0;
+    guarded(c, "prefilter sums", [&] {
+        dbuf<vg_pair_count> d_out((size_t)std::max<unsigned long long>(nu, 1));
+        d_cur.zero(s);
+        if (nu) hipLaunchKernelGGL(k_sum_counts, dim3(dgrid((int64_t)nu)), dim3(256), 0, s, (const uint64_t*)d_uni.p, (int64_t)nu, (const uint32_t*)d_cnt_all.p, W, min_shared, d_out.p, d_cur.p);
+        d_cur.download(&n_out, 1, s); VG_HIP(hipStreamSynchronize(s));
+        out = (vg_pair_count*)malloc(sizeof(vg_pair_count) * std::max<size_t>(1, (size_t)n_out));
+        if (!out) throw vg_error(VG_ENOMEM, "out of host memory");
+        if (n_out) { d_out.download(out, (size_t)n_out, s); VG_HIP(hipStreamSynchronize(s)); }
+        // the cursor order depends on scheduling; every rank returns the same list
+        std::sort(out, out + n_out, [](const vg_pair_count& x, const vg_pair_count& y) { return x.a != y.a ? x.a < y.a : x.b < y.b; });
+    });
+    *pairs = out; *n_pairs = (int64_t)n_out;
     VG_API_END
 }
 
@@ -222,41 +319,47 @@ extern "C" int vg_lz_align_sharded(vg_genomes* g, const vg_task* tasks, int64_t 
                                    vg_pair_stat* stats, vg_region** regions, int64_t* n_regions) {
     VG_API_BEGIN
     if (!g || !c || (!tasks && n_tasks) || !p || (!stats && n_tasks)) throw vg_error(VG_EINVAL, "vg_lz_align_sharded: null argument");
-    if (c->world == 1) { check(vg_lz_align(g, tasks, n_tasks, p, stats, regions, n_regions)); return VG_OK; }
+    if (!c->exchanges()) { check(vg_lz_align(g, tasks, n_tasks, p, stats, regions, n_regions)); return VG_OK; }
     if (regions) { *regions = nullptr; if (n_regions) *n_regions = 0; }
-    std::vector<int32_t> owner((size_t)std::max<int64_t>(n_tasks, 1));
-    check(vg_align_owner(tasks, n_tasks, vg_genomes_count(g), c->world, owner.data()));
-    std::vector<int64_t> mine; std::vector<int64_t> per_rank((size_t)c->world, 0);
-    for (int64_t t = 0; t < n_tasks; ++t) { per_rank[(size_t)owner[(size_t)t]]++; if (owner[(size_t)t] == c->rank) mine.push_back(t); }
-    std::vector<vg_task> my_tasks(mine.size());
-    for (size_t i = 0; i < mine.size(); ++i) my_tasks[i] = tasks[mine[i]];
-    std::vector<vg_pair_stat> my_stats(std::max<size_t>(1, mine.size()));
-    vg_region* my_reg = nullptr; int64_t my_nreg = 0;
-    int rc = vg_lz_align(g, my_tasks.data(), (int64_t)my_tasks.size(), p, my_stats.data(), regions ? &my_reg : nullptr, regions ? &my_nreg : nullptr);
-    struct guard { void* q; ~guard() { if (q) vg_free(q); } } gr{ my_reg };
-    agree(c, rc, "align shard");
-    // rows: sizes are known to every rank (per_rank), one padded all-gather
-    int64_t pad = 1; for (int r = 0; r < c->world; ++r) pad = std::max(pad, per_rank[(size_t)r]);
-    std::vector<vg_pair_stat> send((size_t)pad), all((size_t)pad * c->world);
-    memset(send.data(), 0, sizeof(vg_pair_stat) * (size_t)pad);
-    if (!mine.empty()) memcpy(send.data(), my_stats.data(), sizeof(vg_pair_stat) * mine.size());
+    const int W = c->world;
+    std::vector<int32_t> owner; std::vector<int64_t> mine, per_rank((size_t)W, 0);
+    std::vector<vg_pair_stat> my_stats, send, all;
+    vg_region* my_reg = nullptr; int64_t my_nreg = 0, pad = 1;
+    struct guard { vg_region** q; ~guard() { if (*q) vg_free(*q); } } gr{ &my_reg };
+    guarded(c, "align shard", [&] {
+        owner.resize((size_t)std::max<int64_t>(n_tasks, 1));
+        check(vg_align_owner(tasks, n_tasks, vg_genomes_count(g), W, owner.data()));
+        for (int64_t t = 0; t < n_tasks; ++t) { per_rank[(size_t)owner[(size_t)t]]++; if (owner[(size_t)t] == c->rank) mine.push_back(t); }
+        std::vector<vg_task> my_tasks(mine.size());
+        for (size_t i = 0; i < mine.size(); ++i) my_tasks[i] = tasks[mine[i]];
+        my_stats.resize(std::max<size_t>(1, mine.size()));
+        check(vg_lz_align(g, my_tasks.data(), (int64_t)my_tasks.size(), p, my_stats.data(), regions ? &my_reg : nullptr, regions ? &my_nreg : nullptr));
+        // rows: sizes are known to every rank (per_rank), one padded all-gather
+        for (int r = 0; r < W; ++r) pad = std::max(pad, per_rank[(size_t)r]);
+        send.assign((size_t)pad, vg_pair_stat{}); all.resize((size_t)pad * W);
+        if (!mine.empty()) memcpy(send.data(), my_stats.data(), sizeof(vg_pair_stat) * mine.size());
+        reserve_staging(c, pad * (int64_t)sizeof(vg_pair_stat));
+    });
     gather_host(c, send.data(), all.data(), pad * (int64_t)sizeof(vg_pair_stat));
-    std::vector<int64_t> cursor((size_t)c->world, 0);
+    std::vector<int64_t> cursor((size_t)W, 0);
     for (int64_t t = 0; t < n_tasks; ++t) { const int r = owner[(size_t)t]; stats[t] = all[(size_t)(r * pad + cursor[(size_t)r]++)]; }
     if (regions) {
         // regions: variable length, task ids translated to the global list
         for (int64_t i = 0; i < my_nreg; ++i) my_reg[i].task = (uint32_t)mine[my_reg[i].task];
-        std::vector<int64_t> cnt((size_t)c->world, 0);
+        std::vector<int64_t> cnt((size_t)W, 0);
         gather_host(c, &my_nreg, cnt.data(), sizeof(int64_t));
-        int64_t rpad = 1, tot = 0; for (int r = 0; r < c->world; ++r) { rpad = std::max(rpad, cnt[(size_t)r]); tot += cnt[(size_t)r]; }
-        std::vector<vg_region> rs((size_t)rpad), ra((size_t)rpad * c->world);
-        memset(rs.data(), 0, sizeof(vg_region) * (size_t)rpad);
-        if (my_nreg) memcpy(rs.data(), my_reg, sizeof(vg_region) * (size_t)my_nreg);
+        int64_t rpad = 1, tot = 0; for (int r = 0; r < W; ++r) { rpad = std::max(rpad, cnt[(size_t)r]); tot += cnt[(size_t)r]; }
+        std::vector<vg_region> rs, ra; vg_region* o = nullptr;
+        guarded(c, "align regions", [&] {
+            rs.assign((size_t)rpad, vg_region{}); ra.resize((size_t)rpad * W);
+            if (my_nreg) memcpy(rs.data(), my_reg, sizeof(vg_region) * (size_t)my_nreg);
+            o = (vg_region*)malloc(sizeof(vg_region) * std::max<size_t>(1, (size_t)tot));
+            if (!o) throw vg_error(VG_ENOMEM, "out of host memory");
+            reserve_staging(c, rpad * (int64_t)sizeof(vg_region));
+        });
         gather_host(c, rs.data(), ra.data(), rpad * (int64_t)sizeof(vg_region));
-        vg_region* o = (vg_region*)malloc(sizeof(vg_region) * std::max<size_t>(1, (size_t)tot));
-        if (!o) throw vg_error(VG_ENOMEM, "out of host memory");
         int64_t w = 0;
-        for (int r = 0; r < c->world; ++r) { memcpy(o + w, ra.data() + (size_t)r * rpad, sizeof(vg_region) * (size_t)cnt[(size_t)r]); w += cnt[(size_t)r]; }
+        for (int r = 0; r < W; ++r) { memcpy(o + w, ra.data() + (size_t)r * rpad, sizeof(vg_region) * (size_t)cnt[(size_t)r]); w += cnt[(size_t)r]; }
         *regions = o; if (n_regions) *n_regions = tot;
     }
     VG_API_END

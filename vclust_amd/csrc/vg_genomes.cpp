@@ -313,14 +313,9 @@ extern "C" int vg_genomes_to_device(vg_genomes* g) {
     int dev = 0; VG_HIP(hipGetDevice(&dev));
     if (g->device == dev) return VG_OK;
     if (g->device >= 0) {
-        // resident on another device: those buffers must go back to THAT device's driver, not into this one's cache
-        int cur = dev;
-        (void)hipSetDevice(g->device);
-        for (void* q : { (void*)g->d_packed.p, (void*)g->d_nmask.p, (void*)g->d_base_off.p, (void*)g->d_len.p, (void*)g->d_has_n.p, (void*)g->d_blk2g.p })
-            if (q) (void)hipFree(q);
-        g->d_packed.p = nullptr; g->d_nmask.p = nullptr; g->d_base_off.p = nullptr; g->d_len.p = nullptr; g->d_has_n.p = nullptr; g->d_blk2g.p = nullptr;
-        g->d_packed.n = g->d_nmask.n = g->d_base_off.n = g->d_len.n = g->d_has_n.n = g->d_blk2g.n = 0;
-        (void)hipSetDevice(cur);
+        // resident on another device: the allocator knows every block's device and returns these to THAT device's
+        // driver instead of caching them here (vg_dev_free)
+        g->d_packed.release(); g->d_nmask.release(); g->d_base_off.release(); g->d_len.release(); g->d_has_n.release(); g->d_blk2g.release();
         g->device = -1;
     }
     hipStream_t s = vg_stream();

@@ -1,13 +1,14 @@
-// vg_prefilter.hip — Kmer-db prefilter on gfx950: canonical k-mer extraction from 2-bit
-// packed genomes, inverted index by one stable device radix sort, and the sparse
-// genome x genome shared-k-mer matrix as a row-wise SpGEMM (A * A^T) with LDS hash
-// accumulators.  Replaces `kmer-db build` + `all2all-sp` (vclust.py:953-1017); restates
-// SURVEY §8a K1/K2, parity-checked against oracle/prefilter_oracle.c.
+// vg_prefilter.hip — Kmer-db prefilter on gfx950: canonical k-mer extraction from 2-bit packed genomes, the
+// inverted index by an own two-level MSD partition + LDS bucket sort (no general radix sort on the hot path), and
+// the sparse genome x genome shared-k-mer matrix as a row-wise SpGEMM (A * A^T) with LDS hash accumulators.
+// Replaces `kmer-db build` + `all2all-sp` (vclust.py:953-1017); restates SURVEY §8a K1/K2, parity-checked against
+// oracle/prefilter_oracle.c.
 //
-// All kernels are HBM-streaming integer kernels (no MFMA): per padded base position the
-// pipeline reads 3 bits of sequence, writes/reads one u64 key per sort pass and one u64
-// row pointer for the SpGEMM; the only random traffic is the read of the short genome
-// lists of shared k-mers.
+// All kernels are HBM / latency bound integer kernels (no MFMA).  Per padded base position the pipeline reads 3 bits
+// of sequence (twice: histogram and scatter), writes and reads one 8-byte level-1 record and one 8-byte level-2
+// record, and writes one u32 of genome list (CSC side) and one u32 row pointer (CSR side: 0, or 1 + the start of
+// the k-mer's run in the genome list); the random traffic is the row-pointer scatter of the bucket kernel and the
+// reads of the short genome lists of shared k-mers in the SpGEMM.
 #include "vg_common.h"
 #include <rocprim/rocprim.hpp>
 #include <algorithm>
@@ -1678,10 +1679,10 @@ static void run_extract_sort(vg_genomes* g, int k, double fraction, int shard, i
         const int64_t W = P / 64;
         out.wave_mask.alloc((size_t)W + 1); dbuf<uint32_t> wave_cnt((size_t)W + 1); out.wave_base.alloc((size_t)W + 1);
         VG_HIP(hipMemsetAsync(wave_cnt.p + W, 0, sizeof(uint32_t), s));
-        // slots per 256-position chunk for the kept k-mers (twice the expectation + slack; a chunk that
+        // slots per 256-position chunk for the kept k-mers (1.5 x the expectation + slack; a chunk that
         // overflows sends the call to the recomputing emit pass)
         const double keep = (use_frac ? fraction : 1.0) / n_shards;
-        const int stage_cap = (int)std::min<double>(256.0, std::ceil(2.0 * 256.0 * keep) + 24.0);
+        const int stage_cap = (int)std::min<double>(256.0, std::ceil(1.5 * 256.0 * keep) + 24.0);
         const int64_t n_chunks = (W + 3) / 4;
         dbuf<uint64_t> stage((size_t)n_chunks * stage_cap);
         dbuf<unsigned int> d_over(1); d_over.zero(s);
@@ -1704,7 +1705,9 @@ static void run_extract_sort(vg_genomes* g, int k, double fraction, int shard, i
         if (total64 >= (1LL << 32) - 1) throw vg_error(VG_EOVERFLOW, "more than 2^32 k-mers in one shard: use more shards");
         nv = total; n_sort = (int64_t)total;
         const size_t na = (size_t)std::max<int64_t>(n_sort, 1);
-        keys_a.alloc(na); keys_b.alloc(na); pos_a.alloc(na + 4); pos_b.alloc(na);
+        keys_a.alloc(na); pos_a.alloc(na + 4);
+        if (do_sort) { keys_b.alloc(na); pos_b.alloc(na); }         // the sort's outputs (the bucket pipeline sorts nothing)
+        vg_host_mark("extract: counted");
         if (n_sort > 0 && !over) {
             vg_prof_scope ps("kmer_emit", (double)n_sort * (8.0 + 12.0));
             hipLaunchKernelGGL(k_kmer_gather, dim3(grid_for(n_chunks * 64)), dim3(256), 0, s, stage.p, stage_cap, out.wave_base.p, W, keys_a.p, pos_a.p);
@@ -1728,6 +1731,7 @@ static void run_extract_sort(vg_genomes* g, int k, double fraction, int shard, i
     if (!do_sort) {
         // the bucket pipeline takes the kept k-mers as they are (compact mode only: every entry is a real k-mer)
         VG_HIP(hipStreamSynchronize(s));
+        vg_host_mark("extract: emitted");
         out.keys = std::move(keys_a); out.pos = std::move(pos_a); out.n_valid = (int64_t)nv; out.low_bit = (int)end_bit;
         return;
     }
@@ -1931,8 +1935,10 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
 }
 
 // one pass over the k-mers of one shard: per-genome set sizes and (a, b, shared) of every pair
+// dev_out != nullptr: the pairs stay in HBM (*dev_out, *dev_n of them) and host_pairs is left empty
 static void kmer_shared_pass(vg_genomes* g, int k, double fraction, int shard, int n_shards, uint32_t min_shared,
-                             int64_t* set_sizes, std::vector<vg_pair_count>& host_pairs) {
+                             int64_t* set_sizes, std::vector<vg_pair_count>& host_pairs,
+                             dbuf<vg_pair_count>* dev_out = nullptr, unsigned long long* dev_n = nullptr) {
     hipStream_t s = vg_stream();
     const int n = g->n;
     sorted_index si;
@@ -2038,11 +2044,13 @@ static void kmer_shared_pass(vg_genomes* g, int k, double fraction, int shard, i
         // one round trip in the common case: overflow count, pair count and the first pairs together
         constexpr size_t EAGER = 1 << 16;
         uint32_t nover = 0; unsigned long long produced = 0;
-        host_pairs.resize(std::min<size_t>(EAGER, (size_t)cap));
-        d_nover.download(&nover, 1, s); d_cursor.download(&produced, 1, s); d_out.download(host_pairs.data(), host_pairs.size(), s);
+        host_pairs.resize(dev_out ? 0 : std::min<size_t>(EAGER, (size_t)cap));
+        d_nover.download(&nover, 1, s); d_cursor.download(&produced, 1, s);
+        if (!dev_out) d_out.download(host_pairs.data(), host_pairs.size(), s);
         VG_HIP(hipStreamSynchronize(s));
         vg_host_mark("spgemm done");
-        if (nover == 0 && produced <= host_pairs.size()) { host_pairs.resize((size_t)produced); break; }
+        if (dev_out && nover == 0 && produced <= cap) { *dev_out = std::move(d_out); *dev_n = produced; break; }
+        if (!dev_out && nover == 0 && produced <= host_pairs.size()) { host_pairs.resize((size_t)produced); break; }
         if (nover > 0) {
             // second try with the 64 KiB table for the rows that overflowed the small one
             dbuf<uint32_t> d_rows2(nover), d_over2(nover);
@@ -2075,6 +2083,7 @@ static void kmer_shared_pass(vg_genomes* g, int k, double fraction, int shard, i
         d_cursor.download(&produced, 1, s);
         VG_HIP(hipStreamSynchronize(s));
         if (produced <= cap) {
+            if (dev_out) { *dev_out = std::move(d_out); *dev_n = produced; break; }
             host_pairs.resize((size_t)produced);
             if (produced) d_out.download(host_pairs.data(), (size_t)produced, s);
             VG_HIP(hipStreamSynchronize(s));
@@ -2082,6 +2091,46 @@ static void kmer_shared_pass(vg_genomes* g, int k, double fraction, int shard, i
         }
         cap = produced + produced / 8 + 1024;     // rerun with a buffer that fits
     }
+}
+
+// sum of partial pair records (the sub-shards of one call): device radix sort on (a << 32 | b) + reduce by key
+namespace {
+__global__ void k_pair_keys(const vg_pair_count* __restrict__ rec, int64_t n, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const vg_pair_count r = rec[i]; keys[i] = ((uint64_t)r.a << 32) | r.b; vals[i] = r.shared;
+    }
+}
+__global__ void k_pair_emit(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ sums, int64_t n, uint32_t min_shared,
+                            vg_pair_count* __restrict__ out, unsigned long long* __restrict__ cursor) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (sums[i] < min_shared) continue;
+        const unsigned long long o = atomicAdd(cursor, 1ULL);
+        out[o].a = (uint32_t)(keys[i] >> 32); out[o].b = (uint32_t)keys[i]; out[o].shared = sums[i];
+    }
+}
+}
+static void sum_partial_pairs(const std::vector<vg_pair_count>& all, uint32_t min_shared, std::vector<vg_pair_count>& out) {
+    out.clear();
+    const size_t n = all.size();
+    if (!n) return;
+    hipStream_t s = vg_stream();
+    dbuf<vg_pair_count> d_rec(n); d_rec.upload(all.data(), n, s);
+    dbuf<uint64_t> k1(n), k2(n), uk(n); dbuf<uint32_t> v1(n), v2(n), us(n); dbuf<unsigned long long> d_nu(1), d_cur(1);
+    hipLaunchKernelGGL(k_pair_keys, dim3(grid_for((int64_t)n)), dim3(256), 0, s, (const vg_pair_count*)d_rec.p, (int64_t)n, k1.p, v1.p);
+    size_t tb = 0, tb2 = 0;
+    VG_HIP(rocprim::radix_sort_pairs(nullptr, tb, k1.p, k2.p, v1.p, v2.p, n, 0u, 64u, s));
+    VG_HIP(rocprim::reduce_by_key(nullptr, tb2, k2.p, v2.p, n, uk.p, us.p, d_nu.p, rocprim::plus<uint32_t>(), rocprim::equal_to<uint64_t>(), s));
+    dbuf<char> tmp(std::max(tb, tb2));
+    VG_HIP(rocprim::radix_sort_pairs((void*)tmp.p, tb, k1.p, k2.p, v1.p, v2.p, n, 0u, 64u, s));
+    VG_HIP(rocprim::reduce_by_key((void*)tmp.p, tb2, k2.p, v2.p, n, uk.p, us.p, d_nu.p, rocprim::plus<uint32_t>(), rocprim::equal_to<uint64_t>(), s));
+    unsigned long long nu = 0, no = 0; d_nu.download(&nu, 1, s); VG_HIP(hipStreamSynchronize(s));
+    d_cur.zero(s);
+    hipLaunchKernelGGL(k_pair_emit, dim3(grid_for((int64_t)nu)), dim3(256), 0, s, (const uint64_t*)uk.p, (const uint32_t*)us.p, (int64_t)nu, min_shared, d_rec.p, d_cur.p);
+    d_cur.download(&no, 1, s); VG_HIP(hipStreamSynchronize(s));
+    out.resize((size_t)no);
+    if (no) { d_rec.download(out.data(), (size_t)no, s); VG_HIP(hipStreamSynchronize(s)); }
+    // (the emit order depends on scheduling: callers that need an order sort; vg_kmer_shared promises none)
+    std::sort(out.begin(), out.end(), [](const vg_pair_count& x, const vg_pair_count& y) { return x.a != y.a ? x.a < y.a : x.b < y.b; });
 }
 
 extern "C" int vg_kmer_shared(vg_genomes* g, int k, double fraction, int shard, int n_shards, uint32_t min_shared,
@@ -2104,30 +2153,25 @@ extern "C" int vg_kmer_shared(vg_genomes* g, int k, double fraction, int shard, 
     const bool dense = fraction >= 1.0 && n_shards == 1;
     int sub = 1;
     if (g_force_subshards > 0) sub = g_force_subshards;
-    else if (dense ? P >= (1LL << 32) : expect >= 3.0e9) sub = (int)std::ceil(expect / 2.0e9);
+    else if (dense ? P >= (1LL << 32) : expect >= 3.9e9) sub = (int)std::ceil(expect / 3.6e9);      // row numbers of one pass are 32 bits
     if (sub < 1) sub = 1;
     std::vector<vg_pair_count> acc;
     if (sub == 1) {
         kmer_shared_pass(g, k, fraction, shard, n_shards, min_shared, set_sizes, acc);
     } else {
+        // partial (a, b, count) records of every sub-shard are collected as they come and summed ONCE on the
+        // device: sort on (a, b), reduce by key, threshold on the sum
         std::vector<int64_t> part((size_t)n);
         for (int i = 0; i < n; ++i) set_sizes[i] = 0;
-        auto key_less = [](const vg_pair_count& x, const vg_pair_count& y) { return x.a != y.a ? x.a < y.a : x.b < y.b; };
+        std::vector<vg_pair_count> all;
         for (int t = 0; t < sub; ++t) {
             std::vector<vg_pair_count> cur;
             kmer_shared_pass(g, k, fraction, shard * sub + t, n_shards * sub, 1u, part.data(), cur);
             for (int i = 0; i < n; ++i) set_sizes[i] += part[i];
-            std::sort(cur.begin(), cur.end(), key_less);
-            std::vector<vg_pair_count> merged; merged.reserve(acc.size() + cur.size());
-            size_t i = 0, j = 0;
-            while (i < acc.size() || j < cur.size()) {
-                if (j == cur.size() || (i < acc.size() && key_less(acc[i], cur[j]))) merged.push_back(acc[i++]);
-                else if (i == acc.size() || key_less(cur[j], acc[i])) merged.push_back(cur[j++]);
-                else { vg_pair_count m = acc[i++]; m.shared += cur[j++].shared; merged.push_back(m); }
-            }
-            acc.swap(merged);
+            all.insert(all.end(), cur.begin(), cur.end());
         }
-        if (min_shared > 1) acc.erase(std::remove_if(acc.begin(), acc.end(), [&](const vg_pair_count& x) { return x.shared < min_shared; }), acc.end());
+        vg_host_mark("sub-shards done");
+        sum_partial_pairs(all, min_shared, acc);
     }
     vg_host_mark("pass done");
     vg_pair_count* outp = (vg_pair_count*)malloc(sizeof(vg_pair_count) * std::max<size_t>(1, acc.size()));
@@ -2136,6 +2180,34 @@ extern "C" int vg_kmer_shared(vg_genomes* g, int k, double fraction, int shard, 
     *pairs = outp; *n_pairs = (int64_t)acc.size();
     vg_host_mark("vg_kmer_shared: return");
     VG_API_END
+}
+
+// internal (vg_dist.hip): one shard's pairs left in HBM.  A shard that needs sub-shards goes through the host sum
+// and is uploaded again (sets beyond 2^32 positions per rank).
+void vg_kmer_shared_device(vg_genomes* g, int k, double fraction, int shard, int n_shards, uint32_t min_shared,
+                           int64_t* set_sizes, dbuf<vg_pair_count>& pairs, int64_t* n_pairs) {
+    vg_require_device();
+    int rc = vg_genomes_to_device(g); if (rc) throw vg_error(rc, vg_last_error());
+    *n_pairs = 0;
+    if (g->n == 0) return;
+    const int64_t P = g->padded_total();
+    const double expect = (double)P * fraction / n_shards;
+    const bool dense = fraction >= 1.0 && n_shards == 1;
+    const bool one_pass = g_force_subshards <= 1 && !(dense ? P >= (1LL << 32) : expect >= 3.9e9);
+    hipStream_t s = vg_stream();
+    if (one_pass) {
+        std::vector<vg_pair_count> none; unsigned long long n = 0;
+        kmer_shared_pass(g, k, fraction, shard, n_shards, min_shared, set_sizes, none, &pairs, &n);
+        *n_pairs = (int64_t)n;
+        return;
+    }
+    vg_pair_count* hp = nullptr; int64_t np = 0;
+    rc = vg_kmer_shared(g, k, fraction, shard, n_shards, min_shared, set_sizes, &hp, &np);
+    if (rc) { if (hp) free(hp); throw vg_error(rc, vg_last_error()); }
+    pairs.alloc((size_t)std::max<int64_t>(np, 1));
+    if (np) { pairs.upload(hp, (size_t)np, s); VG_HIP(hipStreamSynchronize(s)); }
+    free(hp);
+    *n_pairs = np;
 }
 
 // developer/test knob: force the sub-shard loop on small inputs (0 = automatic)
