@@ -191,10 +191,13 @@ def _scrambled_key(kmer_codes, k):
     return (min(fwd, rc) * 0x9E3779B97F4A7C15) & ((1 << (2 * k)) - 1)
 
 
-def test_two_frequent_kmers_in_one_prefix_group():
-    """Two k-mers that each occur 1 400 times AND share the 24-bit radix prefix: their group is longer
-    than a staged window and mixed, so the call must take the general path (full-bit sort + galloping
-    run search)."""
+def test_two_frequent_kmers_in_one_prefix_group(tmp_path):
+    """Two k-mers that each occur 1 400 times AND share the 24-bit radix prefix.  Own pipeline: their bucket exceeds
+    both LDS variants and is finished by k_bucket_big (no radix sort).  General path (VG_INDEX_PATH=radix, a second
+    process): their equal-prefix group is longer than a staged window and mixed, so that path must go through the
+    full-bit sort + galloping run search.  Both equal the oracle."""
+    import subprocess
+    import sys
     k = 25
     rng = np.random.default_rng(21)
     seen = {}
@@ -219,7 +222,21 @@ def test_two_frequent_kmers_in_one_prefix_group():
     finally:
         api.profile_enable(False)
     assert len(pairs) == 1400 * 1399 // 2 and int(pairs['shared'].min()) >= 2
-    assert 'index_long_runs' in scopes and 'index_runs_general' in scopes, scopes
+    assert 'bucket_big' in scopes and 'radix_sort_pairs' not in scopes, scopes
+    np.save(tmp_path / 'codes.npy', codes); np.save(tmp_path / 'offsets.npy', offsets)
+    np.save(tmp_path / 'pairs.npy', np.sort((pairs['a'].astype(np.int64) << 40) | (pairs['b'].astype(np.int64) << 20) | pairs['shared']))
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); from vclust_amd import api\n"
+            "c = np.load(%r); o = np.load(%r); gs = api.GenomeSet.from_codes(c, o)\n"
+            "api.profile_enable(True); api.profile_reset(); s, p = gs.kmer_shared(k=25)\n"
+            "sc = {e['name'] for e in api.profile_get()}\n"
+            "assert 'index_long_runs' in sc and 'index_runs_general' in sc and 'radix_sort_pairs' in sc, sc\n"
+            "q = np.sort((p['a'].astype(np.int64) << 40) | (p['b'].astype(np.int64) << 20) | p['shared'])\n"
+            "assert np.array_equal(q, np.load(%r)); print('general ok')\n"
+            % (str(__import__('pathlib').Path(__file__).resolve().parent.parent), str(tmp_path / 'codes.npy'), str(tmp_path / 'offsets.npy'),
+               str(tmp_path / 'pairs.npy')))
+    r = subprocess.run([sys.executable, '-c', code], env=dict(__import__('os').environ, VG_INDEX_PATH='radix'), stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0 and 'general ok' in r.stdout, (r.stdout[-300:], r.stderr[-1500:])
 
 
 def _core_set(n, rng, core_len=40, flank=(30, 60)):

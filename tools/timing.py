@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""Developer timing tools (one script, sub-commands; none is part of the product or the tests):
+
+  timing.py cli [families]      end-to-end wall of the drop-in CLI on a phage-100k slice: FASTA on disk -> ani.tsv on
+                                disk, two cold processes, with the host-side phase marks (VG_HOST_TRACE) and the
+                                allocator trace (VG_ALLOC_TRACE) of each process
+  timing.py phases [families]   the same chain inside ONE process through the API, call by call
+  timing.py step [families]     wall-clock split of one bench step (host + device)
+  timing.py lz                  LZ parse kernel on synthetic pairs of graded divergence
+"""
+import os
+import pathlib
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from vclust_amd import api, synth  # noqa: E402
+
+
+def _fasta(td, nf):
+    codes, offsets, names, _ = synth.make_workload('phage-100k', nf)
+    fa = os.path.join(td, 'g.fna')
+    synth.write_fasta(fa, codes, offsets, names)
+    return fa
+
+
+def cli(nf):
+    with tempfile.TemporaryDirectory(dir=os.environ.get('TMPDIR', '/tmp')) as td:
+        fa = _fasta(td, nf)
+        print(f'{os.path.getsize(fa) / 1e6:.0f} MB FASTA', flush=True)
+        env = dict(os.environ, VG_HOST_TRACE='1', VG_ALLOC_TRACE='1')
+        tot = 0.0
+        for cmd in (['prefilter', '-i', fa, '-o', os.path.join(td, 'fltr.txt'), '-v', '0'],
+                    ['align', '-i', fa, '-o', os.path.join(td, 'ani.tsv'), '--filter', os.path.join(td, 'fltr.txt'), '-v', '0']):
+            t0 = time.perf_counter()
+            p = subprocess.run([sys.executable, str(ROOT / 'vclust.py'), *cmd], env=env, stderr=subprocess.PIPE, text=True)
+            dt = time.perf_counter() - t0; tot += dt
+            print(f'== {cmd[0]}: {dt:.3f} s (rc {p.returncode})')
+            print(p.stderr, flush=True)
+        print(f'== total {tot:.3f} s, rows', sum(1 for _ in open(os.path.join(td, 'ani.tsv'))) - 1)
+
+
+def phases(nf):
+    with tempfile.TemporaryDirectory(dir=os.environ.get('TMPDIR', '/tmp')) as td:
+        fa = _fasta(td, nf)
+        t = [time.perf_counter()]
+        api.set_device(0); t.append(time.perf_counter())
+        gs = api.GenomeSet.load([fa], True, n_threads=64); t.append(time.perf_counter())
+        gs.to_device(); t.append(time.perf_counter())
+        sizes, pairs = gs.kmer_shared(k=25, min_shared=20); t.append(time.perf_counter())
+        sizes, pairs = gs.kmer_shared(k=25, min_shared=20); t.append(time.perf_counter())
+        gs.write_fltr(os.path.join(td, 'f.txt'), sizes, pairs); t.append(time.perf_counter())
+        flt = gs.read_filter(os.path.join(td, 'f.txt'), 0.0); t.append(time.perf_counter())
+        tasks = gs.align_tasks(flt); t.append(time.perf_counter())
+        st = gs.lz_align(tasks); t.append(time.perf_counter())
+        st = gs.lz_align(tasks); t.append(time.perf_counter())
+        gs.write_ani(os.path.join(td, 'a.tsv'), tasks, st, columns=None); t.append(time.perf_counter())
+        names_ = ['set_device', 'load', 'to_device', 'kmer_shared#1', 'kmer_shared#2', 'write_fltr', 'read_filter', 'align_tasks',
+                  'lz_align#1', 'lz_align#2', 'write_ani']
+        for n_, a, b in zip(names_, t, t[1:]):
+            print(f'{n_:14s} {b - a:7.2f} s')
+
+
+def step(nf):
+    api.set_device(0)
+    codes, offsets, names, _ = synth.make_workload('phage-100k', nf)
+    gs = api.GenomeSet.from_codes(codes, offsets, names); gs.to_device()
+    for it in range(4):
+        api.profile_enable(True); api.profile_reset()
+        t = [time.perf_counter()]
+        sizes, pairs = gs.kmer_shared(k=25, min_shared=20); t.append(time.perf_counter())
+        k1 = sum(e['total_ms'] for e in api.profile_get()); api.profile_reset()
+        cand = gs.filter_pairs(sizes, pairs, k=25, min_kmers=20, min_ident=0.7); t.append(time.perf_counter())
+        tasks = gs.align_tasks(cand); t.append(time.perf_counter())
+        stats = gs.lz_align(tasks); t.append(time.perf_counter())
+        k2 = sum(e['total_ms'] for e in api.profile_get())
+        d = np.diff(t) * 1e3
+        print('kmer_shared %.2f (kernels %.2f)  candidate %.2f  tasks %.2f  lz_align %.2f (kernels %.2f)  total %.2f ms'
+              % (d[0], k1, d[1], d[2], d[3], k2, d.sum()))
+
+
+def lz():
+    def run(label, codes, offsets, pairs, reps=3):
+        gs = api.GenomeSet.from_codes(codes, offsets); gs.to_device()
+        tasks = gs.align_tasks(pairs)
+        gs.lz_align(tasks)
+        api.profile_enable(True); api.profile_reset()
+        for _ in range(reps):
+            st = gs.lz_align(tasks)
+        prof = {e['name']: e['total_ms'] / e['launches'] for e in api.profile_get()}
+        api.profile_enable(False)
+        print(f'{label:28s} tasks {len(tasks):6d}  parse {prof.get("lz_parse", 0):8.3f} ms  build {prof.get("lz_build_index", 0):7.3f} ms  '
+              f'per-task {prof.get("lz_parse", 0) * 1e3 / len(tasks):7.3f} us  sumM {int(st["n_match"].sum())} regs {int(st["n_regions"].sum())}')
+
+    def ident(n, L, rate, seed=5):
+        rng = np.random.default_rng(seed)
+        seqs = []
+        for i in range(n):
+            a = rng.integers(0, 4, size=L, dtype=np.uint8)
+            b = a.copy()
+            m = rng.random(L) < rate
+            b[m] = (b[m] + rng.integers(1, 4, size=int(m.sum()), dtype=np.uint8)) & 3
+            seqs += [a, b]
+        off = np.zeros(len(seqs) + 1, dtype=np.int64); off[1:] = np.cumsum([len(s) for s in seqs])
+        pairs = np.array([(2 * i + 1, 2 * i, 0) for i in range(n)], dtype=api.PAIR_DTYPE)
+        return np.concatenate(seqs), off, pairs
+    api.set_device(0)
+    for rate in (0.0, 0.01, 0.05, 0.10, 0.20, 0.30, 0.75):
+        c, o, p = ident(4500, 40000, rate)
+        run(f'subst rate {rate}', c, o, p)
+    c, o, n = synth.make_families(100, 10, 40000, seed=1)
+    run('phage-1k families', c, o, synth.family_pairs(100, 10))
+
+
+if __name__ == '__main__':
+    what = sys.argv[1] if len(sys.argv) > 1 else 'cli'
+    nf = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
+    {'cli': lambda: cli(nf), 'phases': lambda: phases(nf), 'step': lambda: step(nf), 'lz': lz}[what]()

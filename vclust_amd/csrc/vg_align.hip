@@ -43,7 +43,7 @@ struct ref_desc {
     int32_t tag_bits;  // tag = the first tag_bits / 2 bases behind the msl-mer (<= mal - msl bases, <= 14 bits, <= 32 - pos_bits)
 };
 
-struct lz_dev_params { int mal, msl, mrd, mqd, reg, aw, am, ar; int ablate; };   // ablate: developer timing experiments only
+struct lz_dev_params { int mal, msl, mrd, mqd, reg, aw, am, ar; int ablate; int pw_after, pw_miss; };   // ablate: developer timing experiments only; pw_*: probe widths
 
 // ------------------------------------------------------------------ bit helpers
 // 32 bases (2-bit codes, first base in the low bits) starting at base position p (p >= 0)
@@ -1062,11 +1062,11 @@ __device__ __forceinline__ void lz_parse_body(PARSE_ARGS) {
             // pw literals (or the tail); widen the next probe: a stretch without matches is scanned 64 at a time
             const int n = min(pw, lim - i);
             i += n; lit += n; if (alive) { pred += n; if (lit > P.mqd) alive = false; }
-            pw = 64;
+            pw = pw < P.pw_miss ? P.pw_miss : 64;
             continue;
         }
         const int f = __builtin_ctzll(hb);
-        pw = PW_AFTER_EVENT;        // the next match usually starts within a few positions of the end of this one
+        pw = P.pw_after;            // the next match usually starts within a few positions of the end of this one
         // Pairs that need many events are the tail of the launch: a wave raises its own issue priority
         // as its event count grows, so the heavy pairs overtake the light ones sharing their SIMD.
         if (!(ABL & 64)) {
@@ -1312,7 +1312,11 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
     }
     vg_host_mark("lz: tasks grouped");
     const char* abl = getenv("VG_LZ_ABLATE");
-    const lz_dev_params P{ p->mal, p->msl, p->mrd, p->mqd, p->reg, p->aw, p->am, p->ar, abl ? atoi(abl) : 0 };
+    // probe widths (speculation only: results do not depend on them): positions probed right after an event, and after a
+    // first miss, before the scan goes to 64 per trip
+    static const int pw_after = [] { const char* e = getenv("VG_LZ_PW"); const int v = e ? atoi(e) : PW_AFTER_EVENT; return std::max(1, std::min(v, 64)); }();
+    static const int pw_miss = [] { const char* e = getenv("VG_LZ_PW2"); const int v = e ? atoi(e) : 64; return std::max(1, std::min(v, 64)); }();
+    const lz_dev_params P{ p->mal, p->msl, p->mrd, p->mqd, p->reg, p->aw, p->am, p->ar, abl ? atoi(abl) : 0, pw_after, pw_miss };
     const int64_t stab_n = 1LL << (2 * p->msl);
     // default parameters on a set without N: the kernel with those as compile-time constants (VG_LZ_KERNEL=general: never)
     static const bool no_fast = [] { const char* e = getenv("VG_LZ_KERNEL"); return e && !strcmp(e, "general"); }();
