@@ -68,6 +68,9 @@ int         vg_genomes_count(const vg_genomes* g);
 int64_t     vg_genomes_total_len(const vg_genomes* g);
 int         vg_genomes_lengths(const vg_genomes* g, int64_t* out /* n */);
 const char* vg_genomes_name(const vg_genomes* g, int idx);
+/* the bases of genome idx as the set holds them on the host (codes 0..3 = ACGT, 4 = N), out = len[idx] bytes:
+ * the inverse of the packing, for checks of the reader (no reference call site) */
+int         vg_genomes_codes(const vg_genomes* g, int idx, uint8_t* out);
 /* 2-bit packed bases + N mask -> HBM of the current device (idempotent) */
 int vg_genomes_to_device(vg_genomes* g);
 

@@ -182,6 +182,44 @@ def test_ingest_messy_fasta(tmp_path):
         gs = api.GenomeSet.load([path], multisample=True, n_threads=3)
         assert gs.names() == names
         assert list(gs.lengths()) == list(np.diff(offsets))
+        for i in range(len(names)):
+            assert np.array_equal(gs.codes(i), np.minimum(codes[offsets[i]:offsets[i + 1]], 4)), i
+
+
+def test_ingest_random_fasta_equals_oracle_reader(tmp_path):
+    """The packer (sixteen symbols per trip through a shift register, symbol-by-symbol fall-back) against the
+    oracle's reader on random FASTA: line widths 1..200, CRLF or LF, lower case, N runs, IUPAC codes, blanks and tabs
+    inside lines, empty lines, records of 0..5 000 symbols; multi-record (one genome per record) and directory mode
+    (records of a file joined by one N)."""
+    rng = np.random.default_rng(8)
+    alphabet = np.frombuffer(b'ACGTacgtNnRYKMSWBDHV-*', dtype=np.uint8)
+    weights = np.array([20, 20, 20, 20, 5, 5, 5, 5, 2, 1] + [0.25] * 12); weights = weights / weights.sum()
+    files = []
+    for fi in range(4):
+        out = bytearray()
+        for r in range(int(rng.integers(1, 40))):
+            n = int(rng.integers(0, 5000)) if rng.random() > 0.1 else 0
+            seq = rng.choice(alphabet, size=n, p=weights).tobytes()
+            width = int(rng.integers(1, 200)); eol = b'\r\n' if rng.random() < 0.3 else b'\n'
+            out += b'>f%d_r%d some text' % (fi, r) + eol
+            for o in range(0, n, width):
+                line = seq[o:o + width]
+                if rng.random() < 0.05 and len(line) > 2:
+                    k = int(rng.integers(1, len(line))); line = line[:k] + (b' ' if rng.random() < 0.5 else b'\t') + line[k:]
+                out += line + eol
+                if rng.random() < 0.03:
+                    out += eol
+        p = tmp_path / ('f%d.fna' % fi); p.write_bytes(bytes(out)); files.append(p)
+    for path in files:
+        codes, offsets, names = orc.read_fasta_codes(path)
+        gs = api.GenomeSet.load([path], multisample=True, n_threads=4)
+        assert gs.names() == names and list(gs.lengths()) == list(np.diff(offsets))
+        for i in range(len(names)):
+            assert np.array_equal(gs.codes(i), np.minimum(codes[offsets[i]:offsets[i + 1]], 4)), (path.name, i)
+    gs = api.GenomeSet.load(files, multisample=False, n_threads=4)
+    for i, path in enumerate(files):
+        codes, offsets, names = orc.read_fasta_codes(path, multisample=False)
+        assert int(gs.lengths()[i]) == len(codes) and np.array_equal(gs.codes(i), np.minimum(codes, 4)), path.name
 
 
 def test_filter_pairs_equals_fltr_file(tmp_path, golden_dir):

@@ -29,18 +29,31 @@ def _fasta(td, nf):
     return fa
 
 
+def _bare():
+    t0 = time.perf_counter()
+    subprocess.run([sys.executable, '-c', 'import sys; sys.path.insert(0, %r); import vclust_amd.cli' % str(ROOT)], check=True)
+    return time.perf_counter() - t0
+
+
 def cli(nf):
     with tempfile.TemporaryDirectory(dir=os.environ.get('TMPDIR', '/tmp')) as td:
         fa = _fasta(td, nf)
         print(f'{os.path.getsize(fa) / 1e6:.0f} MB FASTA', flush=True)
         env = dict(os.environ, VG_HOST_TRACE='1', VG_ALLOC_TRACE='1')
         tot = 0.0
+        gap = float(os.environ.get('CLI_GAP', '0'))
         for cmd in (['prefilter', '-i', fa, '-o', os.path.join(td, 'fltr.txt'), '-v', '0'],
                     ['align', '-i', fa, '-o', os.path.join(td, 'ani.tsv'), '--filter', os.path.join(td, 'fltr.txt'), '-v', '0']):
-            t0 = time.perf_counter()
+            if cmd[0] == 'align' and gap > 0:
+                time.sleep(gap)
+            t0 = time.perf_counter(); w0 = time.time()
             p = subprocess.run([sys.executable, str(ROOT / 'vclust.py'), *cmd], env=env, stderr=subprocess.PIPE, text=True)
-            dt = time.perf_counter() - t0; tot += dt
-            print(f'== {cmd[0]}: {dt:.3f} s (rc {p.returncode})')
+            dt = time.perf_counter() - t0; tot += dt; w1 = time.time()
+            stamps = [float(l.rsplit('@', 1)[1]) for l in p.stderr.splitlines() if l.startswith('[vg host]') and '@' in l]
+            if stamps:
+                print(f'   process start -> first mark {stamps[0] - w0:.3f} s; last mark -> process gone {w1 - stamps[-1]:.3f} s')
+            print(f'== {cmd[0]}: {dt:.3f} s (rc {p.returncode}); bare interpreter + imports: '
+                  f'{_bare():.3f} s')
             print(p.stderr, flush=True)
         print(f'== total {tot:.3f} s, rows', sum(1 for _ in open(os.path.join(td, 'ani.tsv'))) - 1)
 

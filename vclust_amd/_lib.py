@@ -77,6 +77,7 @@ SYMBOLS = {
     'vg_genomes_total_len': (C.c_int64, [C.c_void_p]),
     'vg_genomes_lengths': (C.c_int, [C.c_void_p, P(C.c_int64)]),
     'vg_genomes_name': (C.c_char_p, [C.c_void_p, C.c_int]),
+    'vg_genomes_codes': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     'vg_genomes_to_device': (C.c_int, [C.c_void_p]),
     'vg_kmer_shared': (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_uint32,
                                  P(C.c_int64), P(P(PairCount)), P(C.c_int64)]),

@@ -120,6 +120,12 @@ class GenomeSet:
     def names(self):
         return [self._lib.vg_genomes_name(self._h, i).decode() for i in range(len(self))]
 
+    def codes(self, idx):
+        """Bases of genome idx as held on the host (0..3 = ACGT, 4 = N)."""
+        out = np.empty(int(self.lengths()[idx]), dtype=np.uint8)
+        _lib.check(_lib.load().vg_genomes_codes(self._h, int(idx), out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def to_device(self):
         check(self._lib.vg_genomes_to_device(self._h))
 

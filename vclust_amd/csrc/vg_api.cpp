@@ -4,12 +4,21 @@
 // Both are compositions of the finer C-ABI calls (ingest -> HBM -> integer kernels -> writers).
 #include "vg_common.h"
 #include <stdlib.h>
+#include <thread>
 #include <vector>
 
 namespace {
 struct genomes_guard { vg_genomes* g = nullptr; ~genomes_guard() { if (g) vg_genomes_free(g); } };
 struct free_guard { void* p = nullptr; ~free_guard() { if (p) vg_free(p); } };
 void check(int rc) { if (rc != VG_OK) throw vg_error(rc, vg_last_error()); }
+// The HIP context (120-170 ms on a cold process) is created on a helper thread while the FASTA is parsed; the
+// caller joins before its first device call.  Failures are left to that call, which reports them.
+struct device_warmup {
+    std::thread th;
+    device_warmup() { try { th = std::thread([] { try { vg_require_device(); (void)vg_stream(); (void)hipFree(nullptr); } catch (...) {} }); } catch (...) {} }
+    void join() { if (th.joinable()) th.join(); }
+    ~device_warmup() { join(); }
+};
 }
 
 extern "C" int vg_prefilter(const char* const* fasta_paths, int n_paths, const char* out_path,
@@ -18,32 +27,46 @@ extern "C" int vg_prefilter(const char* const* fasta_paths, int n_paths, const c
     if (!fasta_paths || n_paths <= 0 || !out_path || !p) throw vg_error(VG_EINVAL, "vg_prefilter: null argument");
     if (p->k < 15 || p->k > 30) throw vg_error(VG_EINVAL, "k must be in 15..30");
     if (!(p->kmers_fraction > 0.0) || p->kmers_fraction > 1.0) throw vg_error(VG_EINVAL, "kmers_fraction must be in (0,1]");
-    vg_require_device();
+    vg_host_mark("vg_prefilter: enter");
+    device_warmup warm;
     genomes_guard gg;
-    check(vg_genomes_load(fasta_paths, n_paths, p->is_multifasta, p->num_threads, &gg.g));
+    check(vg_genomes_load_resident(fasta_paths, n_paths, p->is_multifasta, p->num_threads, &gg.g));
+    warm.join();
+    vg_require_device();
     std::vector<int64_t> sizes((size_t)std::max(1, vg_genomes_count(gg.g)));
     free_guard pairs; int64_t np = 0;
     // on a single device the --min-kmers cut can be applied on the GPU already
     uint32_t min_emit = (uint32_t)std::max(1, p->min_kmers);
     check(vg_kmer_shared(gg.g, p->k, p->kmers_fraction, 0, 1, min_emit, sizes.data(),
                          (vg_pair_count**)&pairs.p, &np));
+    // a one-shot process: the tens of GB of workspace go back to the driver NOW, so that the scrub of that memory
+    // runs beside the writer and the start of the next process (`vclust.py align`) instead of in front of its
+    // first allocation
+    vg_release_device_memory();
     check(vg_write_fltr(gg.g, p->k, p->kmers_fraction, p->min_kmers, p->min_ident, p->max_seqs,
                         sizes.data(), (const vg_pair_count*)pairs.p, np, out_path));
+    vg_host_mark("fltr.txt written");
     VG_API_END
 }
 
 extern "C" int vg_align(const char* const* fasta_paths, int n_paths, const char* out_path, const vg_align_params* p) {
     VG_API_BEGIN
     if (!fasta_paths || n_paths <= 0 || !out_path || !p) throw vg_error(VG_EINVAL, "vg_align: null argument");
-    vg_require_device();
+    vg_host_mark("vg_align: enter");
+    device_warmup warm;
     genomes_guard gg;
-    check(vg_genomes_load(fasta_paths, n_paths, p->is_multifasta, p->num_threads, &gg.g));
+    check(vg_genomes_load_resident(fasta_paths, n_paths, p->is_multifasta, p->num_threads, &gg.g));
+    warm.join();
+    vg_require_device();
     free_guard pairs, tasks, regions; int64_t np = 0, nt = 0, nr = 0;
     check(vg_read_filter(gg.g, p->filter_path, p->filter_threshold, (vg_pair_count**)&pairs.p, &np));
+    vg_host_mark("filter read");
     check(vg_align_tasks(gg.g, (const vg_pair_count*)pairs.p, np, (vg_task**)&tasks.p, &nt));
     std::vector<vg_pair_stat> stats((size_t)std::max<int64_t>(1, nt));
     const bool want_aln = p->out_aln_path != nullptr;
     check(vg_lz_align(gg.g, (const vg_task*)tasks.p, nt, &p->lz, stats.data(), want_aln ? (vg_region**)&regions.p : nullptr, &nr));
+    vg_release_device_memory();
     check(vg_write_ani(gg.g, (const vg_task*)tasks.p, stats.data(), nt, (const vg_region*)regions.p, nr, out_path, p));
+    vg_host_mark("ani.tsv written");
     VG_API_END
 }

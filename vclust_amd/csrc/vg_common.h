@@ -103,6 +103,8 @@ struct vg_genomes {
 };
 void vg_length_order(const vg_genomes* g);        // fills g->len_order / g->len_rank on first use
 
+// vg_genomes_load with the upload to the library's device overlapped with the packing (vg_genomes.cpp; whole-stage calls)
+int vg_genomes_load_resident(const char* const* paths, int n_paths, int multisample, int n_threads, vg_genomes** out);
 // one k-mer range shard of vg_kmer_shared with the (a, b, shared) records left in HBM (vg_prefilter.hip; used by vg_dist.hip)
 void vg_kmer_shared_device(vg_genomes* g, int k, double fraction, int shard, int n_shards, uint32_t min_shared,
                            int64_t* set_sizes, dbuf<vg_pair_count>& pairs, int64_t* n_pairs);

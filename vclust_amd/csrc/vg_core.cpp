@@ -24,6 +24,7 @@ extern "C" void vg_free(void* p) { free(p); }
 
 static int g_device = -1;
 static hipStream_t g_stream = nullptr;
+static bool g_pool_ready = false;          // release threshold of the current device's memory pool set (vg_dev_alloc)
 
 extern "C" int vg_device_count(void) {
     int n = 0;
@@ -41,24 +42,35 @@ extern "C" int vg_set_device(int device) {
         // (genome sets re-upload themselves on their next use, vg_genomes_to_device)
         vg_dev_trim();
         if (g_stream) { (void)hipStreamDestroy(g_stream); g_stream = nullptr; }
+        g_pool_ready = false;
     }
     VG_HIP(hipSetDevice(device));
     g_device = device;
     VG_API_END
 }
 
+// HIP's current device is a per-thread setting: every thread that comes through here (helper threads of the
+// library included) is bound to the library's device
 void vg_require_device() {
+    static std::mutex mu;
+    thread_local int bound = -1;
+    if (g_device >= 0 && bound == g_device) return;
+    std::lock_guard<std::mutex> lk(mu);
     if (g_device < 0) {
         int n = vg_device_count();
         if (n <= 0) throw vg_error(VG_ENODEV, "no HIP device visible: libvclust_gpu has no CPU fallback");
         VG_HIP(hipSetDevice(0));
         g_device = 0;
-    }
+    } else VG_HIP(hipSetDevice(g_device));
+    bound = g_device;
 }
 
 hipStream_t vg_stream() {
     vg_require_device();
-    if (!g_stream) VG_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    if (!g_stream) {
+        static std::mutex mu; std::lock_guard<std::mutex> lk(mu);
+        if (!g_stream) VG_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    }
     return g_stream;
 }
 
@@ -67,7 +79,8 @@ void vg_host_mark(const char* what) {
     if (!on) return;
     static thread_local std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
     const auto now = std::chrono::steady_clock::now();
-    fprintf(stderr, "[vg host] %-28s +%.3f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
+    fprintf(stderr, "[vg host] %-28s +%.3f ms  @%.3f\n", what, std::chrono::duration<double, std::milli>(now - last).count(),
+            std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count());
     last = now;
 }
 
@@ -87,6 +100,30 @@ constexpr size_t ALLOC_GRAN = 1 << 12;
 const bool g_alloc_trace = [] { const char* e = getenv("VG_ALLOC_TRACE"); return e && *e && *e != '0'; }();
 }
 
+// Blocks come from the device's stream-ordered memory pool (hipMallocAsync on the library stream, release threshold
+// "never"): one hipMalloc of tens of GB costs ~30 ms per GiB on this platform (0.97 s for 32 GiB, measured with
+// tools/micro/malloc_cost.hip), the pool hands out the same 32 GiB in 45 ms -- the CLI's wall time was mostly that.
+// VG_ALLOC=malloc goes back to plain hipMalloc / hipFree.
+static const bool g_pool_alloc = [] { const char* e = getenv("VG_ALLOC"); return !(e && !strcmp(e, "malloc")); }();
+static hipError_t raw_alloc(void** p, size_t bytes) {
+    if (g_pool_alloc) {
+        hipStream_t s = vg_stream();
+        if (!g_pool_ready) {
+            hipMemPool_t pool; uint64_t thr = ~0ULL;
+            if (hipDeviceGetDefaultMemPool(&pool, g_device) == hipSuccess) (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
+            g_pool_ready = true;
+        }
+        hipError_t e = hipMallocAsync(p, bytes, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);     // usable from any stream (and by blocking copies) from here on
+        return e;
+    }
+    return hipMalloc(p, bytes);
+}
+static void raw_free(void* p) {
+    if (g_pool_alloc) { if (hipFreeAsync(p, vg_stream()) == hipSuccess) return; (void)hipGetLastError(); }
+    (void)hipFree(p);
+}
+
 void* vg_dev_alloc(size_t bytes) {
     vg_require_device();
     size_t want = (bytes + ALLOC_GRAN - 1) / ALLOC_GRAN * ALLOC_GRAN;
@@ -99,18 +136,18 @@ void* vg_dev_alloc(size_t bytes) {
         }
     }
     void* p = nullptr;
-    hipError_t e = hipMalloc(&p, want);
+    hipError_t e = raw_alloc(&p, want);
     if (e != hipSuccess) {
         (void)hipGetLastError();                      // the failure is handled here: do not leave it as the sticky "last error"
-        if (g_alloc_trace) fprintf(stderr, "[vg alloc] hipMalloc(%.1f MB) failed: trimming %.1f GB of cached blocks (live %.1f GB)\n", want / 1048576.0, g_cached_bytes / 1073741824.0, g_live_bytes / 1073741824.0);
+        if (g_alloc_trace) fprintf(stderr, "[vg alloc] allocation of %.1f MB failed: trimming %.1f GB of cached blocks (live %.1f GB)\n", want / 1048576.0, g_cached_bytes / 1073741824.0, g_live_bytes / 1073741824.0);
         vg_dev_trim();                                // give cached blocks back and retry once
-        e = hipMalloc(&p, want);
-        if (e != hipSuccess) { (void)hipGetLastError(); throw vg_error(VG_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+        e = raw_alloc(&p, want);
+        if (e != hipSuccess) { (void)hipGetLastError(); throw vg_error(VG_ENOMEM, std::string("device allocation: ") + hipGetErrorString(e)); }
     }
     std::lock_guard<std::mutex> lk(g_alloc_mu);
     g_block_size[p] = { want, g_device };
     g_live_bytes += want;
-    if (g_alloc_trace && want >= (64u << 20)) fprintf(stderr, "[vg alloc] hipMalloc %.1f MB (live %.1f GB, cached %.1f GB)\n", want / 1048576.0, g_live_bytes / 1073741824.0, g_cached_bytes / 1073741824.0);
+    if (g_alloc_trace && want >= (64u << 20)) fprintf(stderr, "[vg alloc] new block %.1f MB (live %.1f GB, cached %.1f GB)\n", want / 1048576.0, g_live_bytes / 1073741824.0, g_cached_bytes / 1073741824.0);
     return p;
 }
 
@@ -118,11 +155,11 @@ void vg_dev_free(void* p) {
     if (!p) return;
     std::unique_lock<std::mutex> lk(g_alloc_mu);
     auto it = g_block_size.find(p);
-    if (it == g_block_size.end()) { lk.unlock(); (void)hipFree(p); return; }
+    if (it == g_block_size.end()) { lk.unlock(); raw_free(p); return; }
     g_live_bytes -= it->second.size;
     if (it->second.device != g_device) {
         // a block of another device (a genome set freed after vg_set_device): it must not be handed out here
-        g_block_size.erase(it); lk.unlock(); (void)hipFree(p); return;
+        g_block_size.erase(it); lk.unlock(); (void)hipFree(p); return;       // (hipFree takes pool memory of any device)
     }
     g_free_blocks.emplace(it->second.size, p); g_cached_bytes += it->second.size;
 }
@@ -134,7 +171,15 @@ void vg_dev_trim() {
         for (auto& kv : g_free_blocks) { blocks.push_back(kv.second); g_block_size.erase(kv.second); }
         g_free_blocks.clear(); g_cached_bytes = 0;
     }
-    if (!blocks.empty()) { (void)hipDeviceSynchronize(); for (void* b : blocks) (void)hipFree(b); }
+    if (!blocks.empty()) {
+        (void)hipDeviceSynchronize();
+        for (void* b : blocks) raw_free(b);
+        if (g_pool_alloc) {
+            // the pool keeps what it is given back: return it to the driver as well
+            (void)hipStreamSynchronize(vg_stream());
+            hipMemPool_t pool; if (hipDeviceGetDefaultMemPool(&pool, g_device) == hipSuccess) (void)hipMemPoolTrimTo(pool, 0);
+        }
+    }
 }
 
 extern "C" void vg_release_device_memory(void) { vg_dev_trim(); }

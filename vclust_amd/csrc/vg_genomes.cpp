@@ -10,6 +10,8 @@
 #include <atomic>
 #include <algorithm>
 #include <memory>
+#include <mutex>
+#include <condition_variable>
 
 static inline uint8_t code_of(unsigned char ch) {
     switch (ch) {
@@ -131,6 +133,13 @@ void find_records(const filebuf& fb, std::vector<record>& out, int n_threads) {
     std::vector<std::vector<const char*>> starts(T);
     auto scan = [&](int t) {
         const char* lo = p + fb.size() * t / T; const char* hi = p + fb.size() * (t + 1) / T;
+#ifdef MADV_POPULATE_READ
+        if (fb.map && hi > lo) {
+            // map this thread's stretch of the page cache in one call instead of one minor fault per 64 KB
+            const uintptr_t a = (uintptr_t)lo & ~(uintptr_t)4095, b = ((uintptr_t)hi + 4095) & ~(uintptr_t)4095;
+            (void)madvise((void*)a, (size_t)(b - a), MADV_POPULATE_READ);
+        }
+#endif
         for (const char* q = lo; q < hi;) {
             const char* g = (const char*)memchr(q, '>', (size_t)(hi - q));
             if (!g) break;
@@ -154,29 +163,55 @@ void find_records(const filebuf& fb, std::vector<record>& out, int n_threads) {
     }
 }
 
+// symbols of a record = its bytes minus white space (\n \r space \t), counted eight bytes at a time: an exact
+// per-byte "equals v" mask for each of the four values (no borrow between bytes), one popcount
+inline uint64_t eq_mask(uint64_t x, uint64_t v) {
+    const uint64_t y = x ^ (v * 0x0101010101010101ULL), lo = 0x7F7F7F7F7F7F7F7FULL;
+    return ~(((y & lo) + lo) | y | lo);                 // 0x80 in every byte of x that equals v
+}
 int64_t count_bases(const record& r) {
-    int64_t n = 0;
-    for (const char* q = r.seq; q < r.end; ++q) n += !is_ws(*q);
-    return n;
+    int64_t ws = 0; const char* q = r.seq;
+    for (; q + 8 <= r.end; q += 8) {
+        uint64_t x; memcpy(&x, q, 8);
+        ws += __builtin_popcountll(eq_mask(x, '\n') | eq_mask(x, '\r') | eq_mask(x, ' ') | eq_mask(x, '\t'));
+    }
+    for (; q < r.end; ++q) ws += is_ws(*q);
+    return (int64_t)(r.end - r.seq) - ws;
 }
 
-// pack the bases of one record into the set's arrays starting at padded base position `at`
-// (2-bit codes + N mask); returns true if an N was seen.  Callers own disjoint word ranges.
+// pack the bases of one record into the set's arrays starting at padded base position `at` (2-bit codes + N mask);
+// returns true if an N was seen.  Callers own disjoint word ranges and the arrays are zero.  Line by line (memchr
+// for the line end), sixteen symbols per trip: sixteen table look-ups OR-ed into one 32-bit group, no per-symbol
+// branch, appended to the output through a 64-bit shift register (the output need not be word aligned).  A group
+// with anything unusual in it (N, white space inside a line) goes symbol by symbol.
+struct pack_lut { uint8_t t[256]; pack_lut() { for (int i = 0; i < 256; ++i) { const char ch = (char)i; t[i] = is_ws(ch) ? 5 : code_of((unsigned char)i); } } };
+const pack_lut PLUT;
 bool pack_record(const record& r, vg_genomes* g, int64_t at) {
     uint32_t* pk = g->packed.data(); uint32_t* mk = g->nmask.data();
-    bool any_n = false; int64_t i = at;
-    uint32_t w = pk[i >> 4], m = mk[i >> 5];
-    for (const char* q = r.seq; q < r.end; ++q) {
-        const char ch = *q;
-        if (is_ws(ch)) continue;
-        const uint8_t c = LUT.t[(unsigned char)ch];
-        if (c > 3) { m |= 1u << (i & 31); any_n = true; } else w |= (uint32_t)c << (2 * (i & 15));
-        ++i;
-        if ((i & 15) == 0) { pk[(i - 1) >> 4] = w; w = pk[i >> 4]; }
-        if ((i & 31) == 0) { mk[(i - 1) >> 5] = m; m = mk[i >> 5]; }
+    bool any_n = false; int64_t i = at;                       // i = position of the next symbol
+    uint64_t acc = 0; int nb = 2 * (int)(at & 15);            // pending output bits of word (i - pending symbols) >> 4
+    int64_t wo = at >> 4;                                     // word the low bits of acc belong to
+    auto flush = [&]() { while (nb >= 32) { pk[wo++] |= (uint32_t)acc; acc >>= 32; nb -= 32; } };
+    const char* q = r.seq; const char* const end = r.end;
+    while (q < end) {
+        const char* nl = (const char*)memchr(q, '\n', (size_t)(end - q));
+        const char* const le = nl ? nl : end;
+        while (q < le) {
+            const int m = (int)std::min<int64_t>(16, le - q);
+            uint32_t w = 0, bad = 0;
+            for (int j = 0; j < m; ++j) { const uint32_t c = PLUT.t[(unsigned char)q[j]]; w |= (c & 3u) << (2 * j); bad |= c; }
+            if (bad < 4) { acc |= (uint64_t)w << nb; nb += 2 * m; i += m; q += m; flush(); continue; }
+            for (int j = 0; j < m; ++j) {
+                const uint32_t c = PLUT.t[(unsigned char)q[j]];
+                if (c == 5) continue;
+                if (c == 4) { mk[i >> 5] |= 1u << (i & 31); any_n = true; } else acc |= (uint64_t)c << nb;
+                nb += 2; ++i; flush();
+            }
+            q += m;
+        }
+        q = nl ? nl + 1 : end;
     }
-    if (i & 15) pk[i >> 4] = w;
-    if (i & 31) mk[i >> 5] = m;
+    if (nb > 0) pk[wo] |= (uint32_t)acc;
     return any_n;
 }
 
@@ -195,14 +230,20 @@ std::string first_token(const char* b, const char* e) {
 }
 }  // namespace
 
-extern "C" int vg_genomes_load(const char* const* paths, int n_paths, int multisample, int n_threads,
-                               vg_genomes** out) {
-    VG_API_BEGIN
+// to_device: the packed arrays travel to the HBM of the library's device WHILE the genomes are packed (a helper
+// thread uploads every stretch of genomes as soon as its last genome is done), and the set comes back resident
+static void genomes_load_impl(const char* const* paths, int n_paths, int multisample, int n_threads, bool to_device, vg_genomes** out) {
     if (!paths || n_paths <= 0 || !out) throw vg_error(VG_EINVAL, "vg_genomes_load: bad arguments");
     const int T = std::max(1, n_threads);
     const bool multi = multisample && n_paths == 1;
-    // 1. whole files into memory (gz inflated), files in parallel
-    std::vector<filebuf> bufs((size_t)n_paths);
+    vg_host_mark("ingest: enter");
+    // 1. whole files into memory (gz inflated), files in parallel.  The mappings and the record lists are given to a
+    // helper thread at the end: unmapping 4 GB of FASTA costs ~80 ms the caller need not wait for.
+    struct input_state { std::vector<filebuf> bufs; std::vector<std::vector<record>> recs; };
+    auto* in_state = new input_state();
+    struct in_guard { input_state* p; ~in_guard() { if (p) { input_state* q = p; try { std::thread([q] { delete q; }).detach(); } catch (...) { delete q; } } } } in_g{ in_state };
+    in_state->bufs = std::vector<filebuf>((size_t)n_paths);
+    std::vector<filebuf>& bufs = in_state->bufs;
     {
         std::string first_err; std::atomic<bool> failed(false);
         parallel_for(n_paths, T, [&](int64_t i) {
@@ -212,8 +253,10 @@ extern "C" int vg_genomes_load(const char* const* paths, int n_paths, int multis
         });
         if (failed.load()) throw vg_error(VG_EIO, first_err);
     }
+    vg_host_mark("ingest: files mapped");
     // 2. records and their lengths
-    std::vector<std::vector<record>> recs((size_t)n_paths);
+    in_state->recs = std::vector<std::vector<record>>((size_t)n_paths);
+    std::vector<std::vector<record>>& recs = in_state->recs;
     for (int i = 0; i < n_paths; ++i) find_records(bufs[(size_t)i], recs[(size_t)i], multi ? T : 1);
     struct gdesc { int file; size_t r0, r1; int64_t len; };
     std::vector<gdesc> gd;
@@ -227,6 +270,7 @@ extern "C" int vg_genomes_load(const char* const* paths, int n_paths, int multis
         for (int i = 0; i < n_paths; ++i) for (size_t r = 0; r < recs[(size_t)i].size(); ++r) flat.push_back({ i, r });
         parallel_for((int64_t)flat.size(), T, [&](int64_t j) { auto& r = recs[(size_t)flat[(size_t)j].first][flat[(size_t)j].second]; r.len = count_bases(r); });
     }
+    vg_host_mark("ingest: records counted");
     int64_t total = 0;
     for (auto& d : gd) {
         for (size_t r = d.r0; r < d.r1; ++r) d.len += recs[(size_t)d.file][r].len;
@@ -249,6 +293,7 @@ extern "C" int vg_genomes_load(const char* const* paths, int n_paths, int multis
         else { std::string pth = paths[d.file]; size_t sl = pth.find_last_of('/'); g->names.push_back(sl == std::string::npos ? pth : pth.substr(sl + 1)); }
         g->n++;
     }
+    vg_host_mark("ingest: layout");
     // first touch in parallel: the arrays are written by the packing threads right below
     g->packed.reserve((size_t)(g->padded_total() / 16) + 16); g->nmask.reserve((size_t)(g->padded_total() / 32) + 16);   // + the slack vg_genomes_finish adds
     g->packed.resize((size_t)(g->padded_total() / 16)); g->nmask.resize((size_t)(g->padded_total() / 32));
@@ -257,10 +302,55 @@ extern "C" int vg_genomes_load(const char* const* paths, int n_paths, int multis
         parallel_for(np + nm, T, [&](int64_t c) {
             std::vector<uint32_t, no_init_alloc<uint32_t>>& v = c < np ? g->packed : g->nmask;
             const int64_t lo = (c < np ? c : c - np) * chunk, hi = std::min<int64_t>(lo + chunk, (int64_t)v.size());
+#ifdef MADV_POPULATE_WRITE
+            {   // fresh anonymous memory: populate the chunk's whole pages in one call (they come zeroed) instead of faulting page by page
+                const uintptr_t a = ((uintptr_t)(v.data() + lo) + 4095) & ~(uintptr_t)4095, b = (uintptr_t)(v.data() + hi) & ~(uintptr_t)4095;
+                if (b > a) (void)madvise((void*)a, (size_t)(b - a), MADV_POPULATE_WRITE);
+            }
+#endif
             memset(v.data() + lo, 0, (size_t)(hi - lo) * sizeof(uint32_t));
         });
     }
-    parallel_for((int64_t)gd.size(), T, [&](int64_t gi) {
+    // stretches of genomes of ~32 MB of packed bases: the unit of the overlapped upload
+    const int64_t n_g = (int64_t)gd.size();
+    std::vector<int64_t> st_first;                          // first genome of every stretch (+ n_g)
+    {
+        const int64_t want = 128LL << 20;                   // bases per stretch (= 32 MB packed + 16 MB mask)
+        int64_t last = 0; st_first.push_back(0);
+        for (int64_t gi = 0; gi < n_g; ++gi) if (g->base_off[(size_t)gi + 1] - g->base_off[(size_t)last] >= want && gi + 1 < n_g) { st_first.push_back(gi + 1); last = gi + 1; }
+        st_first.push_back(n_g);
+    }
+    const int64_t n_st = (int64_t)st_first.size() - 1;
+    std::vector<int> st_of((size_t)n_g);
+    for (int64_t c = 0; c < n_st; ++c) for (int64_t gi = st_first[(size_t)c]; gi < st_first[(size_t)c + 1]; ++gi) st_of[(size_t)gi] = (int)c;
+    std::unique_ptr<std::atomic<int64_t>[]> st_left(new std::atomic<int64_t>[(size_t)std::max<int64_t>(n_st, 1)]);
+    for (int64_t c = 0; c < n_st; ++c) st_left[(size_t)c].store(st_first[(size_t)c + 1] - st_first[(size_t)c]);
+    std::mutex up_mu; std::condition_variable up_cv; std::vector<int64_t> up_queue; bool up_done = false; std::string up_err;
+    std::thread uploader; int dev = 0;
+    const size_t pk_words = (size_t)(g->padded_total() / 16) + 16, mk_words = (size_t)(g->padded_total() / 32) + 16;   // with the slack vg_genomes_finish adds
+    if (to_device && n_g > 0) {
+        vg_require_device();
+        VG_HIP(hipGetDevice(&dev));
+        g->d_packed.alloc(pk_words); g->d_nmask.alloc(mk_words);
+        uploader = std::thread([&]() {
+            try {
+                vg_require_device();
+                hipStream_t st; VG_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+                for (;;) {
+                    int64_t c;
+                    { std::unique_lock<std::mutex> lk(up_mu); up_cv.wait(lk, [&] { return !up_queue.empty() || up_done; }); if (up_queue.empty()) break; c = up_queue.back(); up_queue.pop_back(); }
+                    const int64_t b0 = g->base_off[(size_t)st_first[(size_t)c]], b1 = g->base_off[(size_t)st_first[(size_t)c + 1]];      // multiples of 64 bases
+                    VG_HIP(hipMemcpyAsync(g->d_packed.p + b0 / 16, g->packed.data() + b0 / 16, (size_t)(b1 - b0) / 16 * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+                    VG_HIP(hipMemcpyAsync(g->d_nmask.p + b0 / 32, g->nmask.data() + b0 / 32, (size_t)(b1 - b0) / 32 * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+                    VG_HIP(hipStreamSynchronize(st));
+                }
+                (void)hipStreamDestroy(st);
+            } catch (const std::exception& e) { std::lock_guard<std::mutex> lk(up_mu); up_err = e.what(); }
+        });
+    }
+    struct join_guard { std::thread& t; std::mutex& m; std::condition_variable& cv; bool& done;
+                        ~join_guard() { { std::lock_guard<std::mutex> lk(m); done = true; } cv.notify_all(); if (t.joinable()) t.join(); } } jg{ uploader, up_mu, up_cv, up_done };
+    parallel_for(n_g, T, [&](int64_t gi) {
         const gdesc& d = gd[(size_t)gi];
         int64_t at = g->base_off[(size_t)gi]; bool any_n = false;
         for (size_t r = d.r0; r < d.r1; ++r) {
@@ -270,9 +360,43 @@ extern "C" int vg_genomes_load(const char* const* paths, int n_paths, int multis
         }
         for (int64_t i = at; i < g->base_off[(size_t)gi + 1]; ++i) g->nmask[(size_t)(i >> 5)] |= 1u << (i & 31);   // padding
         g->has_n[(size_t)gi] = any_n ? 1 : 0;
+        if (uploader.joinable() && st_left[(size_t)st_of[(size_t)gi]].fetch_sub(1) == 1) {
+            { std::lock_guard<std::mutex> lk(up_mu); up_queue.push_back(st_of[(size_t)gi]); }
+            up_cv.notify_one();
+        }
     });
     vg_genomes_finish(g);
+    vg_host_mark("ingest: packed");
+    if (uploader.joinable()) {
+        { std::lock_guard<std::mutex> lk(up_mu); up_done = true; }
+        up_cv.notify_all(); uploader.join();
+        if (!up_err.empty()) throw vg_error(VG_EHIP, "upload of the genome arrays failed: " + up_err);
+        // the slack words behind the last genome and the small arrays
+        hipStream_t s = vg_stream();
+        const size_t pk_tail = (size_t)(g->padded_total() / 16), mk_tail = (size_t)(g->padded_total() / 32);
+        VG_HIP(hipMemcpyAsync(g->d_packed.p + pk_tail, g->packed.data() + pk_tail, (g->packed.size() - pk_tail) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        VG_HIP(hipMemcpyAsync(g->d_nmask.p + mk_tail, g->nmask.data() + mk_tail, (g->nmask.size() - mk_tail) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        g->d_base_off.alloc(g->base_off.size()); g->d_base_off.upload(g->base_off.data(), g->base_off.size(), s);
+        g->d_len.alloc(std::max<size_t>(1, g->len.size())); g->d_len.upload(g->len.data(), g->len.size(), s);
+        g->d_has_n.alloc(std::max<size_t>(1, g->has_n.size())); g->d_has_n.upload(g->has_n.data(), g->has_n.size(), s);
+        g->d_blk2g.alloc(g->blk2g.size()); g->d_blk2g.upload(g->blk2g.data(), g->blk2g.size(), s);
+        VG_HIP(hipStreamSynchronize(s));
+        g->device = dev;
+        vg_host_mark("ingest: resident");
+    }
     *out = guard.release();
+}
+
+extern "C" int vg_genomes_load(const char* const* paths, int n_paths, int multisample, int n_threads,
+                               vg_genomes** out) {
+    VG_API_BEGIN
+    genomes_load_impl(paths, n_paths, multisample, n_threads, false, out);
+    VG_API_END
+}
+// internal (vg_api.cpp): ingest with the upload overlapped
+int vg_genomes_load_resident(const char* const* paths, int n_paths, int multisample, int n_threads, vg_genomes** out) {
+    VG_API_BEGIN
+    genomes_load_impl(paths, n_paths, multisample, n_threads, true, out);
     VG_API_END
 }
 
@@ -306,6 +430,17 @@ extern "C" const char* vg_genomes_name(const vg_genomes* g, int idx) {
     return g->names[idx].c_str();
 }
 
+extern "C" int vg_genomes_codes(const vg_genomes* g, int idx, uint8_t* out) {
+    if (!g || !out || idx < 0 || idx >= g->n) return VG_EINVAL;
+    const int64_t p0 = g->base_off[(size_t)idx];
+    for (int64_t j = 0; j < g->len[(size_t)idx]; ++j) {
+        const int64_t p = p0 + j;
+        const bool n = (g->nmask[(size_t)(p >> 5)] >> (p & 31)) & 1u;
+        out[j] = n ? 4 : (uint8_t)((g->packed[(size_t)(p >> 4)] >> (2 * (p & 15))) & 3u);
+    }
+    return VG_OK;
+}
+
 extern "C" int vg_genomes_to_device(vg_genomes* g) {
     VG_API_BEGIN
     if (!g) throw vg_error(VG_EINVAL, "null genome set");
@@ -327,5 +462,6 @@ extern "C" int vg_genomes_to_device(vg_genomes* g) {
     g->d_blk2g.alloc(g->blk2g.size()); g->d_blk2g.upload(g->blk2g.data(), g->blk2g.size(), s);
     VG_HIP(hipStreamSynchronize(s));
     g->device = dev;
+    vg_host_mark("genomes uploaded");
     VG_API_END
 }

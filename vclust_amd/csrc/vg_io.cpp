@@ -128,40 +128,54 @@ extern "C" int vg_write_fltr(const vg_genomes* g, int k, double fraction, int mi
                              int64_t n_pairs, const char* out_path) {
     VG_API_BEGIN
     if (!g || !set_sizes || (!pairs && n_pairs) || !out_path) throw vg_error(VG_EINVAL, "vg_write_fltr: null argument");
-    std::vector<vg_pair_count> v(pairs, pairs + n_pairs);
-    for (auto& p : v) if (p.a < p.b) std::swap(p.a, p.b);
-    std::sort(v.begin(), v.end(), [](const vg_pair_count& x, const vg_pair_count& y) { return x.a != y.a ? x.a < y.a : x.b < y.b; });
-    // sum duplicates (per-shard partial counts)
-    size_t u = 0;
-    for (size_t i = 0; i < v.size(); ++i) {
-        if (u && v[u - 1].a == v[i].a && v[u - 1].b == v[i].b) v[u - 1].shared += v[i].shared;
-        else v[u++] = v[i];
+    // rows by a counting sort on the row genome (the pairs arrive in no order), then every row sorted by column
+    const size_t ng = (size_t)std::max(g->n, 0);
+    std::vector<size_t> first(ng + 2, 0);
+    for (int64_t i = 0; i < n_pairs; ++i) { const uint32_t a = std::max(pairs[i].a, pairs[i].b); if (a < ng) first[a + 1]++; }
+    for (size_t a = 0; a < ng; ++a) first[a + 1] += first[a];
+    struct cell { uint32_t b, shared; };
+    std::vector<cell> cells(first[ng]);
+    {
+        std::vector<size_t> cur(first.begin(), first.begin() + (std::ptrdiff_t)ng);
+        for (int64_t i = 0; i < n_pairs; ++i) {
+            const uint32_t a = std::max(pairs[i].a, pairs[i].b), bb = std::min(pairs[i].a, pairs[i].b);
+            if (a < ng) cells[cur[a]++] = { bb, pairs[i].shared };
+        }
     }
-    v.resize(u);
     FILE* f = fopen(out_path, "w");
     if (!f) throw vg_error(VG_EIO, std::string("cannot write ") + out_path);
     fprintf(f, "kmer-length: %d fraction: %g ,", k, fraction);
     for (int i = 0; i < g->n; ++i) fprintf(f, "%s,", g->names[i].c_str());
     fputc('\n', f);
-    size_t p = 0;
-    struct ent { uint32_t col; double ani; };
-    std::vector<ent> row;
-    for (int a = 0; a < g->n; ++a) {
-        fprintf(f, "%s,", g->names[a].c_str());
-        row.clear();
-        for (; p < v.size() && v[p].a == (uint32_t)a; ++p) {
-            if ((int64_t)v[p].shared < min_kmers || v[p].b >= (uint32_t)g->n) continue;
-            double ani = vg_ani_shorter(v[p].shared, set_sizes[a], set_sizes[v[p].b], k);
-            if (ani >= min_ident) row.push_back({ v[p].b, ani });
+    // rows are formatted by several threads, each its own contiguous range, and written in order
+    const int n_thr = std::max(1, std::min(vg_host_threads(), 16));
+    std::vector<std::string> text((size_t)n_thr);
+    vg_parallel_chunks((int64_t)ng, n_thr, [&](int64_t lo, int64_t hi, int t) {
+        std::string& o = text[(size_t)t];
+        struct ent { uint32_t col; double ani; };
+        std::vector<ent> row; char buf[64];
+        for (int64_t a = lo; a < hi; ++a) {
+            o += g->names[(size_t)a]; o += ',';
+            cell* c0 = cells.data() + first[(size_t)a]; cell* c1 = cells.data() + first[(size_t)a + 1];
+            std::sort(c0, c1, [](const cell& x, const cell& y) { return x.b < y.b; });
+            row.clear();
+            for (cell* c = c0; c < c1;) {
+                uint64_t sh = 0; const uint32_t bcol = c->b;
+                for (; c < c1 && c->b == bcol; ++c) sh += c->shared;           // per-shard partial counts add up
+                if ((int64_t)sh < min_kmers || bcol >= (uint32_t)g->n || bcol == (uint32_t)a) continue;
+                const double ani = vg_ani_shorter((int64_t)sh, set_sizes[a], set_sizes[bcol], k);
+                if (ani >= min_ident) row.push_back({ bcol, ani });
+            }
+            if (max_seqs > 0 && (int)row.size() > max_seqs) {
+                std::sort(row.begin(), row.end(), [](const ent& x, const ent& y) { return x.ani != y.ani ? x.ani > y.ani : x.col < y.col; });
+                row.resize((size_t)max_seqs);
+                std::sort(row.begin(), row.end(), [](const ent& x, const ent& y) { return x.col < y.col; });
+            }
+            for (auto& e : row) { const int n = snprintf(buf, sizeof buf, "%u:%.6f,", e.col + 1, e.ani); o.append(buf, (size_t)n); }
+            o += '\n';
         }
-        if (max_seqs > 0 && (int)row.size() > max_seqs) {
-            std::sort(row.begin(), row.end(), [](const ent& x, const ent& y) { return x.ani != y.ani ? x.ani > y.ani : x.col < y.col; });
-            row.resize(max_seqs);
-            std::sort(row.begin(), row.end(), [](const ent& x, const ent& y) { return x.col < y.col; });
-        }
-        for (auto& e : row) fprintf(f, "%u:%.6f,", e.col + 1, e.ani);
-        fputc('\n', f);
-    }
+    });
+    for (auto& o : text) if (!o.empty() && fwrite(o.data(), 1, o.size(), f) != o.size()) { fclose(f); throw vg_error(VG_EIO, std::string("write error on ") + out_path); }
     if (fclose(f)) throw vg_error(VG_EIO, std::string("write error on ") + out_path);
     VG_API_END
 }
@@ -194,43 +208,75 @@ extern "C" int vg_read_filter(const vg_genomes* g, const char* path, double thr,
         FILE* f = fopen(path, "r");
         if (!f) throw vg_error(VG_EIO, std::string("cannot open filter ") + path);
         std::unordered_map<std::string, uint32_t> by_name;
+        by_name.reserve((size_t)g->n * 2);
         for (int i = 0; i < g->n; ++i) by_name.emplace(g->names[i], (uint32_t)i);
-        std::string data; char buf[1 << 16]; size_t r;
-        while ((r = fread(buf, 1, sizeof buf, f)) > 0) data.append(buf, r);
+        std::string data;
+        { fseek(f, 0, SEEK_END); const long long sz = ftell(f); fseek(f, 0, SEEK_SET); if (sz > 0) data.reserve((size_t)sz); }
+        { char buf[1 << 16]; size_t r; while ((r = fread(buf, 1, sizeof buf, f)) > 0) data.append(buf, r); }
         fclose(f);
-        size_t pos = 0; bool header = true; std::vector<int64_t> col_id;
-        while (pos < data.size()) {
-            size_t e = data.find('\n', pos); if (e == std::string::npos) e = data.size();
-            std::string line = data.substr(pos, e - pos); pos = e + 1;
-            if (!line.empty() && line.back() == '\r') line.pop_back();
-            if (header) {
-                header = false;
-                size_t c = line.find(',');
-                while (c != std::string::npos && c + 1 < line.size()) {
-                    size_t n2 = line.find(',', c + 1); if (n2 == std::string::npos) break;
-                    auto it = by_name.find(line.substr(c + 1, n2 - c - 1));
-                    col_id.push_back(it == by_name.end() ? -1 : (int64_t)it->second);
-                    c = n2;
-                }
-                continue;
-            }
-            size_t c = line.find(','); if (c == std::string::npos) continue;
-            auto it = by_name.find(line.substr(0, c));
-            int64_t row = it == by_name.end() ? -1 : (int64_t)it->second;
-            while (c != std::string::npos && c + 1 < line.size()) {
-                size_t n2 = line.find(',', c + 1);
-                std::string field = line.substr(c + 1, (n2 == std::string::npos ? line.size() : n2) - c - 1);
-                size_t colon = field.find(':');
-                if (colon != std::string::npos) {
-                    long ci = atol(field.c_str()) - 1; double val = atof(field.c_str() + colon + 1);
-                    if (row >= 0 && ci >= 0 && ci < (long)col_id.size() && col_id[ci] >= 0 && col_id[ci] != row && val >= thr) {
-                        uint32_t x = (uint32_t)row, y = (uint32_t)col_id[ci];
-                        v.push_back({ std::max(x, y), std::min(x, y), 0 });
-                    }
-                }
+        // header: column names -> genome ids
+        std::vector<int64_t> col_id;
+        size_t body = data.find('\n'); if (body == std::string::npos) body = data.size();
+        {
+            size_t he = body; if (he > 0 && data[he - 1] == '\r') --he;
+            size_t c = data.find(',');
+            while (c != std::string::npos && c + 1 < he) {
+                size_t n2 = data.find(',', c + 1); if (n2 == std::string::npos || n2 > he) break;
+                auto it = by_name.find(data.substr(c + 1, n2 - c - 1));
+                col_id.push_back(it == by_name.end() ? -1 : (int64_t)it->second);
                 c = n2;
             }
         }
+        // rows: parsed by several threads, each a range of whole lines, in place (no per-field strings)
+        const char* base = data.data(); const size_t n_data = data.size();
+        const size_t b0 = std::min(body + 1, n_data);
+        const int n_thr = std::max(1, std::min(vg_host_threads(), 16));
+        std::vector<std::vector<vg_pair_count>> part((size_t)n_thr);
+        vg_parallel_chunks((int64_t)(n_data - b0), n_thr, [&](int64_t lo, int64_t hi, int t) {
+            size_t p0 = b0 + (size_t)lo, p1 = b0 + (size_t)hi;
+            if (lo > 0) { const char* nl = (const char*)memchr(base + p0 - 1, '\n', n_data - (p0 - 1)); p0 = nl ? (size_t)(nl - base) + 1 : n_data; }   // first whole line
+            if ((size_t)hi < n_data - b0) { const char* nl = (const char*)memchr(base + p1 - 1, '\n', n_data - (p1 - 1)); p1 = nl ? (size_t)(nl - base) + 1 : n_data; }
+            std::vector<vg_pair_count>& out = part[(size_t)t];
+            std::string key;
+            while (p0 < p1) {
+                const char* nl = (const char*)memchr(base + p0, '\n', n_data - p0);
+                size_t le = nl ? (size_t)(nl - base) : n_data; const size_t next = le + 1;
+                if (le > p0 && base[le - 1] == '\r') --le;
+                const char* q = base + p0; const char* const e = base + le;
+                p0 = next;
+                const char* c = (const char*)memchr(q, ',', (size_t)(e - q)); if (!c) continue;
+                key.assign(q, (size_t)(c - q));
+                auto it = by_name.find(key);
+                const int64_t row = it == by_name.end() ? -1 : (int64_t)it->second;
+                q = c + 1;
+                while (q < e) {
+                    const char* n2 = (const char*)memchr(q, ',', (size_t)(e - q)); const char* fe = n2 ? n2 : e;
+                    const char* colon = (const char*)memchr(q, ':', (size_t)(fe - q));
+                    if (colon) {
+                        long ci = 0; const char* d = q; bool ok = d < colon;
+                        for (; d < colon; ++d) { if (*d < '0' || *d > '9') { ok = false; break; } ci = ci * 10 + (*d - '0'); }
+                        if (!ok) ci = atol(std::string(q, colon).c_str());
+                        ci -= 1;
+                        // value: digits '.' digits with <= 15 digits is exact as mantissa / 10^k; anything else goes to strtod
+                        double val; { uint64_t m = 0; int nd = 0, frac = -1; bool plain = colon + 1 < fe;
+                            for (const char* x = colon + 1; x < fe && plain; ++x) {
+                                if (*x >= '0' && *x <= '9') { m = m * 10 + (uint64_t)(*x - '0'); ++nd; if (frac >= 0) ++frac; }
+                                else if (*x == '.' && frac < 0) frac = 0; else plain = false;
+                            }
+                            if (plain && nd <= 15) { static const double p10[16] = { 1, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15 };
+                                val = (double)m / p10[frac < 0 ? 0 : frac]; }
+                            else val = atof(std::string(colon + 1, fe).c_str()); }
+                        if (row >= 0 && ci >= 0 && ci < (long)col_id.size() && col_id[(size_t)ci] >= 0 && col_id[(size_t)ci] != row && val >= thr) {
+                            const uint32_t x = (uint32_t)row, y = (uint32_t)col_id[(size_t)ci];
+                            out.push_back({ std::max(x, y), std::min(x, y), 0 });
+                        }
+                    }
+                    if (!n2) break;
+                    q = n2 + 1;
+                }
+            }
+        });
+        for (auto& pv : part) v.insert(v.end(), pv.begin(), pv.end());
         std::sort(v.begin(), v.end(), [](const vg_pair_count& x, const vg_pair_count& y) { return x.a != y.a ? x.a < y.a : x.b < y.b; });
         v.erase(std::unique(v.begin(), v.end(), [](const vg_pair_count& x, const vg_pair_count& y) { return x.a == y.a && x.b == y.b; }), v.end());
     }

@@ -2152,7 +2152,9 @@ extern "C" int vg_kmer_shared(vg_genomes* g, int k, double fraction, int shard, 
     const double expect = (double)P * fraction / n_shards;                 // k-mers kept by this shard, at most
     const bool dense = fraction >= 1.0 && n_shards == 1;
     int sub = 1;
+    static const int env_sub = [] { const char* e = getenv("VG_SUBSHARDS"); return e ? atoi(e) : 0; }();      // developer experiments
     if (g_force_subshards > 0) sub = g_force_subshards;
+    else if (env_sub > 0) sub = env_sub;
     else if (dense ? P >= (1LL << 32) : expect >= 3.9e9) sub = (int)std::ceil(expect / 3.6e9);      // row numbers of one pass are 32 bits
     if (sub < 1) sub = 1;
     std::vector<vg_pair_count> acc;
