@@ -79,24 +79,59 @@ def cpu_baseline(sample_families, members, length, seed, threads, k, min_kmers, 
                        'own CPU restatement (oracle/), not upstream: kmer-db / lz-ani sources are absent from the reference checkout')
 
 
+def _run_traced(cmd, env):
+    """One CLI process with the library's host-side phase marks (VG_HOST_TRACE): wall seconds, marks {name: ms since
+    the previous mark}, and the two stretches the library cannot see (process start -> first mark, last mark -> gone)."""
+    w0 = time.time(); t0 = time.perf_counter()
+    p = subprocess.run(cmd, check=True, env=dict(env, VG_HOST_TRACE='1'), stderr=subprocess.PIPE, text=True)
+    dt = time.perf_counter() - t0; w1 = time.time()
+    import re
+    marks, stamps = {}, []
+    for line in p.stderr.splitlines():
+        m = re.match(r'\[vg host\] (.*?)\s+\+([0-9.]+) ms\s+@([0-9.]+)\s*$', line)
+        if m:
+            name = m.group(1).strip()
+            marks[name] = round(marks.get(name, 0.0) + float(m.group(2)), 1)
+            stamps.append(float(m.group(3)))
+    out = dict(wall_s=round(dt, 3), marks_ms=marks)
+    if stamps:
+        out['start_to_first_mark_s'] = round(stamps[0] - w0, 3)      # interpreter, imports, dlopen of the library + HIP runtime
+        out['last_mark_to_exit_s'] = round(w1 - stamps[-1], 3)       # process tear-down (the driver releases the device context)
+    return out
+
+
+def _phase_sums(tr):
+    """Condensed view of one process's marks: seconds per phase."""
+    m = tr['marks_ms']
+    def tot(*prefixes):
+        return round(sum(v for k, v in m.items() if k.startswith(prefixes)) / 1e3, 3)
+    return dict(process_start=tr.get('start_to_first_mark_s'), ingest_and_upload=tot('ingest:', 'genomes uploaded', 'device ready'),
+                device_work=tot('buckets:', 'index built', 'spgemm', 'pass done', 'vg_kmer_shared', 'vg_lz_align', 'lz:', 'extract:'),
+                filter_and_tasks=tot('filter read', 'align_tasks'), writer_and_release=tot('fltr.txt written', 'ani.tsv written'),
+                process_exit=tr.get('last_mark_to_exit_s'))
+
+
 def cli_wall(codes, offsets, names, n_pairs):
     """End-to-end wall of the drop-in CLI: FASTA on disk -> fltr.txt -> ani.tsv on disk,
-    two processes (`vclust.py prefilter`, `vclust.py align --filter`), including process start, ingest and writers."""
+    two processes (`vclust.py prefilter`, `vclust.py align --filter`), including process start, ingest and writers,
+    with the per-process split of where the wall time goes."""
     with tempfile.TemporaryDirectory(dir=os.environ.get('TMPDIR', '/tmp')) as td:
         fa = os.path.join(td, 's.fna')
         synth.write_fasta(fa, codes, offsets, names)
         fl, ani = os.path.join(td, 'fltr.txt'), os.path.join(td, 'ani.tsv')
         env = dict(os.environ)
         t0 = time.perf_counter()
-        subprocess.run([sys.executable, str(ROOT / 'vclust.py'), 'prefilter', '-i', fa, '-o', fl, '-v', '0'], check=True, env=env)
+        pre = _run_traced([sys.executable, str(ROOT / 'vclust.py'), 'prefilter', '-i', fa, '-o', fl, '-v', '0'], env)
         t1 = time.perf_counter()
-        subprocess.run([sys.executable, str(ROOT / 'vclust.py'), 'align', '-i', fa, '-o', ani, '--filter', fl, '-v', '0'], check=True, env=env)
+        aln = _run_traced([sys.executable, str(ROOT / 'vclust.py'), 'align', '-i', fa, '-o', ani, '--filter', fl, '-v', '0'], env)
         t2 = time.perf_counter()
         rows = sum(1 for _ in open(ani)) - 1
         size = os.path.getsize(fa)
     return dict(prefilter_s=round(t1 - t0, 3), align_s=round(t2 - t1, 3), total_s=round(t2 - t0, 3), rows=rows,
                 fasta_bytes=size, pairs_per_s=round(rows / 2 / (t2 - t0), 1),
-                note='python vclust.py prefilter + align --filter, FASTA on disk -> ani.tsv on disk, two cold processes')
+                breakdown_s=dict(prefilter=_phase_sums(pre), align=_phase_sums(aln)),
+                note='python vclust.py prefilter + align --filter, FASTA on disk -> ani.tsv on disk, two cold processes; '
+                     'breakdown from the library\'s host-side phase marks (VG_HOST_TRACE)')
 
 
 def main():
@@ -176,12 +211,22 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
+    dt_local = dt
     if dist:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
     prof = api.profile_get()
     api.profile_enable(False)
+    # every rank reports its own stage times (stderr, one line each) and rank 0 carries them in the JSON line: a
+    # scaling run that goes wrong is diagnosable from its tail
+    mine = dict(rank=rank, s_per_step=round(dt_local / args.steps, 6), pairs=state.get('n_pairs'),
+                ms_per_step_by_scope={e['name']: round(e['total_ms'] / args.steps, 3) for e in prof})
+    print(f'[bench rank {rank}/{world}] ' + json.dumps(mine), file=sys.stderr, flush=True)
+    per_rank = [mine]
+    if dist:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
     if rank == 0:
         n_pairs = state['n_pairs']
@@ -252,12 +297,13 @@ def main():
             'config': {
                 'workload': f'{desc}, k={args.k}, min-kmers={min_kmers}, min-ident={args.min_ident}, lz defaults',
                 'genomes': int(len(gs)), 'pairs_per_step': int(n_pairs), 'total_bases': int(lens.sum()),
-                'sha256': synth.sha256(codes, offsets) if len(codes) <= (1 << 28) else None,
+                'sha256': synth.sha256(codes, offsets) if len(codes) <= (1 << 33) else None,      # (the headline set: pinned in tests/golden/synth_sha256.json)
                 'parallelism': f'kmer-range x{world} prefilter, reference-range x{world} align',
             },
             'roofline': roofline,
             'cpu_baseline': cpu,
             'cli_wall': e2e,
+            'per_rank': per_rank if world > 1 else None,
         }
         print(json.dumps(out))
     comm.close()

@@ -3,7 +3,7 @@
 # Usage: tools/collect_profiles.sh <round-tag> [workload] [n] [steps]
 #   -> gpurun_out/prof_<tag>_<workload>/{stats,fetch,write}/ + summary/ (copy summary/* into profiles/)
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 WL=${2:-phage-100k}
 N=${3:-}
 STEPS=${4:-3}

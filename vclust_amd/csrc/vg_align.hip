@@ -943,7 +943,10 @@ __device__ __forceinline__ void lz_parse_body(PARSE_ARGS) {
                     // slot = this task's offset (prefix sum of the stats pass) + regions kept so far: exact size, fixed order
                     vg_region rg; rg.task = tk.out_idx; rg.qstart = r_qstart; rg.qend = r_qend;
                     rg.rstart = r_rstart; rg.rend = r_rend; rg.n_match = r_match;
-                    regions[region_off[t] + (NR - 1)] = rg;
+                    // (the slots were sized by the counting pass: a region beyond them -- the two passes disagreeing -- is
+                    // dropped here and reported by the host, which compares the region counts of the two passes)
+                    const unsigned long long at = region_off[t] + (NR - 1);
+                    if (at < region_off[t + 1]) regions[at] = rg;
                 }
             }
             in_region = false;
@@ -1327,6 +1330,7 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
     const bool want_regions = regions != nullptr;
     std::vector<vg_region> h_regions;                 // all kept regions, batch after batch
     std::vector<vg_pair_stat> h_stats;                // host copy of the rows (sizes the region buffer)
+    std::vector<vg_pair_stat> first_pass;             // --out-aln: the rows of the counting pass, batch after batch
 
     // ---- plan: references are taken in id order, batch after batch, each batch's indexes under the budget.
     // (Building batch b + 1 on a second stream while batch b is parsed was measured: the 160 KiB-LDS build
@@ -1497,7 +1501,12 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
                 d_stats.download(h_stats.data(), (size_t)n_tasks, s);
                 VG_HIP(hipStreamSynchronize(s));
                 std::vector<unsigned long long> off((size_t)nt + 1, 0);
-                for (int64_t t = 0; t < nt; ++t) off[(size_t)t + 1] = off[(size_t)t] + h_stats[td[(size_t)(B.pos + t)].out_idx].n_regions;
+                if (first_pass.empty()) first_pass.resize((size_t)n_tasks);
+                for (int64_t t = 0; t < nt; ++t) {
+                    const uint32_t oi = td[(size_t)(B.pos + t)].out_idx;
+                    first_pass[oi] = h_stats[oi];
+                    off[(size_t)t + 1] = off[(size_t)t] + h_stats[oi].n_regions;
+                }
                 const unsigned long long nr = off[(size_t)nt];
                 if (nr) {
                     dbuf<unsigned long long> d_off((size_t)nt + 1); d_off.upload(off.data(), off.size(), s);
@@ -1522,6 +1531,10 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
     VG_HIP(hipStreamSynchronize(s));
     vg_host_mark("lz: rows downloaded");
     if (want_regions) {
+        // the region pass (general kernel) rewrote the rows: they must be the rows the slots were sized from
+        for (int64_t t = 0; t < n_tasks && !first_pass.empty(); ++t)
+            if (stats[t].n_regions != first_pass[(size_t)t].n_regions || stats[t].n_match != first_pass[(size_t)t].n_match || stats[t].aln_len != first_pass[(size_t)t].aln_len)
+                throw vg_error(VG_EHIP, "internal error: the region pass and the counting pass of the LZ parse disagree on task " + std::to_string(t));
         vg_region* o = (vg_region*)malloc(sizeof(vg_region) * std::max<size_t>(1, h_regions.size()));
         if (!o) throw vg_error(VG_ENOMEM, "out of host memory");
         if (!h_regions.empty()) memcpy(o, h_regions.data(), sizeof(vg_region) * h_regions.size());
