@@ -172,7 +172,9 @@ int vg_align(const char* const* fasta_paths, int n_paths, const char* out_path,
  *                        means send / recv are device pointers of the current HIP device, else host pointers
  *   vg_comm_rccl_create  built-in: RCCL (ncclAllGather over xGMI) on the library's stream; rank 0 obtains the
  *                        128-byte id with vg_rccl_unique_id and hands it to the other ranks by any means
- * A rank that fails makes every rank return the error (status words are agreed on before each exchange). */
+ * A rank that fails -- in its shard, in an allocation, in a merge -- makes every rank return the error: every compute
+ * section between two exchanges feeds its status into the next agreement.  VG_DIST_FORCE=1 (tests) runs the exchanges
+ * with a world of one. */
 typedef struct vg_comm vg_comm;
 typedef int (*vg_allgather_fn)(void* ctx, const void* send, void* recv, int64_t bytes, int on_device);
 int  vg_comm_create(int rank, int world, vg_allgather_fn allgather, void* ctx, vg_comm** out);
@@ -184,9 +186,11 @@ int  vg_comm_world(const vg_comm* c);
 /* exchange self-test: every rank sends a pattern of `bytes` bytes and checks what it receives (no GPU needed
  * for a callback communicator over host memory) */
 int  vg_comm_selftest(const vg_comm* c, int64_t bytes);
-/* vg_kmer_shared over all ranks: rank r counts the k-mers of hash range r; the partial (a, b, count) records
- * and set sizes are all-gathered and summed on the device; every rank receives the global result
- * (pairs with >= min_shared shared k-mers; the threshold is applied to the SUM) */
+/* vg_kmer_shared over all ranks: rank r counts the k-mers of hash range r and keeps its partial (a, b, count)
+ * list in HBM.  Exchanged: the set sizes, the KEYS of the pairs a rank holds >= ceil(min_shared / world) of (a pair
+ * that reaches min_shared in total has that many on some rank), and every rank's count for each pair of the union of
+ * those keys; the counts are summed and the threshold is applied to the SUM.  Every rank receives the global result,
+ * sorted by (a, b); device-to-device all-gathers only. */
 int vg_kmer_shared_sharded(vg_genomes* g, int k, double fraction, uint32_t min_shared, const vg_comm* c,
                            int64_t* set_sizes, vg_pair_count** pairs, int64_t* n_pairs);
 /* owner rank of every task: references cut into `world` contiguous id ranges with about equal task counts */

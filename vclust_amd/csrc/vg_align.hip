@@ -1215,7 +1215,7 @@ inline int grid_for(int64_t n, int block = 256, int max_blocks = 256 * 16) {
 
 }  // namespace
 
-static int64_t g_index_budget_bytes = 24LL << 30;
+static int64_t g_index_budget_bytes = [] { const char* e = getenv("VG_INDEX_BUDGET_GB"); const double v = e ? atof(e) : 0.0; return v >= 0.0625 ? (int64_t)(v * 1073741824.0) : (24LL << 30); }();
 // ---- task grouping on the device: the caller's (q, r) list is counted per reference, stably sorted on r
 // (rocPRIM radix sort of the 17..32-bit reference ids with the list position as value) and turned into the
 // device task records -- the host only sees the per-reference counts it plans the batches from.

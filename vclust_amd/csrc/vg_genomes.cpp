@@ -163,22 +163,6 @@ void find_records(const filebuf& fb, std::vector<record>& out, int n_threads) {
     }
 }
 
-// symbols of a record = its bytes minus white space (\n \r space \t), counted eight bytes at a time: an exact
-// per-byte "equals v" mask for each of the four values (no borrow between bytes), one popcount
-inline uint64_t eq_mask(uint64_t x, uint64_t v) {
-    const uint64_t y = x ^ (v * 0x0101010101010101ULL), lo = 0x7F7F7F7F7F7F7F7FULL;
-    return ~(((y & lo) + lo) | y | lo);                 // 0x80 in every byte of x that equals v
-}
-int64_t count_bases(const record& r) {
-    int64_t ws = 0; const char* q = r.seq;
-    for (; q + 8 <= r.end; q += 8) {
-        uint64_t x; memcpy(&x, q, 8);
-        ws += __builtin_popcountll(eq_mask(x, '\n') | eq_mask(x, '\r') | eq_mask(x, ' ') | eq_mask(x, '\t'));
-    }
-    for (; q < r.end; ++q) ws += is_ws(*q);
-    return (int64_t)(r.end - r.seq) - ws;
-}
-
 // pack the bases of one record into the set's arrays starting at padded base position `at` (2-bit codes + N mask);
 // returns true if an N was seen.  Callers own disjoint word ranges and the arrays are zero.  Line by line (memchr
 // for the line end), sixteen symbols per trip: sixteen table look-ups OR-ed into one 32-bit group, no per-symbol
@@ -186,7 +170,7 @@ int64_t count_bases(const record& r) {
 // with anything unusual in it (N, white space inside a line) goes symbol by symbol.
 struct pack_lut { uint8_t t[256]; pack_lut() { for (int i = 0; i < 256; ++i) { const char ch = (char)i; t[i] = is_ws(ch) ? 5 : code_of((unsigned char)i); } } };
 const pack_lut PLUT;
-bool pack_record(const record& r, vg_genomes* g, int64_t at) {
+bool pack_record(const record& r, vg_genomes* g, int64_t at, int64_t* n_symbols) {
     uint32_t* pk = g->packed.data(); uint32_t* mk = g->nmask.data();
     bool any_n = false; int64_t i = at;                       // i = position of the next symbol
     uint64_t acc = 0; int nb = 2 * (int)(at & 15);            // pending output bits of word (i - pending symbols) >> 4
@@ -212,6 +196,7 @@ bool pack_record(const record& r, vg_genomes* g, int64_t at) {
         q = nl ? nl + 1 : end;
     }
     if (nb > 0) pk[wo] |= (uint32_t)acc;
+    *n_symbols = i - at;
     return any_n;
 }
 
@@ -265,18 +250,17 @@ static void genomes_load_impl(const char* const* paths, int n_paths, int multisa
         if (multi) for (size_t r = 0; r < v.size(); ++r) gd.push_back({ i, r, r + 1, 0 });
         else if (!v.empty()) gd.push_back({ i, 0, v.size(), 0 });
     }
-    {
-        std::vector<std::pair<int, size_t>> flat;
-        for (int i = 0; i < n_paths; ++i) for (size_t r = 0; r < recs[(size_t)i].size(); ++r) flat.push_back({ i, r });
-        parallel_for((int64_t)flat.size(), T, [&](int64_t j) { auto& r = recs[(size_t)flat[(size_t)j].first][flat[(size_t)j].second]; r.len = count_bases(r); });
-    }
-    vg_host_mark("ingest: records counted");
+    // No counting pass over the text: the layout is made from an UPPER BOUND of every genome's length -- the bytes of its
+    // sequence lines, line ends included (1/60 more than the truth for 60-column FASTA) --, the true length is what the
+    // packer has written when it reaches the end of the record, and the difference is padding (masked like the padding
+    // that aligns the next genome anyway).  One pass over 4 GB of text less per process.
     int64_t total = 0;
     for (auto& d : gd) {
-        for (size_t r = d.r0; r < d.r1; ++r) d.len += recs[(size_t)d.file][r].len;
+        for (size_t r = d.r0; r < d.r1; ++r) d.len += (int64_t)(recs[(size_t)d.file][r].end - recs[(size_t)d.file][r].seq);
         d.len += (int64_t)(d.r1 - d.r0) - 1;                 // records of one genome are joined by one N
         total += d.len;
     }
+    vg_host_mark("ingest: records found");
     // 3. layout, then parallel packing straight into the 2-bit arrays
     vg_genomes* g = new vg_genomes();
     std::unique_ptr<vg_genomes> guard(g);
@@ -287,7 +271,7 @@ static void genomes_load_impl(const char* const* paths, int n_paths, int multisa
         const int64_t padded = (d.len / al + 1) * al;          // >= 1 masked base behind the genome (see vg_genomes_append)
         for (int64_t b = g->base_off.back() >> g->align_shift; b < (g->base_off.back() + padded) >> g->align_shift; ++b) g->blk2g.push_back((uint32_t)g->n);
         g->base_off.push_back(g->base_off.back() + padded);
-        g->len.push_back(d.len); g->n_parts.push_back((int32_t)(d.r1 - d.r0)); g->has_n.push_back(0);
+        g->len.push_back(0); g->n_parts.push_back((int32_t)(d.r1 - d.r0)); g->has_n.push_back(0);      // (the length: set by the packer)
         const record& r0 = recs[(size_t)d.file][d.r0];
         if (multi) g->names.push_back(first_token(r0.hdr, r0.hdr_end));
         else { std::string pth = paths[d.file]; size_t sl = pth.find_last_of('/'); g->names.push_back(sl == std::string::npos ? pth : pth.substr(sl + 1)); }
@@ -355,10 +339,17 @@ static void genomes_load_impl(const char* const* paths, int n_paths, int multisa
         int64_t at = g->base_off[(size_t)gi]; bool any_n = false;
         for (size_t r = d.r0; r < d.r1; ++r) {
             if (r > d.r0) { g->nmask[(size_t)(at >> 5)] |= 1u << (at & 31); ++at; any_n = true; }   // joining N
-            any_n |= pack_record(recs[(size_t)d.file][r], g, at);
-            at += recs[(size_t)d.file][r].len;
+            int64_t n_sym = 0;
+            any_n |= pack_record(recs[(size_t)d.file][r], g, at, &n_sym);
+            at += n_sym;
         }
-        for (int64_t i = at; i < g->base_off[(size_t)gi + 1]; ++i) g->nmask[(size_t)(i >> 5)] |= 1u << (i & 31);   // padding
+        g->len[(size_t)gi] = at - g->base_off[(size_t)gi];
+        {   // padding up to the next genome: single bits up to a word boundary, then whole words
+            int64_t i = at; const int64_t e = g->base_off[(size_t)gi + 1];
+            for (; i < e && (i & 31); ++i) g->nmask[(size_t)(i >> 5)] |= 1u << (i & 31);
+            for (; i + 32 <= e; i += 32) g->nmask[(size_t)(i >> 5)] = 0xffffffffu;
+            for (; i < e; ++i) g->nmask[(size_t)(i >> 5)] |= 1u << (i & 31);
+        }
         g->has_n[(size_t)gi] = any_n ? 1 : 0;
         if (uploader.joinable() && st_left[(size_t)st_of[(size_t)gi]].fetch_sub(1) == 1) {
             { std::lock_guard<std::mutex> lk(up_mu); up_queue.push_back(st_of[(size_t)gi]); }
