@@ -1,5 +1,5 @@
 // malloc_cost.hip -- developer tool: what a cold allocation of tens of GB costs on this box (the CLI's wall time was
-// dominated by it).  One strategy per process: malloc_cost <GiB> <mode>, mode = big | pieces | async | vmm
+// dominated by it).  One strategy per process: malloc_cost <GiB> <mode>, mode = big | pieces <n> | async | vmm <GiB per chunk>
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
@@ -26,6 +26,26 @@ int main(int argc, char** argv) {
         hipMemPool_t pool; CK(hipDeviceGetDefaultMemPool(&pool, 0)); uint64_t thr = ~0ULL; CK(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr));
         void* p; CK(hipMallocAsync(&p, bytes, 0)); CK(hipStreamSynchronize(0)); t1 = now(); printf("  alloc %.3f s", t1 - t0);
         t0 = now(); CK(hipMemset(p, 1, bytes)); CK(hipDeviceSynchronize()); t1 = now(); printf("  memset %.3f s", t1 - t0);
+    }
+    else if (!strcmp(mode, "vmm")) {
+        // virtual memory management API: one address range, physical chunks of `piece` GiB mapped into it
+        const double piece_gib = argc > 3 ? atof(argv[3]) : 1.0;
+        hipMemAllocationProp prop = {}; prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = 0;
+        size_t gran = 0; CK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+        size_t piece = (size_t)(piece_gib * 1073741824.0); piece = (piece + gran - 1) / gran * gran;
+        const size_t n = (bytes + piece - 1) / piece, total = n * piece;
+        void* va = nullptr; CK(hipMemAddressReserve(&va, total, 0, nullptr, 0));
+        std::vector<hipMemGenericAllocationHandle_t> h(n);
+        for (size_t i = 0; i < n; ++i) { CK(hipMemCreate(&h[i], piece, &prop, 0)); CK(hipMemMap((char*)va + i * piece, piece, 0, h[i], 0)); }
+        hipMemAccessDesc acc = {}; acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
+        CK(hipMemSetAccess(va, total, &acc, 1));
+        t1 = now(); printf("  alloc %zu x %.2f GiB (granularity %zu KiB) %.3f s", n, piece / 1073741824.0, gran >> 10, t1 - t0);
+        t0 = now(); CK(hipMemset(va, 1, total)); CK(hipDeviceSynchronize()); t1 = now(); printf("  memset %.3f s", t1 - t0);
+        size_t fr = 0, tot = 0; CK(hipMemGetInfo(&fr, &tot)); printf("  free before release %.1f GiB", fr / 1073741824.0);
+        t0 = now();
+        CK(hipMemUnmap(va, total)); for (size_t i = 0; i < n; ++i) CK(hipMemRelease(h[i])); CK(hipMemAddressFree(va, total));
+        t1 = now(); CK(hipMemGetInfo(&fr, &tot)); printf("  release %.3f s, free after %.1f GiB", t1 - t0, fr / 1073741824.0);
+        t0 = now(); void* p2; CK(hipMalloc(&p2, 1 << 30)); t1 = now(); printf("  next hipMalloc(1 GiB) %.3f s", t1 - t0);
     }
     printf("\n");
     return 0;

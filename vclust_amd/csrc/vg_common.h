@@ -31,6 +31,7 @@ hipStream_t vg_stream();         // the library's compute stream on the current 
 void* vg_dev_alloc(size_t bytes); // caching device allocator (throws vg_error)
 void  vg_dev_free(void* p);
 void  vg_dev_trim();             // return all cached blocks to the driver
+void  vg_alloc_one_shot();       // a cold one-shot process (the CLI's whole-stage calls): large blocks through the VMM API
 
 // ---------------------------------------------------------------- device buffers
 template <class T> struct dbuf {

@@ -24,7 +24,6 @@ extern "C" void vg_free(void* p) { free(p); }
 
 static int g_device = -1;
 static hipStream_t g_stream = nullptr;
-static bool g_pool_ready = false;          // release threshold of the current device's memory pool set (vg_dev_alloc)
 
 extern "C" int vg_device_count(void) {
     int n = 0;
@@ -42,7 +41,6 @@ extern "C" int vg_set_device(int device) {
         // (genome sets re-upload themselves on their next use, vg_genomes_to_device)
         vg_dev_trim();
         if (g_stream) { (void)hipStreamDestroy(g_stream); g_stream = nullptr; }
-        g_pool_ready = false;
     }
     VG_HIP(hipSetDevice(device));
     g_device = device;
@@ -100,27 +98,82 @@ constexpr size_t ALLOC_GRAN = 1 << 12;
 const bool g_alloc_trace = [] { const char* e = getenv("VG_ALLOC_TRACE"); return e && *e && *e != '0'; }();
 }
 
-// Blocks come from the device's stream-ordered memory pool (hipMallocAsync on the library stream, release threshold
-// "never"): one hipMalloc of tens of GB costs ~30 ms per GiB on this platform (0.97 s for 32 GiB, measured with
-// tools/micro/malloc_cost.hip), the pool hands out the same 32 GiB in 45 ms -- the CLI's wall time was mostly that.
-// VG_ALLOC=malloc goes back to plain hipMalloc / hipFree.
-static const bool g_pool_alloc = [] { const char* e = getenv("VG_ALLOC"); return !(e && !strcmp(e, "malloc")); }();
+// Large blocks (>= 1 GiB) are assembled with the virtual memory management API: one reserved address range, physical
+// chunks of 2 GiB mapped into it.  One hipMalloc of 32 GiB costs up to 0.97 s on this platform (the driver clears the
+// memory as it hands it out; the round-2 CLI spent 1.9 s of its 3.2 s prefilter there), the same 32 GiB through
+// hipMemCreate / hipMemMap 0.02 s (tools/micro/malloc_cost.hip), and hipMemUnmap / hipMemRelease return the memory to
+// the driver at once.  (The device's stream-ordered pool, hipMallocAsync, is as fast, but what hipMemPoolTrimTo takes
+// out of it did not come back to the device here: a 1 M-contig run after other work in the same process ran out of
+// memory with 190 GB "free".)
+// It is used by the one-shot whole-stage calls of a COLD process only (vg_alloc_one_shot: the CLI), where the cost of the
+// first allocations is the wall time; a long-lived process (API users, bench, tests) amortises hipMalloc through the
+// caching allocator above it and keeps to the plain path (two aborts inside a long test process were seen with the
+// VMM path on for everything; they did not reproduce, the cause is open).  VG_ALLOC=vmm / malloc forces one.
+static int g_vmm_mode = [] { const char* e = getenv("VG_ALLOC"); return !e ? 0 : !strcmp(e, "vmm") ? 1 : !strcmp(e, "malloc") ? -1 : 0; }();
+static bool g_vmm_alloc = g_vmm_mode > 0;
+static bool g_ever_allocated = false;
+void vg_alloc_one_shot() { if (g_vmm_mode == 0 && !g_ever_allocated) g_vmm_alloc = true; }
+namespace {
+struct vmm_block { std::vector<hipMemGenericAllocationHandle_t> handles; size_t total; };
+std::map<void*, vmm_block> g_vmm_blocks;
+std::mutex g_vmm_mu;
+constexpr size_t VMM_MIN = 1ull << 30, VMM_CHUNK = 2ull << 30;
+}
+static void vmm_release(void* va, vmm_block& b, size_t mapped_chunks) {
+    if (mapped_chunks) (void)hipMemUnmap(va, std::min(b.total, mapped_chunks * VMM_CHUNK));
+    for (auto& h : b.handles) (void)hipMemRelease(h);
+    (void)hipMemAddressFree(va, b.total);
+}
+static hipError_t vmm_alloc(void** p, size_t bytes) {
+    hipMemAllocationProp prop = {}; prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = g_device;
+    size_t gran = 0;
+    hipError_t e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended);
+    if (e != hipSuccess) return e;
+    if (gran < (2u << 20)) gran = 2u << 20;
+    vmm_block b; b.total = (bytes + gran - 1) / gran * gran;
+    void* va = nullptr;
+    e = hipMemAddressReserve(&va, b.total, 0, nullptr, 0);
+    if (e != hipSuccess) return e;
+    size_t mapped = 0;
+    for (size_t off = 0; off < b.total; off += VMM_CHUNK) {
+        const size_t n = std::min(VMM_CHUNK, b.total - off);
+        hipMemGenericAllocationHandle_t h;
+        e = hipMemCreate(&h, n, &prop, 0);
+        if (e != hipSuccess) break;
+        b.handles.push_back(h);
+        e = hipMemMap((char*)va + off, n, 0, h, 0);
+        if (e != hipSuccess) break;
+        ++mapped;
+    }
+    if (e == hipSuccess) {
+        hipMemAccessDesc acc = {}; acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
+        e = hipMemSetAccess(va, b.total, &acc, 1);
+    }
+    if (e != hipSuccess) { vmm_release(va, b, mapped); return e; }
+    std::lock_guard<std::mutex> lk(g_vmm_mu);
+    g_vmm_blocks[va] = std::move(b);
+    *p = va;
+    return hipSuccess;
+}
 static hipError_t raw_alloc(void** p, size_t bytes) {
-    if (g_pool_alloc) {
-        hipStream_t s = vg_stream();
-        if (!g_pool_ready) {
-            hipMemPool_t pool; uint64_t thr = ~0ULL;
-            if (hipDeviceGetDefaultMemPool(&pool, g_device) == hipSuccess) (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
-            g_pool_ready = true;
-        }
-        hipError_t e = hipMallocAsync(p, bytes, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);     // usable from any stream (and by blocking copies) from here on
-        return e;
+    g_ever_allocated = true;
+    if (g_vmm_alloc && bytes >= VMM_MIN) {
+        const hipError_t e = vmm_alloc(p, bytes);
+        if (e == hipSuccess || e == hipErrorOutOfMemory) return e;
+        (void)hipGetLastError();                      // the API is not usable here: plain allocation
     }
     return hipMalloc(p, bytes);
 }
 static void raw_free(void* p) {
-    if (g_pool_alloc) { if (hipFreeAsync(p, vg_stream()) == hipSuccess) return; (void)hipGetLastError(); }
+    {
+        std::unique_lock<std::mutex> lk(g_vmm_mu);
+        auto it = g_vmm_blocks.find(p);
+        if (it != g_vmm_blocks.end()) {
+            vmm_block b = std::move(it->second); g_vmm_blocks.erase(it); lk.unlock();
+            vmm_release(p, b, b.handles.size());
+            return;
+        }
+    }
     (void)hipFree(p);
 }
 
@@ -159,7 +212,7 @@ void vg_dev_free(void* p) {
     g_live_bytes -= it->second.size;
     if (it->second.device != g_device) {
         // a block of another device (a genome set freed after vg_set_device): it must not be handed out here
-        g_block_size.erase(it); lk.unlock(); (void)hipFree(p); return;       // (hipFree takes pool memory of any device)
+        g_block_size.erase(it); lk.unlock(); raw_free(p); return;
     }
     g_free_blocks.emplace(it->second.size, p); g_cached_bytes += it->second.size;
 }
@@ -174,11 +227,6 @@ void vg_dev_trim() {
     if (!blocks.empty()) {
         (void)hipDeviceSynchronize();
         for (void* b : blocks) raw_free(b);
-        if (g_pool_alloc) {
-            // the pool keeps what it is given back: return it to the driver as well
-            (void)hipStreamSynchronize(vg_stream());
-            hipMemPool_t pool; if (hipDeviceGetDefaultMemPool(&pool, g_device) == hipSuccess) (void)hipMemPoolTrimTo(pool, 0);
-        }
     }
 }
 
