@@ -785,6 +785,126 @@ k_build_index_reg(const ref_desc* __restrict__ refs, const int* __restrict__ slo
     }
 }
 
+// ---- path A1 (references of REG_MAX_RR .. MID_MAX_RR symbols -- genomes of 49 .. 262 kb --, msl <= 7): the positions do
+// not fit the registers, and k_build_index_lds parks every position's (bucket, tag) in a global scratch that each
+// staging window reads again (30 bytes of traffic per RR symbol).  Here NOTHING is parked: RR is written once (2 bits
+// per symbol: it stays in the L2) and every pass recomputes (bucket, tag) from it.  Pass 0 counts the buckets (table in
+// the LDS); the entries then leave bucket range by bucket range -- a window is the longest run of whole buckets whose
+// entries fit the staging part of the LDS: the table entry of a bucket of the window is its cursor (LDS atomics), the
+// staged entries go out as one coalesced copy.  5 bytes per RR symbol reach the HBM.
+constexpr int MID_MAX_RR = 1 << 19;
+constexpr int MID_STAGE = 23552;                        // staged entries per window (92 KiB beside the 64 KiB table)
+__global__ void __launch_bounds__(1024)
+k_build_index_mid(const ref_desc* __restrict__ refs, const int* __restrict__ slot_list, int n_list,
+                  const uint32_t* __restrict__ packed, const uint32_t* __restrict__ nmask, const int64_t* __restrict__ base_off,
+                  uint32_t* __restrict__ rr_pool, uint32_t* __restrict__ mask_pool, int msl,
+                  uint32_t* __restrict__ stab_pool, uint32_t* __restrict__ sent_pool) {
+    __shared__ uint32_t tab[LDS_TAB];
+    __shared__ uint32_t stage[MID_STAGE];
+    __shared__ uint32_t wtot[16];
+    const uint32_t smask = (1u << (2 * msl)) - 1u;
+    const int nb = 1 << (2 * msl);
+    const int tid = threadIdx.x;
+    for (int li = blockIdx.x; li < n_list; li += gridDim.x) {
+        const ref_desc rd = refs[slot_list[li]];
+        const int64_t g0 = base_off[rd.genome];
+        const uint32_t* gpk = packed + (g0 >> 4); const uint32_t* gmk = nmask + (g0 >> 5);
+        uint32_t* pk = rr_pool + rd.rr_w; uint32_t* mk = mask_pool + rd.mask_w;
+        uint32_t* gtab = stab_pool + rd.stab; uint32_t* gent = sent_pool + rd.sent;
+        const int chunks = (rd.n_rr + RR_PAD + 31) / 32 + 2;
+        for (int ch = tid; ch < chunks; ch += 1024) {
+            uint64_t bits; uint32_t m;
+            rr_chunk(gpk, gmk, rd.L, ch, &bits, &m);
+            pk[2 * ch] = (uint32_t)bits; pk[2 * ch + 1] = (uint32_t)(bits >> 32); mk[ch] = m;
+        }
+        for (int i = tid; i < nb; i += 1024) tab[i] = 0;
+        __threadfence_block();
+        __syncthreads();                                          // RR is read back below (this workgroup's own stores)
+        const uint32_t tagmask = rd.tag_bits ? ((1u << rd.tag_bits) - 1u) : 0u;
+        const int n16 = (rd.n_rr + 15) & ~15;
+        // a thread takes 16 positions per trip: one RR word, its successor and the N mask of the stretch.  The words of
+        // the NEXT trip are asked for before this trip's are used (the passes are latency-bound: 16 waves per CU).
+        auto load16 = [&](int p0, uint32_t& w0, uint32_t& w1, uint32_t& ok) {
+            const int wi = p0 >> 4;
+            w0 = pk[wi]; w1 = pk[wi + 1];
+            const uint32_t m = __builtin_amdgcn_alignbit(mk[(p0 >> 5) + 1], mk[p0 >> 5], (uint32_t)(p0 & 31));
+            uint32_t bad = m;                                     // bit j: an N among the symbols j .. j + msl - 1
+            for (int q = 1; q < msl; ++q) bad |= m >> q;
+            ok = ~bad & 0xffffu;
+            const int last = rd.n_rr - msl - p0;                  // the last j at which a whole msl-mer starts
+            if (last < 15) ok &= last < 0 ? 0u : (2u << last) - 1u;
+        };
+        // pass 0: bucket sizes
+        {
+            int p0 = 16 * tid; uint32_t w0 = 0, w1 = 0, ok = 0;
+            if (p0 < n16) load16(p0, w0, w1, ok);
+            while (p0 < n16) {
+                const int pn = p0 + 16384; uint32_t a0 = 0, a1 = 0, aok = 0;
+                if (pn < n16) load16(pn, a0, a1, aok);
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    if ((ok >> j) & 1u) atomicAdd(&tab[__builtin_amdgcn_alignbit(w1, w0, 2u * j) & smask], 1u);
+                p0 = pn; w0 = a0; w1 = a1; ok = aok;
+            }
+        }
+        lds_sync();
+        const uint32_t total = lds_scan_exclusive_waves(tab, nb, wtot);     // tab[b] = first slot of bucket b
+        // windows of whole buckets; tab[b] of a bucket not yet taken is still its START
+        for (int b_lo = 0; b_lo < nb;) {
+            const uint32_t base = tab[b_lo];
+            // largest b_hi in (b_lo, nb] with (start of b_hi, or the total) - base <= MID_STAGE
+            int lo = b_lo, hi = nb;                               // invariant: the buckets [b_lo, lo) fit
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; const uint32_t e = mid < nb ? tab[mid] : total; if (e - base <= (uint32_t)MID_STAGE) lo = mid; else hi = mid - 1; }
+            const bool direct = lo == b_lo;                       // ONE bucket beyond the staging window: its entries go straight out
+            const int b_hi = direct ? b_lo + 1 : lo;
+            const uint32_t w_end = b_hi < nb ? tab[b_hi] : total;
+            const uint32_t width = (uint32_t)(b_hi - b_lo);
+            lds_sync();                                           // (everybody has read the table before its cursors move)
+            if (w_end > base) {
+                int p0 = 16 * tid; uint32_t w0 = 0, w1 = 0, ok = 0;
+                if (p0 < n16) load16(p0, w0, w1, ok);
+                while (p0 < n16) {
+                    const int pn = p0 + 16384; uint32_t a0 = 0, a1 = 0, aok = 0;
+                    if (pn < n16) load16(pn, a0, a1, aok);
+                    uint32_t hits = 0;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j)
+                        if ((__builtin_amdgcn_alignbit(w1, w0, 2u * j) & smask) - (uint32_t)b_lo < width) hits |= 1u << j;
+                    hits &= ok;
+                    while (hits) {                                // two hits per trip: both cursors are asked for before either entry is stored
+                        const int j1 = __ffs(hits) - 1; hits &= hits - 1;
+                        const int j2 = hits ? __ffs(hits) - 1 : -1; hits &= hits - 1;     // (0 & anything stays 0)
+                        const uint32_t x1 = __builtin_amdgcn_alignbit(w1, w0, 2u * (uint32_t)j1);
+                        const uint32_t s1 = atomicAdd(&tab[x1 & smask], 1u);
+                        uint32_t x2 = 0, s2 = 0;
+                        if (j2 >= 0) { x2 = __builtin_amdgcn_alignbit(w1, w0, 2u * (uint32_t)j2); s2 = atomicAdd(&tab[x2 & smask], 1u); }
+                        const uint32_t e1 = (uint32_t)(p0 + j1) | (((x1 >> (2 * msl)) & tagmask) << rd.pos_bits);
+                        if (direct) gent[s1] = e1; else stage[s1 - base] = e1;
+                        if (j2 >= 0) {
+                            const uint32_t e2 = (uint32_t)(p0 + j2) | (((x2 >> (2 * msl)) & tagmask) << rd.pos_bits);
+                            if (direct) gent[s2] = e2; else stage[s2 - base] = e2;
+                        }
+                    }
+                    p0 = pn; w0 = a0; w1 = a1; ok = aok;
+                }
+                lds_sync();
+                if (!direct) {
+                    const uint32_t n = w_end - base;
+                    for (uint32_t i = 4u * (uint32_t)tid; i < n; i += 4096u) {
+                        if (i + 4 <= n && ((base + i) & 3u) == 0) { const uint4 v = make_uint4(stage[i], stage[i + 1], stage[i + 2], stage[i + 3]); __builtin_memcpy(gent + base + i, &v, 16); }
+                        else for (uint32_t j = i; j < min(n, i + 4); ++j) gent[base + j] = stage[j];
+                    }
+                    lds_sync();
+                }
+            }
+            b_lo = b_hi;
+        }
+        // every cursor now stands at the END of its bucket: the table the parse reads
+        for (uint32_t i = 4u * (uint32_t)tid; i < (uint32_t)nb; i += 4096u) { const uint4 v = make_uint4(tab[i], tab[i + 1], tab[i + 2], tab[i + 3]); __builtin_memcpy(gtab + i, &v, 16); }
+        lds_sync();
+    }
+}
+
 // ---- path B (large references / long seeds): global-memory counting sort
 __global__ void __launch_bounds__(256)
 k_build_rr(const ref_desc* __restrict__ refs, const int* __restrict__ slot_list, int n_list,
@@ -1340,7 +1460,7 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
         int64_t pos = 0, end = 0;            // sorted task range
         int first_ref = 0, n_refs = 0;       // reference ordinals [first_ref, first_ref + n_refs)
         std::vector<int64_t> chunk_off{ 0 };
-        std::vector<int> reg_list, small_list, large_list; std::vector<int64_t> large_chunks{ 0 };
+        std::vector<int> reg_list, mid_list, small_list, large_list; std::vector<int64_t> large_chunks{ 0 };
         int64_t rr_words = 0, mask_words = 0, stab_tot = 0, sent_n = 0, scratch_words = 0, stride = 0;
         int nblk_build = 0;
         double bytes_alg = 0; int64_t q_max = 0, q_sum = 0;          // SURVEY 8(d) bytes of the batch; longest / total query
@@ -1384,6 +1504,7 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
             const int gi = B.first_ref + i;                      // ordinal = index into all_refs / the device array
             const bool small = all_refs[(size_t)gi].n_rr <= (1 << 21) && p->msl <= 7;
             if (small && all_refs[(size_t)gi].n_rr <= REG_MAX_RR && !g_no_reg_build) B.reg_list.push_back(gi);
+            else if (small && all_refs[(size_t)gi].n_rr <= MID_MAX_RR && !g_no_reg_build) B.mid_list.push_back(gi);
             else if (small) B.small_list.push_back(gi);
             else { B.large_list.push_back(gi); B.large_chunks.push_back(B.large_chunks.back() + (B.chunk_off[(size_t)i + 1] - B.chunk_off[(size_t)i])); }
         }
@@ -1399,7 +1520,7 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
                 for (size_t i = 0; i < keyed.size(); ++i) list[i] = (int)(uint32_t)keyed[i];
             }
         };
-        longest_first(B.reg_list); longest_first(B.small_list);
+        longest_first(B.reg_list); longest_first(B.mid_list); longest_first(B.small_list);
         if (!B.small_list.empty()) {
             int64_t max_rr = 0; for (int i : B.small_list) max_rr = std::max<int64_t>(max_rr, all_refs[(size_t)i].n_rr);
             B.nblk_build = (int)std::min<size_t>(B.small_list.size(), 512);
@@ -1412,19 +1533,19 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
     // sized for the largest batch, is reused by every batch
     dbuf<ref_desc> d_refs(std::max<size_t>(1, all_refs.size()));
     if (!all_refs.empty()) d_refs.upload(all_refs.data(), all_refs.size(), s);
-    struct lz_slot { dbuf<uint32_t> rr_pool, mask_pool, stab_pool, sent_pool, scratch; dbuf<int> d_reg, d_small, d_large; dbuf<int64_t> d_lchunk; };
+    struct lz_slot { dbuf<uint32_t> rr_pool, mask_pool, stab_pool, sent_pool, scratch; dbuf<int> d_reg, d_mid, d_small, d_large; dbuf<int64_t> d_lchunk; };
     lz_slot slot;
     {
-        size_t m_rr = 0, m_mask = 0, m_stab = 1, m_sent = 0, m_scr = 1, m_reg = 1, m_small = 1, m_large = 1, m_lch = 1;
+        size_t m_rr = 0, m_mask = 0, m_stab = 1, m_sent = 0, m_scr = 1, m_reg = 1, m_mid = 1, m_small = 1, m_large = 1, m_lch = 1;
         for (auto& B : batches) {
             m_rr = std::max(m_rr, (size_t)B.rr_words); m_mask = std::max(m_mask, (size_t)B.mask_words);
             m_stab = std::max(m_stab, (size_t)B.stab_tot); m_sent = std::max(m_sent, (size_t)B.sent_n); m_scr = std::max(m_scr, (size_t)B.scratch_words);
-            m_reg = std::max(m_reg, B.reg_list.size()); m_small = std::max(m_small, B.small_list.size()); m_large = std::max(m_large, B.large_list.size());
+            m_reg = std::max(m_reg, B.reg_list.size()); m_mid = std::max(m_mid, B.mid_list.size()); m_small = std::max(m_small, B.small_list.size()); m_large = std::max(m_large, B.large_list.size());
             m_lch = std::max(m_lch, B.large_chunks.size());
         }
         lz_slot& L = slot;
         L.rr_pool.alloc(m_rr + 8); L.mask_pool.alloc(m_mask + 8); L.stab_pool.alloc(m_stab); L.sent_pool.alloc(m_sent + 4);
-        L.scratch.alloc(m_scr); L.d_reg.alloc(m_reg); L.d_small.alloc(m_small); L.d_large.alloc(m_large); L.d_lchunk.alloc(m_lch);
+        L.scratch.alloc(m_scr); L.d_reg.alloc(m_reg); L.d_mid.alloc(m_mid); L.d_small.alloc(m_small); L.d_large.alloc(m_large); L.d_lchunk.alloc(m_lch);
     }
     hipStream_t sb = s;
     static const char* seg_env = getenv("VG_LZ_SEGMENTS");
@@ -1432,6 +1553,7 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
         lz_batch& B = batches[bi];
         lz_slot& L = slot;
         if (!B.reg_list.empty()) L.d_reg.upload(B.reg_list.data(), B.reg_list.size(), sb);
+        if (!B.mid_list.empty()) L.d_mid.upload(B.mid_list.data(), B.mid_list.size(), sb);
         if (!B.small_list.empty()) L.d_small.upload(B.small_list.data(), B.small_list.size(), sb);
         if (!B.large_list.empty()) { L.d_large.upload(B.large_list.data(), B.large_list.size(), sb); L.d_lchunk.upload(B.large_chunks.data(), B.large_chunks.size(), sb); }
         const int64_t total_chunks = B.chunk_off.back();
@@ -1441,6 +1563,11 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
             if (!B.reg_list.empty()) {
                 hipLaunchKernelGGL(k_build_index_reg, dim3((unsigned)std::min<size_t>(B.reg_list.size(), 512)), dim3(1024), 0, sb, d_refs.p, L.d_reg.p,
                                    (int)B.reg_list.size(), g->d_packed.p, g->d_nmask.p, g->d_base_off.p, L.rr_pool.p, L.mask_pool.p, p->msl,
+                                   L.stab_pool.p, L.sent_pool.p);
+            }
+            if (!B.mid_list.empty()) {
+                hipLaunchKernelGGL(k_build_index_mid, dim3((unsigned)std::min<size_t>(B.mid_list.size(), 512)), dim3(1024), 0, sb, d_refs.p, L.d_mid.p,
+                                   (int)B.mid_list.size(), g->d_packed.p, g->d_nmask.p, g->d_base_off.p, L.rr_pool.p, L.mask_pool.p, p->msl,
                                    L.stab_pool.p, L.sent_pool.p);
             }
             if (!B.small_list.empty()) {
