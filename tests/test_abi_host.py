@@ -222,6 +222,43 @@ def test_ingest_random_fasta_equals_oracle_reader(tmp_path):
         assert int(gs.lengths()[i]) == len(codes) and np.array_equal(gs.codes(i), np.minimum(codes, 4)), path.name
 
 
+def _bgzf(data: bytes, block: int = 65280) -> bytes:
+    """bgzip's container: gzip members of <= 64 KiB with their compressed size in a 'BC' extra subfield, and the
+    empty end-of-file member."""
+    import struct
+    import zlib
+    out = bytearray()
+    for o in list(range(0, len(data), block)) + [len(data)]:
+        chunk = data[o:o + block] if o < len(data) else b''
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        cdata = co.compress(chunk) + co.flush()
+        bsize = 12 + 6 + len(cdata) + 8
+        out += struct.pack('<BBBBIBBH', 0x1f, 0x8b, 8, 4, 0, 0, 0xff, 6) + b'BC' + struct.pack('<HH', 2, bsize - 1)
+        out += cdata + struct.pack('<II', zlib.crc32(chunk) & 0xffffffff, len(chunk))
+    return bytes(out)
+
+
+def test_ingest_bgzf_blocks_in_parallel(tmp_path, golden_dir):
+    """A bgzip-compressed FASTA (block-parallel inflate) gives the genomes of the plain file and of the same text as
+    an ordinary one-member gzip; a damaged block is a read error, not a short set."""
+    import gzip
+    text = (golden_dir / 'multifasta.fna').read_bytes()
+    bg = _bgzf(text, block=4093)                      # odd block size: records and lines straddle members
+    assert gzip.decompress(bg) == text               # (a valid multi-member gzip stream for everybody else)
+    (tmp_path / 'b.fna.gz').write_bytes(bg)
+    (tmp_path / 'g.fna.gz').write_bytes(gzip.compress(text))
+    plain = api.GenomeSet.load([golden_dir / 'multifasta.fna'], multisample=True, n_threads=4)
+    for name in ('b.fna.gz', 'g.fna.gz'):
+        gs = api.GenomeSet.load([tmp_path / name], multisample=True, n_threads=4)
+        assert gs.names() == plain.names() and list(gs.lengths()) == list(plain.lengths()), name
+        for i in range(len(plain.names())):
+            assert np.array_equal(gs.codes(i), plain.codes(i)), (name, i)
+    bad = bytearray(bg); bad[len(bad) // 2] ^= 0x55
+    (tmp_path / 'bad.fna.gz').write_bytes(bytes(bad))
+    with pytest.raises(_lib.VclustGpuError):
+        api.GenomeSet.load([tmp_path / 'bad.fna.gz'], multisample=True, n_threads=4)
+
+
 def test_filter_pairs_equals_fltr_file(tmp_path, golden_dir):
     """vg_filter_pairs keeps exactly the pairs vg_write_fltr prints (golden fltr.txt: 13 entries)."""
     codes, offsets, names = orc.read_fasta_codes(golden_dir / 'multifasta.fna')

@@ -7,6 +7,7 @@
   timing.py phases [families]   the same chain inside ONE process through the API, call by call
   timing.py step [families]     wall-clock split of one bench step (host + device)
   timing.py lz                  LZ parse kernel on synthetic pairs of graded divergence
+  timing.py gz [families]       host ingest of the same FASTA as plain text, one-member gzip and bgzip (BGZF) blocks
 """
 import os
 import pathlib
@@ -130,7 +131,37 @@ def lz():
     run('phage-1k families', c, o, synth.family_pairs(100, 10))
 
 
+def _bgzf(data, block=65280):
+    """bgzip's container (no bgzip binary in the image): gzip members of <= 64 KiB, compressed size in a 'BC' subfield"""
+    import struct
+    import zlib
+    out = bytearray()
+    for o in list(range(0, len(data), block)) + [len(data)]:
+        chunk = data[o:o + block] if o < len(data) else b''
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        cdata = co.compress(chunk) + co.flush()
+        out += struct.pack('<BBBBIBBH', 0x1f, 0x8b, 8, 4, 0, 0, 0xff, 6) + b'BC' + struct.pack('<HH', 2, 12 + 6 + len(cdata) + 8 - 1)
+        out += cdata + struct.pack('<II', zlib.crc32(chunk) & 0xffffffff, len(chunk))
+    return bytes(out)
+
+
+def gz(nf):
+    import gzip
+    with tempfile.TemporaryDirectory(dir=os.environ.get('TMPDIR', '/tmp')) as td:
+        fa = _fasta(td, nf)
+        text = open(fa, 'rb').read()
+        open(fa + '.gz', 'wb').write(gzip.compress(text, 6))
+        open(fa + '.bgz.gz', 'wb').write(_bgzf(text))
+        for name in (fa, fa + '.gz', fa + '.bgz.gz'):
+            for threads in (1, 16, os.cpu_count() or 16):
+                t0 = time.perf_counter()
+                gs = api.GenomeSet.load([name], multisample=True, n_threads=threads)
+                dt = time.perf_counter() - t0
+                print(f'{os.path.basename(name):14s} {os.path.getsize(name) / 1e6:7.0f} MB on disk, {len(text) / 1e6:.0f} MB of text, '
+                      f'{threads:3d} threads: {dt:.3f} s ({len(text) / 1e6 / dt:.0f} MB/s of text), {len(gs.names())} genomes', flush=True)
+
+
 if __name__ == '__main__':
     what = sys.argv[1] if len(sys.argv) > 1 else 'cli'
     nf = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
-    {'cli': lambda: cli(nf), 'phases': lambda: phases(nf), 'step': lambda: step(nf), 'lz': lz}[what]()
+    {'cli': lambda: cli(nf), 'phases': lambda: phases(nf), 'step': lambda: step(nf), 'lz': lz, 'gz': lambda: gz(nf)}[what]()

@@ -74,7 +74,79 @@ struct filebuf {            // plain files are mapped (no copy), gzip files are 
     size_t size() const { return len; }
 };
 
-void slurp(const std::string& path, filebuf& fb) {
+// BGZF (bgzip, htslib): a series of gzip members of <= 64 KiB each, every member carrying its own compressed size in
+// a 'BC' extra subfield -- the members can be found without inflating anything, so they are inflated in parallel.
+// Returns false (nothing touched) when the file is not BGZF from its first to its last byte.
+struct bgzf_block { size_t cdata, clen, out_off; uint32_t isize, crc; };
+bool bgzf_blocks(const unsigned char* p, size_t n, std::vector<bgzf_block>& blocks, size_t* total) {
+    size_t at = 0, out = 0;
+    while (at < n) {
+        if (n - at < 28 || p[at] != 0x1f || p[at + 1] != 0x8b || p[at + 2] != 8 || !(p[at + 3] & 4)) return false;
+        const size_t xlen = (size_t)p[at + 10] | ((size_t)p[at + 11] << 8);
+        if (at + 12 + xlen > n) return false;
+        size_t bsize = 0;
+        for (size_t x = at + 12; x + 4 <= at + 12 + xlen;) {
+            const size_t slen = (size_t)p[x + 2] | ((size_t)p[x + 3] << 8);
+            if (p[x] == 'B' && p[x + 1] == 'C' && slen == 2 && x + 6 <= at + 12 + xlen) bsize = ((size_t)p[x + 4] | ((size_t)p[x + 5] << 8)) + 1;
+            x += 4 + slen;
+        }
+        if (bsize < 12 + xlen + 8 || at + bsize > n || (p[at + 3] & ~4)) return false;     // (no name / comment / hcrc fields in BGZF)
+        const unsigned char* tail = p + at + bsize - 8;
+        bgzf_block b; b.cdata = at + 12 + xlen; b.clen = bsize - 12 - xlen - 8; b.out_off = out;
+        b.crc = (uint32_t)tail[0] | ((uint32_t)tail[1] << 8) | ((uint32_t)tail[2] << 16) | ((uint32_t)tail[3] << 24);
+        b.isize = (uint32_t)tail[4] | ((uint32_t)tail[5] << 8) | ((uint32_t)tail[6] << 16) | ((uint32_t)tail[7] << 24);
+        if (b.isize > 65536u) return false;
+        out += b.isize; at += bsize;
+        blocks.push_back(b);
+    }
+    *total = out;
+    return !blocks.empty();
+}
+template <class F> void parallel_for(int64_t n, int n_threads, F fn) {
+    std::atomic<int64_t> next(0);
+    auto work = [&]() { for (;;) { int64_t i = next.fetch_add(1); if (i >= n) break; fn(i); } };
+    std::vector<std::thread> th;
+    for (int t = 1; t < std::min<int64_t>(n_threads, n); ++t) th.emplace_back(work);
+    work();
+    for (auto& x : th) x.join();
+}
+
+bool slurp_bgzf(const std::string& path, FILE* f, filebuf& fb, int n_threads) {
+    fseek(f, 0, SEEK_END); const long long sz = ftell(f);
+    if (sz < 28) return false;
+    void* m = mmap(nullptr, (size_t)sz, PROT_READ, MAP_PRIVATE, fileno(f), 0);
+    if (m == MAP_FAILED) return false;
+    struct unmap { void* m; size_t n; ~unmap() { munmap(m, n); } } um{ m, (size_t)sz };
+    const unsigned char* p = (const unsigned char*)m;
+    std::vector<bgzf_block> blocks; size_t total = 0;
+    if (!bgzf_blocks(p, (size_t)sz, blocks, &total)) return false;
+    vg_host_mark("ingest: bgzf members found");
+    (void)madvise(m, (size_t)sz, MADV_WILLNEED);
+    fb.own.resize(total);
+    std::atomic<bool> bad(false);
+    // runs of 64 blocks (<= 4 MiB of text) per work item
+    const int64_t n_items = ((int64_t)blocks.size() + 63) / 64;
+    parallel_for(n_items, n_threads, [&](int64_t it) {
+        z_stream zs; memset(&zs, 0, sizeof zs);
+        if (inflateInit2(&zs, -15) != Z_OK) { bad = true; return; }
+        for (size_t b = (size_t)it * 64; b < std::min(blocks.size(), (size_t)(it + 1) * 64) && !bad.load(std::memory_order_relaxed); ++b) {
+            const bgzf_block& k = blocks[b];
+            if (b != (size_t)it * 64 && inflateReset(&zs) != Z_OK) { bad = true; break; }
+            zs.next_in = (Bytef*)(p + k.cdata); zs.avail_in = (uInt)k.clen;
+            zs.next_out = (Bytef*)fb.own.data() + k.out_off; zs.avail_out = k.isize;
+            const int rc = inflate(&zs, Z_FINISH);
+            if (rc != Z_STREAM_END || zs.avail_out != 0 || zs.avail_in != 0 ||
+                (uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef*)fb.own.data() + k.out_off, k.isize) != k.crc) { bad = true; break; }
+        }
+        inflateEnd(&zs);
+    });
+    vg_host_mark("ingest: bgzf inflated");
+    if (bad.load()) throw vg_error(VG_EIO, "read error in " + path + " (corrupt BGZF block)");
+    fb.ptr = fb.own.data(); fb.len = total;
+    return true;
+}
+
+void slurp(const std::string& path, filebuf& fb, int n_threads) {
     FILE* f = fopen(path.c_str(), "rb");
     if (!f) throw vg_error(VG_EIO, "cannot open " + path);
     unsigned char magic[2] = { 0, 0 };
@@ -100,7 +172,11 @@ void slurp(const std::string& path, filebuf& fb) {
         fb.ptr = fb.own.data(); fb.len = fb.own.size();
         return;
     }
+    // bgzip output inflates block-parallel; any other gzip stream (one member, or members of unknown size) serially
+    bool done = false;
+    try { done = slurp_bgzf(path, f, fb, n_threads); } catch (...) { fclose(f); throw; }
     fclose(f);
+    if (done) return;
     gzFile g = gzopen(path.c_str(), "rb");
     if (!g) throw vg_error(VG_EIO, "cannot open " + path);
     gzbuffer(g, 1 << 20);
@@ -200,15 +276,6 @@ bool pack_record(const record& r, vg_genomes* g, int64_t at, int64_t* n_symbols)
     return any_n;
 }
 
-template <class F> void parallel_for(int64_t n, int n_threads, F fn) {
-    std::atomic<int64_t> next(0);
-    auto work = [&]() { for (;;) { int64_t i = next.fetch_add(1); if (i >= n) break; fn(i); } };
-    std::vector<std::thread> th;
-    for (int t = 1; t < std::min<int64_t>(n_threads, n); ++t) th.emplace_back(work);
-    work();
-    for (auto& x : th) x.join();
-}
-
 std::string first_token(const char* b, const char* e) {
     const char* q = b; while (q < e && *q != ' ' && *q != '\t' && *q != '\r') ++q;
     return std::string(b, q);
@@ -233,7 +300,7 @@ static void genomes_load_impl(const char* const* paths, int n_paths, int multisa
         std::string first_err; std::atomic<bool> failed(false);
         parallel_for(n_paths, T, [&](int64_t i) {
             if (failed.load()) return;
-            try { slurp(paths[i], bufs[(size_t)i]); }
+            try { slurp(paths[i], bufs[(size_t)i], std::max(1, T / (int)std::min<int64_t>(n_paths, T))); }
             catch (const std::exception& e) { if (!failed.exchange(true)) first_err = e.what(); }
         });
         if (failed.load()) throw vg_error(VG_EIO, first_err);
