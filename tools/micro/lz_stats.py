@@ -1,4 +1,5 @@
 """Developer tool: per-pair trip / event / time statistics of the LZ parse through the dev kernel (VG_LZ_ABLATE).
+Needs the developer build (VG_DEV=1 python -m vclust_amd.build --force; rebuild without VG_DEV afterwards).
 Run as: python tools/micro/lz_stats.py [families]  (spawns one process per setting: the knob is read once per process)."""
 import os, sys, subprocess, pathlib, json
 ROOT = pathlib.Path(__file__).resolve().parent.parent.parent

@@ -48,12 +48,12 @@ struct lz_dev_params { int mal, msl, mrd, mqd, reg, aw, am, ar; int ablate; int 
 // ------------------------------------------------------------------ bit helpers
 // 32 bases (2-bit codes, first base in the low bits) starting at base position p (p >= 0)
 __device__ __forceinline__ uint64_t load32(const uint32_t* __restrict__ pk, int64_t p) {
-    const int64_t w = p >> 4; const int sh = 2 * (int)(p & 15);
-    uint4 v; __builtin_memcpy(&v, pk + w, 16);          // one 16-byte load (4-byte aligned); every packed array has slack words
+    // (a 32-bit byte offset: with a wave-uniform base the load takes the SGPR-base + VGPR-offset form, no 64-bit adds)
+    const uint32_t off = ((uint32_t)p >> 4) << 2; const int sh = 2 * (int)(p & 15);
+    uint4 v; __builtin_memcpy(&v, (const char*)pk + off, 16);          // one 16-byte load (4-byte aligned); every packed array has slack words
     asm volatile("" :: "v"(v.w));                      // keep it one instruction (the narrowed form is two loads)
-    const uint64_t lo = (uint64_t)v.x | ((uint64_t)v.y << 32);
-    if (sh == 0) return lo;
-    return (lo >> sh) | ((uint64_t)v.z << (64 - sh));
+    // two funnel shifts (v_alignbit_b32: ({hi, lo} >> s)[31:0], s = 0 .. 30) instead of a 64-bit shift pair and its s = 0 case
+    return (uint64_t)__builtin_amdgcn_alignbit(v.y, v.x, (uint32_t)sh) | ((uint64_t)__builtin_amdgcn_alignbit(v.z, v.y, (uint32_t)sh) << 32);
 }
 // 32 mask bits starting at base position p
 __device__ __forceinline__ uint32_t loadm32(const uint32_t* __restrict__ mk, int64_t p) {
@@ -1326,7 +1326,9 @@ PARSE_KERNEL(k_lz_parse, 1, false, 8, false)
 PARSE_KERNEL(k_lz_parse_fast, 1, false, 8, true)
 PARSE_KERNEL(k_lz_parse_seg, 4, false, 8, false)
 PARSE_KERNEL(k_lz_parse_seg_fast, 4, false, 8, true)
+#ifdef VG_DEV_KERNELS      // developer build only (VG_DEV=1 python -m vclust_amd.build --force): timing knobs and counters
 PARSE_KERNEL(k_lz_parse_dev, 1, true, 3, false)
+#endif
 
 inline int grid_for(int64_t n, int block = 256, int max_blocks = 256 * 16) {
     int64_t b = (n + block - 1) / block; if (b < 1) b = 1;
@@ -1434,7 +1436,11 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
         VG_HIP(hipStreamSynchronize(s));                      // the scratch buffers go out of scope
     }
     vg_host_mark("lz: tasks grouped");
+#ifdef VG_DEV_KERNELS
     const char* abl = getenv("VG_LZ_ABLATE");
+#else
+    const char* abl = nullptr;                                // (the product library has no timing knobs)
+#endif
     // probe widths (speculation only: results do not depend on them): positions probed right after an event, and after a
     // first miss, before the scan goes to 64 per trip
     static const int pw_after = [] { const char* e = getenv("VG_LZ_PW"); const int v = e ? atoi(e) : PW_AFTER_EVENT; return std::max(1, std::min(v, 64)); }();
@@ -1606,11 +1612,14 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
                                    L.sent_pool.p, P, d_stats.p, (vg_region*)nullptr, no_off);
             } else {
                 const int64_t nblk = ((nt + 3) / 4 + 7) / 8 * 8;
+#ifdef VG_DEV_KERNELS
                 if (P.ablate) {
                     hipLaunchKernelGGL(k_lz_parse_dev, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p + B.pos, nt, d_refs.p, g->d_packed.p, g->d_nmask.p,
                                    g->d_base_off.p, g->d_len.p, g->d_has_n.p, L.rr_pool.p, L.mask_pool.p, L.stab_pool.p,
                                    L.sent_pool.p, P, d_stats.p, (vg_region*)nullptr, no_off);
-                } else if (fast_params) {
+                } else
+#endif
+                if (fast_params) {
                     hipLaunchKernelGGL(k_lz_parse_fast, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p + B.pos, nt, d_refs.p, g->d_packed.p, g->d_nmask.p,
                                    g->d_base_off.p, g->d_len.p, g->d_has_n.p, L.rr_pool.p, L.mask_pool.p, L.stab_pool.p,
                                    L.sent_pool.p, P, d_stats.p, (vg_region*)nullptr, no_off);
