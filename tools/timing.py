@@ -84,7 +84,8 @@ def step(nf):
     api.set_device(0)
     codes, offsets, names, _ = synth.make_workload('phage-100k', nf)
     gs = api.GenomeSet.from_codes(codes, offsets, names); gs.to_device()
-    for it in range(4):
+    keep = []                 # STEP_KEEP=1: results of earlier iterations stay alive (nothing is unmapped between calls)
+    for it in range(int(os.environ.get('STEP_ITERS', '4'))):
         api.profile_enable(True); api.profile_reset()
         t = [time.perf_counter()]
         sizes, pairs = gs.kmer_shared(k=25, min_shared=20); t.append(time.perf_counter())
@@ -93,6 +94,8 @@ def step(nf):
         tasks = gs.align_tasks(cand); t.append(time.perf_counter())
         stats = gs.lz_align(tasks); t.append(time.perf_counter())
         k2 = sum(e['total_ms'] for e in api.profile_get())
+        if os.environ.get('STEP_KEEP') == '1':
+            keep.append((sizes, pairs, cand, tasks, stats))
         d = np.diff(t) * 1e3
         print('kmer_shared %.2f (kernels %.2f)  candidate %.2f  tasks %.2f  lz_align %.2f (kernels %.2f)  total %.2f ms'
               % (d[0], k1, d[1], d[2], d[3], k2, d.sum()))

@@ -1393,6 +1393,7 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
     int rc = vg_genomes_to_device(g); if (rc) return rc;
     hipStream_t s = vg_stream();
     vg_host_mark("vg_lz_align: enter");
+
     if (regions) { *regions = nullptr; if (n_regions) *n_regions = 0; }
     if (n_tasks == 0) return VG_OK;
     for (int i = 0; i < g->n; ++i) if (g->len[i] > (1 << 29)) throw vg_error(VG_EOVERFLOW, "genome longer than 2^29 bases");

@@ -30,6 +30,10 @@ void vg_require_device();        // throws VG_ENODEV when no HIP device is usabl
 hipStream_t vg_stream();         // the library's compute stream on the current device
 void* vg_dev_alloc(size_t bytes); // caching device allocator (throws vg_error)
 void  vg_dev_free(void* p);
+// copies between a caller's (pageable) buffer and the device on stream s, staged through the library's pinned buffers
+// (vg_core.cpp); a download of 32 KiB or more has completed when the call returns
+void  vg_upload_bytes(void* dst, const void* src, size_t bytes, hipStream_t s);
+void  vg_download_bytes(void* dst, const void* src, size_t bytes, hipStream_t s);
 void  vg_dev_trim();             // return all cached blocks to the driver
 void  vg_alloc_one_shot();       // a cold one-shot process (the CLI's whole-stage calls): large blocks through the VMM API
 
@@ -54,8 +58,8 @@ template <class T> struct dbuf {
     void view(T* ptr, size_t count) { release(); p = ptr; n = count; owned = false; }
     size_t bytes() const { return n * sizeof(T); }
     void zero(hipStream_t s) { if (n) VG_HIP(hipMemsetAsync(p, 0, bytes(), s)); }
-    void upload(const T* h, size_t count, hipStream_t s) { VG_HIP(hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, s)); }
-    void download(T* h, size_t count, hipStream_t s) const { VG_HIP(hipMemcpyAsync(h, p, count * sizeof(T), hipMemcpyDeviceToHost, s)); }
+    void upload(const T* h, size_t count, hipStream_t s) { vg_upload_bytes(p, h, count * sizeof(T), s); }
+    void download(T* h, size_t count, hipStream_t s) const { vg_download_bytes(h, p, count * sizeof(T), s); }
 };
 
 // ---------------------------------------------------------------- profiling (HIP events on vg_stream)

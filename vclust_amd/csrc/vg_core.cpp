@@ -72,6 +72,71 @@ hipStream_t vg_stream() {
     return g_stream;
 }
 
+// Copies between a caller's (pageable) buffer and the device.  hipMemcpyAsync on pageable memory registers the pages
+// with the driver for the copy; when such a buffer is later unmapped (a freed result array, a freed task list) the
+// driver's notifier evicts and restores the queues of the process, and the NEXT submission waits 12 .. 35 ms for that
+// (seen as an erratic pause in front of the first kernel of vg_lz_align in a long-lived process; with the results of
+// earlier calls kept alive the pause is gone).  So no caller's buffer is ever handed to the runtime: copies of 32 KiB
+// and more go through the library's own pinned buffers (two of 8 MiB per direction, an event per buffer, the host
+// memcpy of one chunk overlapping the transfer of the next); smaller ones use the runtime's staging path, and genome
+// sets (GBs, uploaded once, freed at the end) keep their own upload.
+namespace {
+constexpr size_t RING = 8u << 20;
+struct pin_ring {
+    char* pin[2] = { nullptr, nullptr }; hipEvent_t ev[2] = { nullptr, nullptr }; bool busy[2] = { false, false }; int dev = -1;
+    void ready() {
+        int d = 0; VG_HIP(hipGetDevice(&d));
+        if (d == dev) return;                                  // (events belong to a device: the library's device was changed)
+        for (int k = 0; k < 2; ++k) {
+            if (busy[k]) { (void)hipEventSynchronize(ev[k]); busy[k] = false; }
+            if (ev[k]) { (void)hipEventDestroy(ev[k]); ev[k] = nullptr; }
+            if (!pin[k]) VG_HIP(hipHostMalloc((void**)&pin[k], RING, hipHostMallocPortable));
+            VG_HIP(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+        }
+        dev = d;
+    }
+    void wait(int k) { if (busy[k]) { VG_HIP(hipEventSynchronize(ev[k])); busy[k] = false; } }
+};
+std::mutex g_ring_mu; pin_ring g_up, g_down;
+constexpr size_t STAGE_MIN = 32u << 10;
+}
+
+// asynchronous on s (the caller's buffer may be reused when the call returns)
+void vg_upload_bytes(void* dst, const void* src, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return;
+    if (bytes < STAGE_MIN) { VG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s)); return; }
+    std::lock_guard<std::mutex> lk(g_ring_mu);
+    g_up.ready();
+    int k = 0;
+    for (size_t off = 0; off < bytes; off += RING, k ^= 1) {
+        const size_t n = std::min(RING, bytes - off);
+        g_up.wait(k);
+        memcpy(g_up.pin[k], (const char*)src + off, n);
+        VG_HIP(hipMemcpyAsync((char*)dst + off, g_up.pin[k], n, hipMemcpyHostToDevice, s));
+        VG_HIP(hipEventRecord(g_up.ev[k], s)); g_up.busy[k] = true;
+    }
+}
+// 32 KiB and more: complete when the call returns (everything queued on s before it has run); smaller: asynchronous
+void vg_download_bytes(void* dst, const void* src, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return;
+    if (bytes < STAGE_MIN) { VG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s)); return; }
+    std::lock_guard<std::mutex> lk(g_ring_mu);
+    g_down.ready();
+    const size_t nch = (bytes + RING - 1) / RING;
+    for (size_t c = 0; c <= nch; ++c) {
+        if (c < nch) {
+            const int k = (int)(c & 1); const size_t off = c * RING, n = std::min(RING, bytes - off);
+            VG_HIP(hipMemcpyAsync(g_down.pin[k], (const char*)src + off, n, hipMemcpyDeviceToHost, s));
+            VG_HIP(hipEventRecord(g_down.ev[k], s)); g_down.busy[k] = true;
+        }
+        if (c >= 1) {
+            const int k = (int)((c - 1) & 1); const size_t off = (c - 1) * RING, n = std::min(RING, bytes - off);
+            g_down.wait(k);
+            memcpy((char*)dst + off, g_down.pin[k], n);
+        }
+    }
+}
+
 void vg_host_mark(const char* what) {
     static const bool on = [] { const char* e = getenv("VG_HOST_TRACE"); return e && *e && *e != '0'; }();
     if (!on) return;
@@ -234,7 +299,11 @@ extern "C" void vg_release_device_memory(void) { vg_dev_trim(); }
 extern "C" int vg_copy(void* dst, const void* src, int64_t bytes, int to_host) {
     VG_API_BEGIN
     vg_require_device();
-    if (bytes > 0) VG_HIP(hipMemcpy(dst, src, (size_t)bytes, to_host ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice));
+    if (bytes > 0) {
+        hipStream_t s = vg_stream();
+        if (to_host) vg_download_bytes(dst, src, (size_t)bytes, s); else vg_upload_bytes(dst, src, (size_t)bytes, s);
+        VG_HIP(hipStreamSynchronize(s));
+    }
     VG_API_END
 }
 

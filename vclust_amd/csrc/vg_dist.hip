@@ -65,9 +65,9 @@ void gather_host(const vg_comm* c, const void* send, void* recv, int64_t bytes) 
     // RCCL moves device memory: stage through HBM
     hipStream_t s = vg_stream();
     reserve_staging(c, bytes);
-    VG_HIP(hipMemcpyAsync(c->st_send.p, send, (size_t)bytes, hipMemcpyHostToDevice, s));
+    vg_upload_bytes(c->st_send.p, send, (size_t)bytes, s);
     if (c->p_allgather(c->st_send.p, c->st_recv.p, (size_t)bytes, ncclChar, c->nccl_comm, s) != ncclSuccess) throw vg_error(VG_EIO, "ncclAllGather failed");
-    VG_HIP(hipMemcpyAsync(recv, c->st_recv.p, (size_t)bytes * c->world, hipMemcpyDeviceToHost, s));
+    vg_download_bytes(recv, c->st_recv.p, (size_t)bytes * c->world, s);
     VG_HIP(hipStreamSynchronize(s));
 }
 // the same for DEVICE memory (buffers of the current device)
