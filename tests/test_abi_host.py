@@ -222,6 +222,43 @@ def test_ingest_random_fasta_equals_oracle_reader(tmp_path):
         assert int(gs.lengths()[i]) == len(codes) and np.array_equal(gs.codes(i), np.minimum(codes, 4)), path.name
 
 
+def test_read_filter_with_genomes_in_another_order(tmp_path, golden_dir):
+    """The filter names genomes, not positions: read against a set whose records come in another order (reversed, and
+    with one genome the filter does not know), the same couples of NAMES come back; and a large filter (counting-sort
+    path of the reader) equals the small-filter path on the same couples."""
+    text = (golden_dir / 'multifasta.fna').read_text()
+    recs = ['>' + r for r in text.split('>') if r]
+    (tmp_path / 'rev.fna').write_text(''.join(reversed(recs)) + '>stranger\nACGTACGTACGTACGTACGTAGCTAGCTAGCATCGATCGATGCATGCAT\n')
+    gs = api.GenomeSet.load([golden_dir / 'multifasta.fna'], multisample=True)
+    rv = api.GenomeSet.load([tmp_path / 'rev.fna'], multisample=True)
+    def couples(g, arr):
+        nm = g.names()
+        return sorted(tuple(sorted((nm[int(e['a'])], nm[int(e['b'])]))) for e in arr)
+    for thr in (0.0, 0.99):
+        a = gs.read_filter(golden_dir / 'output' / 'fltr.txt', thr)
+        b = rv.read_filter(golden_dir / 'output' / 'fltr.txt', thr)
+        assert couples(gs, a) == couples(rv, b) and len(a) in (13, 8)
+        assert all(b['a'] > b['b']) and list(map(tuple, b[['a', 'b']])) == sorted(map(tuple, b[['a', 'b']]))
+    # a dense filter over 60 genomes: 1 770 couples > 4 x 60 -> the counting-sort path; rows and columns shuffled
+    rng = np.random.default_rng(3)
+    n = 60
+    names = ['g%03d' % i for i in range(n)]
+    (tmp_path / 'many.fna').write_text(''.join('>%s\n%s\n' % (nm, 'ACGT' * 10) for nm in names))
+    order = rng.permutation(n)
+    lines = ['kmer-length: 25 fraction: 1,' + ','.join(names[i] for i in order) + ',']
+    want = set()
+    for r in rng.permutation(n):
+        cells = []
+        for ci, c in enumerate(order):
+            if names[c] < names[r]:
+                cells.append('%d:%.6f' % (ci + 1, 0.5 + 0.4 * rng.random())); want.add((max(r, c), min(r, c)))
+        lines.append(names[r] + ',' + ','.join(cells))
+    (tmp_path / 'many.txt').write_text('\n'.join(lines) + '\n')
+    many = api.GenomeSet.load([tmp_path / 'many.fna'], multisample=True)
+    got = many.read_filter(tmp_path / 'many.txt', 0.0)
+    assert [(int(e['a']), int(e['b'])) for e in got] == sorted(want) and len(got) == n * (n - 1) // 2
+
+
 def _bgzf(data: bytes, block: int = 65280) -> bytes:
     """bgzip's container: gzip members of <= 64 KiB with their compressed size in a 'BC' extra subfield, and the
     empty end-of-file member."""

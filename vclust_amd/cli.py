@@ -291,7 +291,7 @@ def align_call(args):
 def handle_prefilter(args, parser, logger):
     args = validate_args_prefilter(args, parser)
     args = validate_args_fasta_input(args, parser)
-    from . import api, distributed
+    from . import stages
     rank, world, local_rank = _dist_env()
     desc = (f'libvclust_gpu prefilter -k {args.k} --min-kmers {args.min_kmers} --min-ident {args.min_ident} '
             f'--kmers-fraction {args.kmers_fraction} --max-seqs {args.max_seqs} [{world} GPU] -> {args.output_path}')
@@ -300,15 +300,16 @@ def handle_prefilter(args, parser, logger):
         kw = prefilter_call(args)
         paths, out_path, multi = kw.pop('paths'), kw.pop('out_path'), kw.pop('is_multifasta')
         if world == 1:
-            api.prefilter(paths, out_path, multi, batch_size=args.batch_size, verbosity=args.verbosity_level, **kw)
+            stages.prefilter(paths, out_path, multi, batch_size=args.batch_size, verbosity=args.verbosity_level, **kw)
         else:
+            from . import distributed
             distributed.prefilter(paths, out_path, multi, **kw)
     run_native(desc, work, args.verbosity_level, logger)
 
 
 def handle_align(args, parser, logger):
     args = validate_args_fasta_input(args, parser)
-    from . import api, distributed
+    from . import stages
     rank, world, local_rank = _dist_env()
     call = align_call(args)
     desc = ('libvclust_gpu align ' + ' '.join(f'--{k} {v}' for k, v in call['lz'].items())
@@ -319,8 +320,9 @@ def handle_align(args, parser, logger):
         kw = dict(call)
         paths, out_path, multi = kw.pop('paths'), kw.pop('out_path'), kw.pop('is_multifasta')
         if world == 1:
-            api.align(paths, out_path, multi, verbosity=args.verbosity_level, **kw)
+            stages.align(paths, out_path, multi, verbosity=args.verbosity_level, **kw)
         else:
+            from . import distributed
             distributed.align(paths, out_path, multi, **kw)
     run_native(desc, work, args.verbosity_level, logger)
 

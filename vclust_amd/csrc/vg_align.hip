@@ -1661,6 +1661,7 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
         }
     }
     vg_host_mark("lz: launched");
+    vg_deferred_start();                                      // (the host now waits for the kernels: parked clean-up runs beside them)
     VG_HIP(hipStreamSynchronize(s));
     VG_HIP(hipGetLastError());
     vg_host_mark("lz: kernels done");
@@ -1681,3 +1682,7 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
 }
 
 extern "C" void vg_set_index_budget(int64_t bytes) { if (bytes > (64 << 20)) g_index_budget_bytes = bytes; }
+
+// (see vg_warm_prefilter)
+namespace { __global__ void k_warm_align() {} }
+void vg_warm_align(hipStream_t s) { hipLaunchKernelGGL(k_warm_align, dim3(1), dim3(64), 0, s); }

@@ -11,11 +11,30 @@ namespace {
 struct genomes_guard { vg_genomes* g = nullptr; ~genomes_guard() { if (g) vg_genomes_free(g); } };
 struct free_guard { void* p = nullptr; ~free_guard() { if (p) vg_free(p); } };
 void check(int rc) { if (rc != VG_OK) throw vg_error(rc, vg_last_error()); }
+// parked clean-up (vg_defer) is released when the stage's kernels are in flight, and in any case when the call ends
+struct defer_scope { defer_scope() { vg_defer_mode(true); } ~defer_scope() { vg_defer_mode(false); vg_deferred_start(); } };
 // The HIP context (120-170 ms on a cold process) is created on a helper thread while the FASTA is parsed; the
 // caller joins before its first device call.  Failures are left to that call, which reports them.
+// It also pays the other one-time costs of the first device operations there: the runtime's fill kernel (the first
+// hipMemsetAsync of a process loads it: 50-90 ms were seen in front of the first kernel of vg_kmer_shared) and the code
+// object of the stage's own kernels.
 struct device_warmup {
     std::thread th;
-    device_warmup() { try { th = std::thread([] { try { vg_require_device(); (void)vg_stream(); (void)hipFree(nullptr); } catch (...) {} }); } catch (...) {} }
+    explicit device_warmup(bool align_stage) {
+        try {
+            th = std::thread([align_stage] {
+                try {
+                    vg_require_device(); hipStream_t s = vg_stream(); (void)hipFree(nullptr);
+                    void* p = vg_dev_alloc(4096);
+                    (void)hipMemsetAsync(p, 0, 4096, s);
+                    if (align_stage) vg_warm_align(s); else vg_warm_prefilter(s);
+                    (void)hipStreamSynchronize(s);
+                    vg_dev_free(p);
+                    vg_host_mark("device warm");
+                } catch (...) {}
+            });
+        } catch (...) {}
+    }
     void join() { if (th.joinable()) th.join(); }
     ~device_warmup() { join(); }
 };
@@ -29,7 +48,8 @@ extern "C" int vg_prefilter(const char* const* fasta_paths, int n_paths, const c
     if (!(p->kmers_fraction > 0.0) || p->kmers_fraction > 1.0) throw vg_error(VG_EINVAL, "kmers_fraction must be in (0,1]");
     vg_host_mark("vg_prefilter: enter");
     vg_alloc_one_shot();
-    device_warmup warm;
+    defer_scope parked;
+    device_warmup warm(false);
     genomes_guard gg;
     check(vg_genomes_load_resident(fasta_paths, n_paths, p->is_multifasta, p->num_threads, &gg.g));
     warm.join();
@@ -55,7 +75,8 @@ extern "C" int vg_align(const char* const* fasta_paths, int n_paths, const char*
     if (!fasta_paths || n_paths <= 0 || !out_path || !p) throw vg_error(VG_EINVAL, "vg_align: null argument");
     vg_host_mark("vg_align: enter");
     vg_alloc_one_shot();
-    device_warmup warm;
+    defer_scope parked;
+    device_warmup warm(true);
     genomes_guard gg;
     check(vg_genomes_load_resident(fasta_paths, n_paths, p->is_multifasta, p->num_threads, &gg.g));
     warm.join();

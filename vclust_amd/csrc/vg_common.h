@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <stdint.h>
 #include <string>
+#include <functional>
 #include <vector>
 #include <stdexcept>
 #include <thread>
@@ -34,7 +35,16 @@ void  vg_dev_free(void* p);
 // (vg_core.cpp); a download of 32 KiB or more has completed when the call returns
 void  vg_upload_bytes(void* dst, const void* src, size_t bytes, hipStream_t s);
 void  vg_download_bytes(void* dst, const void* src, size_t bytes, hipStream_t s);
+// one empty launch out of the translation unit (loads its code object): for the warm-up thread of the whole-stage calls
+void  vg_warm_prefilter(hipStream_t s);
+void  vg_warm_align(hipStream_t s);
 void  vg_dev_trim();             // return all cached blocks to the driver
+// Clean-up work that takes the address-space lock for long (unmapping GBs of FASTA): a whole-stage call parks it
+// (vg_defer_mode) until the main thread sits in a long wait for the GPU (vg_deferred_start); otherwise it runs at once
+// on a helper thread.
+void  vg_defer_mode(bool on);
+void  vg_defer(std::function<void()> fn);
+void  vg_deferred_start();
 void  vg_alloc_one_shot();       // a cold one-shot process (the CLI's whole-stage calls): large blocks through the VMM API
 
 // ---------------------------------------------------------------- device buffers

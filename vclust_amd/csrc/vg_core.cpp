@@ -6,6 +6,8 @@
 #include <string.h>
 #include <stdlib.h>
 #include <map>
+#include <vector>
+#include <functional>
 #include <algorithm>
 #include <thread>
 #include <mutex>
@@ -135,6 +137,28 @@ void vg_download_bytes(void* dst, const void* src, size_t bytes, hipStream_t s) 
             memcpy((char*)dst + off, g_down.pin[k], n);
         }
     }
+}
+
+namespace { std::mutex g_def_mu; std::vector<std::function<void()>> g_deferred; bool g_defer_on = false; }
+void vg_defer_mode(bool on) { std::lock_guard<std::mutex> lk(g_def_mu); g_defer_on = on; }
+static void run_detached(std::vector<std::function<void()>> fns) {
+    if (fns.empty()) return;
+    auto* box = new std::vector<std::function<void()>>(std::move(fns));
+    try { std::thread([box] { for (auto& f : *box) { try { f(); } catch (...) {} } delete box; }).detach(); }
+    catch (...) { for (auto& f : *box) { try { f(); } catch (...) {} } delete box; }
+}
+void vg_defer(std::function<void()> fn) {
+    {
+        std::lock_guard<std::mutex> lk(g_def_mu);
+        if (g_defer_on) { g_deferred.push_back(std::move(fn)); return; }
+    }
+    std::vector<std::function<void()>> one; one.push_back(std::move(fn));
+    run_detached(std::move(one));
+}
+void vg_deferred_start() {
+    std::vector<std::function<void()>> fns;
+    { std::lock_guard<std::mutex> lk(g_def_mu); fns.swap(g_deferred); }
+    run_detached(std::move(fns));
 }
 
 void vg_host_mark(const char* what) {

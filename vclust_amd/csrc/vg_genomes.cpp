@@ -67,9 +67,33 @@ namespace {
 // ---- whole-file buffers ---------------------------------------------------------------------
 struct filebuf {            // plain files are mapped (no copy), gzip files are inflated into `own`
     std::vector<char> own; const char* ptr = nullptr; size_t len = 0; void* map = nullptr; size_t map_len = 0;
+    std::mutex hole_mu; std::vector<std::pair<size_t, size_t>> holes;      // page ranges of the mapping already given back
     filebuf() {}
     filebuf(const filebuf&) = delete; filebuf& operator=(const filebuf&) = delete;
-    ~filebuf() { if (map) munmap(map, map_len); }
+    // Unmapping 4 GB of FASTA in one call holds the address-space lock for 55-80 ms: wherever that call was put -- a
+    // helper thread right after the ingest, or parked until the kernels run -- allocations, mappings and page faults of
+    // the main thread queued up behind it (120 ms in front of the first small hipMalloc of vg_kmer_shared, 50 ms inside
+    // the filter reader, 80 ms inside the bucket pipeline).  So the text is given back WHILE it is packed: the thread
+    // that completes a stretch of genomes unmaps the whole pages of that stretch (drop; ~130 MB, 1-2 ms, beside 63
+    // threads that do not fault), and what is left at the end (page edges, files of a directory) goes in slices.
+    void drop(const char* lo, const char* hi) {
+        if (!map || hi <= lo) return;
+        const size_t pg = 4096;
+        size_t a = ((size_t)(lo - (const char*)map) + pg - 1) / pg * pg, b = (size_t)(hi - (const char*)map) / pg * pg;
+        if (b > map_len) b = map_len / pg * pg;
+        if (b <= a) return;
+        { std::lock_guard<std::mutex> lk(hole_mu); holes.emplace_back(a, b); }
+        munmap((char*)map + a, b - a);
+    }
+    ~filebuf() {
+        if (!map) return;
+        std::sort(holes.begin(), holes.end());
+        const size_t slice = 32u << 20;
+        auto give = [&](size_t a, size_t b) { for (size_t off = a; off < b; off += slice) munmap((char*)map + off, std::min(slice, b - off)); };
+        size_t at = 0;
+        for (auto& h : holes) { if (h.first > at) give(at, h.first); at = std::max(at, h.second); }
+        if (map_len > at) give(at, map_len);
+    }
     const char* data() const { return ptr; }
     size_t size() const { return len; }
 };
@@ -209,18 +233,25 @@ void find_records(const filebuf& fb, std::vector<record>& out, int n_threads) {
     std::vector<std::vector<const char*>> starts(T);
     auto scan = [&](int t) {
         const char* lo = p + fb.size() * t / T; const char* hi = p + fb.size() * (t + 1) / T;
+        // piece by piece: the pages of a piece are mapped in one call (instead of one minor fault per 64 KB) and scanned
+        // while they are hot.  Small pieces on purpose: a populate call holds the address-space lock shared, and the
+        // HIP context that is being created on the warm-up thread needs it exclusively for every mapping it makes --
+        // with one call per 64 MB stretch the context took 350 ms instead of 150.
+        const size_t piece = 2u << 20;
+        for (const char* c0 = lo; c0 < hi; c0 += piece) {
+            const char* c1 = std::min(hi, c0 + piece);
 #ifdef MADV_POPULATE_READ
-        if (fb.map && hi > lo) {
-            // map this thread's stretch of the page cache in one call instead of one minor fault per 64 KB
-            const uintptr_t a = (uintptr_t)lo & ~(uintptr_t)4095, b = ((uintptr_t)hi + 4095) & ~(uintptr_t)4095;
-            (void)madvise((void*)a, (size_t)(b - a), MADV_POPULATE_READ);
-        }
+            if (fb.map) {
+                const uintptr_t a = (uintptr_t)c0 & ~(uintptr_t)4095, b = ((uintptr_t)c1 + 4095) & ~(uintptr_t)4095;
+                (void)madvise((void*)a, (size_t)(b - a), MADV_POPULATE_READ);
+            }
 #endif
-        for (const char* q = lo; q < hi;) {
-            const char* g = (const char*)memchr(q, '>', (size_t)(hi - q));
-            if (!g) break;
-            if (g == p || g[-1] == '\n') starts[t].push_back(g);
-            q = g + 1;
+            for (const char* q = c0; q < c1;) {
+                const char* g = (const char*)memchr(q, '>', (size_t)(c1 - q));
+                if (!g) break;
+                if (g == p || g[-1] == '\n') starts[t].push_back(g);
+                q = g + 1;
+            }
         }
     };
     std::vector<std::thread> th;
@@ -230,13 +261,16 @@ void find_records(const filebuf& fb, std::vector<record>& out, int n_threads) {
     std::vector<const char*> all;
     for (auto& v : starts) all.insert(all.end(), v.begin(), v.end());
     out.resize(all.size());
-    for (size_t i = 0; i < all.size(); ++i) {
-        record& r = out[i];
-        r.hdr = all[i] + 1;
-        const char* rec_end = i + 1 < all.size() ? all[i + 1] : e;
-        const char* nl = (const char*)memchr(r.hdr, '\n', (size_t)(rec_end - r.hdr));
-        r.hdr_end = nl ? nl : rec_end; r.seq = nl ? nl + 1 : rec_end; r.end = rec_end; r.len = 0;
-    }
+    // (the header line of every record is touched here: 10^5 cache misses when done by one thread)
+    parallel_for(((int64_t)all.size() + 1023) / 1024, T, [&](int64_t c) {
+        for (size_t i = (size_t)c * 1024; i < std::min(all.size(), (size_t)(c + 1) * 1024); ++i) {
+            record& r = out[i];
+            r.hdr = all[i] + 1;
+            const char* rec_end = i + 1 < all.size() ? all[i + 1] : e;
+            const char* nl = (const char*)memchr(r.hdr, '\n', (size_t)(rec_end - r.hdr));
+            r.hdr_end = nl ? nl : rec_end; r.seq = nl ? nl + 1 : rec_end; r.end = rec_end; r.len = 0;
+        }
+    });
 }
 
 // pack the bases of one record into the set's arrays starting at padded base position `at` (2-bit codes + N mask);
@@ -293,7 +327,7 @@ static void genomes_load_impl(const char* const* paths, int n_paths, int multisa
     // helper thread at the end: unmapping 4 GB of FASTA costs ~80 ms the caller need not wait for.
     struct input_state { std::vector<filebuf> bufs; std::vector<std::vector<record>> recs; };
     auto* in_state = new input_state();
-    struct in_guard { input_state* p; ~in_guard() { if (p) { input_state* q = p; try { std::thread([q] { delete q; }).detach(); } catch (...) { delete q; } } } } in_g{ in_state };
+    struct in_guard { input_state* p; ~in_guard() { if (p) { input_state* q = p; try { vg_defer([q] { delete q; }); } catch (...) { delete q; } } } } in_g{ in_state };
     in_state->bufs = std::vector<filebuf>((size_t)n_paths);
     std::vector<filebuf>& bufs = in_state->bufs;
     {
@@ -362,6 +396,7 @@ static void genomes_load_impl(const char* const* paths, int n_paths, int multisa
             memset(v.data() + lo, 0, (size_t)(hi - lo) * sizeof(uint32_t));
         });
     }
+    vg_host_mark("ingest: arrays cleared");
     // stretches of genomes of ~32 MB of packed bases: the unit of the overlapped upload
     const int64_t n_g = (int64_t)gd.size();
     std::vector<int64_t> st_first;                          // first genome of every stretch (+ n_g)
@@ -418,9 +453,17 @@ static void genomes_load_impl(const char* const* paths, int n_paths, int multisa
             for (; i < e; ++i) g->nmask[(size_t)(i >> 5)] |= 1u << (i & 31);
         }
         g->has_n[(size_t)gi] = any_n ? 1 : 0;
-        if (uploader.joinable() && st_left[(size_t)st_of[(size_t)gi]].fetch_sub(1) == 1) {
-            { std::lock_guard<std::mutex> lk(up_mu); up_queue.push_back(st_of[(size_t)gi]); }
-            up_cv.notify_one();
+        if (st_left[(size_t)st_of[(size_t)gi]].fetch_sub(1) == 1) {
+            // the last genome of its stretch: the stretch can travel, and nobody reads its text again
+            const int64_t c = st_of[(size_t)gi];
+            if (uploader.joinable()) {
+                { std::lock_guard<std::mutex> lk(up_mu); up_queue.push_back(c); }
+                up_cv.notify_one();
+            }
+            if (multi) {
+                const gdesc& d0 = gd[(size_t)st_first[(size_t)c]]; const gdesc& d1 = gd[(size_t)st_first[(size_t)c + 1] - 1];
+                bufs[(size_t)d0.file].drop(recs[(size_t)d0.file][d0.r0].hdr - 1, recs[(size_t)d1.file][d1.r1 - 1].end);
+            }
         }
     });
     vg_genomes_finish(g);

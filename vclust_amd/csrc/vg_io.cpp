@@ -12,6 +12,7 @@
 #include <string.h>
 #include <algorithm>
 #include <unordered_map>
+#include <mutex>
 #include <numeric>
 #include <atomic>
 #include <thread>
@@ -207,12 +208,20 @@ extern "C" int vg_read_filter(const vg_genomes* g, const char* path, double thr,
     } else {
         FILE* f = fopen(path, "r");
         if (!f) throw vg_error(VG_EIO, std::string("cannot open filter ") + path);
-        std::unordered_map<std::string, uint32_t> by_name;
-        by_name.reserve((size_t)g->n * 2);
-        for (int i = 0; i < g->n; ++i) by_name.emplace(g->names[i], (uint32_t)i);
+        // names -> genome ids.  A filter written from the same FASTA lists the genomes in the set's own order: a name is
+        // first compared with the name the order predicts (one string compare); the hash map over all names is only
+        // built when a name turns up somewhere else.
+        std::unordered_map<std::string, uint32_t> by_name; std::once_flag by_name_once;
+        auto lookup = [&](const char* b, size_t len, int64_t guess) -> int64_t {
+            if (guess >= 0 && guess < (int64_t)g->n) { const std::string& nm = g->names[(size_t)guess]; if (nm.size() == len && memcmp(nm.data(), b, len) == 0) return guess; }
+            std::call_once(by_name_once, [&] { by_name.reserve((size_t)g->n * 2); for (int i = 0; i < g->n; ++i) by_name.emplace(g->names[i], (uint32_t)i); });
+            auto it = by_name.find(std::string(b, len));
+            return it == by_name.end() ? -1 : (int64_t)it->second;
+        };
         std::string data;
-        { fseek(f, 0, SEEK_END); const long long sz = ftell(f); fseek(f, 0, SEEK_SET); if (sz > 0) data.reserve((size_t)sz); }
-        { char buf[1 << 16]; size_t r; while ((r = fread(buf, 1, sizeof buf, f)) > 0) data.append(buf, r); }
+        { fseek(f, 0, SEEK_END); const long long sz = ftell(f); fseek(f, 0, SEEK_SET);
+          if (sz > 0) { data.resize((size_t)sz); const size_t r = fread(&data[0], 1, (size_t)sz, f); data.resize(r); } }
+        { char buf[1 << 16]; size_t r; while ((r = fread(buf, 1, sizeof buf, f)) > 0) data.append(buf, r); }    // (a file that grew, or no size: the rest)
         fclose(f);
         // header: column names -> genome ids
         std::vector<int64_t> col_id;
@@ -222,8 +231,7 @@ extern "C" int vg_read_filter(const vg_genomes* g, const char* path, double thr,
             size_t c = data.find(',');
             while (c != std::string::npos && c + 1 < he) {
                 size_t n2 = data.find(',', c + 1); if (n2 == std::string::npos || n2 > he) break;
-                auto it = by_name.find(data.substr(c + 1, n2 - c - 1));
-                col_id.push_back(it == by_name.end() ? -1 : (int64_t)it->second);
+                col_id.push_back(lookup(data.data() + c + 1, n2 - c - 1, (int64_t)col_id.size()));
                 c = n2;
             }
         }
@@ -237,7 +245,7 @@ extern "C" int vg_read_filter(const vg_genomes* g, const char* path, double thr,
             if (lo > 0) { const char* nl = (const char*)memchr(base + p0 - 1, '\n', n_data - (p0 - 1)); p0 = nl ? (size_t)(nl - base) + 1 : n_data; }   // first whole line
             if ((size_t)hi < n_data - b0) { const char* nl = (const char*)memchr(base + p1 - 1, '\n', n_data - (p1 - 1)); p1 = nl ? (size_t)(nl - base) + 1 : n_data; }
             std::vector<vg_pair_count>& out = part[(size_t)t];
-            std::string key;
+            int64_t guess = -1;                                   // the row in front of this one, + 1
             while (p0 < p1) {
                 const char* nl = (const char*)memchr(base + p0, '\n', n_data - p0);
                 size_t le = nl ? (size_t)(nl - base) : n_data; const size_t next = le + 1;
@@ -245,9 +253,8 @@ extern "C" int vg_read_filter(const vg_genomes* g, const char* path, double thr,
                 const char* q = base + p0; const char* const e = base + le;
                 p0 = next;
                 const char* c = (const char*)memchr(q, ',', (size_t)(e - q)); if (!c) continue;
-                key.assign(q, (size_t)(c - q));
-                auto it = by_name.find(key);
-                const int64_t row = it == by_name.end() ? -1 : (int64_t)it->second;
+                const int64_t row = lookup(q, (size_t)(c - q), guess);
+                if (row >= 0) guess = row + 1;
                 q = c + 1;
                 while (q < e) {
                     const char* n2 = (const char*)memchr(q, ',', (size_t)(e - q)); const char* fe = n2 ? n2 : e;
@@ -277,6 +284,17 @@ extern "C" int vg_read_filter(const vg_genomes* g, const char* path, double thr,
             }
         });
         for (auto& pv : part) v.insert(v.end(), pv.begin(), pv.end());
+        // ascending (a, b): two stable counting passes over the genome ids (b, then a) instead of a comparison sort
+        if ((int64_t)v.size() > 4 * (int64_t)g->n) {
+            std::vector<vg_pair_count> tmp(v.size()); std::vector<int64_t> at((size_t)g->n + 1);
+            for (int pass = 0; pass < 2; ++pass) {
+                std::fill(at.begin(), at.end(), 0);
+                for (const auto& e : v) at[(size_t)(pass ? e.a : e.b) + 1]++;
+                for (int i = 0; i < g->n; ++i) at[(size_t)i + 1] += at[(size_t)i];
+                for (const auto& e : v) tmp[(size_t)at[(size_t)(pass ? e.a : e.b)]++] = e;
+                v.swap(tmp);
+            }
+        } else
         std::sort(v.begin(), v.end(), [](const vg_pair_count& x, const vg_pair_count& y) { return x.a != y.a ? x.a < y.a : x.b < y.b; });
         v.erase(std::unique(v.begin(), v.end(), [](const vg_pair_count& x, const vg_pair_count& y) { return x.a == y.a && x.b == y.b; }), v.end());
     }

@@ -1874,6 +1874,7 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
         }
         VG_HIP(hipStreamSynchronize(s));                       // the tables and level-1 records go out of scope below
         vg_host_mark("buckets: level 2 done");
+        vg_deferred_start();                                  // (the bucket kernel and the SpGEMM are the long waits of the call)
         f_rec = b_rec.p; f_stride = narrow ? 2 : 3;
         arena = std::move(a_rec);
         rowinfo.view(arena.p, (size_t)n_rows_info);
@@ -2248,3 +2249,8 @@ extern "C" int vg_kmer_set(vg_genomes* g, int idx, int k, double fraction, uint6
     *out = o; *n_out = (int64_t)mine.size();
     VG_API_END
 }
+
+// One empty launch: the first launch out of a translation unit loads its code object onto the device (tens of ms for
+// this one).  The whole-stage calls do it on their warm-up thread while the FASTA is parsed (vg_api.cpp).
+namespace { __global__ void k_warm_prefilter() {} }
+void vg_warm_prefilter(hipStream_t s) { hipLaunchKernelGGL(k_warm_prefilter, dim3(1), dim3(64), 0, s); }
