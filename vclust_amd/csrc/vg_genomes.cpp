@@ -316,6 +316,21 @@ std::string first_token(const char* b, const char* e) {
 }
 }  // namespace
 
+// The N mask of a genome without N is its padding and nothing else: it is written on the device from the genome's
+// length instead of travelling (a third of the upload of a set).  One thread per mask word; words of genomes that do
+// hold an N are left alone (they are uploaded).
+__global__ void __launch_bounds__(256)
+k_mask_of_lengths(uint32_t* __restrict__ nmask, int64_t n_words, const uint32_t* __restrict__ blk2g, int align_shift,
+                  const int64_t* __restrict__ base_off, const int64_t* __restrict__ len, const uint8_t* __restrict__ has_n) {
+    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p0 = w * 32;
+        const uint32_t gi = blk2g[p0 >> align_shift];
+        if (has_n[gi]) continue;
+        const int64_t end = base_off[gi] + len[gi];              // first padding position of the genome
+        nmask[w] = end >= p0 + 32 ? 0u : end <= p0 ? 0xffffffffu : (0xffffffffu << (uint32_t)(end - p0));
+    }
+}
+
 // to_device: the packed arrays travel to the HBM of the library's device WHILE the genomes are packed (a helper
 // thread uploads every stretch of genomes as soon as its last genome is done), and the set comes back resident
 static void genomes_load_impl(const char* const* paths, int n_paths, int multisample, int n_threads, bool to_device, vg_genomes** out) {
@@ -411,6 +426,8 @@ static void genomes_load_impl(const char* const* paths, int n_paths, int multisa
     for (int64_t c = 0; c < n_st; ++c) for (int64_t gi = st_first[(size_t)c]; gi < st_first[(size_t)c + 1]; ++gi) st_of[(size_t)gi] = (int)c;
     std::unique_ptr<std::atomic<int64_t>[]> st_left(new std::atomic<int64_t>[(size_t)std::max<int64_t>(n_st, 1)]);
     for (int64_t c = 0; c < n_st; ++c) st_left[(size_t)c].store(st_first[(size_t)c + 1] - st_first[(size_t)c]);
+    std::unique_ptr<std::atomic<int>[]> st_has_n(new std::atomic<int>[(size_t)std::max<int64_t>(n_st, 1)]);      // a genome of the stretch holds an N: its mask travels
+    for (int64_t c = 0; c < n_st; ++c) st_has_n[(size_t)c].store(0);
     std::mutex up_mu; std::condition_variable up_cv; std::vector<int64_t> up_queue; bool up_done = false; std::string up_err;
     std::thread uploader; int dev = 0;
     const size_t pk_words = (size_t)(g->padded_total() / 16) + 16, mk_words = (size_t)(g->padded_total() / 32) + 16;   // with the slack vg_genomes_finish adds
@@ -427,7 +444,7 @@ static void genomes_load_impl(const char* const* paths, int n_paths, int multisa
                     { std::unique_lock<std::mutex> lk(up_mu); up_cv.wait(lk, [&] { return !up_queue.empty() || up_done; }); if (up_queue.empty()) break; c = up_queue.back(); up_queue.pop_back(); }
                     const int64_t b0 = g->base_off[(size_t)st_first[(size_t)c]], b1 = g->base_off[(size_t)st_first[(size_t)c + 1]];      // multiples of 64 bases
                     VG_HIP(hipMemcpyAsync(g->d_packed.p + b0 / 16, g->packed.data() + b0 / 16, (size_t)(b1 - b0) / 16 * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-                    VG_HIP(hipMemcpyAsync(g->d_nmask.p + b0 / 32, g->nmask.data() + b0 / 32, (size_t)(b1 - b0) / 32 * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+                    if (st_has_n[(size_t)c].load()) VG_HIP(hipMemcpyAsync(g->d_nmask.p + b0 / 32, g->nmask.data() + b0 / 32, (size_t)(b1 - b0) / 32 * sizeof(uint32_t), hipMemcpyHostToDevice, st));
                     VG_HIP(hipStreamSynchronize(st));
                 }
                 (void)hipStreamDestroy(st);
@@ -453,6 +470,7 @@ static void genomes_load_impl(const char* const* paths, int n_paths, int multisa
             for (; i < e; ++i) g->nmask[(size_t)(i >> 5)] |= 1u << (i & 31);
         }
         g->has_n[(size_t)gi] = any_n ? 1 : 0;
+        if (any_n) st_has_n[(size_t)st_of[(size_t)gi]].store(1);
         if (st_left[(size_t)st_of[(size_t)gi]].fetch_sub(1) == 1) {
             // the last genome of its stretch: the stretch can travel, and nobody reads its text again
             const int64_t c = st_of[(size_t)gi];
@@ -481,6 +499,9 @@ static void genomes_load_impl(const char* const* paths, int n_paths, int multisa
         g->d_len.alloc(std::max<size_t>(1, g->len.size())); g->d_len.upload(g->len.data(), g->len.size(), s);
         g->d_has_n.alloc(std::max<size_t>(1, g->has_n.size())); g->d_has_n.upload(g->has_n.data(), g->has_n.size(), s);
         g->d_blk2g.alloc(g->blk2g.size()); g->d_blk2g.upload(g->blk2g.data(), g->blk2g.size(), s);
+        // the masks that did not travel (the uploader's stream has been drained: its copies are in place)
+        hipLaunchKernelGGL(k_mask_of_lengths, dim3(4096), dim3(256), 0, s, g->d_nmask.p, (int64_t)mk_tail, (const uint32_t*)g->d_blk2g.p, g->align_shift,
+                           (const int64_t*)g->d_base_off.p, (const int64_t*)g->d_len.p, (const uint8_t*)g->d_has_n.p);
         VG_HIP(hipStreamSynchronize(s));
         g->device = dev;
         vg_host_mark("ingest: resident");
