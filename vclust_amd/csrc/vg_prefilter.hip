@@ -2110,28 +2110,73 @@ __global__ void k_pair_emit(const uint64_t* __restrict__ keys, const uint32_t* _
     }
 }
 }
-static void sum_partial_pairs(const std::vector<vg_pair_count>& all, uint32_t min_shared, std::vector<vg_pair_count>& out) {
-    out.clear();
-    const size_t n = all.size();
+namespace {
+__global__ void k_pair_keep(const uint32_t* __restrict__ sums, int64_t n, uint32_t min_shared, uint32_t* __restrict__ keep) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) keep[i] = sums[i] >= min_shared ? 1u : 0u;
+}
+__global__ void k_pair_place(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ sums, const uint32_t* __restrict__ keep,
+                             const uint32_t* __restrict__ at, int64_t n, vg_pair_count* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (!keep[i]) continue;
+        vg_pair_count r; r.a = (uint32_t)(keys[i] >> 32); r.b = (uint32_t)keys[i]; r.shared = sums[i];
+        out[at[i]] = r;
+    }
+}
+}
+// The partial lists of the sub-shards (device memory: they never travel) -> the list of pairs whose SUM reaches
+// min_shared, ascending on (a, b), in HBM: keys gathered into one array, sorted, reduced by key, and the kept sums
+// placed through a prefix sum of their flags (so the order is that of the keys: no host sort of millions of records).
+static void sum_partial_pairs(const std::vector<dbuf<vg_pair_count>>& parts, const std::vector<unsigned long long>& counts, uint32_t min_shared,
+                              dbuf<vg_pair_count>& out, unsigned long long* n_out) {
+    *n_out = 0;
+    size_t n = 0; for (unsigned long long c : counts) n += (size_t)c;
     if (!n) return;
+    if (n >= (1ull << 32)) throw vg_error(VG_EOVERFLOW, "more than 2^32 partial pair records in one call");
     hipStream_t s = vg_stream();
-    dbuf<vg_pair_count> d_rec(n); d_rec.upload(all.data(), n, s);
-    dbuf<uint64_t> k1(n), k2(n), uk(n); dbuf<uint32_t> v1(n), v2(n), us(n); dbuf<unsigned long long> d_nu(1), d_cur(1);
-    hipLaunchKernelGGL(k_pair_keys, dim3(grid_for((int64_t)n)), dim3(256), 0, s, (const vg_pair_count*)d_rec.p, (int64_t)n, k1.p, v1.p);
-    size_t tb = 0, tb2 = 0;
+    dbuf<uint64_t> k1(n), k2(n), uk(n); dbuf<uint32_t> v1(n), v2(n), us(n); dbuf<unsigned long long> d_nu(1);
+    size_t off = 0;
+    for (size_t t = 0; t < parts.size(); ++t) {
+        if (!counts[t]) continue;
+        hipLaunchKernelGGL(k_pair_keys, dim3(grid_for((int64_t)counts[t])), dim3(256), 0, s, (const vg_pair_count*)parts[t].p, (int64_t)counts[t], k1.p + off, v1.p + off);
+        off += (size_t)counts[t];
+    }
+    size_t tb = 0, tb2 = 0, tb3 = 0;
     VG_HIP(rocprim::radix_sort_pairs(nullptr, tb, k1.p, k2.p, v1.p, v2.p, n, 0u, 64u, s));
     VG_HIP(rocprim::reduce_by_key(nullptr, tb2, k2.p, v2.p, n, uk.p, us.p, d_nu.p, rocprim::plus<uint32_t>(), rocprim::equal_to<uint64_t>(), s));
-    dbuf<char> tmp(std::max(tb, tb2));
+    VG_HIP(rocprim::exclusive_scan(nullptr, tb3, v1.p, v2.p, 0u, n, rocprim::plus<uint32_t>(), s));
+    dbuf<char> tmp(std::max(tb, std::max(tb2, tb3)));
     VG_HIP(rocprim::radix_sort_pairs((void*)tmp.p, tb, k1.p, k2.p, v1.p, v2.p, n, 0u, 64u, s));
     VG_HIP(rocprim::reduce_by_key((void*)tmp.p, tb2, k2.p, v2.p, n, uk.p, us.p, d_nu.p, rocprim::plus<uint32_t>(), rocprim::equal_to<uint64_t>(), s));
-    unsigned long long nu = 0, no = 0; d_nu.download(&nu, 1, s); VG_HIP(hipStreamSynchronize(s));
-    d_cur.zero(s);
-    hipLaunchKernelGGL(k_pair_emit, dim3(grid_for((int64_t)nu)), dim3(256), 0, s, (const uint64_t*)uk.p, (const uint32_t*)us.p, (int64_t)nu, min_shared, d_rec.p, d_cur.p);
-    d_cur.download(&no, 1, s); VG_HIP(hipStreamSynchronize(s));
-    out.resize((size_t)no);
-    if (no) { d_rec.download(out.data(), (size_t)no, s); VG_HIP(hipStreamSynchronize(s)); }
-    // (the emit order depends on scheduling: callers that need an order sort; vg_kmer_shared promises none)
-    std::sort(out.begin(), out.end(), [](const vg_pair_count& x, const vg_pair_count& y) { return x.a != y.a ? x.a < y.a : x.b < y.b; });
+    unsigned long long nu = 0; d_nu.download(&nu, 1, s); VG_HIP(hipStreamSynchronize(s));
+    if (!nu) return;
+    // keep flags in v1, their exclusive prefix sum in v2 (both free after the sort)
+    hipLaunchKernelGGL(k_pair_keep, dim3(grid_for((int64_t)nu)), dim3(256), 0, s, (const uint32_t*)us.p, (int64_t)nu, min_shared, v1.p);
+    VG_HIP(rocprim::exclusive_scan((void*)tmp.p, tb3, v1.p, v2.p, 0u, (size_t)nu, rocprim::plus<uint32_t>(), s));
+    uint32_t last_at = 0, last_keep = 0;
+    VG_HIP(hipMemcpyAsync(&last_at, v2.p + (nu - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    VG_HIP(hipMemcpyAsync(&last_keep, v1.p + (nu - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    VG_HIP(hipStreamSynchronize(s));
+    const unsigned long long no = (unsigned long long)last_at + last_keep;
+    out.alloc((size_t)std::max<unsigned long long>(no, 1));
+    if (no) hipLaunchKernelGGL(k_pair_place, dim3(grid_for((int64_t)nu)), dim3(256), 0, s, (const uint64_t*)uk.p, (const uint32_t*)us.p, (const uint32_t*)v1.p,
+                               (const uint32_t*)v2.p, (int64_t)nu, out.p);
+    VG_HIP(hipStreamSynchronize(s));                           // the scratch buffers go out of scope
+    *n_out = no;
+}
+// the sub-shard loop of one call: every pass leaves its partial list in HBM
+static void kmer_shared_subshards(vg_genomes* g, int k, double fraction, int shard, int n_shards, int sub, uint32_t min_shared,
+                                  int64_t* set_sizes, dbuf<vg_pair_count>& out, unsigned long long* n_out) {
+    const int n = g->n;
+    std::vector<int64_t> part((size_t)n);
+    for (int i = 0; i < n; ++i) set_sizes[i] = 0;
+    std::vector<dbuf<vg_pair_count>> parts((size_t)sub); std::vector<unsigned long long> counts((size_t)sub, 0ULL);
+    std::vector<vg_pair_count> none;
+    for (int t = 0; t < sub; ++t) {
+        kmer_shared_pass(g, k, fraction, shard * sub + t, n_shards * sub, 1u, part.data(), none, &parts[(size_t)t], &counts[(size_t)t]);
+        for (int i = 0; i < n; ++i) set_sizes[i] += part[i];
+    }
+    vg_host_mark("sub-shards done");
+    sum_partial_pairs(parts, counts, min_shared, out, n_out);
 }
 
 extern "C" int vg_kmer_shared(vg_genomes* g, int k, double fraction, int shard, int n_shards, uint32_t min_shared,
@@ -2162,19 +2207,12 @@ extern "C" int vg_kmer_shared(vg_genomes* g, int k, double fraction, int shard, 
     if (sub == 1) {
         kmer_shared_pass(g, k, fraction, shard, n_shards, min_shared, set_sizes, acc);
     } else {
-        // partial (a, b, count) records of every sub-shard are collected as they come and summed ONCE on the
-        // device: sort on (a, b), reduce by key, threshold on the sum
-        std::vector<int64_t> part((size_t)n);
-        for (int i = 0; i < n; ++i) set_sizes[i] = 0;
-        std::vector<vg_pair_count> all;
-        for (int t = 0; t < sub; ++t) {
-            std::vector<vg_pair_count> cur;
-            kmer_shared_pass(g, k, fraction, shard * sub + t, n_shards * sub, 1u, part.data(), cur);
-            for (int i = 0; i < n; ++i) set_sizes[i] += part[i];
-            all.insert(all.end(), cur.begin(), cur.end());
-        }
-        vg_host_mark("sub-shards done");
-        sum_partial_pairs(all, min_shared, acc);
+        // partial (a, b, count) records of every sub-shard stay in HBM and are summed ONCE there: sort on (a, b), reduce
+        // by key, threshold on the sum
+        dbuf<vg_pair_count> d_sum; unsigned long long n_sum = 0;
+        kmer_shared_subshards(g, k, fraction, shard, n_shards, sub, min_shared, set_sizes, d_sum, &n_sum);
+        acc.resize((size_t)n_sum);
+        if (n_sum) { d_sum.download(acc.data(), (size_t)n_sum, vg_stream()); VG_HIP(hipStreamSynchronize(vg_stream())); }
     }
     vg_host_mark("pass done");
     vg_pair_count* outp = (vg_pair_count*)malloc(sizeof(vg_pair_count) * std::max<size_t>(1, acc.size()));
@@ -2185,8 +2223,7 @@ extern "C" int vg_kmer_shared(vg_genomes* g, int k, double fraction, int shard, 
     VG_API_END
 }
 
-// internal (vg_dist.hip): one shard's pairs left in HBM.  A shard that needs sub-shards goes through the host sum
-// and is uploaded again (sets beyond 2^32 positions per rank).
+// internal (vg_dist.hip): one shard's pairs left in HBM (sub-shards included)
 void vg_kmer_shared_device(vg_genomes* g, int k, double fraction, int shard, int n_shards, uint32_t min_shared,
                            int64_t* set_sizes, dbuf<vg_pair_count>& pairs, int64_t* n_pairs) {
     vg_require_device();
@@ -2204,13 +2241,12 @@ void vg_kmer_shared_device(vg_genomes* g, int k, double fraction, int shard, int
         *n_pairs = (int64_t)n;
         return;
     }
-    vg_pair_count* hp = nullptr; int64_t np = 0;
-    rc = vg_kmer_shared(g, k, fraction, shard, n_shards, min_shared, set_sizes, &hp, &np);
-    if (rc) { if (hp) free(hp); throw vg_error(rc, vg_last_error()); }
-    pairs.alloc((size_t)std::max<int64_t>(np, 1));
-    if (np) { pairs.upload(hp, (size_t)np, s); VG_HIP(hipStreamSynchronize(s)); }
-    free(hp);
-    *n_pairs = np;
+    int sub = g_force_subshards > 1 ? g_force_subshards : (int)std::ceil(expect / 3.6e9);
+    if (sub < 2) sub = 2;
+    unsigned long long n = 0;
+    kmer_shared_subshards(g, k, fraction, shard, n_shards, sub, min_shared, set_sizes, pairs, &n);
+    if (!pairs.p) pairs.alloc(1);
+    *n_pairs = (int64_t)n;
 }
 
 // developer/test knob: force the sub-shard loop on small inputs (0 = automatic)
