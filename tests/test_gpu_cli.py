@@ -247,6 +247,18 @@ for ms in (1, 20, 200):
     o0 = np.lexsort((p0['b'], p0['a'])); o1 = np.lexsort((p1['b'], p1['a']))
     assert np.array_equal(s0, s1) and np.array_equal(p0[o0], p1[o1]), ms
 assert any(d for _, d in calls)                      # device-to-device exchanges happened
+# the shard's own sub-shard loop (sets beyond 2^32 positions per rank) under the same protocol: partial lists of the
+# sub-shards summed in HBM, then nominated / counted as one list
+lib.vg_set_subshards(3)
+try:
+    for ms in (1, 20):
+        s0, p0 = gs.kmer_shared(k=25, min_shared=ms); s1, p1 = D.prefilter_counts(gs, comm, 25, 1.0, min_shared=ms)
+        o0 = np.lexsort((p0['b'], p0['a'])); o1 = np.lexsort((p1['b'], p1['a']))
+        assert np.array_equal(s0, s1) and np.array_equal(p0[o0], p1[o1]), ('sub-shards', ms)
+        assert np.array_equal(p0, p0[o0])               # the summed list comes back in (a, b) order
+finally:
+    lib.vg_set_subshards(0)
+s1, p1 = D.prefilter_counts(gs, comm, 25, 1.0, min_shared=20)
 tasks = gs.align_tasks(gs.filter_pairs(s1, p1))
 st0, rg0 = gs.lz_align(tasks, want_regions=True); st1, rg1 = D.align_rows(gs, tasks, comm, None, True)
 assert np.array_equal(st0, st1) and len(rg0) == len(rg1)

@@ -1520,7 +1520,15 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
         auto longest_first = [&](std::vector<int>& list) {
             int32_t mn = INT32_MAX, mx = 0;
             for (int i : list) { mn = std::min(mn, all_refs[(size_t)i].n_rr); mx = std::max(mx, all_refs[(size_t)i].n_rr); }
-            if (!list.empty() && (int64_t)mx * 4 > (int64_t)mn * 5) {
+            if (!list.empty() && (int64_t)mx * 4 > (int64_t)mn * 5 && (int64_t)(mx - mn) <= 8 * (int64_t)list.size() + 65536) {
+                // a stable counting sort on the length, descending (10^6 references: a comparison sort costs 40 ms)
+                std::vector<int64_t> at((size_t)(mx - mn) + 2, 0);
+                for (int i : list) at[(size_t)(mx - all_refs[(size_t)i].n_rr) + 1]++;
+                for (size_t b = 1; b < at.size(); ++b) at[b] += at[b - 1];
+                std::vector<int> sorted(list.size());
+                for (int i : list) sorted[(size_t)at[(size_t)(mx - all_refs[(size_t)i].n_rr)]++] = i;
+                list.swap(sorted);
+            } else if (!list.empty() && (int64_t)mx * 4 > (int64_t)mn * 5) {
                 std::vector<uint64_t> keyed(list.size());
                 for (size_t i = 0; i < keyed.size(); ++i) keyed[i] = ((uint64_t)(0x7fffffffu - (uint32_t)all_refs[(size_t)list[i]].n_rr) << 32) | (uint32_t)list[i];
                 std::sort(keyed.begin(), keyed.end());           // length descending, ordinal ascending (= the stable order)

@@ -316,6 +316,45 @@ extern "C" int vg_align_tasks(const vg_genomes* g, const vg_pair_count* pairs, i
     // couples sorted by (lo, hi) of the length ranks: two stable counting passes, on hi and then on lo (LSD order).
     // One thread: 10^5..10^6 couples are a few milliseconds of cache-resident work, less than starting helpers costs.
     struct rp { int32_t lo, hi; };
+    if (n_pairs >= (1 << 18) && vg_host_threads() > 1) {
+        // millions of couples (contigs-1M: 3.5 M, 75 ms on one thread): range partition on lo over the threads (counts,
+        // offsets, scatter), every range sorted on its own, the task couples written in parallel
+        const int T = std::max(2, std::min(vg_host_threads(), 16));
+        const int64_t ng = std::max<int64_t>(1, g->n);
+        std::vector<rp> v((size_t)n_pairs), tmp((size_t)n_pairs);
+        std::vector<std::vector<int64_t>> cnt((size_t)T, std::vector<int64_t>((size_t)T + 1, 0));
+        std::atomic<bool> bad(false);
+        auto bucket_of = [&](int32_t lo) { return (int)((int64_t)lo * T / ng); };
+        vg_parallel_chunks(n_pairs, T, [&](int64_t a, int64_t b, int t) {
+            for (int64_t i = a; i < b; ++i) {
+                if (pairs[i].a >= (uint32_t)g->n || pairs[i].b >= (uint32_t)g->n) { bad = true; return; }
+                const int32_t x = rank[pairs[i].a], y = rank[pairs[i].b];
+                v[(size_t)i] = { std::min(x, y), std::max(x, y) };
+                cnt[(size_t)t][(size_t)bucket_of(v[(size_t)i].lo)]++;
+            }
+        });
+        if (bad.load()) throw vg_error(VG_EINVAL, "pair id out of range");
+        std::vector<int64_t> b_first((size_t)T + 1, 0);
+        { int64_t run = 0; for (int bk = 0; bk < T; ++bk) { b_first[(size_t)bk] = run; for (int t = 0; t < T; ++t) { const int64_t c = cnt[(size_t)t][(size_t)bk]; cnt[(size_t)t][(size_t)bk] = run; run += c; } } b_first[(size_t)T] = run; }
+        vg_parallel_chunks(n_pairs, T, [&](int64_t a, int64_t b, int t) {
+            for (int64_t i = a; i < b; ++i) tmp[(size_t)cnt[(size_t)t][(size_t)bucket_of(v[(size_t)i].lo)]++] = v[(size_t)i];
+        });
+        vg_task* o = (vg_task*)malloc(sizeof(vg_task) * std::max<size_t>(1, 2 * tmp.size()));
+        if (!o) throw vg_error(VG_ENOMEM, "out of host memory");
+        auto finish = [&](int64_t a, int64_t b) {
+            for (int64_t bk = a; bk < b; ++bk) {
+                std::sort(tmp.begin() + b_first[(size_t)bk], tmp.begin() + b_first[(size_t)bk + 1], [](const rp& x, const rp& y) { return x.lo != y.lo ? x.lo < y.lo : x.hi < y.hi; });
+                for (int64_t i = b_first[(size_t)bk]; i < b_first[(size_t)bk + 1]; ++i) {
+                    o[2 * i] = { (uint32_t)order[(size_t)tmp[(size_t)i].hi], (uint32_t)order[(size_t)tmp[(size_t)i].lo] };
+                    o[2 * i + 1] = { (uint32_t)order[(size_t)tmp[(size_t)i].lo], (uint32_t)order[(size_t)tmp[(size_t)i].hi] };
+                }
+            }
+        };
+        { std::vector<std::thread> th; for (int t = 1; t < T; ++t) th.emplace_back(finish, (int64_t)t, (int64_t)t + 1); finish(0, 1); for (auto& x : th) x.join(); }
+        vg_host_mark("align_tasks: done");
+        *tasks = o; *n_tasks = (int64_t)(2 * tmp.size());
+        return VG_OK;
+    }
     std::vector<rp> v((size_t)n_pairs), tmp((size_t)n_pairs);
     std::vector<int64_t> at_lo((size_t)g->n + 1, 0), at_hi((size_t)g->n + 1, 0);
     for (int64_t i = 0; i < n_pairs; ++i) {
