@@ -161,9 +161,12 @@ __device__ __forceinline__ unsigned long long spread16x4(unsigned long long x) {
 }
 
 // four positions per thread: a wave covers 256 consecutive positions = four 64-position masks
+// KC > 0: k = KC and no --kmers-fraction as compile-time constants (shift counts and masks of the k-mer arithmetic fold)
+template <int KC>
 __global__ void __launch_bounds__(256)
 k_kmer_count(kmer_args A, unsigned long long* __restrict__ wave_mask, uint32_t* __restrict__ wave_cnt,
              int* __restrict__ kept_per_genome, uint64_t* __restrict__ stage, int stage_cap, unsigned int* __restrict__ stage_over) {
+    if (KC > 0) { A.k = KC; A.use_frac = 0; }
     const int lane = threadIdx.x & 63;
     const unsigned long long below = (1ULL << lane) - 1ULL;
     for (int64_t p0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; p0 < A.P + 252; p0 += (int64_t)gridDim.x * blockDim.x * 4) {
@@ -1688,8 +1691,12 @@ static void run_extract_sort(vg_genomes* g, int k, double fraction, int shard, i
         dbuf<unsigned int> d_over(1); d_over.zero(s);
         {
             vg_prof_scope ps("kmer_count", (double)P * (3.0 / 8.0 + 12.0 / 64.0));
-            hipLaunchKernelGGL(k_kmer_count, dim3(grid_for((P + 255) / 4)), dim3(256), 0, s, A, out.wave_mask.p, wave_cnt.p, out.kept.p,
-                               stage.p, stage_cap, d_over.p);
+            if (A.k == 25 && !A.use_frac)
+                hipLaunchKernelGGL(k_kmer_count<25>, dim3(grid_for((P + 255) / 4)), dim3(256), 0, s, A, out.wave_mask.p, wave_cnt.p, out.kept.p,
+                                   stage.p, stage_cap, d_over.p);
+            else
+                hipLaunchKernelGGL(k_kmer_count<0>, dim3(grid_for((P + 255) / 4)), dim3(256), 0, s, A, out.wave_mask.p, wave_cnt.p, out.kept.p,
+                                   stage.p, stage_cap, d_over.p);
         }
         size_t tb = 0;
         VG_HIP(rocprim::exclusive_scan(nullptr, tb, wave_cnt.p, out.wave_base.p, 0u, (size_t)W + 1, rocprim::plus<uint32_t>(), s));
