@@ -2041,11 +2041,31 @@ static void kmer_shared_pass(vg_genomes* g, int k, double fraction, int shard, i
     dbuf<unsigned long long> d_cursor(1);
     dbuf<uint32_t> d_over((size_t)n), d_nover(1);
     unsigned long long cap = std::max<unsigned long long>(1u << 20, (unsigned long long)n * 16);
+    // Rows of a few thousand k-mers (10^6 contigs cut into sub-shards: 3 600 per row and pass) are one trip of a
+    // 256-thread workgroup: a chain of dependent round trips with eight workgroups per CU to cover it.  Those rows go to
+    // ONE-WAVE workgroups with a 512-slot table (26 per CU); a row that outgrows the table joins the overflow list.
+    constexpr int64_t SMALL_ROW = 4096;
+    dbuf<uint32_t> d_small, d_large; int n_small = 0, n_large = 0;
+    if (n >= (1 << 16)) {
+        std::vector<uint32_t> small_rows, large_rows;
+        for (int i = 0; i < n; ++i) ((compact_rows ? (int64_t)kept[(size_t)i] : g->len[(size_t)i]) <= SMALL_ROW ? small_rows : large_rows).push_back((uint32_t)i);
+        if (small_rows.size() * 2 >= (size_t)n) {
+            n_small = (int)small_rows.size(); n_large = (int)large_rows.size();
+            d_small.alloc(small_rows.size()); d_small.upload(small_rows.data(), small_rows.size(), s);
+            if (n_large) { d_large.alloc(large_rows.size()); d_large.upload(large_rows.data(), large_rows.size(), s); }
+        }
+    }
     for (;;) {
         dbuf<vg_pair_count> d_out((size_t)cap);
         d_cursor.zero(s); d_nover.zero(s);
         {
             vg_prof_scope ps("spgemm_rows", (double)n_rows_info * 4.0);
+            if (n_small) {
+                if (n_large) hipLaunchKernelGGL(k_spgemm<11>, dim3((n_large + 7) / 8 * 8), dim3(256), 0, s, rowinfo.p, gen.p, (uint64_t)gen.n, g->d_base_off.p, g->d_len.p, wbase, n,
+                                                min_shared, (const uint32_t*)d_large.p, n_large, d_out.p, d_cursor.p, cap, d_over.p, d_nover.p);
+                hipLaunchKernelGGL(k_spgemm<9>, dim3((n_small + 7) / 8 * 8), dim3(64), 0, s, rowinfo.p, gen.p, (uint64_t)gen.n, g->d_base_off.p, g->d_len.p, wbase, n,
+                                   min_shared, (const uint32_t*)d_small.p, n_small, d_out.p, d_cursor.p, cap, d_over.p, d_nover.p);
+            } else
             hipLaunchKernelGGL(k_spgemm<11>, dim3((n + 7) / 8 * 8), dim3(256), 0, s, rowinfo.p, gen.p, (uint64_t)gen.n, g->d_base_off.p, g->d_len.p, wbase, n,
                                min_shared, (const uint32_t*)nullptr, n, d_out.p, d_cursor.p, cap, d_over.p, d_nover.p);
         }
