@@ -260,7 +260,7 @@ def test_read_filter_with_genomes_in_another_order(tmp_path, golden_dir):
 
 
 def test_align_tasks_large_lists_take_the_parallel_path():
-    """vg_align_tasks on 300 000 couples (range partition over the threads) and on 50 000 (one thread) against the same
+    """vg_align_tasks on 2.4 M couples (range partition over the threads) and on 50 000 (one thread) against the same
     restatement: couples sorted on the length ranks (lo, hi), two rows per couple, longer genome first as the reference."""
     rng = np.random.default_rng(5)
     n = 60000
@@ -268,7 +268,7 @@ def test_align_tasks_large_lists_take_the_parallel_path():
     offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     gs = api.GenomeSet.from_codes(np.zeros(int(lens.sum()), dtype=np.uint8), offsets, ['g%d' % i for i in range(n)])
     order = np.asarray(gs.align_order()); rank = np.empty(n, dtype=np.int64); rank[order] = np.arange(n)
-    for m in (300000, 50000):
+    for m in (2400000, 50000):
         a = rng.integers(1, n, size=m).astype(np.uint32); b = (rng.random(m) * a).astype(np.uint32)
         pairs = np.zeros(m, dtype=api.PAIR_DTYPE); pairs['a'] = a; pairs['b'] = b
         pairs = np.unique(pairs)
@@ -278,7 +278,7 @@ def test_align_tasks_large_lists_take_the_parallel_path():
         exp = np.zeros(2 * len(lo), dtype=api.TASK_DTYPE)
         exp['q'][0::2] = order[hi]; exp['r'][0::2] = order[lo]; exp['q'][1::2] = order[lo]; exp['r'][1::2] = order[hi]
         assert np.array_equal(got, exp), m
-    bad = np.zeros(300000, dtype=api.PAIR_DTYPE); bad['a'] = n + 5
+    bad = np.zeros(2200000, dtype=api.PAIR_DTYPE); bad['a'] = n + 5
     with pytest.raises(_lib.VclustGpuError):
         gs.align_tasks(bad)
 

@@ -316,7 +316,7 @@ extern "C" int vg_align_tasks(const vg_genomes* g, const vg_pair_count* pairs, i
     // couples sorted by (lo, hi) of the length ranks: two stable counting passes, on hi and then on lo (LSD order).
     // One thread: 10^5..10^6 couples are a few milliseconds of cache-resident work, less than starting helpers costs.
     struct rp { int32_t lo, hi; };
-    if (n_pairs >= (1 << 18) && vg_host_threads() > 1) {
+    if (n_pairs >= (1 << 21) && vg_host_threads() > 1) {
         // millions of couples (contigs-1M: 3.5 M, 75 ms on one thread): range partition on lo over the threads (counts,
         // offsets, scatter), every range sorted on its own, the task couples written in parallel
         const int T = std::max(2, std::min(vg_host_threads(), 16));
