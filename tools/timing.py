@@ -43,8 +43,9 @@ def cli(nf):
         env = dict(os.environ, VG_HOST_TRACE='1', VG_ALLOC_TRACE='1')
         tot = 0.0
         gap = float(os.environ.get('CLI_GAP', '0'))
-        for cmd in (['prefilter', '-i', fa, '-o', os.path.join(td, 'fltr.txt'), '-v', '0'],
-                    ['align', '-i', fa, '-o', os.path.join(td, 'ani.tsv'), '--filter', os.path.join(td, 'fltr.txt'), '-v', '0']):
+        thr = ['-t', os.environ['CLI_THREADS']] if os.environ.get('CLI_THREADS') else []      # (default: min(cores, 64))
+        for cmd in (['prefilter', '-i', fa, '-o', os.path.join(td, 'fltr.txt'), '-v', '0', *thr],
+                    ['align', '-i', fa, '-o', os.path.join(td, 'ani.tsv'), '--filter', os.path.join(td, 'fltr.txt'), '-v', '0', *thr]):
             if cmd[0] == 'align' and gap > 0:
                 time.sleep(gap)
             t0 = time.perf_counter(); w0 = time.time()
