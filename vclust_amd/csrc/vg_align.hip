@@ -275,14 +275,15 @@ __device__ __forceinline__ int extend(const pair_ctx& c, const lz_dev_params& P,
 }
 
 // even-bit mask (one base per 2 bits) -> one bit per base
-__device__ __forceinline__ uint32_t squeeze(uint64_t x) {
-    x &= EVEN;
-    x = (x | (x >> 1)) & 0x3333333333333333ULL;
-    x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0FULL;
-    x = (x | (x >> 4)) & 0x00FF00FF00FF00FFULL;
-    x = (x | (x >> 8)) & 0x0000FFFF0000FFFFULL;
-    x = (x | (x >> 16)) & 0x00000000FFFFFFFFULL;
-    return (uint32_t)x;
+__device__ __forceinline__ uint32_t squeeze16(uint32_t x) {       // the 16 even bits of x -> its low 16 bits
+    x &= 0x55555555u;
+    x = (x | (x >> 1)) & 0x33333333u;
+    x = (x | (x >> 2)) & 0x0F0F0F0Fu;
+    x = (x | (x >> 4)) & 0x00FF00FFu;
+    return (x | (x >> 8)) & 0x0000FFFFu;
+}
+__device__ __forceinline__ uint32_t squeeze(uint64_t x) {         // per 32-bit half: no 64-bit shifts
+    return squeeze16((uint32_t)x) | (squeeze16((uint32_t)(x >> 32)) << 16);
 }
 __device__ __forceinline__ uint64_t low_bits64(int n) { return n >= 64 ? ~0ULL : (n <= 0 ? 0ULL : ((1ULL << n) - 1)); }
 
@@ -1113,6 +1114,8 @@ __device__ __forceinline__ void lz_parse_body(PARSE_ARGS) {
             const int win_lo = pred0;
             const int win_hi = pred_rc ? pred_l + P.mrd - 1 : min(pred_l + P.mrd - 1, c.L - 1);
             int sbest_len = 0, sbest_pos = 0, sbest_ad = 0, ncap_a = 0, ncap_s = 0;
+            const uint32_t win_span = (uint32_t)(win_hi - win_lo);                  // window test: one unsigned compare
+            const bool win_any = win_hi >= win_lo;
             while (s_u < s_e) {
                 if (DEV) { ++n_ab; }
                 // four consecutive entries = one 16-byte load (the pool carries four entries of slack; entries past
@@ -1120,13 +1123,16 @@ __device__ __forceinline__ void lz_parse_body(PARSE_ARGS) {
                 uint4 v; __builtin_memcpy(&v, sent + s_u, 16);
                 const uint32_t e4[4] = { v.x, v.y, v.z, v.w };
                 unsigned am = 0, sm = 0;
+                // (all four entries are tested without a branch; those past the bucket end are masked out afterwards)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    if (s_u + j >= s_e) continue;
-                    const int ps = (int)(e4[j] & posmask);
-                    if (do_a && (rd.tag_bits == 0 || (e4[j] >> rd.pos_bits) == qtag)) am |= 1u << j;
-                    if (do_s && ps >= win_lo && ps <= win_hi) sm |= 1u << j;
+                    const uint32_t ps = e4[j] & posmask;
+                    am |= (uint32_t)(rd.tag_bits == 0 || (e4[j] >> rd.pos_bits) == qtag) << j;
+                    sm |= (uint32_t)(ps - (uint32_t)win_lo <= win_span) << j;
                 }
+                const uint32_t left = s_e - s_u;
+                const unsigned vm = left >= 4u ? 0xfu : ((1u << left) - 1u);
+                am &= do_a ? vm : 0u; sm &= (do_s && win_any) ? vm : 0u;
                 unsigned cm = am | sm;
                 while (cm) {
                     const int j = __builtin_ctz(cm); cm &= cm - 1;
