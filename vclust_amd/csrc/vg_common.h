@@ -29,6 +29,7 @@ struct vg_error : std::runtime_error {
 
 void vg_require_device();        // throws VG_ENODEV when no HIP device is usable
 hipStream_t vg_stream();         // the library's compute stream on the current device
+hipStream_t vg_side_stream();                     // a second queue of the same device (created on first use)
 void* vg_dev_alloc(size_t bytes); // caching device allocator (throws vg_error)
 void  vg_dev_free(void* p);
 // copies between a caller's (pageable) buffer and the device on stream s, staged through the library's pinned buffers

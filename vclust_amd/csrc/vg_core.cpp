@@ -26,6 +26,7 @@ extern "C" void vg_free(void* p) { free(p); }
 
 static int g_device = -1;
 static hipStream_t g_stream = nullptr;
+static hipStream_t g_side_stream = nullptr;     // a second queue for work that may run beside the library stream (buffer clears)
 
 extern "C" int vg_device_count(void) {
     int n = 0;
@@ -43,6 +44,7 @@ extern "C" int vg_set_device(int device) {
         // (genome sets re-upload themselves on their next use, vg_genomes_to_device)
         vg_dev_trim();
         if (g_stream) { (void)hipStreamDestroy(g_stream); g_stream = nullptr; }
+        if (g_side_stream) { (void)hipStreamDestroy(g_side_stream); g_side_stream = nullptr; }
     }
     VG_HIP(hipSetDevice(device));
     g_device = device;
@@ -159,6 +161,15 @@ void vg_deferred_start() {
     std::vector<std::function<void()>> fns;
     { std::lock_guard<std::mutex> lk(g_def_mu); fns.swap(g_deferred); }
     run_detached(std::move(fns));
+}
+
+hipStream_t vg_side_stream() {
+    vg_require_device();
+    if (!g_side_stream) {
+        static std::mutex mu; std::lock_guard<std::mutex> lk(mu);
+        if (!g_side_stream) VG_HIP(hipStreamCreateWithFlags(&g_side_stream, hipStreamNonBlocking));
+    }
+    return g_side_stream;
 }
 
 void vg_host_mark(const char* what) {

@@ -1793,6 +1793,30 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
     dbuf<uint32_t> slab((size_t)n_slabs * nb1), d_off1((size_t)nb1 + 1);
     dbuf<uint32_t> a_rec, b_rec;
     uint32_t n1 = 0;
+    // The row pointers start as zeros (only the later members of a run get one): 15 GB at 100 k genomes, 2.7 ms of
+    // fill.  With room to spare (they otherwise move into the level-1 record buffer once level 2 has read it) they get
+    // their own block, cleared on the side queue beside the k-mer kernels of level 1, which are bound by arithmetic.
+    hipEvent_t ev_rows_zero = nullptr;
+    // (whatever way the function is left: everything that touches the block later is queued on s behind the clear)
+    struct ev_guard { hipEvent_t& e; hipStream_t st; ~ev_guard() { if (e) { (void)hipStreamWaitEvent(st, e, 0); (void)hipEventDestroy(e); } } } ev_g{ ev_rows_zero, s };
+    // (dense single-pass sets only, whose whole workspace is a fraction of the HBM: with sub-shards of 10^6 contigs the
+    // extra 14 GB block pushed the caching allocator into trims and fresh hipMallocs -- 8.2 s per pass instead of 2.7)
+    static const bool no_prezero = [] { const char* e = getenv("VG_ROWS_PREZERO"); return e && *e == '0'; }();      // developer A/B
+    if (levels == 2 && dense && !no_prezero) {
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess && (size_t)n_rows_info * 4 * 8 <= tot / 2) {
+            rowinfo.alloc((size_t)n_rows_info);
+            hipStream_t side = vg_side_stream();
+            hipEvent_t ev_s = nullptr;
+            VG_HIP(hipEventCreateWithFlags(&ev_s, hipEventDisableTiming));
+            VG_HIP(hipEventRecord(ev_s, s));                   // (the block may have just been handed back by work still queued on s)
+            VG_HIP(hipStreamWaitEvent(side, ev_s, 0));
+            (void)hipEventDestroy(ev_s);
+            VG_HIP(hipMemsetAsync(rowinfo.p, 0, (size_t)n_rows_info * sizeof(uint32_t), side));
+            VG_HIP(hipEventCreateWithFlags(&ev_rows_zero, hipEventDisableTiming));
+            VG_HIP(hipEventRecord(ev_rows_zero, side));
+        } else (void)hipGetLastError();
+    }
     // level-2 units and (dense source, k <= 25 at 2^11 buckets) short level-1 records, see lvl2_tab
     lvl2_tab L2; memset(&L2, 0, sizeof L2);
     const int64_t st_pos = (int64_t)st_tiles * PT_TILE;
@@ -1829,7 +1853,8 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
         *n_valid_out = (int64_t)n1;
         if (n1 == 0) {
             // no valid k-mer at all (every record shorter than k, or all N): empty outputs the SpGEMM can read
-            rowinfo.alloc((size_t)n_rows_info); rowinfo.zero(s); gen.alloc(4); gen.zero(s);
+            if (!ev_rows_zero) { rowinfo.alloc((size_t)n_rows_info); rowinfo.zero(s); }
+            gen.alloc(4); gen.zero(s);
             return true;
         }
         // two levels: the level-1 records are dead once level 2 has scattered them, and the genome list + row
@@ -1884,7 +1909,7 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
         vg_deferred_start();                                  // (the bucket kernel and the SpGEMM are the long waits of the call)
         f_rec = b_rec.p; f_stride = narrow ? 2 : 3;
         arena = std::move(a_rec);
-        rowinfo.view(arena.p, (size_t)n_rows_info);
+        if (!ev_rows_zero) rowinfo.view(arena.p, (size_t)n_rows_info);
         gen.view(arena.p + (((size_t)n_rows_info + 3) & ~(size_t)3), (size_t)n1 + 4);
     }
     if (gen.n < (size_t)n1 + 4) gen.alloc((size_t)n1 + 4);
@@ -1895,7 +1920,8 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
     // Every bucket is finished by exactly one of the three: nothing is redone, nothing leaves the own pipeline.
     dbuf<unsigned int> d_nover(2); d_nover.zero(s);
     dbuf<uint32_t> over1((size_t)nbk), over2;
-    VG_HIP(hipMemsetAsync(rowinfo.p, 0, (size_t)n_rows_info * sizeof(uint32_t), s));
+    if (ev_rows_zero) VG_HIP(hipStreamWaitEvent(s, ev_rows_zero, 0));
+    else VG_HIP(hipMemsetAsync(rowinfo.p, 0, (size_t)n_rows_info * sizeof(uint32_t), s));
     const int pb = narrow ? 0 : total_bits;
     unsigned int n_over[2] = {0, 0};
 #define VG_BUCKET_LAUNCH(NARROW_, THREADS_, SUBBITS_, GRID_, COUNT_, LIST_, OVER_, NOVER_) \
