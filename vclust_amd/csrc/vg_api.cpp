@@ -27,7 +27,7 @@ struct device_warmup {
                     vg_require_device(); hipStream_t s = vg_stream(); (void)hipFree(nullptr);
                     void* p = vg_dev_alloc(4096);
                     (void)hipMemsetAsync(p, 0, 4096, s);
-                    if (align_stage) vg_warm_align(s); else vg_warm_prefilter(s);
+                    if (align_stage) vg_warm_align(s); else { vg_warm_prefilter(s); (void)vg_side_stream(); }     // (a second queue costs 8-20 ms to create)
                     (void)hipStreamSynchronize(s);
                     vg_dev_free(p);
                     vg_host_mark("device warm");
