@@ -140,7 +140,8 @@ int vg_read_filter(const vg_genomes* g, const char* path, double thr,
  * (q = b, r = a), (q = a, r = b), couples ascending in (a, b).  ids are input-order ids. */
 int vg_align_tasks(const vg_genomes* g, const vg_pair_count* pairs, int64_t n_pairs,
                    vg_task** tasks, int64_t* n_tasks);
-/* HBM budget (bytes) for the per-reference indexes of one vg_lz_align batch (default 24 GiB) */
+/* HBM budget (bytes) for the per-reference indexes of one vg_lz_align batch (default 24 GiB; without a call a set whose
+ * indexes all fit in twice the default is built as one batch) */
 void vg_set_index_budget(int64_t bytes);
 /* vg_kmer_shared cuts sets that exceed the 32-bit row numbering of one pass (2^32 padded bases)
  * into sub-shards of the k-mer range automatically -- the role of `--batch-size` in the
