@@ -125,6 +125,36 @@ def test_workflow_equals_oracle_files(tmp_path):
     assert filecmp.cmp(flt, oflt, shallow=False) and filecmp.cmp(ani, oani, shallow=False)
 
 
+def test_workflow_with_n_runs_and_several_upload_stretches(tmp_path):
+    """The whole-stage calls upload the packed genomes stretch by stretch (128 M bases) while they pack; the N mask
+    travels only for stretches that hold an N, the other stretches' masks are written on the device from the lengths.
+    A 150 Mbp multi-FASTA (two stretches) with N runs in a few genomes of the second one, plain and bgzip-compressed:
+    both files of both formats equal the CPU oracle's."""
+    sys.path.insert(0, str(ROOT / 'tests'))
+    import filecmp
+    import numpy as np
+    import oracle_lib as orc
+    from test_abi_host import _bgzf
+    from vclust_amd import synth
+    codes, offsets, names = synth.make_families(375, 4, length=100000, seed=21)       # 1 500 genomes x 100 kb
+    codes = np.array(codes, copy=True)
+    for gi in (1400, 1401, 1403, 1460):                                                # N runs inside related genomes
+        o = int(offsets[gi]); codes[o + 5000:o + 5400] = 4; codes[o + 60000:o + 60003] = 4
+    fa = tmp_path / 'g.fna'
+    synth.write_fasta(str(fa), codes, offsets, names)
+    bg = tmp_path / 'g.fna.gz'
+    bg.write_bytes(_bgzf(fa.read_bytes()))
+    oflt, oani = tmp_path / 'of.txt', tmp_path / 'oa.tsv'
+    orc.run_cli('prefilter', '-o', oflt, fa)
+    orc.run_cli('align', '-o', oani, '--filter', oflt, '0', '--outfmt', 'complete', fa)
+    for inp in (fa, bg):
+        flt, ani = tmp_path / 'f.txt', tmp_path / 'a.tsv'
+        assert run('prefilter', '-i', inp, '-o', flt, '-v', '0').returncode == 0
+        assert run('align', '-i', inp, '-o', ani, '--filter', flt, '--outfmt', 'complete', '-v', '0').returncode == 0
+        assert filecmp.cmp(flt, oflt, shallow=False) and filecmp.cmp(ani, oani, shallow=False), inp.name
+    assert sum(1 for _ in open(oani)) > 2 * 375 * 5
+
+
 def test_kernel_variants_write_the_same_files(tmp_path):
     """The specialised kernels against the general ones they replace, through the CLI on a 7 000-genome set (280 M
     positions: 18 partition bits) without N and with the default parameters, so that the default run takes
