@@ -10,6 +10,7 @@
 // the k-mer's run in the genome list); the random traffic is the row-pointer scatter of the bucket kernel and the
 // reads of the short genome lists of shared k-mers in the SpGEMM.
 #include "vg_common.h"
+#include <functional>
 #include <rocprim/rocprim.hpp>
 #include <algorithm>
 #include <cmath>
@@ -1657,10 +1658,49 @@ static void finish_sort(sorted_index& si, int k) {
     si.low_bit = 0;
 }
 
+// The k-mer scan of a sub-shard (k_kmer_count: arithmetic-bound, it reads the genomes and writes only its own buffers)
+// does not depend on anything the previous sub-shard computes: the sub-shard loop launches the scan of sub-shard t + 1
+// on the second queue when sub-shard t has finished its own scan, beside t's partition / bucket / SpGEMM kernels
+// (memory- and LDS-bound).  Safe with the single-queue caching allocator: the buffers are taken while the library
+// queue is idle (run_extract_sort has just synchronised), so no block they receive has work pending on it, and they
+// are handed on to run_extract_sort(t + 1), which waits for the scan's event before anything reads them.
+struct precount {
+    dbuf<int> kept; dbuf<unsigned long long> wave_mask; dbuf<uint32_t> wave_cnt; dbuf<uint64_t> stage; dbuf<unsigned int> d_over;
+    const vg_genomes* g = nullptr; int k = 0, shard = -1, n_shards = 0, stage_cap = 0; hipEvent_t done = nullptr;
+    void drop() {
+        if (done) { (void)hipEventSynchronize(done); (void)hipEventDestroy(done); done = nullptr; }     // nothing is freed under a running scan
+        kept.release(); wave_mask.release(); wave_cnt.release(); stage.release(); d_over.release(); shard = -1; g = nullptr;
+    }
+    ~precount() { drop(); }
+};
+static precount g_precount;
+static int compact_stage_cap(double keep) { return (int)std::min<double>(256.0, std::ceil(1.5 * 256.0 * keep) + 24.0); }
+// to be called while the library queue is idle
+static void launch_precount(vg_genomes* g, int k, int shard, int n_shards) {
+    precount& pc = g_precount;
+    pc.drop();
+    const int64_t P = g->padded_total(), W = P / 64, n_chunks = (W + 3) / 4;
+    pc.stage_cap = compact_stage_cap(1.0 / n_shards);
+    pc.kept.alloc((size_t)std::max(1, g->n)); pc.wave_mask.alloc((size_t)W + 1); pc.wave_cnt.alloc((size_t)W + 1);
+    pc.stage.alloc((size_t)n_chunks * pc.stage_cap); pc.d_over.alloc(1);
+    hipStream_t side = vg_side_stream();
+    pc.kept.zero(side); pc.d_over.zero(side);
+    VG_HIP(hipMemsetAsync(pc.wave_cnt.p + W, 0, sizeof(uint32_t), side));
+    kmer_args A{ g->d_packed.p, g->d_nmask.p, g->d_blk2g.p, g->d_base_off.p, g->d_len.p, P, k, 0, ~0ULL, (uint32_t)shard, (uint32_t)n_shards, g->align_shift };
+    if (k == 25) hipLaunchKernelGGL(k_kmer_count<25>, dim3(grid_for((P + 255) / 4)), dim3(256), 0, side, A, pc.wave_mask.p, pc.wave_cnt.p, pc.kept.p, pc.stage.p, pc.stage_cap, pc.d_over.p);
+    else hipLaunchKernelGGL(k_kmer_count<0>, dim3(grid_for((P + 255) / 4)), dim3(256), 0, side, A, pc.wave_mask.p, pc.wave_cnt.p, pc.kept.p, pc.stage.p, pc.stage_cap, pc.d_over.p);
+    VG_HIP(hipEventCreateWithFlags(&pc.done, hipEventDisableTiming));
+    VG_HIP(hipEventRecord(pc.done, side));
+    pc.g = g; pc.k = k; pc.shard = shard; pc.n_shards = n_shards;
+}
+
 static void run_extract_sort(vg_genomes* g, int k, double fraction, int shard, int n_shards, sorted_index& out, bool finish = true, bool do_sort = true) {
     hipStream_t s = vg_stream();
     const int64_t P = g->padded_total();
-    out.kept.alloc((size_t)std::max(1, g->n)); out.kept.zero(s);
+    // the scan of this very sub-shard may already be running (or done) on the second queue
+    const bool pre = g_precount.g == g && g_precount.k == k && g_precount.shard == shard && g_precount.n_shards == n_shards && !(fraction < 1.0) && n_shards > 1;
+    if (pre) { VG_HIP(hipStreamWaitEvent(s, g_precount.done, 0)); out.kept = std::move(g_precount.kept); }
+    else { out.kept.alloc((size_t)std::max(1, g->n)); out.kept.zero(s); }
     const int use_frac = fraction < 1.0;
     kmer_args A{ g->d_packed.p, g->d_nmask.p, g->d_blk2g.p, g->d_base_off.p, g->d_len.p, P, k, use_frac,
                  use_frac ? (uint64_t)std::ldexp(fraction, 64) : ~0ULL, (uint32_t)shard, (uint32_t)n_shards, g->align_shift };
@@ -1680,16 +1720,24 @@ static void run_extract_sort(vg_genomes* g, int k, double fraction, int shard, i
         d_nvalid.download(&nv, 1, s);
     } else {
         const int64_t W = P / 64;
-        out.wave_mask.alloc((size_t)W + 1); dbuf<uint32_t> wave_cnt((size_t)W + 1); out.wave_base.alloc((size_t)W + 1);
-        VG_HIP(hipMemsetAsync(wave_cnt.p + W, 0, sizeof(uint32_t), s));
         // slots per 256-position chunk for the kept k-mers (1.5 x the expectation + slack; a chunk that
         // overflows sends the call to the recomputing emit pass)
         const double keep = (use_frac ? fraction : 1.0) / n_shards;
-        const int stage_cap = (int)std::min<double>(256.0, std::ceil(1.5 * 256.0 * keep) + 24.0);
+        const int stage_cap = compact_stage_cap(keep);
         const int64_t n_chunks = (W + 3) / 4;
-        dbuf<uint64_t> stage((size_t)n_chunks * stage_cap);
-        dbuf<unsigned int> d_over(1); d_over.zero(s);
-        {
+        dbuf<uint32_t> wave_cnt; dbuf<uint64_t> stage; dbuf<unsigned int> d_over;
+        out.wave_base.alloc((size_t)W + 1);
+        if (pre) {
+            out.wave_mask = std::move(g_precount.wave_mask); wave_cnt = std::move(g_precount.wave_cnt);
+            stage = std::move(g_precount.stage); d_over = std::move(g_precount.d_over);
+            (void)hipEventDestroy(g_precount.done); g_precount.done = nullptr; g_precount.shard = -1; g_precount.g = nullptr;
+        } else {
+            out.wave_mask.alloc((size_t)W + 1); wave_cnt.alloc((size_t)W + 1);
+            VG_HIP(hipMemsetAsync(wave_cnt.p + W, 0, sizeof(uint32_t), s));
+            stage.alloc((size_t)n_chunks * stage_cap);
+            d_over.alloc(1); d_over.zero(s);
+        }
+        if (!pre) {
             vg_prof_scope ps("kmer_count", (double)P * (3.0 / 8.0 + 12.0 / 64.0));
             if (A.k == 25 && !A.use_frac)
                 hipLaunchKernelGGL(k_kmer_count<25>, dim3(grid_for((P + 255) / 4)), dim3(256), 0, s, A, out.wave_mask.p, wave_cnt.p, out.kept.p,
@@ -1970,6 +2018,7 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
 
 // one pass over the k-mers of one shard: per-genome set sizes and (a, b, shared) of every pair
 // dev_out != nullptr: the pairs stay in HBM (*dev_out, *dev_n of them) and host_pairs is left empty
+static std::function<void()> g_after_extract;       // set by the sub-shard loop (kmer_shared_subshards), run once in front of the SpGEMM
 static void kmer_shared_pass(vg_genomes* g, int k, double fraction, int shard, int n_shards, uint32_t min_shared,
                              int64_t* set_sizes, std::vector<vg_pair_count>& host_pairs,
                              dbuf<vg_pair_count>* dev_out = nullptr, unsigned long long* dev_n = nullptr) {
@@ -2063,6 +2112,10 @@ static void kmer_shared_pass(vg_genomes* g, int k, double fraction, int shard, i
     const uint32_t* wbase = compact_rows ? si.wave_base.p : nullptr;
     for (int i = 0; i < n; ++i) set_sizes[i] = (int64_t)kept[i] - dups[i];
     si.keys.release();
+    // (the library queue is idle here -- the index stage ended with a synchronisation --: the sub-shard loop starts the
+    // k-mer scan of the NEXT sub-shard on the second queue, beside this sub-shard's SpGEMM: arithmetic beside random
+    // reads.  Started earlier, beside the partition kernels, the scan only took their CUs: 2.70 against 2.74 s.)
+    if (g_after_extract) { auto hook = std::move(g_after_extract); g_after_extract = nullptr; hook(); }
     // SpGEMM with a growing output buffer
     dbuf<unsigned long long> d_cursor(1);
     dbuf<uint32_t> d_over((size_t)n), d_nover(1);
@@ -2224,7 +2277,12 @@ static void kmer_shared_subshards(vg_genomes* g, int k, double fraction, int sha
     for (int i = 0; i < n; ++i) set_sizes[i] = 0;
     std::vector<dbuf<vg_pair_count>> parts((size_t)sub); std::vector<unsigned long long> counts((size_t)sub, 0ULL);
     std::vector<vg_pair_count> none;
+    static const bool no_overlap = [] { const char* e = getenv("VG_SUBSHARD_OVERLAP"); return e && *e == '0'; }();      // developer A/B
+    struct hook_guard { ~hook_guard() { g_after_extract = nullptr; g_precount.drop(); } } hg;
     for (int t = 0; t < sub; ++t) {
+        g_after_extract = nullptr;
+        if (t + 1 < sub && !(fraction < 1.0) && !no_overlap)
+            g_after_extract = [=] { launch_precount(g, k, shard * sub + t + 1, n_shards * sub); };
         kmer_shared_pass(g, k, fraction, shard * sub + t, n_shards * sub, 1u, part.data(), none, &parts[(size_t)t], &counts[(size_t)t]);
         for (int i = 0; i < n; ++i) set_sizes[i] += part[i];
     }
