@@ -22,6 +22,8 @@
  * block.  Paths are UTF-8, owned by the caller.  Arrays returned through `T** out` are
  * owned by the library and released with vg_free().  No C++ exceptions cross the ABI.
  * There is NO CPU fallback: without a HIP device every compute call fails with VG_ENODEV.
+ * One process drives one GPU: the library keeps one device, one pair of queues and one workspace cache per process, and
+ * its compute entry points are to be called by one thread at a time (they use many threads and the whole GPU themselves).
  */
 #ifndef VCLUST_GPU_H
 #define VCLUST_GPU_H
