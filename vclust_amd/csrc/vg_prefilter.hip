@@ -1852,7 +1852,7 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
     static const bool no_prezero = [] { const char* e = getenv("VG_ROWS_PREZERO"); return e && *e == '0'; }();      // developer A/B
     if (levels == 2 && dense && !no_prezero) {
         size_t fr = 0, tot = 0;
-        if (hipMemGetInfo(&fr, &tot) == hipSuccess && (size_t)n_rows_info * 4 * 8 <= tot / 2) {
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess && (size_t)n_rows_info * 4 * 8 <= tot / 2) try {
             rowinfo.alloc((size_t)n_rows_info);
             hipStream_t side = vg_side_stream();
             hipEvent_t ev_s = nullptr;
@@ -1863,6 +1863,11 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
             VG_HIP(hipMemsetAsync(rowinfo.p, 0, (size_t)n_rows_info * sizeof(uint32_t), side));
             VG_HIP(hipEventCreateWithFlags(&ev_rows_zero, hipEventDisableTiming));
             VG_HIP(hipEventRecord(ev_rows_zero, side));
+        } catch (...) {
+            // (an optimisation only: the row pointers then live in the level-1 record buffer and are cleared in line)
+            (void)hipGetLastError(); (void)hipDeviceSynchronize();
+            if (ev_rows_zero) { (void)hipEventDestroy(ev_rows_zero); ev_rows_zero = nullptr; }
+            rowinfo.release();
         } else (void)hipGetLastError();
     }
     // level-2 units and (dense source, k <= 25 at 2^11 buckets) short level-1 records, see lvl2_tab
@@ -2282,7 +2287,10 @@ static void kmer_shared_subshards(vg_genomes* g, int k, double fraction, int sha
     for (int t = 0; t < sub; ++t) {
         g_after_extract = nullptr;
         if (t + 1 < sub && !(fraction < 1.0) && !no_overlap)
-            g_after_extract = [=] { launch_precount(g, k, shard * sub + t + 1, n_shards * sub); };
+            g_after_extract = [=] {
+                // (an optimisation only: without room for the second set of scan buffers the next sub-shard scans in line)
+                try { launch_precount(g, k, shard * sub + t + 1, n_shards * sub); } catch (...) { (void)hipGetLastError(); g_precount.drop(); }
+            };
         kmer_shared_pass(g, k, fraction, shard * sub + t, n_shards * sub, 1u, part.data(), none, &parts[(size_t)t], &counts[(size_t)t]);
         for (int i = 0; i < n; ++i) set_sizes[i] += part[i];
     }
