@@ -320,6 +320,55 @@ def test_ingest_bgzf_blocks_in_parallel(tmp_path, golden_dir):
         api.GenomeSet.load([tmp_path / 'bad.fna.gz'], multisample=True, n_threads=4)
 
 
+def test_ingest_gzip_through_the_own_decoder(tmp_path, golden_dir):
+    """One-member and multi-member gzip files (levels 1/6/9, stored blocks, a header with a file name) go through the
+    library's own inflate (vg_inflate.cpp) and give the genomes of the plain text; with VG_GZ=zlib (a fresh process) the
+    same; a damaged stream is an error from either decoder, never a short or altered set."""
+    import gzip
+    import io
+    import subprocess
+    import sys
+    import zlib
+    rng = np.random.default_rng(11)
+    recs = []
+    for r in range(60):
+        n = int(rng.integers(0, 30000))
+        seq = rng.choice(np.frombuffer(b'ACGTacgtN', dtype=np.uint8), size=n, p=[.24, .24, .24, .24, .01, .01, .005, .005, .01]).tobytes()
+        w = int(rng.integers(20, 120))
+        recs.append(b'>r%d x\n' % r + b'\n'.join(seq[o:o + w] for o in range(0, n, w)) + b'\n')
+    text = b''.join(recs)
+    (tmp_path / 'p.fna').write_bytes(text)
+    plain = api.GenomeSet.load([tmp_path / 'p.fna'], multisample=True, n_threads=4)
+    files = {}
+    for lvl in (1, 6, 9):
+        files['l%d.fna.gz' % lvl] = gzip.compress(text, lvl)
+    files['stored.fna.gz'] = gzip.compress(text, 0)
+    cut = text.index(b'>r30 ')
+    files['multi.fna.gz'] = gzip.compress(text[:cut], 6) + gzip.compress(b'', 6) + gzip.compress(text[cut:], 2)
+    bio = io.BytesIO()
+    with gzip.GzipFile(filename='genomes.fna', mode='wb', fileobj=bio, mtime=12345) as fh:
+        fh.write(text)
+    files['named.fna.gz'] = bio.getvalue()
+    co = zlib.compressobj(6, zlib.DEFLATED, 31, 9, zlib.Z_FIXED)
+    files['fixed.fna.gz'] = co.compress(text) + co.flush()
+    for name, data in files.items():
+        (tmp_path / name).write_bytes(data)
+        gs = api.GenomeSet.load([tmp_path / name], multisample=True, n_threads=4)
+        assert gs.names() == plain.names() and list(gs.lengths()) == list(plain.lengths()), name
+        for i in range(len(plain.names())):
+            assert np.array_equal(gs.codes(i), plain.codes(i)), (name, i)
+    code = ("import sys; sys.path.insert(0, %r); from vclust_amd import api; "
+            "gs = api.GenomeSet.load([%r], multisample=True, n_threads=2); print(sum(int(x) for x in gs.lengths()), len(gs.names()))"
+            % (str(__import__('pathlib').Path(__file__).resolve().parent.parent), str(tmp_path / 'l6.fna.gz')))
+    import os
+    out = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, VG_GZ='zlib'), stdout=subprocess.PIPE, text=True, check=True).stdout.split()
+    assert [int(out[0]), int(out[1])] == [int(sum(plain.lengths())), len(plain.names())]
+    bad = bytearray(files['l6.fna.gz']); bad[len(bad) // 3] ^= 0x10
+    (tmp_path / 'bad.fna.gz').write_bytes(bytes(bad))
+    with pytest.raises(_lib.VclustGpuError):
+        api.GenomeSet.load([tmp_path / 'bad.fna.gz'], multisample=True, n_threads=2)
+
+
 def test_filter_pairs_equals_fltr_file(tmp_path, golden_dir):
     """vg_filter_pairs keeps exactly the pairs vg_write_fltr prints (golden fltr.txt: 13 entries)."""
     codes, offsets, names = orc.read_fasta_codes(golden_dir / 'multifasta.fna')

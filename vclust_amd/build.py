@@ -16,7 +16,7 @@ CSRC = PKG_DIR / 'csrc'
 LIB_PATH = PKG_DIR / 'libvclust_gpu.so'
 ORACLE_DIR = ROOT / 'oracle'
 
-SOURCES = ['vg_core.cpp', 'vg_genomes.cpp', 'vg_io.cpp', 'vg_api.cpp', 'vg_synth.cpp', 'vg_prefilter.hip', 'vg_align.hip', 'vg_dist.hip']
+SOURCES = ['vg_core.cpp', 'vg_genomes.cpp', 'vg_inflate.cpp', 'vg_io.cpp', 'vg_api.cpp', 'vg_synth.cpp', 'vg_prefilter.hip', 'vg_align.hip', 'vg_dist.hip']
 
 
 def _hipcc() -> str:
