@@ -131,6 +131,7 @@ void vg_kmer_shared_device(vg_genomes* g, int k, double fraction, int shard, int
 int vg_host_threads();
 // developer aid: with VG_HOST_TRACE=1 prints the wall time since the previous mark (host-side phases of a call)
 void vg_host_mark(const char* what);
+double vg_alloc_wait_ms();            // wall time this process has spent inside the driver's device-allocation calls
 template <class F> void vg_parallel_chunks(int64_t n, int n_thr, F fn);
 // append one genome given codes (0..3, >3 = N); used by the FASTA reader and vg_genomes_from_codes
 void vg_genomes_append(vg_genomes* g, const std::string& name, const uint8_t* codes, int64_t len, int n_parts);

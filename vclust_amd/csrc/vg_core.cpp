@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <thread>
 #include <mutex>
+#include <atomic>
 
 static thread_local char g_err[1024] = "";
 
@@ -172,14 +173,23 @@ hipStream_t vg_side_stream() {
     return g_side_stream;
 }
 
+// time this process has spent inside the driver's allocation calls (hipMalloc / hipMemCreate + hipMemMap), all threads
+static std::atomic<int64_t> g_alloc_wait_us{0};
+double vg_alloc_wait_ms() { return (double)g_alloc_wait_us.load() / 1e3; }
+
+// "[vg host] <phase> +<ms since the previous mark of this thread> ms  alloc <ms of that spent waiting for device
+// allocations> ms  @<wall clock>": the allocation wait is the driver's (it clears memory as it hands it out), not the
+// kernels' -- bench.py's cli_wall.breakdown_s books it on its own line
 void vg_host_mark(const char* what) {
     static const bool on = [] { const char* e = getenv("VG_HOST_TRACE"); return e && *e && *e != '0'; }();
     if (!on) return;
     static thread_local std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+    static thread_local double last_alloc = 0.0;
     const auto now = std::chrono::steady_clock::now();
-    fprintf(stderr, "[vg host] %-28s +%.3f ms  @%.3f\n", what, std::chrono::duration<double, std::milli>(now - last).count(),
-            std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count());
-    last = now;
+    const double al = vg_alloc_wait_ms();
+    fprintf(stderr, "[vg host] %-28s +%.3f ms  alloc %.3f ms  @%.3f\n", what, std::chrono::duration<double, std::milli>(now - last).count(),
+            std::max(0.0, al - last_alloc), std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count());
+    last = now; last_alloc = al;
 }
 
 int vg_host_threads() {
@@ -255,14 +265,27 @@ static hipError_t vmm_alloc(void** p, size_t bytes) {
     *p = va;
     return hipSuccess;
 }
-static hipError_t raw_alloc(void** p, size_t bytes) {
+static hipError_t raw_alloc_untimed(void** p, size_t bytes, const char** path) {
     g_ever_allocated = true;
     if (g_vmm_alloc && bytes >= VMM_MIN) {
+        *path = "vmm";
         const hipError_t e = vmm_alloc(p, bytes);
         if (e == hipSuccess || e == hipErrorOutOfMemory) return e;
         (void)hipGetLastError();                      // the API is not usable here: plain allocation
     }
+    *path = "hipMalloc";
     return hipMalloc(p, bytes);
+}
+static hipError_t raw_alloc(void** p, size_t bytes) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const char* path = "";
+    const hipError_t e = raw_alloc_untimed(p, bytes, &path);
+    const int64_t us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+    g_alloc_wait_us += us;
+    if (g_alloc_trace && bytes >= (256u << 20))
+        fprintf(stderr, "[vg alloc] %s of %.2f GiB took %.1f ms (%.1f ms per GiB)%s\n", path, bytes / 1073741824.0, us / 1e3,
+                us / 1e3 / (bytes / 1073741824.0), e == hipSuccess ? "" : " -- FAILED");
+    return e;
 }
 static void raw_free(void* p) {
     {
