@@ -180,7 +180,11 @@ def test_kernel_variants_write_the_same_files(tmp_path):
     assert sum(1 for _ in open(base[1])) > 50000
     for tag, env in (('general_parse', dict(VG_LZ_KERNEL='general')), ('lds_build', dict(VG_LZ_BUILD='lds')),
                      ('long_records', dict(VG_LEVEL1_RECORDS='long')), ('staged', dict(VG_DENSE_SCATTER='staged', VG_LEVEL2_SCATTER='staged')),
-                     ('radix', dict(VG_INDEX_PATH='radix'))):
+                     ('radix', dict(VG_INDEX_PATH='radix')),
+                     # the cold CLI's bounded footprint at a budget that bites here: eight RANGE sub-shards of the prefilter
+                     # (k_part_scatter_range; then the all-positions scatter it replaces), many small index batches
+                     ('subshards', dict(VG_WORKSPACE_GB='0.6')), ('subshards_dense', dict(VG_WORKSPACE_GB='1.5', VG_RANGE_SCATTER='dense')),
+                     ('index_batches', dict(VG_ONESHOT_INDEX_GB='0.25')), ('vmm_blocks', dict(VG_ALLOC='vmm', VG_WORKSPACE_GB='100', VG_ONESHOT_INDEX_GB='24'))):
         other = go(tag, **env)
         assert filecmp.cmp(base[0], other[0], shallow=False) and filecmp.cmp(base[1], other[1], shallow=False), tag
 

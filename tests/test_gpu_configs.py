@@ -59,6 +59,16 @@ def test_config2_imgvr_10k_full_size():
     lens = gs.lengths()
     assert np.all(stats['n_match'] <= stats['aln_len']) and np.all(stats['aln_len'] <= lens[tasks['q']])
     assert np.array_equal(stats, gs.lz_align(tasks))
+    # RANGE shards at this size (32 768-position tiles, 8-byte level-1 records carrying row numbers): three uneven
+    # digit ranges add up to the single pass
+    tot = np.zeros(len(gs), dtype=np.int64); acc = {}
+    for sh in range(3):
+        sz, pr = gs.kmer_shared(k=25, shard=sh, n_shards=3)
+        tot += sz
+        for p in pr:
+            acc[(int(p['a']), int(p['b']))] = acc.get((int(p['a']), int(p['b'])), 0) + int(p['shared'])
+    assert np.array_equal(tot, sizes)
+    assert {kv: c for kv, c in acc.items() if c >= 20} == {(int(p['a']), int(p['b'])): int(p['shared']) for p in pairs}
     order = np.argsort(lens[tasks['r']])
     idx = np.concatenate([order[:8], order[-8:], np.random.default_rng(3).choice(len(tasks), 24, replace=False)])
     for i in idx:
@@ -78,6 +88,15 @@ def test_config3_phage_100k_slice():
     lens = gs.lengths()
     assert np.all(stats['n_regions'] >= 1) and np.all(stats['n_match'] <= stats['aln_len']) and np.all(stats['aln_len'] <= lens[tasks['q']])
     assert np.array_equal(stats, gs.lz_align(tasks))
+    # the cold CLI's way through the prefilter: eight RANGE sub-shards inside one call (partial lists summed on the device)
+    from vclust_amd import _lib
+    _lib.load().vg_set_subshards(8)
+    try:
+        sizes8, pairs8 = gs.kmer_shared(k=25, min_shared=20)
+    finally:
+        _lib.load().vg_set_subshards(0)
+    o1, o8 = np.lexsort((pairs['b'], pairs['a'])), np.lexsort((pairs8['b'], pairs8['a']))
+    assert np.array_equal(sizes, sizes8) and np.array_equal(pairs[o1], pairs8[o8])
     for i in np.random.default_rng(5).choice(len(tasks), 40, replace=False):
         q, r = int(tasks[i]['q']), int(tasks[i]['r'])
         assert orc.lz_pair_stat(codes[offsets[q]:offsets[q + 1]], codes[offsets[r]:offsets[r + 1]]) == tuple(int(x) for x in stats[i]), (q, r)

@@ -1488,7 +1488,12 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
     // default budget 24 GiB; a set whose indexes all fit in twice that is built in ONE batch (every batch boundary is a
     // tail of the parse launch with idle CUs: 100 k genomes, 40 GB of indexes, 43.5 vs 44.3 ms of parse)
     int64_t batch_budget = g_index_budget_bytes;
-    if (!g_index_budget_set) {
+    if (!g_index_budget_set && vg_one_shot()) {
+        // a cold one-shot call (the CLI): one small set of index pools reused by every batch -- 6 GiB of device memory to
+        // touch for the first time instead of 40 (vg_core.cpp), for a few batch boundaries (1-3 ms each)
+        static const double gb = [] { const char* e = getenv("VG_ONESHOT_INDEX_GB"); const double v = e ? atof(e) : 0.0; return v >= 0.0625 ? v : 6.0; }();
+        batch_budget = (int64_t)(gb * 1073741824.0);
+    } else if (!g_index_budget_set) {
         int64_t all = 0;
         for (size_t ri = 0; ri < ref_ids.size() && all <= 2 * batch_budget; ++ri) all += ref_need(ref_ids[ri], nullptr);
         if (all <= 2 * batch_budget) batch_budget = std::max(batch_budget, all);

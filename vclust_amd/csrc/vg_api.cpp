@@ -47,7 +47,7 @@ extern "C" int vg_prefilter(const char* const* fasta_paths, int n_paths, const c
     if (p->k < 15 || p->k > 30) throw vg_error(VG_EINVAL, "k must be in 15..30");
     if (!(p->kmers_fraction > 0.0) || p->kmers_fraction > 1.0) throw vg_error(VG_EINVAL, "kmers_fraction must be in (0,1]");
     vg_host_mark("vg_prefilter: enter");
-    vg_alloc_one_shot();
+    vg_one_shot_scope one_shot;
     defer_scope parked;
     device_warmup warm(false);
     genomes_guard gg;
@@ -74,7 +74,7 @@ extern "C" int vg_align(const char* const* fasta_paths, int n_paths, const char*
     VG_API_BEGIN
     if (!fasta_paths || n_paths <= 0 || !out_path || !p) throw vg_error(VG_EINVAL, "vg_align: null argument");
     vg_host_mark("vg_align: enter");
-    vg_alloc_one_shot();
+    vg_one_shot_scope one_shot;
     defer_scope parked;
     device_warmup warm(true);
     genomes_guard gg;

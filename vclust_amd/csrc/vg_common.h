@@ -46,7 +46,10 @@ void  vg_dev_trim();             // return all cached blocks to the driver
 void  vg_defer_mode(bool on);
 void  vg_defer(std::function<void()> fn);
 void  vg_deferred_start();
-void  vg_alloc_one_shot();       // a cold one-shot process (the CLI's whole-stage calls): large blocks through the VMM API
+// a cold one-shot call (vg_prefilter / vg_align, the CLI): the library keeps its device footprint small for its duration
+// (the first use of device memory is what such a process may have to wait for, vg_core.cpp)
+void  vg_one_shot_begin(); void vg_one_shot_end(); bool vg_one_shot();
+struct vg_one_shot_scope { vg_one_shot_scope() { vg_one_shot_begin(); } ~vg_one_shot_scope() { vg_one_shot_end(); } };
 
 // ---------------------------------------------------------------- device buffers
 template <class T> struct dbuf {

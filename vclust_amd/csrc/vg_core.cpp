@@ -184,12 +184,13 @@ void vg_host_mark(const char* what) {
     static const bool on = [] { const char* e = getenv("VG_HOST_TRACE"); return e && *e && *e != '0'; }();
     if (!on) return;
     static thread_local std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
-    static thread_local double last_alloc = 0.0;
+    static std::atomic<int64_t> reported_us{0};          // every microsecond of allocation wait is printed by exactly one mark
     const auto now = std::chrono::steady_clock::now();
-    const double al = vg_alloc_wait_ms();
+    const int64_t al = g_alloc_wait_us.load();
+    const int64_t before = reported_us.exchange(al);
     fprintf(stderr, "[vg host] %-28s +%.3f ms  alloc %.3f ms  @%.3f\n", what, std::chrono::duration<double, std::milli>(now - last).count(),
-            std::max(0.0, al - last_alloc), std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count());
-    last = now; last_alloc = al;
+            (double)std::max<int64_t>(0, al - before) / 1e3, std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count());
+    last = now;
 }
 
 int vg_host_threads() {
@@ -208,21 +209,23 @@ constexpr size_t ALLOC_GRAN = 1 << 12;
 const bool g_alloc_trace = [] { const char* e = getenv("VG_ALLOC_TRACE"); return e && *e && *e != '0'; }();
 }
 
-// Large blocks (>= 1 GiB) are assembled with the virtual memory management API: one reserved address range, physical
-// chunks of 2 GiB mapped into it.  One hipMalloc of 32 GiB costs up to 0.97 s on this platform (the driver clears the
-// memory as it hands it out; the round-2 CLI spent 1.9 s of its 3.2 s prefilter there), the same 32 GiB through
-// hipMemCreate / hipMemMap 0.02 s (tools/micro/malloc_cost.hip), and hipMemUnmap / hipMemRelease return the memory to
-// the driver at once.  (The device's stream-ordered pool, hipMallocAsync, is as fast, but what hipMemPoolTrimTo takes
-// out of it did not come back to the device here: a 1 M-contig run after other work in the same process ran out of
-// memory with 190 GB "free".)
-// It is used by the one-shot whole-stage calls of a COLD process only (vg_alloc_one_shot: the CLI), where the cost of the
-// first allocations is the wall time; a long-lived process (API users, bench, tests) amortises hipMalloc through the
-// caching allocator above it and keeps to the plain path (two aborts inside a long test process were seen with the
-// VMM path on for everything; they did not reproduce, the cause is open).  VG_ALLOC=vmm / malloc forces one.
+// Device blocks come from plain hipMalloc.  What an allocation costs on this platform is not a property of the call but
+// of the memory it lands on (tools/micro/first_touch.hip, profiles/r04_first_touch.txt): memory the driver holds clean
+// is handed out in well under a millisecond per 8 GiB, memory it still has to wipe -- what the PREVIOUS process on the
+// device released, or never-cleared memory of a fresh box -- costs 25-32 ms per GiB, paid as a stall of one allocation
+// call (up to 6 s were seen when a 240 GiB process had just gone).  Nothing in the process can shorten that, so the
+// cold one-shot calls of the CLI keep their footprint small instead (vg_one_shot: k-mer sub-shards under a workspace
+// budget in the prefilter, small index batches in the align stage): the exposure is ~10 GB, not ~100 GB.
+// The virtual memory management path (one reserved range, 2 GiB physical chunks: hipMemCreate / hipMemMap) remains behind
+// VG_ALLOC=vmm for experiments: round 3 used it for the CLI's large blocks and took its speed on clean memory for a
+// property of the API; two aborts inside a long test process were seen with it on for everything and never explained.
 static int g_vmm_mode = [] { const char* e = getenv("VG_ALLOC"); return !e ? 0 : !strcmp(e, "vmm") ? 1 : !strcmp(e, "malloc") ? -1 : 0; }();
 static bool g_vmm_alloc = g_vmm_mode > 0;
-static bool g_ever_allocated = false;
-void vg_alloc_one_shot() { if (g_vmm_mode == 0 && !g_ever_allocated) g_vmm_alloc = true; }
+// one-shot mode: set by the whole-stage calls (vg_prefilter / vg_align) for their duration
+static std::atomic<int> g_one_shot{0};
+void vg_one_shot_begin() { ++g_one_shot; }
+void vg_one_shot_end() { --g_one_shot; }
+bool vg_one_shot() { return g_one_shot.load() > 0; }
 namespace {
 struct vmm_block { std::vector<hipMemGenericAllocationHandle_t> handles; size_t total; };
 std::map<void*, vmm_block> g_vmm_blocks;
@@ -266,7 +269,6 @@ static hipError_t vmm_alloc(void** p, size_t bytes) {
     return hipSuccess;
 }
 static hipError_t raw_alloc_untimed(void** p, size_t bytes, const char** path) {
-    g_ever_allocated = true;
     if (g_vmm_alloc && bytes >= VMM_MIN) {
         *path = "vmm";
         const hipError_t e = vmm_alloc(p, bytes);

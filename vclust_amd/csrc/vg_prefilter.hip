@@ -51,7 +51,17 @@ __device__ __forceinline__ uint64_t rev2(uint64_t x) {
 struct kmer_args {
     const uint32_t* packed; const uint32_t* nmask; const uint32_t* blk2g; const int64_t* base_off; const int64_t* len;
     int64_t P; int k; int use_frac; uint64_t frac_thr; uint32_t shard, n_shards; int blk_shift;
+    uint32_t dig_lo, dig_n;          // RANGE shards: keep the keys whose top DIG_BITS bits d satisfy d - dig_lo < dig_n (all: 0, 1 << DIG_BITS)
 };
+// A k-mer range shard is one of two things (shard_mode, one rule for every rank and pass of a set):
+//  RANGE  whole set below 2^32 padded bases, no --kmers-fraction: shard s of S owns the keys whose top 11 bits -- the
+//         level-1 digit of the bucket pipeline -- fall into [s * 2048 / S, (s + 1) * 2048 / S).  The pass keeps the DENSE
+//         kernels (k-mers from the packed bases, 8-byte records, a bucket's segment of a tile as long as in a whole
+//         pass: 16 records, whatever S is) and only a 1/S slice of every table and record buffer exists.
+//  HASH   otherwise (sets beyond 2^32 bases, fractions): a second multiplicative hash of the key's low half picks the
+//         shard; the kept k-mers are materialised first (compact source).  Sub-sampling every bucket thins the buckets,
+//         which is what a set of 25 G bases needs: its final buckets would hold 6 000 entries otherwise.
+constexpr int DIG_BITS = 11;
 
 // scrambled canonical k-mer starting at padded base position p, or SENT (window crosses the genome
 // end, contains N, or the k-mer is not kept by --kmers-fraction / belongs to another shard).  Every genome
@@ -72,8 +82,10 @@ __device__ __forceinline__ uint64_t canon_key(const kmer_args& A, uint32_t xl, u
     const uint64_t cano = fwd < rc ? fwd : rc;
     if (A.use_frac && !(mix64(cano) < A.frac_thr)) return SENT;
     const uint64_t key = scramble_key(cano, A.k);               // bit 2k stays 0; SENT has it set
-    if (A.n_shards > 1) {
-        // shard = a cheap second multiplicative hash of the key's LOW half (one 32-bit multiply): it
+    if (A.dig_n < (1u << DIG_BITS)) {
+        if ((uint32_t)(key >> (2 * A.k - DIG_BITS)) - A.dig_lo >= A.dig_n) return SENT;     // RANGE shard
+    } else if (A.n_shards > 1) {
+        // HASH shard = a cheap second multiplicative hash of the key's LOW half (one 32-bit multiply): it
         // must not be a function of the high bits, which the partition relies on being uniform
         const uint32_t h2 = (uint32_t)key * 0x85ebca6bu;
         if ((uint32_t)(((uint64_t)h2 * A.n_shards) >> 32) != A.shard) return SENT;
@@ -670,7 +682,16 @@ struct part_src {                        // where the elements of a partition le
     const uint32_t* rec;                 // level 2: the level-1 records (w0, w1, pay), 12 bytes each
     int64_t n;                           // number of source slots (positions or elements)
     int k2;                              // key bits = 2k
+    // RANGE shard of the dense source: level-1 bins are counted from the shard's first bucket, and the payload of a
+    // record is the k-mer's ROW NUMBER = its rank among the kept k-mers in position order (wbase[p / 64] + the kept
+    // positions below p in its 64-position word of wmask), so the row pointers of a pass are as few as its k-mers
+    int bin_lo;
+    const unsigned long long* wmask; const uint32_t* wbase;
 };
+// row number of padded position p (a kept one) in a RANGE pass
+__device__ __forceinline__ uint32_t row_of(const unsigned long long* __restrict__ wmask, const uint32_t* __restrict__ wbase, int64_t p) {
+    return wbase[p >> 6] + (uint32_t)__popcll(wmask[p >> 6] & ((1ULL << (p & 63)) - 1ULL));
+}
 enum { SRC_DENSE = 0, SRC_ARRAYS = 1, SRC_PLANES = 2 };
 
 __device__ __forceinline__ void key_words(uint64_t key, int k2, uint32_t* w0, uint32_t* w1) {
@@ -796,10 +817,10 @@ __device__ __forceinline__ void decode_tile(const part_src& S, int64_t t0, int64
 // KC > 0: k = KC, all k-mers kept, one shard -- as compile-time constants (the default k = 25 of a whole set)
 template <int SRC, int KC = 0>
 __global__ void __launch_bounds__(PT_THREADS)
-k_part_count(part_src S, int B1, int st_tiles, int64_t n_st, uint32_t* __restrict__ T, int* __restrict__ kept_per_genome) {
-    if (KC > 0) { S.A.k = KC; S.k2 = 2 * KC; S.A.use_frac = 0; S.A.n_shards = 1; }
+k_part_count(part_src S, int B1, int nb /* level-1 buckets of this pass */, int st_tiles, int64_t n_st, uint32_t* __restrict__ T, int* __restrict__ kept_per_genome,
+             unsigned long long* __restrict__ wave_mask, uint32_t* __restrict__ wave_cnt /* RANGE shards of the dense source: kept mask and count of every 64 positions */) {
+    if (KC > 0) { S.A.k = KC; S.k2 = 2 * KC; S.A.use_frac = 0; S.A.n_shards = 1; }      // (RANGE shards keep their digits: KC = 25 serves them too)
     __shared__ uint32_t hist[PT_MAXBINS];
-    const int nb = 1 << B1;
     const int lane = threadIdx.x & 63;
     for (int64_t st = blockIdx.x; st < n_st; st += gridDim.x) {
         for (int b = threadIdx.x; b < nb; b += PT_THREADS) hist[b] = 0;
@@ -823,7 +844,22 @@ k_part_count(part_src S, int B1, int st_tiles, int64_t n_st, uint32_t* __restric
             for (int q = 0; q < PT_PER / 4; ++q) g4[q] = gq[q];
             if (t0 + PT_TILE < s1) { fetch_tile<SRC>(S, t0 + PT_TILE, s1, raw); fetch_genomes(t0 + PT_TILE); }
 #pragma unroll
-            for (int j = 0; j < PT_PER; ++j) if (ok[j]) atomicAdd(&hist[B1 ? (w0[j] >> (32 - B1)) : 0u], 1u);
+            for (int j = 0; j < PT_PER; ++j) if (ok[j]) atomicAdd(&hist[B1 ? (w0[j] >> (32 - B1)) - (uint32_t)S.bin_lo : 0u], 1u);
+            if (SRC == SRC_DENSE && wave_mask) {
+                // the wave's 256 consecutive positions of every group q = four 64-position words: a lane's four flags are a
+                // nibble, eight lanes OR their nibbles into a 32-bit half-word (three cross-lane steps), two halves make a word
+#pragma unroll
+                for (int q = 0; q < PT_PER / 4; ++q) {
+                    uint32_t v = ((uint32_t)ok[4 * q] | ((uint32_t)ok[4 * q + 1] << 1) | ((uint32_t)ok[4 * q + 2] << 2) | ((uint32_t)ok[4 * q + 3] << 3)) << (4 * (lane & 7));
+                    v |= (uint32_t)__shfl_xor((int)v, 1); v |= (uint32_t)__shfl_xor((int)v, 2); v |= (uint32_t)__shfl_xor((int)v, 4);
+                    const uint32_t hi = (uint32_t)__shfl_down((int)v, 8);
+                    const int64_t wfirst = (t0 + ((int64_t)q * PT_THREADS + (threadIdx.x & ~63u)) * 4) >> 6;
+                    if ((lane & 15) == 0 && ((wfirst + (lane >> 4)) << 6) < S.n) {
+                        wave_mask[wfirst + (lane >> 4)] = (unsigned long long)v | ((unsigned long long)hi << 32);
+                        wave_cnt[wfirst + (lane >> 4)] = (uint32_t)(__popc(v) + __popc(hi));
+                    }
+                }
+            }
             if (SRC == SRC_DENSE && kept_per_genome) {
 #pragma unroll
                 for (int q = 0; q < PT_PER / 4; ++q) {
@@ -862,6 +898,7 @@ struct lvl2_tab {
     int g_st;                               // SHORT: super-tiles per position group (0: a unit lies inside one group)
     int st_shift;                           // SHORT: log2(positions per super-tile)
     int kr;                                 // SHORT: key bits kept in a record = 2k - B1
+    const uint32_t* wbase; int64_t W;       // SHORT, RANGE shard: rows before every 64-position word (payloads are row numbers), words
 };
 __device__ __forceinline__ void lvl2_unit(const lvl2_tab& L, int64_t u, uint32_t* b1, uint32_t* U, int64_t* r0, int64_t* r1) {
     *b1 = (uint32_t)(u / L.n_u); *U = (uint32_t)(u % L.n_u);
@@ -934,11 +971,11 @@ k_part_count2(const uint32_t* __restrict__ rec, int B1, int B2, int64_t n_units,
 template <int SRC, int LEVEL>
 __global__ void __launch_bounds__(PT_THREADS)
 k_part_scatter(part_src S, int B1, int B2, int unit_tiles, int64_t n_units, const uint32_t* __restrict__ Ts, lvl2_tab L,
-               uint32_t* __restrict__ o_rec, int narrow_shift) {
+               uint32_t* __restrict__ o_rec, int narrow_shift, int nbins1 /* LEVEL 1: buckets of this pass */) {
     __shared__ uint32_t s_w0[PT_TILE], s_w1[PT_TILE], s_pay[PT_TILE];
     __shared__ uint32_t thist[PT_MAXBINS], tstart[PT_MAXBINS], cursor[PT_MAXBINS];
     __shared__ uint32_t s_wave[16];
-    const int nbins = LEVEL == 1 ? (1 << B1) : (1 << B2);
+    const int nbins = LEVEL == 1 ? nbins1 : (1 << B2);
     for (int64_t u = blockIdx.x; u < n_units; u += gridDim.x) {
         int64_t s0 = u * unit_tiles * PT_TILE, s1 = min(S.n, s0 + (int64_t)unit_tiles * PT_TILE);
         uint32_t b1 = 0, cl = 0;
@@ -960,12 +997,24 @@ k_part_scatter(part_src S, int B1, int B2, int unit_tiles, int64_t n_units, cons
             lds_sync();
             uint32_t w0[PT_PER], w1[PT_PER], pay[PT_PER], bin[PT_PER], rk[PT_PER]; bool ok[PT_PER];
             decode_tile<SRC>(S, t0, s1, raw, w0, w1, pay, ok);
+            if (SRC == SRC_DENSE && S.wbase) {
+                // RANGE shard: the payload is the row number (the four positions of a group lie in one 64-position word)
+#pragma unroll
+                for (int q = 0; q < PT_PER / 4; ++q) {
+                    const int64_t p0 = t0 + ((int64_t)q * PT_THREADS + threadIdx.x) * 4;
+                    if (p0 < s1) {
+                        const unsigned long long m = S.wmask[p0 >> 6]; const uint32_t rb = S.wbase[p0 >> 6];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) pay[4 * q + j] = rb + (uint32_t)__popcll(m & ((1ULL << ((p0 & 63) + j)) - 1ULL));
+                    }
+                }
+            }
             if (t0 + PT_TILE < s1) fetch_tile<SRC>(S, t0 + PT_TILE, s1, raw);
 #pragma unroll
             for (int j = 0; j < PT_PER; ++j) {
                 bin[j] = 0; rk[j] = 0;
                 if (ok[j]) {
-                    bin[j] = LEVEL == 1 ? (B1 ? (w0[j] >> (32 - B1)) : 0u) : ((w0[j] >> (32 - B1 - B2)) & (uint32_t)(nbins - 1));
+                    bin[j] = LEVEL == 1 ? (B1 ? (w0[j] >> (32 - B1)) - (uint32_t)S.bin_lo : 0u) : ((w0[j] >> (32 - B1 - B2)) & (uint32_t)(nbins - 1));
                     rk[j] = atomicAdd(&thist[bin[j]], 1u);
                 }
             }
@@ -994,7 +1043,7 @@ k_part_scatter(part_src S, int B1, int B2, int unit_tiles, int64_t n_units, cons
             // hold consecutive slots, so a wave writes each bin's segment of the tile as one contiguous run
             for (uint32_t slot = threadIdx.x; slot < n_tile; slot += PT_THREADS) {
                 const uint32_t w = s_w0[slot];
-                const uint32_t b = LEVEL == 1 ? (B1 ? (w >> (32 - B1)) : 0u) : ((w >> (32 - B1 - B2)) & (uint32_t)(nbins - 1));
+                const uint32_t b = LEVEL == 1 ? (B1 ? (w >> (32 - B1)) - (uint32_t)S.bin_lo : 0u) : ((w >> (32 - B1 - B2)) & (uint32_t)(nbins - 1));
                 const uint64_t dst = (uint64_t)cursor[b] + (slot - tstart[b]);
                 if (narrow_shift >= 0) {
                     // the bucket fixes the top narrow_shift key bits and at most 32 remain: one word carries them
@@ -1031,14 +1080,14 @@ __device__ __forceinline__ uint64_t kmer_key_lds(const kmer_args& A, const uint3
 }
 template <int KC>
 __global__ void __launch_bounds__(PT_THREADS)
-k_part_scatter_dense(part_src S, int B1, int unit_tiles, int64_t n_units, const uint32_t* __restrict__ Ts, uint32_t* __restrict__ o_rec,
-                     int short_kr /* > 0: SHORT 8-byte records keeping this many key bits */) {
-    if (KC > 0) { S.A.k = KC; S.k2 = 2 * KC; S.A.use_frac = 0; S.A.n_shards = 1; }
+k_part_scatter_dense(part_src S, int B1, int nbins /* level-1 buckets of this pass: 2^B1, or the RANGE shard's share */, int unit_tiles, int64_t n_units,
+                     const uint32_t* __restrict__ Ts, uint32_t* __restrict__ o_rec, int short_kr /* > 0: SHORT 8-byte records keeping this many key bits */) {
+    if (KC > 0) { S.A.k = KC; S.k2 = 2 * KC; S.A.use_frac = 0; S.A.n_shards = 1; S.A.dig_lo = 0; S.A.dig_n = 1u << DIG_BITS; S.bin_lo = 0; }
     __shared__ uint32_t s_pk[RT_TILE / 16 + 8], s_mk[RT_TILE / 32 + 4];
     __shared__ uint16_t s_perm[RT_TILE];
     __shared__ uint32_t thist[PT_MAXBINS], tstart[PT_MAXBINS], cursor[PT_MAXBINS];
     __shared__ uint32_t s_wave[16];
-    const int nbins = 1 << B1;
+    __shared__ unsigned long long s_wm[RT_TILE / 64]; __shared__ uint32_t s_wb[RT_TILE / 64];      // RANGE shard: kept masks and row bases of the tile
     const int64_t n_pk = (S.A.P >> 4) + 16, n_mk = (S.A.P >> 5) + 16;      // words the arrays hold (vg_genomes_finish: 16 of slack)
     for (int64_t u = blockIdx.x; u < n_units; u += gridDim.x) {
         const int64_t s0 = u * unit_tiles * RT_TILE, s1 = min(S.n, s0 + (int64_t)unit_tiles * RT_TILE);
@@ -1061,6 +1110,15 @@ k_part_scatter_dense(part_src S, int B1, int unit_tiles, int64_t n_units, const 
 #pragma unroll
             for (int v = 0; v < NMK; ++v) { const int i = v * PT_THREADS + (int)threadIdx.x; if (i < RT_TILE / 32 + 2) s_mk[i] = pf_mk[v]; }
             for (int b = threadIdx.x; b < nbins; b += PT_THREADS) thist[b] = 0;
+            uint32_t grp_row0 = 0;                                // RANGE: row number of the first kept k-mer of the tile's 2^25-position group
+            if (S.wbase) {
+                const int64_t W = S.n >> 6;
+                if (threadIdx.x < RT_TILE / 64) {
+                    const int64_t w = (t0 >> 6) + threadIdx.x;
+                    s_wm[threadIdx.x] = w < W ? S.wmask[w] : 0ULL; s_wb[threadIdx.x] = S.wbase[w < W ? w : W];
+                }
+                grp_row0 = S.wbase[(t0 >> SR_POS_BITS) << (SR_POS_BITS - 6)];
+            }
             lds_sync();
             if (t0 + RT_TILE < s1) fetch_bases(t0 + RT_TILE);
             uint32_t br[RT_PER];                                  // bin | rank in bin << 12, or all ones
@@ -1076,7 +1134,7 @@ k_part_scatter_dense(part_src S, int B1, int unit_tiles, int64_t n_units, const 
                 for (int j = 0; j < 4; ++j) {
                     br[4 * q + j] = 0xffffffffu;
                     if (kk[j] != SENT) {
-                        const uint32_t bin = B1 ? (uint32_t)(kk[j] >> (S.k2 - B1)) : 0u;
+                        const uint32_t bin = B1 ? (uint32_t)(kk[j] >> (S.k2 - B1)) - (uint32_t)S.bin_lo : 0u;
                         br[4 * q + j] = bin | (atomicAdd(&thist[bin], 1u) << 12);
                     }
                 }
@@ -1108,16 +1166,130 @@ k_part_scatter_dense(part_src S, int B1, int unit_tiles, int64_t n_units, const 
                 uint32_t v[3];
                 key_words(key, S.k2, &v[0], &v[1]);
                 v[2] = (uint32_t)(t0 + lp);
-                const uint32_t b = B1 ? (v[0] >> (32 - B1)) : 0u;
+                uint32_t low = v[2];                              // SHORT: the payload inside its 2^25-position group
+                if (S.wbase) {
+                    // RANGE shard: row number instead of position; inside the group it is counted from the group's first row
+                    v[2] = s_wb[lp >> 6] + (uint32_t)__popcll(s_wm[lp >> 6] & ((1ULL << (lp & 63u)) - 1ULL));
+                    low = v[2] - grp_row0;
+                }
+                const uint32_t b = B1 ? (v[0] >> (32 - B1)) - (uint32_t)S.bin_lo : 0u;
                 const uint64_t dst = (uint64_t)cursor[b] + (slot - tstart[b]);
                 if (short_kr > 0) {
-                    const uint64_t r = ((key & ((1ULL << short_kr) - 1)) << SR_POS_BITS) | (uint64_t)(v[2] & ((1u << SR_POS_BITS) - 1u));
+                    const uint64_t r = ((key & ((1ULL << short_kr) - 1)) << SR_POS_BITS) | (uint64_t)(low & ((1u << SR_POS_BITS) - 1u));
                     __builtin_memcpy(o_rec + 2 * dst, &r, 8);
                 } else __builtin_memcpy(o_rec + 3 * dst, v, 12);
             }
             lds_sync();
             for (int b = threadIdx.x; b < nbins; b += PT_THREADS) cursor[b] += thist[b];
             lds_sync();
+        }
+    }
+}
+
+// Level-1 scatter of a RANGE shard (dense source, 32 768-position tiles): only 1/n_shards of the positions are kept,
+// and the count pass has left their mask.  The kept positions of the tile are first LISTED in position order (s_list:
+// one cheap loop over the set bits of the thread's half-word), then every step works on list entries, evenly spread
+// over the threads: the k-mer arithmetic is done for the kept positions only (k_part_scatter_dense computes all
+// 32 768 k-mers of a tile to throw 7/8 of them away at eight shards), and an entry's row number is the row of the
+// tile's first kept k-mer + its index in the list.  A tile (or half-tile: a tile whose kept k-mers exceed the list is
+// taken as two halves, each of 16 384 positions) is sorted as a permutation of list indices, the record is computed
+// again at output, exactly as in k_part_scatter_dense.
+constexpr int RG_LIST = 16384;
+constexpr int RG_PER = RG_LIST / PT_THREADS;
+constexpr int RG_MAXBINS = 2048;
+template <int KC>
+__global__ void __launch_bounds__(PT_THREADS)
+k_part_scatter_range(part_src S, int B1, int nbins /* <= 2048 */, int unit_tiles, int64_t n_units, const uint32_t* __restrict__ Ts,
+                     uint32_t* __restrict__ o_rec, int short_kr /* > 0: SHORT 8-byte records keeping this many key bits */) {
+    if (KC > 0) { S.A.k = KC; S.k2 = 2 * KC; S.A.use_frac = 0; }
+    __shared__ uint32_t s_pk[RT_TILE / 16 + 8];
+    __shared__ uint16_t s_list[RG_LIST], s_perm[RG_LIST];
+    __shared__ uint32_t thist[RG_MAXBINS], tstart[RG_MAXBINS], cursor[RG_MAXBINS];
+    __shared__ uint32_t s_wave[16];
+    __shared__ unsigned long long s_wm[RT_TILE / 64]; __shared__ uint32_t s_wb[RT_TILE / 64 + 1];
+    const int64_t n_pk = (S.A.P >> 4) + 16;
+    const int64_t W = S.n >> 6;
+    for (int64_t u = blockIdx.x; u < n_units; u += gridDim.x) {
+        const int64_t s0 = u * unit_tiles * RT_TILE, s1 = min(S.n, s0 + (int64_t)unit_tiles * RT_TILE);
+        lds_sync();
+        for (int b = threadIdx.x; b < nbins; b += PT_THREADS) cursor[b] = Ts[u * nbins + b];
+        constexpr int NPK = (RT_TILE / 16 + 4 + PT_THREADS - 1) / PT_THREADS;
+        uint32_t pf_pk[NPK];
+        auto fetch_bases = [&](int64_t t0) {
+#pragma unroll
+            for (int v = 0; v < NPK; ++v) { const int i = v * PT_THREADS + (int)threadIdx.x; const int64_t w = (t0 >> 4) + i; pf_pk[v] = (i < RT_TILE / 16 + 4 && w < n_pk) ? S.A.packed[w] : 0u; }
+        };
+        fetch_bases(s0);
+        for (int64_t t0 = s0; t0 < s1; t0 += RT_TILE) {
+#pragma unroll
+            for (int v = 0; v < NPK; ++v) { const int i = v * PT_THREADS + (int)threadIdx.x; if (i < RT_TILE / 16 + 4) s_pk[i] = pf_pk[v]; }
+            if (threadIdx.x <= RT_TILE / 64) {
+                const int64_t w = (t0 >> 6) + threadIdx.x;
+                if (threadIdx.x < RT_TILE / 64) s_wm[threadIdx.x] = w < W ? S.wmask[w] : 0ULL;
+                s_wb[threadIdx.x] = S.wbase[w < W ? w : W];
+            }
+            const uint32_t grp_row0 = S.wbase[(t0 >> SR_POS_BITS) << (SR_POS_BITS - 6)];      // first row of the tile's 2^25-position group
+            lds_sync();
+            if (t0 + RT_TILE < s1) fetch_bases(t0 + RT_TILE);
+            const int wn = (s_wb[RT_TILE / 64] - s_wb[0]) <= (uint32_t)RG_LIST ? RT_TILE / 64 : RT_TILE / 128;      // words per sub-tile
+            for (int w0 = 0; w0 < RT_TILE / 64; w0 += wn) {
+                const uint32_t row0 = s_wb[w0], n_sub = s_wb[w0 + wn] - row0;
+                for (int b = threadIdx.x; b < nbins; b += PT_THREADS) thist[b] = 0;
+                // list the kept positions: thread t takes the 32-position half-word t of the sub-tile
+                if ((int)threadIdx.x < 2 * wn) {
+                    const int w = w0 + ((int)threadIdx.x >> 1);
+                    const unsigned long long m64 = s_wm[w];
+                    uint32_t m = (threadIdx.x & 1) ? (uint32_t)(m64 >> 32) : (uint32_t)m64;
+                    uint32_t at = s_wb[w] - row0 + ((threadIdx.x & 1) ? (uint32_t)__popc((uint32_t)m64) : 0u);
+                    const uint32_t lp_base = (uint32_t)w * 64u + (threadIdx.x & 1) * 32u;
+                    while (m) { s_list[at++] = (uint16_t)(lp_base + (uint32_t)__builtin_ctz(m)); m &= m - 1u; }
+                }
+                lds_sync();
+                uint32_t br[RG_PER];                              // bin | rank in bin << 12
+#pragma unroll
+                for (int q = 0; q < RG_PER; ++q) {
+                    const uint32_t i = (uint32_t)q * PT_THREADS + threadIdx.x;
+                    br[q] = 0xffffffffu;
+                    if (i < n_sub) {
+                        const uint64_t key = kmer_key_lds(S.A, s_pk, s_list[i]);
+                        const uint32_t bin = B1 ? (uint32_t)(key >> (S.k2 - B1)) - (uint32_t)S.bin_lo : 0u;
+                        br[q] = bin | (atomicAdd(&thist[bin], 1u) << 12);
+                    }
+                }
+                lds_sync();
+                {
+                    constexpr int BPT = RG_MAXBINS / PT_THREADS;
+                    uint32_t c[BPT], tot = 0;
+#pragma unroll
+                    for (int v = 0; v < BPT; ++v) { const int b = BPT * (int)threadIdx.x + v; c[v] = b < nbins ? thist[b] : 0u; tot += c[v]; }
+                    uint32_t run = block_scan_1024(tot, s_wave, nullptr);
+#pragma unroll
+                    for (int v = 0; v < BPT; ++v) { const int b = BPT * (int)threadIdx.x + v; if (b < nbins) tstart[b] = run; run += c[v]; }
+                }
+                lds_sync();
+#pragma unroll
+                for (int q = 0; q < RG_PER; ++q) {
+                    const uint32_t v = br[q];
+                    if (v != 0xffffffffu) s_perm[tstart[v & 0xfffu] + (v >> 12)] = (uint16_t)((uint32_t)q * PT_THREADS + threadIdx.x);
+                }
+                lds_sync();
+                for (uint32_t slot = threadIdx.x; slot < n_sub; slot += PT_THREADS) {
+                    const uint32_t i = s_perm[slot];
+                    const uint64_t key = kmer_key_lds(S.A, s_pk, s_list[i]);
+                    uint32_t v[3];
+                    key_words(key, S.k2, &v[0], &v[1]);
+                    v[2] = row0 + i;                              // the row number
+                    const uint32_t b = B1 ? (v[0] >> (32 - B1)) - (uint32_t)S.bin_lo : 0u;
+                    const uint64_t dst = (uint64_t)cursor[b] + (slot - tstart[b]);
+                    if (short_kr > 0) {
+                        const uint64_t r = ((key & ((1ULL << short_kr) - 1)) << SR_POS_BITS) | (uint64_t)((v[2] - grp_row0) & ((1u << SR_POS_BITS) - 1u));
+                        __builtin_memcpy(o_rec + 2 * dst, &r, 8);
+                    } else __builtin_memcpy(o_rec + 3 * dst, v, 12);
+                }
+                lds_sync();
+                for (int b = threadIdx.x; b < nbins; b += PT_THREADS) cursor[b] += thist[b];
+                lds_sync();
+            }
         }
     }
 }
@@ -1142,7 +1314,14 @@ k_part_scatter2_narrow(const uint32_t* __restrict__ rec, int B1, int B2, int64_t
         uint32_t b1, U; int64_t s0, s1;
         lvl2_unit(L, u, &b1, &U, &s0, &s1);
         uint32_t gbase = 0, gb[3] = {0, 0, 0};
-        if (SHORT) lvl2_groups(L, b1, U, s1, &gbase, gb);
+        uint32_t grow0 = 0, grow1 = 0, grow2 = 0, grow3 = 0;      // RANGE shard: first row of each of the unit's (up to four) position groups
+        if (SHORT) {
+            lvl2_groups(L, b1, U, s1, &gbase, gb);
+            if (L.wbase) {
+                const int64_t w0 = (int64_t)(gbase >> 6), gw = 1LL << (SR_POS_BITS - 6);
+                grow0 = L.wbase[min(w0, L.W)]; grow1 = L.wbase[min(w0 + gw, L.W)]; grow2 = L.wbase[min(w0 + 2 * gw, L.W)]; grow3 = L.wbase[min(w0 + 3 * gw, L.W)];
+            }
+        }
         lds_sync();
         for (int b = threadIdx.x; b < nbins; b += PT_THREADS) cursor[b] = Ts[((uint64_t)b1 * L.n_u + U) * nbins + b];
         for (int64_t t0 = s0; t0 < s1; t0 += NT_TILE) {
@@ -1172,7 +1351,8 @@ k_part_scatter2_narrow(const uint32_t* __restrict__ rec, int B1, int B2, int64_t
                             const uint32_t ui = (uint32_t)i;
                             const uint32_t gsel = (uint32_t)(ui >= gb[0]) + (uint32_t)(ui >= gb[1]) + (uint32_t)(ui >= gb[2]);
                             key[j] = (uint32_t)(r >> SR_POS_BITS) << (32 - (L.kr - B2));
-                            pay[j] = gbase + (gsel << SR_POS_BITS) + ((uint32_t)r & ((1u << SR_POS_BITS) - 1u));
+                            const uint32_t low = (uint32_t)r & ((1u << SR_POS_BITS) - 1u);
+                            pay[j] = L.wbase ? (gsel == 0 ? grow0 : gsel == 1 ? grow1 : gsel == 2 ? grow2 : grow3) + low : gbase + (gsel << SR_POS_BITS) + low;
                             br[j] = (uint32_t)(r >> (SR_POS_BITS + L.kr - B2)) & (uint32_t)(nbins - 1);
                         }
                     }
@@ -1630,6 +1810,21 @@ struct max_op { __device__ __host__ uint32_t operator()(uint32_t a, uint32_t b) 
 
 static int g_force_subshards = 0;
 
+// RANGE or HASH shards (see kmer_args): a property of the set and the fraction, the same on every rank and in every pass
+static bool range_shards(const vg_genomes* g, double fraction, int n_shards) {
+    return n_shards > 1 && n_shards <= 256 && !(fraction < 1.0) && g->padded_total() < (1LL << 32);
+}
+static kmer_args make_kmer_args(const vg_genomes* g, int k, double fraction, int shard, int n_shards) {
+    const int use_frac = fraction < 1.0;
+    kmer_args A{ g->d_packed.p, g->d_nmask.p, g->d_blk2g.p, g->d_base_off.p, g->d_len.p, g->padded_total(), k, use_frac,
+                 use_frac ? (uint64_t)std::ldexp(fraction, 64) : ~0ULL, (uint32_t)shard, (uint32_t)n_shards, g->align_shift, 0u, 1u << DIG_BITS };
+    if (range_shards(g, fraction, n_shards)) {
+        const uint32_t lo = (uint32_t)(((uint64_t)shard << DIG_BITS) / (uint64_t)n_shards), hi = (uint32_t)(((uint64_t)(shard + 1) << DIG_BITS) / (uint64_t)n_shards);
+        A.shard = 0; A.n_shards = 1; A.dig_lo = lo; A.dig_n = hi - lo;
+    }
+    return A;
+}
+
 // shared pipeline: extract -> sort.  Returns sorted keys/pos of the n_valid real k-mers and the
 // per-genome number of k-mers kept by extraction.  compact = true: only kept k-mers were written
 // and the sort payload is the compact index itself (wave_base / cblk map it back to its genome).
@@ -1686,7 +1881,7 @@ static void launch_precount(vg_genomes* g, int k, int shard, int n_shards) {
     hipStream_t side = vg_side_stream();
     pc.kept.zero(side); pc.d_over.zero(side);
     VG_HIP(hipMemsetAsync(pc.wave_cnt.p + W, 0, sizeof(uint32_t), side));
-    kmer_args A{ g->d_packed.p, g->d_nmask.p, g->d_blk2g.p, g->d_base_off.p, g->d_len.p, P, k, 0, ~0ULL, (uint32_t)shard, (uint32_t)n_shards, g->align_shift };
+    const kmer_args A = make_kmer_args(g, k, 1.0, shard, n_shards);
     if (k == 25) hipLaunchKernelGGL(k_kmer_count<25>, dim3(grid_for((P + 255) / 4)), dim3(256), 0, side, A, pc.wave_mask.p, pc.wave_cnt.p, pc.kept.p, pc.stage.p, pc.stage_cap, pc.d_over.p);
     else hipLaunchKernelGGL(k_kmer_count<0>, dim3(grid_for((P + 255) / 4)), dim3(256), 0, side, A, pc.wave_mask.p, pc.wave_cnt.p, pc.kept.p, pc.stage.p, pc.stage_cap, pc.d_over.p);
     VG_HIP(hipEventCreateWithFlags(&pc.done, hipEventDisableTiming));
@@ -1702,8 +1897,7 @@ static void run_extract_sort(vg_genomes* g, int k, double fraction, int shard, i
     if (pre) { VG_HIP(hipStreamWaitEvent(s, g_precount.done, 0)); out.kept = std::move(g_precount.kept); }
     else { out.kept.alloc((size_t)std::max(1, g->n)); out.kept.zero(s); }
     const int use_frac = fraction < 1.0;
-    kmer_args A{ g->d_packed.p, g->d_nmask.p, g->d_blk2g.p, g->d_base_off.p, g->d_len.p, P, k, use_frac,
-                 use_frac ? (uint64_t)std::ldexp(fraction, 64) : ~0ULL, (uint32_t)shard, (uint32_t)n_shards, g->align_shift };
+    const kmer_args A = make_kmer_args(g, k, fraction, shard, n_shards);
     out.compact = use_frac || n_shards > 1;
     if (!out.compact && P >= (1LL << 32)) throw vg_error(VG_EOVERFLOW, "dense k-mer pass needs < 2^32 padded bases");
     if (P >= (1LL << 37)) throw vg_error(VG_EOVERFLOW, "genome set exceeds 2^37 padded bases");
@@ -1809,15 +2003,21 @@ static void run_extract_sort(vg_genomes* g, int k, double fraction, int shard, i
 // k-mers of a shard / fraction (keys, row numbers).  Fills gen[] and rowinfo[] like k_group_runs; false = the
 // input does not suit it (tiny, skewed, a bucket beyond the LDS): the caller takes the general path.
 static int g_index_path = -1;      // -1 = not read yet; 0 = radix (rocPRIM) path forced; 1 = buckets
+// A RANGE shard of the dense source (A.dig_n < 2^11): `ri` receives the kept masks, the row bases and the row -> genome
+// map of the pass, n_rows_info becomes the number of kept k-mers, and the row pointers are indexed by row number.
 static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_args& A, const uint64_t* keys, const uint32_t* pos, int64_t n_src,
-                                const compact_map& cmap, int* d_kept, dbuf<uint32_t>& gen, dbuf<uint32_t>& rowinfo, dbuf<uint32_t>& arena,
-                                int64_t n_rows_info, int* d_dups, int64_t* n_valid_out) {
+                                const compact_map& cmap_in, int* d_kept, dbuf<uint32_t>& gen, dbuf<uint32_t>& rowinfo, dbuf<uint32_t>& arena,
+                                int64_t& n_rows_info, int* d_dups, int64_t* n_valid_out, sorted_index* ri = nullptr) {
+    compact_map cmap = cmap_in;
+    const bool range = dense && A.dig_n < (1u << DIG_BITS);
+    if (range && !ri) throw vg_error(VG_EINVAL, "internal error: a range shard needs its row map");
     hipStream_t s = vg_stream();
     vg_host_mark("buckets: enter");
     if (g_index_path < 0) { const char* e = getenv("VG_INDEX_PATH"); g_index_path = (e && !strcmp(e, "radix")) ? 0 : 1; }
     if (!g_index_path || n_src < (1 << 16) || n_src >= (1LL << 32)) return false;
     static const int tb_env = [] { const char* e = getenv("VG_TOTAL_BITS"); return e ? atoi(e) : 0; }();     // developer experiments
-    const int64_t n_expect = dense ? n_src / std::max<uint32_t>(1u, A.n_shards) : n_src;       // elements the partition will hold
+    // elements the partition will hold (a RANGE shard holds whole buckets of the set's own partition: the digits follow from n_src)
+    const int64_t n_expect = dense && !range ? n_src / std::max<uint32_t>(1u, A.n_shards) : n_src;
     int total_bits = 0; while ((n_expect >> total_bits) > 1024 && total_bits < 22) ++total_bits;
     if (tb_env > 0 && tb_env < total_bits) total_bits = tb_env;
     const bool big_buckets = (n_expect >> total_bits) > 1024;
@@ -1828,10 +2028,13 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
     // 32 768), level 2's grows as its digit shrinks, and 2k - 11 key bits fit the short records up to k = 25
     const int B2 = levels == 2 ? (b2_env ? atoi(b2_env) : total_bits - 11) : 0;
     const int B1 = total_bits - B2;
-    const int nb1 = 1 << B1, nb2 = 1 << B2;
+    if (range && B1 > DIG_BITS) return false;
+    // level-1 buckets of this pass: all 2^B1, or those the RANGE shard's digits fall into
+    const int bin_lo = range ? (int)(A.dig_lo >> (DIG_BITS - B1)) : 0;
+    const int nb1g = 1 << B1, nb1 = range ? (int)(((A.dig_lo + A.dig_n - 1) >> (DIG_BITS - B1)) - (uint32_t)bin_lo + 1) : nb1g, nb2 = 1 << B2;
     const bool narrow = levels == 2 && 2 * k - total_bits <= 32;      // level-2 output: one key word instead of two
     part_src S; memset(&S, 0, sizeof S);
-    S.A = A; S.keys = keys; S.pos = pos; S.n = n_src; S.k2 = 2 * k;
+    S.A = A; S.keys = keys; S.pos = pos; S.n = n_src; S.k2 = 2 * k; S.bin_lo = bin_lo;
     int st_tiles = (int)std::max<int64_t>(1, std::min<int64_t>(dense ? 16 : 8, n_src / ((int64_t)PT_TILE * 2048)));
     if (dense && st_tiles >= 4) st_tiles &= ~3;             // whole 32 768-position tiles for k_part_scatter_dense
     const int64_t n_st = (n_src + (int64_t)st_tiles * PT_TILE - 1) / ((int64_t)st_tiles * PT_TILE);
@@ -1840,7 +2043,7 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
     const int n_slabs = (int)((n_st + SC_SLAB - 1) / SC_SLAB);
     dbuf<uint32_t> slab((size_t)n_slabs * nb1), d_off1((size_t)nb1 + 1);
     dbuf<uint32_t> a_rec, b_rec;
-    uint32_t n1 = 0;
+    uint32_t n1 = 0; size_t n_cap = 0;                        // records of this pass; capacity its record buffers are sized for
     // The row pointers start as zeros (only the later members of a run get one): 15 GB at 100 k genomes, 2.7 ms of
     // fill.  With room to spare (they otherwise move into the level-1 record buffer once level 2 has read it) they get
     // their own block, cleared on the side queue beside the k-mer kernels of level 1, which are bound by arithmetic.
@@ -1850,7 +2053,7 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
     // (dense single-pass sets only, whose whole workspace is a fraction of the HBM: with sub-shards of 10^6 contigs the
     // extra 14 GB block pushed the caching allocator into trims and fresh hipMallocs -- 8.2 s per pass instead of 2.7)
     static const bool no_prezero = [] { const char* e = getenv("VG_ROWS_PREZERO"); return e && *e == '0'; }();      // developer A/B
-    if (levels == 2 && dense && !no_prezero) {
+    if (levels == 2 && dense && !no_prezero && !range) {
         size_t fr = 0, tot = 0;
         if (hipMemGetInfo(&fr, &tot) == hipSuccess && (size_t)n_rows_info * 4 * 8 <= tot / 2) try {
             rowinfo.alloc((size_t)n_rows_info);
@@ -1874,7 +2077,7 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
     lvl2_tab L2; memset(&L2, 0, sizeof L2);
     const int64_t st_pos = (int64_t)st_tiles * PT_TILE;
     L2.T1s = T1s.p; L2.n_st = n_st; L2.off1 = d_off1.p; L2.nb1 = nb1;
-    L2.u_st = (int)std::max<int64_t>(1, std::min<int64_t>(n_st, (65536LL * nb1) / st_pos));
+    L2.u_st = (int)std::max<int64_t>(1, std::min<int64_t>(n_st, (65536LL * nb1g) / st_pos));
     L2.n_u = (int)((n_st + L2.u_st - 1) / L2.u_st);
     L2.kr = 2 * k - B1;
     { int sh = 0; while ((1LL << sh) < st_pos) ++sh; L2.st_shift = sh; }
@@ -1893,9 +2096,28 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
         vg_prof_scope ps("kmer_partition", (double)n_src * (dense ? 2 * 3.0 / 8.0 : 8.0 + 12.0) + (double)n_src * (short_rec ? 8.0 : 12.0));
         const int grid_c = (int)std::min<int64_t>(n_st, 512);
         const bool k25 = dense && k == 25 && !A.use_frac && A.n_shards == 1;          // the default: kernels with k as a constant
-        if (k25) hipLaunchKernelGGL((k_part_count<SRC_DENSE, 25>), dim3(grid_c), dim3(PT_THREADS), 0, s, S, B1, st_tiles, n_st, T1s.p, d_kept);
-        else if (dense) hipLaunchKernelGGL(k_part_count<SRC_DENSE>, dim3(grid_c), dim3(PT_THREADS), 0, s, S, B1, st_tiles, n_st, T1s.p, d_kept);
-        else hipLaunchKernelGGL(k_part_count<SRC_ARRAYS>, dim3(grid_c), dim3(PT_THREADS), 0, s, S, B1, st_tiles, n_st, T1s.p, (int*)nullptr);
+        unsigned long long* no_mask = nullptr; uint32_t* no_cnt = nullptr;
+        dbuf<uint32_t> wave_cnt;
+        const int64_t W = n_src / 64;
+        if (range) {
+            ri->compact = true;
+            ri->wave_mask.alloc((size_t)W + 1); ri->wave_base.alloc((size_t)W + 1); wave_cnt.alloc((size_t)W + 1);
+            VG_HIP(hipMemsetAsync(wave_cnt.p + W, 0, sizeof(uint32_t), s));
+        }
+        if (k25) hipLaunchKernelGGL((k_part_count<SRC_DENSE, 25>), dim3(grid_c), dim3(PT_THREADS), 0, s, S, B1, nb1, st_tiles, n_st, T1s.p, d_kept,
+                                    range ? ri->wave_mask.p : no_mask, range ? wave_cnt.p : no_cnt);
+        else if (dense) hipLaunchKernelGGL(k_part_count<SRC_DENSE>, dim3(grid_c), dim3(PT_THREADS), 0, s, S, B1, nb1, st_tiles, n_st, T1s.p, d_kept,
+                                           range ? ri->wave_mask.p : no_mask, range ? wave_cnt.p : no_cnt);
+        else hipLaunchKernelGGL(k_part_count<SRC_ARRAYS>, dim3(grid_c), dim3(PT_THREADS), 0, s, S, B1, nb1, st_tiles, n_st, T1s.p, (int*)nullptr, no_mask, no_cnt);
+        dbuf<char> scan_tmp;
+        if (range) {
+            // rows before every 64-position word (the payloads of the level-1 records and the SpGEMM's row ranges)
+            size_t tb = 0;
+            VG_HIP(rocprim::exclusive_scan(nullptr, tb, wave_cnt.p, ri->wave_base.p, 0u, (size_t)W + 1, rocprim::plus<uint32_t>(), s));
+            scan_tmp.alloc(tb);
+            VG_HIP(rocprim::exclusive_scan((void*)scan_tmp.p, tb, wave_cnt.p, ri->wave_base.p, 0u, (size_t)W + 1, rocprim::plus<uint32_t>(), s));
+            S.wmask = ri->wave_mask.p; S.wbase = ri->wave_base.p; L2.wbase = ri->wave_base.p; L2.W = W;
+        }
         // counts -> write offsets, in place (see k_scan_columns_*)
         hipLaunchKernelGGL(k_scan_columns_a, dim3(n_slabs), dim3(PT_THREADS), 0, s, (const uint32_t*)T1s.p, n_st, nb1, slab.p);
         hipLaunchKernelGGL(k_scan_columns_b, dim3(1), dim3(PT_THREADS), 0, s, slab.p, n_slabs, nb1, d_off1.p);
@@ -1903,7 +2125,15 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
         VG_HIP(hipMemcpyAsync(&n1, d_off1.p + nb1, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         VG_HIP(hipStreamSynchronize(s));
         vg_host_mark("buckets: count+scan done");
-        *n_valid_out = (int64_t)n1;
+        *n_valid_out = (int64_t)n1; n_cap = (size_t)n1;
+        if (range) {
+            n_rows_info = std::max<int64_t>((int64_t)n1, 1);
+            ri->n_valid = (int64_t)n1;
+            ri->cblk.alloc((size_t)(n1 >> CBLK_SHIFT) + 2); ri->cblk.zero(s);
+            ri->goff.alloc((size_t)g->n + 1);
+            hipLaunchKernelGGL(k_cblk, dim3(grid_for(g->n)), dim3(256), 0, s, (const uint32_t*)ri->wave_base.p, g->d_base_off.p, g->n, ri->cblk.p, ri->goff.p);
+            cmap = compact_map{ ri->goff.p, ri->cblk.p };
+        }
         if (n1 == 0) {
             // no valid k-mer at all (every record shorter than k, or all N): empty outputs the SpGEMM can read
             if (!ev_rows_zero) { rowinfo.alloc((size_t)n_rows_info); rowinfo.zero(s); }
@@ -1912,17 +2142,27 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
         }
         // two levels: the level-1 records are dead once level 2 has scattered them, and the genome list + row
         // descriptors are born after that: they take over the same block (48 GB less to allocate at 100 k genomes)
-        a_rec.alloc(levels == 2 ? std::max((short_rec ? 2 : 3) * (size_t)n1 + 8, (size_t)n_rows_info + (size_t)n1 + 16) : 3 * (size_t)n1 + 8);
+        // (the passes of a RANGE sub-shard loop ask for the same sizes, so that each finds the previous pass's blocks in the
+        // allocator's cache: sized for the widest digit range of the loop plus a margin, not for this pass's exact count)
+        if (range) n_cap = std::max<size_t>((size_t)n1, (size_t)((double)n_src * (A.dig_n + 1) / (double)(1u << DIG_BITS) * 1.01) + 65536);
+        const size_t rows_cap = range ? n_cap : (size_t)n_rows_info;
+        a_rec.alloc(levels == 2 ? std::max((short_rec ? 2 : 3) * n_cap + 8, rows_cap + n_cap + 16) : 3 * n_cap + 8);
         const int grid_s = (int)std::min<int64_t>(n_st, 256);
-        if (tile32k)
-            if (k25) hipLaunchKernelGGL(k_part_scatter_dense<25>, dim3(grid_s), dim3(PT_THREADS), 0, s, S, B1, st_tiles / 4, n_st, (const uint32_t*)T1s.p, a_rec.p,
+        static const bool range_dense = [] { const char* e = getenv("VG_RANGE_SCATTER"); return e && !strcmp(e, "dense"); }();      // developer A/B
+        if (tile32k && range && nb1 <= RG_MAXBINS && !range_dense)
+            if (k == 25 && !A.use_frac) hipLaunchKernelGGL(k_part_scatter_range<25>, dim3(grid_s), dim3(PT_THREADS), 0, s, S, B1, nb1, st_tiles / 4, n_st, (const uint32_t*)T1s.p, a_rec.p,
+                                                           short_rec ? L2.kr : 0);
+            else hipLaunchKernelGGL(k_part_scatter_range<0>, dim3(grid_s), dim3(PT_THREADS), 0, s, S, B1, nb1, st_tiles / 4, n_st, (const uint32_t*)T1s.p, a_rec.p,
+                                    short_rec ? L2.kr : 0);
+        else if (tile32k)
+            if (k25 && !range) hipLaunchKernelGGL(k_part_scatter_dense<25>, dim3(grid_s), dim3(PT_THREADS), 0, s, S, B1, nb1, st_tiles / 4, n_st, (const uint32_t*)T1s.p, a_rec.p,
                                         short_rec ? L2.kr : 0);
-            else hipLaunchKernelGGL(k_part_scatter_dense<0>, dim3(grid_s), dim3(PT_THREADS), 0, s, S, B1, st_tiles / 4, n_st, (const uint32_t*)T1s.p, a_rec.p,
+            else hipLaunchKernelGGL(k_part_scatter_dense<0>, dim3(grid_s), dim3(PT_THREADS), 0, s, S, B1, nb1, st_tiles / 4, n_st, (const uint32_t*)T1s.p, a_rec.p,
                                     short_rec ? L2.kr : 0);
         else if (dense) hipLaunchKernelGGL((k_part_scatter<SRC_DENSE, 1>), dim3(grid_s), dim3(PT_THREADS), 0, s, S, B1, 0, st_tiles, n_st, (const uint32_t*)T1s.p,
-                                      lvl2_tab{}, a_rec.p, -1);
+                                      lvl2_tab{}, a_rec.p, -1, nb1);
         else hipLaunchKernelGGL((k_part_scatter<SRC_ARRAYS, 1>), dim3(grid_s), dim3(PT_THREADS), 0, s, S, B1, 0, st_tiles, n_st, (const uint32_t*)T1s.p,
-                                lvl2_tab{}, a_rec.p, -1);
+                                lvl2_tab{}, a_rec.p, -1, nb1);
     }
     const int64_t nbk = levels == 1 ? nb1 : (int64_t)nb1 * nb2;
     dbuf<uint32_t> boff((size_t)nbk + 1);
@@ -1941,7 +2181,7 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
             if (short_rec) hipLaunchKernelGGL(k_part_count2<true>, dim3(grid_c2), dim3(PT_THREADS), 0, s, (const uint32_t*)a_rec.p, B1, B2, n_units, L2, T2s.p);
             else hipLaunchKernelGGL(k_part_count2<false>, dim3(grid_c2), dim3(PT_THREADS), 0, s, (const uint32_t*)a_rec.p, B1, B2, n_units, L2, T2s.p);
             hipLaunchKernelGGL(k_scan_units, dim3(nb1), dim3(PT_THREADS), 0, s, T2s.p, L2.n_u, nb2, (const uint32_t*)d_off1.p, nb1, boff.p);
-            b_rec.alloc((narrow ? 2 : 3) * (size_t)n1 + 8);
+            b_rec.alloc((narrow ? 2 : 3) * n_cap + 8);
             static const bool staged2 = [] { const char* e = getenv("VG_LEVEL2_SCATTER"); return e && !strcmp(e, "staged"); }();
             const int grid_s2 = (int)std::min<int64_t>(n_units, 256);
             if (short_rec)
@@ -1954,7 +2194,7 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
                 part_src S2; memset(&S2, 0, sizeof S2);
                 S2.rec = a_rec.p; S2.n = (int64_t)n1; S2.k2 = 2 * k;
                 hipLaunchKernelGGL((k_part_scatter<SRC_PLANES, 2>), dim3(grid_s2), dim3(PT_THREADS), 0, s, S2, B1, B2, 0, n_units,
-                                   (const uint32_t*)T2s.p, L2, b_rec.p, narrow ? total_bits : -1);
+                                   (const uint32_t*)T2s.p, L2, b_rec.p, narrow ? total_bits : -1, 0);
             }
         }
         VG_HIP(hipStreamSynchronize(s));                       // the tables and level-1 records go out of scope below
@@ -2031,14 +2271,11 @@ static void kmer_shared_pass(vg_genomes* g, int k, double fraction, int shard, i
     const int n = g->n;
     sorted_index si;
     const int64_t P = g->padded_total();
-    // Up to four k-mer range shards of a set below 2^32 padded bases run on the dense source too: every rank scans
-    // the bases and keeps its own k-mers (the other shards' are SENT inside canon_key) -- 85 vs 106 ms per rank at
-    // two shards of 100 k genomes.  With more shards the two full-length passes and the per-position row pointers
-    // cost more than materialising the kept k-mers first (compact source: 40 vs 46 ms at eight shards); that source
-    // also serves --kmers-fraction and sets beyond 2^32.  VG_SHARD_SOURCE=dense|compact forces one.
-    static const int shard_src = [] { const char* e = getenv("VG_SHARD_SOURCE"); return !e ? 0 : !strcmp(e, "compact") ? 1 : !strcmp(e, "dense") ? 2 : 0; }();
-    const bool dense_shards = shard_src == 2 || (shard_src == 0 && n_shards <= 4);
-    const bool dense_src = !(fraction < 1.0) && (n_shards == 1 || (dense_shards && P < (1LL << 32)));
+    // RANGE shards (sets below 2^32 padded bases, no fraction) keep the dense source: the pass scans the bases, keeps the
+    // k-mers of its level-1 buckets and numbers them as rows; everything behind level 1 is a 1/n_shards slice of the whole
+    // pass, row pointers included.  HASH shards (larger sets, fractions) materialise their k-mers first (compact source).
+    const bool range = range_shards(g, fraction, n_shards);
+    const bool dense_src = !(fraction < 1.0) && (n_shards == 1 || range);
     int64_t nv = 0, n_rows_info = 0;
     dbuf<uint32_t> arena;                            // owner of rowinfo / gen when they are windows of one block
     dbuf<uint32_t> rowinfo; dbuf<uint32_t> gen;
@@ -2048,13 +2285,12 @@ static void kmer_shared_pass(vg_genomes* g, int k, double fraction, int shard, i
     bool bucket_ok = false;
     {
         dbuf<int> kept_b((size_t)n); kept_b.zero(s);
-        kmer_args A{ g->d_packed.p, g->d_nmask.p, g->d_blk2g.p, g->d_base_off.p, g->d_len.p, P, k, 0, ~0ULL,
-                     dense_src ? (uint32_t)shard : 0u, dense_src ? (uint32_t)n_shards : 1u, g->align_shift };
+        kmer_args A = make_kmer_args(g, k, 1.0, dense_src ? shard : 0, dense_src ? n_shards : 1);      // (the compact source's keys are filtered already)
         if (dense_src) {
             if (P < (1LL << 32)) {
                 n_rows_info = P;
                 const compact_map none{ nullptr, nullptr };
-                bucket_ok = build_index_buckets(g, k, true, A, nullptr, nullptr, P, none, kept_b.p, gen, rowinfo, arena, n_rows_info, d_dups.p, &nv);
+                bucket_ok = build_index_buckets(g, k, true, A, nullptr, nullptr, P, none, kept_b.p, gen, rowinfo, arena, n_rows_info, d_dups.p, &nv, range ? &si : nullptr);
                 if (bucket_ok) kept_b.download(kept.data(), (size_t)n, s);
             }
         } else {
@@ -2113,7 +2349,7 @@ static void kmer_shared_pass(vg_genomes* g, int k, double fraction, int shard, i
         VG_HIP(hipStreamSynchronize(s));
     }
     }
-    const bool compact_rows = bucket_ok ? !dense_src : si.compact;
+    const bool compact_rows = bucket_ok ? (!dense_src || range) : si.compact;
     const uint32_t* wbase = compact_rows ? si.wave_base.p : nullptr;
     for (int i = 0; i < n; ++i) set_sizes[i] = (int64_t)kept[i] - dups[i];
     si.keys.release();
@@ -2128,7 +2364,7 @@ static void kmer_shared_pass(vg_genomes* g, int k, double fraction, int shard, i
     // Rows of a few thousand k-mers (10^6 contigs cut into sub-shards: 3 600 per row and pass) are one trip of a
     // 256-thread workgroup: a chain of dependent round trips with eight workgroups per CU to cover it.  Those rows go to
     // ONE-WAVE workgroups with a 512-slot table (26 per CU); a row that outgrows the table joins the overflow list.
-    constexpr int64_t SMALL_ROW = 4096;
+    constexpr int64_t SMALL_ROW = 8192;
     dbuf<uint32_t> d_small, d_large; int n_small = 0, n_large = 0;
     if (n >= (1 << 16)) {
         std::vector<uint32_t> small_rows, large_rows;
@@ -2286,7 +2522,7 @@ static void kmer_shared_subshards(vg_genomes* g, int k, double fraction, int sha
     struct hook_guard { ~hook_guard() { g_after_extract = nullptr; g_precount.drop(); } } hg;
     for (int t = 0; t < sub; ++t) {
         g_after_extract = nullptr;
-        if (t + 1 < sub && !(fraction < 1.0) && !no_overlap)
+        if (t + 1 < sub && !(fraction < 1.0) && !no_overlap && !range_shards(g, fraction, n_shards * sub))      // (HASH shards: the compact source scans first)
             g_after_extract = [=] {
                 // (an optimisation only: without room for the second set of scan buffers the next sub-shard scans in line)
                 try { launch_precount(g, k, shard * sub + t + 1, n_shards * sub); } catch (...) { (void)hipGetLastError(); g_precount.drop(); }
@@ -2321,6 +2557,14 @@ extern "C" int vg_kmer_shared(vg_genomes* g, int k, double fraction, int shard, 
     if (g_force_subshards > 0) sub = g_force_subshards;
     else if (env_sub > 0) sub = env_sub;
     else if (dense ? P >= (1LL << 32) : expect >= 3.9e9) sub = (int)std::ceil(expect / 3.6e9);      // row numbers of one pass are 32 bits
+    else if (dense && vg_one_shot()) {
+        // a cold one-shot call (the CLI): RANGE sub-shards under a workspace budget -- 16 bytes of records per kept k-mer
+        // and pass.  Eight passes over 100 k genomes cost eight scans of the bases more than one pass (tens of ms) and
+        // touch 8 GB of device memory instead of 66 GB: what a cold process may wait for is the first use of memory
+        // (25-32 ms per GiB when the driver still has to wipe it, vg_core.cpp).  VG_WORKSPACE_GB sets the budget.
+        static const double ws_gb = [] { const char* e = getenv("VG_WORKSPACE_GB"); const double v = e ? atof(e) : 0.0; return v > 0.01 ? v : 8.0; }();
+        sub = (int)std::min(64.0, std::ceil(16.0 * (double)P / (ws_gb * 1073741824.0)));
+    }
     if (sub < 1) sub = 1;
     std::vector<vg_pair_count> acc;
     if (sub == 1) {
