@@ -49,6 +49,10 @@ int vg_set_device(int device);
 /* the library keeps released device blocks in a cache (no hipMalloc on the hot path); this returns them to
  * the driver, e.g. before another process needs the HBM */
 void vg_release_device_memory(void);
+/* allocator self-test (no reference call site): `cycles` rounds of allocating blocks of the given byte sizes through the
+ * library's device allocator, writing and reading back a pattern at both ends of each, releasing them and returning the
+ * cache to the driver */
+int vg_alloc_selftest(const int64_t* sizes, int n_sizes, int cycles);
 /* blocking copy between host memory and memory of the current device (for vg_comm callbacks that stage through the host) */
 int vg_copy(void* dst, const void* src, int64_t bytes, int to_host);
 

@@ -71,6 +71,8 @@ void vo_lz_default_variant(vo_lz_variant* v) {
     v->trace = 0;
     v->anchor_margin = -1;           /* R2: -1 = msl - 1 */
     v->weak_seed_ratio = 3;          /* R3: a seed shorter than lit / 3 gives one symbol of the margin away */
+    /* (a single-event fit, profiles/r04_lz_fit_leave_one_out.md: the product reads VG_LZ_WEAK_SEED -- 0 = off --, and so does the checker) */
+    { const char* e = getenv("VG_LZ_WEAK_SEED"); if (e && *e) { int r = atoi(e); v->weak_seed_ratio = r < 0 ? 0 : r > 1000 ? 1000 : r; } }
 }
 
 static inline uint64_t mix64(uint64_t x) {

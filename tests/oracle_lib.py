@@ -160,7 +160,7 @@ def read_fasta_codes(path, multisample=True):
     return np.concatenate(seqs), offsets, names
 
 
-def run_cli(*args):
+def run_cli(*args, env=None):
     if not CLI.exists():
         build()
-    subprocess.run([str(CLI), *map(str, args)], check=True)
+    subprocess.run([str(CLI), *map(str, args)], check=True, env=env)

@@ -189,6 +189,34 @@ def test_kernel_variants_write_the_same_files(tmp_path):
         assert filecmp.cmp(base[0], other[0], shallow=False) and filecmp.cmp(base[1], other[1], shallow=False), tag
 
 
+def test_weak_seed_rule_is_exercised_and_switchable(tmp_path):
+    """R3's weak-seed margin (`lit > 3 * seed`: the anchor needs msl - 1 instead of msl more symbols) rests on one event
+    of the reference's example (profiles/r04_lz_fit_leave_one_out.md).  On strongly diverged synthetic families the branch
+    decides several regions: the product equals the oracle with the rule on (default) AND with it switched off
+    (VG_LZ_WEAK_SEED=0 is read by both), and the two settings give different tables -- so the branch is really taken."""
+    import filecmp
+    import os
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / 'tests'))
+    import oracle_lib as orc
+    from vclust_amd import synth
+    codes, offsets, names = synth.make_families(2, 6, length=20000, seed=5, p_lo=0.15, p_hi=0.30)
+    fa = tmp_path / 'div.fna'
+    synth.write_fasta(fa, codes, offsets, names)
+    out = {}
+    for tag, extra in (('on', {}), ('off', dict(VG_LZ_WEAK_SEED='0'))):
+        e = dict(os.environ, **extra)
+        ani, aln, oani, oaln = (tmp_path / f'{tag}.{x}' for x in ('tsv', 'aln', 'o.tsv', 'o.aln'))
+        p = subprocess.run([sys.executable, str(VCLUST), 'align', '-i', str(fa), '-o', str(ani), '--out-aln', str(aln), '--outfmt', 'complete', '-v', '0'],
+                           env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        assert p.returncode == 0, p.stderr[-2000:]
+        orc.run_cli('align', '-o', oani, '--out-aln', oaln, '--outfmt', 'complete', fa, env=e)
+        assert filecmp.cmp(ani, oani, shallow=False), tag
+        assert sorted(open(aln).read().splitlines()) == sorted(open(oaln).read().splitlines()), tag
+        out[tag] = sorted(open(aln).read().splitlines())
+    assert out['on'] != out['off']
+
+
 def _torchrun(nproc, *cmd):
     import os
     import socket

@@ -239,20 +239,31 @@ def test_high_multiplicity_index_time_at_100k_contigs():
     pairs plus the pairs of block carriers (and the poly-A pairs that reach min-kmers)."""
     base, offsets, names, _ = synth.make_workload('contigs-1M', 100000)
 
-    def run(codes):
-        gs = api.GenomeSet.from_codes(codes, offsets, names)
-        gs.kmer_shared(k=25, min_shared=30)            # warm-up (allocator)
+    codes, _, _ = _real_shaped_set(100000, 5000, 2000, seed=10)
+    sets = [api.GenomeSet.from_codes(c, offsets, names) for c in (base, codes)]
+
+    def run(gs):
         api.profile_enable(True); api.profile_reset()
         sizes, pairs = gs.kmer_shared(k=25, min_shared=30)
         prof = {e['name']: e for e in api.profile_get()}
         api.profile_enable(False)
         idx_ms = sum(e['total_ms'] for n, e in prof.items() if n.startswith(('kmer_partition', 'bucket_')))
         return sizes, pairs, prof, idx_ms
-    s0, p0, prof0, t0 = run(base)
-    codes, _, _ = _real_shaped_set(100000, 5000, 2000, seed=10)
-    s1, p1, prof1, t1 = run(codes)
+    for gs in sets:
+        gs.kmer_shared(k=25, min_shared=30)            # warm-up (allocator)
+    # kernel-scope times of the two sets in ALTERNATING runs, best of three each: where the driver places the buffers
+    # moves the scattering kernels by several per cent from one allocation to the next (DESIGN section 4), a single pair
+    # of runs compares two placements as much as two inputs
+    t = [[], []]
+    for _ in range(3):
+        for i, gs in enumerate(sets):
+            out = run(gs)
+            t[i].append(out[3])
+            if i == 0: s0, p0, prof0, _ = out
+            else: s1, p1, prof1, _ = out
+    t0, t1 = min(t[0]), min(t[1])
     assert 'radix_sort_pairs' not in prof1 and 'bucket_big' in prof1
-    assert t1 <= 1.3 * t0, (t0, t1)
+    assert t1 <= 1.3 * t0, (t, t0, t1)
     assert len(p1) >= len(p0) + 5000 * 4999 // 2 * 0.99
 
 

@@ -70,6 +70,7 @@ SYMBOLS = {
     'vg_set_device': (C.c_int, [C.c_int]),
     'vg_release_device_memory': (None, []),
     'vg_copy': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int]),
+    'vg_alloc_selftest': (C.c_int, [C.POINTER(C.c_int64), C.c_int, C.c_int]),
     'vg_genomes_load': (C.c_int, [P(C.c_char_p), C.c_int, C.c_int, C.c_int, P(C.c_void_p)]),
     'vg_genomes_from_codes': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, P(C.c_char_p), P(C.c_void_p)]),
     'vg_genomes_free': (None, [C.c_void_p]),

@@ -43,7 +43,7 @@ struct ref_desc {
     int32_t tag_bits;  // tag = the first tag_bits / 2 bases behind the msl-mer (<= mal - msl bases, <= 14 bits, <= 32 - pos_bits)
 };
 
-struct lz_dev_params { int mal, msl, mrd, mqd, reg, aw, am, ar; int ablate; int pw_after, pw_miss; };   // ablate: developer timing experiments only; pw_*: probe widths
+struct lz_dev_params { int mal, msl, mrd, mqd, reg, aw, am, ar; int ablate; int pw_after, pw_miss; int weak_ratio; };   // ablate: developer timing experiments only; pw_*: probe widths; weak_ratio: R3's weak-seed ratio (3; 0 = the rule is off)
 
 // ------------------------------------------------------------------ bit helpers
 // 32 bases (2-bit codes, first base in the low bits) starting at base position p (p >= 0)
@@ -1016,7 +1016,7 @@ struct seg_rec { int i_ev, ev_pos; uint32_t VM, VA, VN; };     // VN: bit 31 = o
 // and the mask paths fold away); the host launches it when both hold.
 template <int S, bool DEV, bool FAST = false>
 __device__ __forceinline__ void lz_parse_body(PARSE_ARGS) {
-    if (FAST) { P.mal = 11; P.msl = 7; P.mrd = 40; P.mqd = 40; P.reg = 35; P.aw = 15; P.am = 7; P.ar = 3; P.ablate = 0; }
+    if (FAST) { P.mal = 11; P.msl = 7; P.mrd = 40; P.mqd = 40; P.reg = 35; P.aw = 15; P.am = 7; P.ar = 3; P.ablate = 0; P.weak_ratio = 3; }
     const int ABL = DEV ? P.ablate : 0;           // developer timing knobs: compiled out of the production kernels
     __shared__ seg_rec s_log[S > 1 ? S * SEG_LOG_CAP : 1];
     __shared__ int s_cnt[4], s_sync_v[4], s_sync_idx[4];
@@ -1178,8 +1178,10 @@ __device__ __forceinline__ void lz_parse_body(PARSE_ARGS) {
                 if (best_len == 32) best_len = match_len_lane(c, qi, best_pos, 1 << 30);
                 if (sbest_len == 32) sbest_len = match_len_lane(c, qi, sbest_pos, 1 << 30);
             }
-            // (one symbol less when the seed is weak: shorter than a third of the literal run it would bridge)
-            if (best_len > 0 && (sbest_len == 0 || best_len >= sbest_len + P.msl - ((lit + lane > 3 * sbest_len) ? 1 : 0))) {
+            // (one symbol less when the seed is weak: shorter than a third of the literal run it would bridge.  This constant
+            // rests on ONE event of the reference's example -- profiles/r04_lz_fit_leave_one_out.md --, so it is a parameter:
+            // VG_LZ_WEAK_SEED=0 switches the rule off, =n sets the ratio, in the product and, through the variant, in the oracle)
+            if (best_len > 0 && (sbest_len == 0 || best_len >= sbest_len + P.msl - ((P.weak_ratio > 0 && lit + lane > P.weak_ratio * sbest_len) ? 1 : 0))) {
                 const int d = best_pos - pred_l;
                 hit_close = alive_l && ((best_pos > c.L) == pred_rc) && d >= -P.mrd && d <= P.mrd;
             } else if (sbest_len > 0) { best_len = sbest_len; best_pos = sbest_pos; hit_close = true; }
@@ -1453,11 +1455,13 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
     // first miss, before the scan goes to 64 per trip
     static const int pw_after = [] { const char* e = getenv("VG_LZ_PW"); const int v = e ? atoi(e) : PW_AFTER_EVENT; return std::max(1, std::min(v, 64)); }();
     static const int pw_miss = [] { const char* e = getenv("VG_LZ_PW2"); const int v = e ? atoi(e) : 64; return std::max(1, std::min(v, 64)); }();
-    const lz_dev_params P{ p->mal, p->msl, p->mrd, p->mqd, p->reg, p->aw, p->am, p->ar, abl ? atoi(abl) : 0, pw_after, pw_miss };
+    // R3's weak-seed ratio (a single-event fit): 3 unless VG_LZ_WEAK_SEED says otherwise (0 = off)
+    static const int weak_ratio = [] { const char* e = getenv("VG_LZ_WEAK_SEED"); const int v = e && *e ? atoi(e) : 3; return std::max(0, std::min(v, 1000)); }();
+    const lz_dev_params P{ p->mal, p->msl, p->mrd, p->mqd, p->reg, p->aw, p->am, p->ar, abl ? atoi(abl) : 0, pw_after, pw_miss, weak_ratio };
     const int64_t stab_n = 1LL << (2 * p->msl);
     // default parameters on a set without N: the kernel with those as compile-time constants (VG_LZ_KERNEL=general: never)
     static const bool no_fast = [] { const char* e = getenv("VG_LZ_KERNEL"); return e && !strcmp(e, "general"); }();
-    bool fast_params = !no_fast && !abl && p->mal == 11 && p->msl == 7 && p->mrd == 40 && p->mqd == 40 && p->reg == 35 && p->aw == 15 && p->am == 7 && p->ar == 3;
+    bool fast_params = !no_fast && !abl && weak_ratio == 3 && p->mal == 11 && p->msl == 7 && p->mrd == 40 && p->mqd == 40 && p->reg == 35 && p->aw == 15 && p->am == 7 && p->ar == 3;
     for (int i = 0; fast_params && i < g->n; ++i) if (g->has_n[(size_t)i] || g->len[(size_t)i] >= (1 << 22)) fast_params = false;   // (tag: 8 bits beside <= 24 position bits)
 
     dbuf<vg_pair_stat> d_stats((size_t)n_tasks);

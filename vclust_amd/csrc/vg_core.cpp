@@ -356,6 +356,36 @@ void vg_dev_trim() {
 }
 
 extern "C" void vg_release_device_memory(void) { vg_dev_trim(); }
+
+// allocator self-test: `cycles` times allocate blocks of the given sizes from the library's allocator (whichever path
+// VG_ALLOC selects), write a pattern into the first and last MiB of each with a copy from the host, read it back,
+// release the blocks and return the cache to the driver.  (tests/test_gpu_parity.py runs it under VG_ALLOC=vmm.)
+extern "C" int vg_alloc_selftest(const int64_t* sizes, int n_sizes, int cycles) {
+    VG_API_BEGIN
+    if (!sizes || n_sizes <= 0 || cycles <= 0) throw vg_error(VG_EINVAL, "vg_alloc_selftest: bad argument");
+    vg_require_device();
+    hipStream_t s = vg_stream();
+    constexpr size_t MB = 1u << 20;
+    std::vector<uint32_t> pat(MB / 4), back(MB / 4);
+    for (int c = 0; c < cycles; ++c) {
+        std::vector<void*> blocks;
+        struct guard { std::vector<void*>& b; ~guard() { for (void* p : b) vg_dev_free(p); vg_dev_trim(); } } g{ blocks };
+        for (int i = 0; i < n_sizes; ++i) {
+            if (sizes[i] < (int64_t)MB) throw vg_error(VG_EINVAL, "vg_alloc_selftest: blocks of at least 1 MiB");
+            blocks.push_back(vg_dev_alloc((size_t)sizes[i]));
+        }
+        for (int i = 0; i < n_sizes; ++i) {
+            for (size_t off : { (size_t)0, (size_t)sizes[i] - MB }) {
+                for (size_t j = 0; j < pat.size(); ++j) pat[j] = (uint32_t)(j * 2654435761u + (uint32_t)c * 97u + (uint32_t)i * 7919u + (uint32_t)(off >> 20));
+                vg_upload_bytes((char*)blocks[(size_t)i] + off, pat.data(), MB, s);
+                vg_download_bytes(back.data(), (char*)blocks[(size_t)i] + off, MB, s);
+                VG_HIP(hipStreamSynchronize(s));
+                if (memcmp(pat.data(), back.data(), MB) != 0) throw vg_error(VG_EHIP, "vg_alloc_selftest: a block does not hold what was written to it");
+            }
+        }
+    }
+    VG_API_END
+}
 extern "C" int vg_copy(void* dst, const void* src, int64_t bytes, int to_host) {
     VG_API_BEGIN
     vg_require_device();
