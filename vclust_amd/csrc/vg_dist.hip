@@ -24,7 +24,22 @@
 // VG_DIST_FORCE=1 (tests): a world of one still goes through the exchanges and merges (RCCL accepts nranks = 1).
 #include "vg_common.h"
 #include <rocprim/rocprim.hpp>
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+// Build hosts without the RCCL development headers: the few declarations the dlopen'ed entry points are typed by
+// (librccl itself is only needed at run time, by vg_comm_rccl_create).  With the headers present they are the check.
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclChar = 0 } ncclDataType_t;
+ncclResult_t ncclGetUniqueId(ncclUniqueId* uniqueId);
+ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId commId, int rank);
+ncclResult_t ncclCommDestroy(ncclComm_t comm);
+ncclResult_t ncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcount, ncclDataType_t datatype, ncclComm_t comm, hipStream_t stream);
+}
+#endif
 #include <dlfcn.h>
 #include <algorithm>
 #include <cstring>
@@ -65,6 +80,7 @@ void gather_host(const vg_comm* c, const void* send, void* recv, int64_t bytes) 
     // RCCL moves device memory: stage through HBM
     hipStream_t s = vg_stream();
     reserve_staging(c, bytes);
+    vg_prof_scope ps("exchange", (double)bytes * c->world);       // (HIP events on the library stream: bench.py prints it per rank)
     vg_upload_bytes(c->st_send.p, send, (size_t)bytes, s);
     if (c->p_allgather(c->st_send.p, c->st_recv.p, (size_t)bytes, ncclChar, c->nccl_comm, s) != ncclSuccess) throw vg_error(VG_EIO, "ncclAllGather failed");
     vg_download_bytes(recv, c->st_recv.p, (size_t)bytes * c->world, s);
@@ -79,6 +95,7 @@ void gather_device(const vg_comm* c, const void* send, void* recv, int64_t bytes
         if (c->allgather(c->ctx, send, recv, bytes, 1) != 0) throw vg_error(VG_EIO, "vg_comm: allgather callback failed");
         return;
     }
+    vg_prof_scope ps("exchange", (double)bytes * c->world);
     if (c->p_allgather(send, recv, (size_t)bytes, ncclChar, c->nccl_comm, s) != ncclSuccess) throw vg_error(VG_EIO, "ncclAllGather failed");
 }
 // every rank learns whether any rank failed: throws the first failure on all of them
@@ -212,15 +229,20 @@ extern "C" int vg_comm_selftest(const vg_comm* c, int64_t bytes) {
 extern "C" int vg_align_owner(const vg_task* tasks, int64_t n_tasks, int n_genomes, int world, int32_t* owner) {
     VG_API_BEGIN
     if ((!tasks && n_tasks) || (!owner && n_tasks) || world < 1 || n_genomes < 0) throw vg_error(VG_EINVAL, "vg_align_owner: bad arguments");
-    std::vector<int64_t> per_ref((size_t)n_genomes + 1, 0);
-    for (int64_t t = 0; t < n_tasks; ++t) { if (tasks[t].r >= (uint32_t)n_genomes) throw vg_error(VG_EINVAL, "task id out of range"); per_ref[tasks[t].r]++; }
+    // (every rank of a sharded run does this for the whole list: a few threads, per-thread counters)
+    const int n_thr = n_tasks >= (1 << 18) ? std::min(vg_host_threads(), 8) : 1;
+    std::vector<std::vector<int64_t>> part((size_t)n_thr, std::vector<int64_t>((size_t)n_genomes + 1, 0));
+    vg_parallel_chunks(n_tasks, n_thr, [&](int64_t lo, int64_t hi, int t) {
+        auto& pr = part[(size_t)t];
+        for (int64_t i = lo; i < hi; ++i) { if (tasks[i].r >= (uint32_t)n_genomes) throw vg_error(VG_EINVAL, "task id out of range"); pr[tasks[i].r]++; }
+    });
     std::vector<int32_t> own_ref((size_t)n_genomes + 1, 0);
     int64_t before = 0;
     for (int r = 0; r < n_genomes; ++r) {
         own_ref[(size_t)r] = n_tasks ? (int32_t)std::min<int64_t>(world - 1, before * world / n_tasks) : 0;
-        before += per_ref[(size_t)r];
+        for (int t = 0; t < n_thr; ++t) before += part[(size_t)t][(size_t)r];
     }
-    for (int64_t t = 0; t < n_tasks; ++t) owner[t] = own_ref[tasks[t].r];
+    vg_parallel_chunks(n_tasks, n_thr, [&](int64_t lo, int64_t hi, int) { for (int64_t i = lo; i < hi; ++i) owner[i] = own_ref[tasks[i].r]; });
     VG_API_END
 }
 

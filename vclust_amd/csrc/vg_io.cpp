@@ -245,7 +245,11 @@ extern "C" int vg_read_filter(const vg_genomes* g, const char* path, double thr,
             if (lo > 0) { const char* nl = (const char*)memchr(base + p0 - 1, '\n', n_data - (p0 - 1)); p0 = nl ? (size_t)(nl - base) + 1 : n_data; }   // first whole line
             if ((size_t)hi < n_data - b0) { const char* nl = (const char*)memchr(base + p1 - 1, '\n', n_data - (p1 - 1)); p1 = nl ? (size_t)(nl - base) + 1 : n_data; }
             std::vector<vg_pair_count>& out = part[(size_t)t];
-            int64_t guess = -1;                                   // the row in front of this one, + 1
+            // the row in front of this one, + 1.  The first row of a chunk has no row in front of it: the first chunk starts
+            // at genome 0, the others look around the genome their byte offset suggests (rows of similar length: a few
+            // thousand name compares at most) before the hash map over all names is built for them
+            int64_t guess = lo == 0 ? 0 : -1;
+            bool first_row = lo > 0;
             while (p0 < p1) {
                 const char* nl = (const char*)memchr(base + p0, '\n', n_data - p0);
                 size_t le = nl ? (size_t)(nl - base) : n_data; const size_t next = le + 1;
@@ -253,6 +257,17 @@ extern "C" int vg_read_filter(const vg_genomes* g, const char* path, double thr,
                 const char* q = base + p0; const char* const e = base + le;
                 p0 = next;
                 const char* c = (const char*)memchr(q, ',', (size_t)(e - q)); if (!c) continue;
+                if (first_row) {
+                    first_row = false;
+                    const size_t len = (size_t)(c - q);
+                    const int64_t est = (int64_t)((double)g->n * (double)(p0 - b0) / (double)std::max<size_t>(1, n_data - b0));
+                    for (int64_t d = 0; d <= 4096 && guess < 0; ++d)
+                        for (int64_t cand : { est + d, est - d }) {
+                            if (cand < 0 || cand >= (int64_t)g->n) continue;
+                            const std::string& nm = g->names[(size_t)cand];
+                            if (nm.size() == len && memcmp(nm.data(), q, len) == 0) { guess = cand; break; }
+                        }
+                }
                 const int64_t row = lookup(q, (size_t)(c - q), guess);
                 if (row >= 0) guess = row + 1;
                 q = c + 1;

@@ -2573,7 +2573,12 @@ extern "C" int vg_kmer_shared(vg_genomes* g, int k, double fraction, int shard, 
         // partial (a, b, count) records of every sub-shard stay in HBM and are summed ONCE there: sort on (a, b), reduce
         // by key, threshold on the sum
         dbuf<vg_pair_count> d_sum; unsigned long long n_sum = 0;
-        kmer_shared_subshards(g, k, fraction, shard, n_shards, sub, min_shared, set_sizes, d_sum, &n_sum);
+        // (HASH sub-shards are sized on an expectation: a set whose repeated k-mers crowd one sub-shard beyond the 32-bit row
+        // numbers of a pass is cut finer instead of failing)
+        for (int attempt = 0;; ++attempt) {
+            try { kmer_shared_subshards(g, k, fraction, shard, n_shards, sub, min_shared, set_sizes, d_sum, &n_sum); break; }
+            catch (const vg_error& e) { if (e.code != VG_EOVERFLOW || attempt >= 3 || g_force_subshards > 0) throw; ++sub; d_sum.release(); }
+        }
         acc.resize((size_t)n_sum);
         if (n_sum) { d_sum.download(acc.data(), (size_t)n_sum, vg_stream()); VG_HIP(hipStreamSynchronize(vg_stream())); }
     }
@@ -2607,7 +2612,10 @@ void vg_kmer_shared_device(vg_genomes* g, int k, double fraction, int shard, int
     int sub = g_force_subshards > 1 ? g_force_subshards : (int)std::ceil(expect / 3.6e9);
     if (sub < 2) sub = 2;
     unsigned long long n = 0;
-    kmer_shared_subshards(g, k, fraction, shard, n_shards, sub, min_shared, set_sizes, pairs, &n);
+    for (int attempt = 0;; ++attempt) {
+        try { kmer_shared_subshards(g, k, fraction, shard, n_shards, sub, min_shared, set_sizes, pairs, &n); break; }
+        catch (const vg_error& e) { if (e.code != VG_EOVERFLOW || attempt >= 3 || g_force_subshards > 1) throw; ++sub; pairs.release(); }
+    }
     if (!pairs.p) pairs.alloc(1);
     *n_pairs = (int64_t)n;
 }
