@@ -116,11 +116,24 @@ template <class F> void guarded(const vg_comm* c, const char* what, F fn) {
 }
 
 inline int dgrid(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 4096)); }
+// output slot of a kept element behind a global cursor, ONE atomic per wave (a global atomic per element on one word
+// costs ~10 ns each: 4.5 ms per 450 000 records); to be called by all active lanes of the wave
+__device__ __forceinline__ unsigned long long wave_slot(unsigned long long* cursor, bool keep) {
+    const unsigned long long b = __ballot(keep);
+    if (!b) return 0;
+    const int lane = threadIdx.x & 63, leader = __builtin_ctzll(b);
+    unsigned long long base = 0;
+    if (lane == leader) base = atomicAdd(cursor, (unsigned long long)__popcll(b));
+    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)base, leader), hi = (uint32_t)__shfl((int)(uint32_t)(base >> 32), leader);
+    return (((unsigned long long)hi << 32) | lo) + (unsigned long long)__popcll(b & ((1ULL << lane) - 1ULL));
+}
 // keys of the pairs this rank nominates (count >= thr), compacted through a cursor (their order is irrelevant: they are sorted next)
 __global__ void k_nominate(const vg_pair_count* __restrict__ rec, int64_t n, uint32_t thr, uint64_t* __restrict__ keys, unsigned long long* __restrict__ cursor) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const vg_pair_count r = rec[i];
-        if (r.shared >= thr) keys[atomicAdd(cursor, 1ULL)] = ((uint64_t)r.a << 32) | r.b;
+        const bool keep = r.shared >= thr;
+        const unsigned long long o = wave_slot(cursor, keep);
+        if (keep) keys[o] = ((uint64_t)r.a << 32) | r.b;
     }
 }
 __global__ void k_local_keys(const vg_pair_count* __restrict__ rec, int64_t n, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
@@ -150,9 +163,9 @@ __global__ void k_sum_counts(const uint64_t* __restrict__ uni, int64_t nu, const
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nu; i += (int64_t)gridDim.x * blockDim.x) {
         uint64_t t = 0;
         for (int r = 0; r < world; ++r) t += cnt[(int64_t)r * nu + i];
-        if (t < min_shared) continue;
-        const unsigned long long o = atomicAdd(cursor, 1ULL);
-        out[o].a = (uint32_t)(uni[i] >> 32); out[o].b = (uint32_t)uni[i]; out[o].shared = (uint32_t)t;
+        const bool keep = t >= min_shared;
+        const unsigned long long o = wave_slot(cursor, keep);
+        if (keep) { out[o].a = (uint32_t)(uni[i] >> 32); out[o].b = (uint32_t)uni[i]; out[o].shared = (uint32_t)t; }
     }
 }
 }  // namespace

@@ -512,7 +512,12 @@ __device__ __forceinline__ bool ht_add(uint32_t* hk, uint32_t* hc, uint32_t b, u
     return false;
 }
 
-template <int HT_BITS>
+// COMPACT (one-wave workgroups, blockDim = 64): the non-zero row pointers of a trip are first packed into an LDS queue and
+// the list walks then run over the queue with every lane busy.  Only ~1 row pointer in 5 is non-zero (a k-mer with a
+// partner in a smaller genome); walked where they lie, the sixteen walk bodies of a trip execute for a dozen lanes each.
+// For short rows -- shards and sub-shards of the k-mer range, sets of 10^6 contigs -- that issue time, not the list
+// gathers, is what the kernel costs.
+template <int HT_BITS, bool COMPACT = false>
 __global__ void __launch_bounds__(256)
 k_spgemm(const uint32_t* __restrict__ rowinfo, const uint32_t* __restrict__ gen, uint64_t n_gen,
          const int64_t* __restrict__ base_off, const int64_t* __restrict__ len, const uint32_t* __restrict__ wave_base,
@@ -520,9 +525,12 @@ k_spgemm(const uint32_t* __restrict__ rowinfo, const uint32_t* __restrict__ gen,
          vg_pair_count* __restrict__ out, unsigned long long* __restrict__ out_cursor,
          unsigned long long out_cap, uint32_t* __restrict__ overflow_rows, uint32_t* __restrict__ n_overflow) {
     constexpr int HT_SIZE = 1 << HT_BITS;
+    constexpr int ROWS_PER_TRIP = 16;             // independent row-pointer loads per thread and trip
     __shared__ uint32_t hk[HT_SIZE];
     __shared__ uint32_t hc[HT_SIZE];
-    __shared__ uint32_t lq[LQ_CAP];
+    constexpr int LQC = COMPACT ? 64 : LQ_CAP;         // long-run queue (one wave drains it often: a short one keeps the LDS small)
+    __shared__ uint32_t lq[LQC];
+    __shared__ uint32_t rq[COMPACT ? 64 * ROWS_PER_TRIP : 1];
     __shared__ uint32_t s_used, s_lq, s_fail, s_first;
     // XCD-aware dealing (workgroup b runs on XCD b % 8): consecutive rows -- neighbouring genomes, which share
     // their k-mers' genome lists when they are related -- go to ONE XCD, so the lists are re-read from its L2
@@ -536,7 +544,35 @@ k_spgemm(const uint32_t* __restrict__ rowinfo, const uint32_t* __restrict__ gen,
     // row a = its base positions (dense) or its kept k-mers (compact index space)
     const int64_t p0 = wave_base ? (int64_t)wave_base[base_off[a] >> 6] : base_off[a];
     const int64_t L = wave_base ? (int64_t)wave_base[base_off[a + 1] >> 6] - p0 : len[a];
-    constexpr int ROWS_PER_TRIP = 16;             // independent row-pointer loads per thread and trip
+    // one walk: the genome list of the run, four entries per memory round trip; ascending, and genome a itself is
+    // in it: the first genome >= a ends the walk (entries past the run are never reached)
+    auto walk = [&](uint32_t rs) {
+        bool done = false;
+        uint32_t e = 0;
+        for (; e < (uint32_t)LONG_RUN && !done; e += 4) {
+            uint32_t g4[4];
+            __builtin_memcpy(g4, gen + (size_t)rs + e, 16);            // one 16-byte load (the list carries 4 slack entries)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (done) continue;
+                const uint32_t g = g4[j];
+                if (g & DUP_BIT) continue;
+                if (g >= a) { done = true; continue; }
+                if (!ht_add<HT_BITS>(hk, hc, g, &s_used)) s_fail = 1;
+            }
+        }
+        if (!done) {
+            // a long run: the rest is walked by the whole workgroup (queue full: this thread goes on alone)
+            const uint32_t slot = atomicAdd(&s_lq, 1u);
+            if (slot < LQC) lq[slot] = rs + e;
+            else for (uint64_t x = (uint64_t)rs + e; x < n_gen; ++x) {
+                const uint32_t g = gen[x];
+                if (g & DUP_BIT) continue;
+                if (g >= a) break;
+                if (!ht_add<HT_BITS>(hk, hc, g, &s_used)) s_fail = 1;
+            }
+        }
+    };
     for (int64_t base = 0; base < L; base += (int64_t)blockDim.x * ROWS_PER_TRIP) {
         uint32_t rr4[ROWS_PER_TRIP];
 #pragma unroll
@@ -544,42 +580,29 @@ k_spgemm(const uint32_t* __restrict__ rowinfo, const uint32_t* __restrict__ gen,
             const int64_t i = base + (int64_t)u * blockDim.x + threadIdx.x;
             rr4[u] = (i < L) ? rowinfo[p0 + i] : 0u;
         }
+        if (COMPACT) {
+            const int lane = threadIdx.x & 63;
+            uint32_t nq = 0;
+#pragma unroll
+            for (int u = 0; u < ROWS_PER_TRIP; ++u) {
+                const bool nz = rr4[u] != 0u;
+                const unsigned long long b = __ballot(nz);
+                if (nz) rq[nq + (uint32_t)__popcll(b & ((1ULL << lane) - 1ULL))] = rr4[u];
+                nq += (uint32_t)__popcll(b);
+            }
+            __syncthreads();
+            for (uint32_t qi = (uint32_t)lane; qi < nq; qi += 64u) walk(rq[qi] - 1u);
+        } else {
 #pragma unroll
         for (int u = 0; u < ROWS_PER_TRIP; ++u) {
             if (!rr4[u]) continue;
-            const uint32_t rs = rr4[u] - 1u;
-            // the genome list of the run, four entries per memory round trip; ascending, and genome a itself is
-            // in it: the first genome >= a ends the walk (entries past the run are never reached)
-            bool done = false;
-            uint32_t e = 0;
-            for (; e < (uint32_t)LONG_RUN && !done; e += 4) {
-                uint32_t g4[4];
-                __builtin_memcpy(g4, gen + (size_t)rs + e, 16);            // one 16-byte load (the list carries 4 slack entries)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (done) continue;
-                    const uint32_t g = g4[j];
-                    if (g & DUP_BIT) continue;
-                    if (g >= a) { done = true; continue; }
-                    if (!ht_add<HT_BITS>(hk, hc, g, &s_used)) s_fail = 1;
-                }
-            }
-            if (!done) {
-                // a long run: the rest is walked by the whole workgroup (queue full: this thread goes on alone)
-                const uint32_t slot = atomicAdd(&s_lq, 1u);
-                if (slot < LQ_CAP) lq[slot] = rs + e;
-                else for (uint64_t x = (uint64_t)rs + e; x < n_gen; ++x) {
-                    const uint32_t g = gen[x];
-                    if (g & DUP_BIT) continue;
-                    if (g >= a) break;
-                    if (!ht_add<HT_BITS>(hk, hc, g, &s_used)) s_fail = 1;
-                }
-            }
+            walk(rr4[u] - 1u);
+        }
         }
         // drain the long-run queue cooperatively when it fills up
         __syncthreads();
-        if (s_lq >= LQ_CAP / 2 || base + (int64_t)blockDim.x * ROWS_PER_TRIP >= L) {
-            const uint32_t nq = s_lq < LQ_CAP ? s_lq : LQ_CAP;
+        if (s_lq >= LQC / 2 || base + (int64_t)blockDim.x * ROWS_PER_TRIP >= L) {
+            const uint32_t nq = s_lq < LQC ? s_lq : LQC;
             for (uint32_t qi = 0; qi < nq; ++qi) {
                 for (uint64_t c0 = lq[qi]; ; c0 += blockDim.x) {
                     // one chunk of the list: everything in front of the first genome >= a counts
@@ -607,11 +630,22 @@ k_spgemm(const uint32_t* __restrict__ rowinfo, const uint32_t* __restrict__ gen,
         if (threadIdx.x == 0) { uint32_t o = atomicAdd(n_overflow, 1u); overflow_rows[o] = a; }
         return;
     }
-    for (int i = threadIdx.x; i < HT_SIZE; i += blockDim.x) {
-        uint32_t b = hk[i];
-        if (b != HT_EMPTY && hc[i] >= min_emit) {
-            unsigned long long o = atomicAdd(out_cursor, 1ULL);
-            if (o < out_cap) { out[o].a = a; out[o].b = b; out[o].shared = hc[i]; }
+    // output: the workgroup takes ONE range of the global cursor for all its pairs (threads place themselves inside it
+    // through an LDS counter).  One global atomic per PAIR on the one cursor word was the floor of this kernel: ~10 ns
+    // each, 4.5 ms for the 450 000 pairs of 100 k genomes whatever the shard held, most of the time at 10^6 contigs.
+    uint32_t mine = 0;
+    for (int i = threadIdx.x; i < HT_SIZE; i += blockDim.x) mine += (hk[i] != HT_EMPTY && hc[i] >= min_emit) ? 1u : 0u;
+    if (threadIdx.x == 0) s_lq = 0;
+    __syncthreads();
+    const uint32_t at = mine ? atomicAdd(&s_lq, mine) : 0u;
+    __syncthreads();
+    if (threadIdx.x == 0) { const uint32_t tot = s_lq; s_first = 0; if (tot) { const unsigned long long o = atomicAdd(out_cursor, (unsigned long long)tot); lq[0] = (uint32_t)o; lq[1] = (uint32_t)(o >> 32); } }
+    __syncthreads();
+    if (mine) {
+        unsigned long long o = ((unsigned long long)lq[1] << 32 | lq[0]) + at;
+        for (int i = threadIdx.x; i < HT_SIZE; i += blockDim.x) {
+            const uint32_t b = hk[i];
+            if (b != HT_EMPTY && hc[i] >= min_emit) { if (o < out_cap) { out[o].a = a; out[o].b = b; out[o].shared = hc[i]; } ++o; }
         }
     }
 }
@@ -2383,7 +2417,7 @@ static void kmer_shared_pass(vg_genomes* g, int k, double fraction, int shard, i
             if (n_small) {
                 if (n_large) hipLaunchKernelGGL(k_spgemm<11>, dim3((n_large + 7) / 8 * 8), dim3(256), 0, s, rowinfo.p, gen.p, (uint64_t)gen.n, g->d_base_off.p, g->d_len.p, wbase, n,
                                                 min_shared, (const uint32_t*)d_large.p, n_large, d_out.p, d_cursor.p, cap, d_over.p, d_nover.p);
-                hipLaunchKernelGGL(k_spgemm<9>, dim3((n_small + 7) / 8 * 8), dim3(64), 0, s, rowinfo.p, gen.p, (uint64_t)gen.n, g->d_base_off.p, g->d_len.p, wbase, n,
+                hipLaunchKernelGGL((k_spgemm<9, true>), dim3((n_small + 7) / 8 * 8), dim3(64), 0, s, rowinfo.p, gen.p, (uint64_t)gen.n, g->d_base_off.p, g->d_len.p, wbase, n,
                                    min_shared, (const uint32_t*)d_small.p, n_small, d_out.p, d_cursor.p, cap, d_over.p, d_nover.p);
             } else
             hipLaunchKernelGGL(k_spgemm<11>, dim3((n + 7) / 8 * 8), dim3(256), 0, s, rowinfo.p, gen.p, (uint64_t)gen.n, g->d_base_off.p, g->d_len.p, wbase, n,
@@ -2446,14 +2480,6 @@ namespace {
 __global__ void k_pair_keys(const vg_pair_count* __restrict__ rec, int64_t n, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const vg_pair_count r = rec[i]; keys[i] = ((uint64_t)r.a << 32) | r.b; vals[i] = r.shared;
-    }
-}
-__global__ void k_pair_emit(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ sums, int64_t n, uint32_t min_shared,
-                            vg_pair_count* __restrict__ out, unsigned long long* __restrict__ cursor) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        if (sums[i] < min_shared) continue;
-        const unsigned long long o = atomicAdd(cursor, 1ULL);
-        out[o].a = (uint32_t)(keys[i] >> 32); out[o].b = (uint32_t)keys[i]; out[o].shared = sums[i];
     }
 }
 }
