@@ -227,6 +227,8 @@ def main():
         sizes, pairs = D.prefilter_counts(gs, comm, args.k, 1.0, min_shared=min_kmers)
         cand = gs.filter_pairs(sizes, pairs, k=args.k, min_kmers=min_kmers, min_ident=args.min_ident)
         # -- align: canonical task list, reference-range share per rank, rows gathered over RCCL
+        if world == 1:
+            gs.lz_prepare(cand)            # the reference indexes are built on the device while the host assembles the task list
         tasks = gs.align_tasks(cand)
         stats, _ = D.align_rows(gs, tasks, comm, None, False)
         state.update(n_pairs=len(tasks) // 2, stats=stats, tasks=tasks)

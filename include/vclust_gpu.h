@@ -135,6 +135,12 @@ typedef struct {            /* one local alignment, 0-based inclusive; r* in fwd
 int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks, const vg_lz_params* p,
                 vg_pair_stat* stats, vg_region** regions, int64_t* n_regions);
 
+/* Optional head start of vg_lz_align (no reference call site: lz-ani is one process): the indexes of the genomes named
+ * by the candidate pairs are planned and the first batch is queued on the device at once, so that they are built while
+ * the caller assembles the task list (vg_align_tasks).  vg_lz_align takes them over when its tasks name exactly these
+ * references under the same parameters; otherwise they are dropped.  Results never depend on it. */
+int vg_lz_prepare(vg_genomes* g, const vg_pair_count* pairs, int64_t n_pairs, const vg_lz_params* p);
+
 /* L1: stable sort by length, descending.  order[rank] = input index. */
 int vg_align_order(const vg_genomes* g, int32_t* order /* n */);
 /* L2: candidate pairs (input-order ids, a > b) from a Kmer-db filter file with value >= thr,

@@ -277,3 +277,32 @@ def test_allocator_cycles_1_to_64_gib(mode):
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert p.returncode == 0 and p.stdout.strip().endswith('ok'), p.stderr[-3000:]
     assert (' vmm of ' in p.stderr) == (mode == 'vmm')
+
+
+def test_prepared_indexes_do_not_change_the_rows():
+    """vg_lz_prepare queues the reference indexes of the candidate pairs ahead of vg_lz_align: taken over when the task
+    list names the same references (ONE index build in the profile), dropped otherwise; rows identical in every case,
+    and a plan may be pending when the set is freed."""
+    codes, offsets, names = synth.make_families(30, 6, length=20000, seed=17)
+    gs = api.GenomeSet.from_codes(codes, offsets, names)
+    pairs = synth.family_pairs(30, 6)
+    tasks = gs.align_tasks(pairs)
+    ref = gs.lz_align(tasks)
+    api.profile_enable(True); api.profile_reset()
+    gs.lz_prepare(pairs)
+    got = gs.lz_align(tasks)
+    builds = {e['name']: e['launches'] for e in api.profile_get()}.get('lz_build_index')
+    api.profile_enable(False)
+    assert np.array_equal(got, ref) and builds == 1
+    gs.lz_prepare(pairs[:10])                                   # other references: the plan is dropped
+    assert np.array_equal(gs.lz_align(tasks), ref)
+    gs.lz_prepare(pairs)
+    sub = gs.align_tasks(pairs[5:40])
+    want = {(int(t['q']), int(t['r'])): tuple(int(x) for x in s) for t, s in zip(tasks, ref)}
+    assert all(want[(int(t['q']), int(t['r']))] == tuple(int(x) for x in s) for t, s in zip(sub, gs.lz_align(sub)))
+    gs.lz_prepare(pairs, lz=dict(mal=12))                        # other parameters: dropped
+    assert np.array_equal(gs.lz_align(tasks), ref)
+    gs.lz_prepare(pairs)
+    del gs                                                      # a pending plan goes with its set
+    gs2 = api.GenomeSet.from_codes(codes, offsets, names)
+    assert np.array_equal(gs2.lz_align(tasks), ref)

@@ -93,6 +93,7 @@ SYMBOLS = {
     'vg_align_order': (C.c_int, [C.c_void_p, P(C.c_int32)]),
     'vg_read_filter': (C.c_int, [C.c_void_p, C.c_char_p, C.c_double, P(P(PairCount)), P(C.c_int64)]),
     'vg_align_tasks': (C.c_int, [C.c_void_p, P(PairCount), C.c_int64, P(P(Task)), P(C.c_int64)]),
+    'vg_lz_prepare': (C.c_int, [C.c_void_p, P(PairCount), C.c_int64, P(LzParams)]),
     'vg_set_index_budget': (None, [C.c_int64]),
     'vg_set_subshards': (None, [C.c_int]),
     'vg_write_ani': (C.c_int, [C.c_void_p, P(Task), P(PairStat), C.c_int64, P(Region), C.c_int64,

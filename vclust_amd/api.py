@@ -184,6 +184,13 @@ class GenomeSet:
                                        C.byref(tp), C.byref(n)))
         return _take(tp, n.value, TASK_DTYPE)
 
+    def lz_prepare(self, pairs, lz=None):
+        """Optional head start of lz_align: the indexes of the pairs' genomes are queued on the device now (they are built
+        while align_tasks runs on the host); lz_align takes them over when its tasks name the same references."""
+        pairs = np.ascontiguousarray(pairs, dtype=PAIR_DTYPE)
+        prm = LzParams(**{**DEFAULT_LZ, **(lz or {})})
+        check(self._lib.vg_lz_prepare(self._h, pairs.ctypes.data_as(C.POINTER(PairCount)), len(pairs), C.byref(prm)))
+
     def lz_align(self, tasks, lz=None, want_regions=False):
         """LZ parse of the ordered pairs -> stats (and regions)."""
         tasks = np.ascontiguousarray(tasks, dtype=TASK_DTYPE)

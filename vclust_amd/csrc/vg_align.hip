@@ -24,6 +24,8 @@
 #include <algorithm>
 #include <numeric>
 #include <cstring>
+#include <memory>
+#include <mutex>
 
 namespace {
 
@@ -1386,6 +1388,41 @@ k_task_records(const vg_task* __restrict__ tasks, const uint32_t* __restrict__ s
 }
 }  // namespace
 
+// ---- reference plan of a vg_lz_align call: which references are indexed in which batch, their descriptors, the lists
+// of the build kernels and one set of index pools sized for the largest batch.  It depends on the REFERENCES of the task
+// list only (not on the tasks), so vg_lz_prepare can make it -- and build the first batch's indexes -- from the candidate
+// pairs alone, while the caller still assembles the canonical task list on the host.
+namespace {
+struct lz_batch {
+    int64_t pos = 0, end = 0;            // sorted task range
+    int first_ref = 0, n_refs = 0;       // reference ordinals [first_ref, first_ref + n_refs)
+    std::vector<int64_t> chunk_off{ 0 };
+    std::vector<int> reg_list, mid_list, small_list, large_list; std::vector<int64_t> large_chunks{ 0 };
+    int64_t rr_words = 0, mask_words = 0, stab_tot = 0, sent_n = 0, scratch_words = 0, stride = 0;
+    int nblk_build = 0;
+    double bytes_alg = 0; int64_t q_max = 0, q_sum = 0;          // SURVEY 8(d) bytes of the batch; longest / total query
+};
+struct lz_slot { dbuf<uint32_t> rr_pool, mask_pool, stab_pool, sent_pool, scratch; dbuf<int> d_reg, d_mid, d_small, d_large; dbuf<int64_t> d_lchunk; };
+struct lz_plan {
+    std::vector<uint32_t> ref_ids;            // references that have tasks, ascending
+    std::vector<lz_batch> batches;
+    std::vector<ref_desc> all_refs;           // indexed by the reference ordinal the task records carry
+    dbuf<ref_desc> d_refs;
+    lz_slot slot;
+    int64_t budget = 0; int mal = 0, msl = 0; const vg_genomes* g = nullptr;
+    bool batch0_built = false;
+};
+int64_t lz_batch_budget(const vg_genomes* g, const vg_lz_params* p, const std::vector<uint32_t>& ref_ids);
+void lz_plan_references(const vg_genomes* g, const vg_lz_params* p, lz_plan& P);
+void lz_build_batch(const vg_genomes* g, const vg_lz_params* p, lz_plan& P, size_t bi, hipStream_t sb);
+std::mutex g_prep_mu;
+std::unique_ptr<lz_plan> g_prepared;          // left by vg_lz_prepare for the next vg_lz_align
+}
+void vg_lz_drop_prepared(const vg_genomes* g) {
+    std::lock_guard<std::mutex> lk(g_prep_mu);
+    if (g_prepared && (!g || g_prepared->g == g)) { (void)hipStreamSynchronize(vg_stream()); g_prepared.reset(); }
+}
+
 static int64_t g_segment_task_limit = 32768;
 // VG_LZ_BUILD=lds: the scratch-based LDS build also for short references (tests compare the two)
 static const bool g_no_reg_build = [] { const char* e = getenv("VG_LZ_BUILD"); return e && strcmp(e, "lds") == 0; }();
@@ -1458,7 +1495,6 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
     // R3's weak-seed ratio (a single-event fit): 3 unless VG_LZ_WEAK_SEED says otherwise (0 = off)
     static const int weak_ratio = [] { const char* e = getenv("VG_LZ_WEAK_SEED"); const int v = e && *e ? atoi(e) : 3; return std::max(0, std::min(v, 1000)); }();
     const lz_dev_params P{ p->mal, p->msl, p->mrd, p->mqd, p->reg, p->aw, p->am, p->ar, abl ? atoi(abl) : 0, pw_after, pw_miss, weak_ratio };
-    const int64_t stab_n = 1LL << (2 * p->msl);
     // default parameters on a set without N: the kernel with those as compile-time constants (VG_LZ_KERNEL=general: never)
     static const bool no_fast = [] { const char* e = getenv("VG_LZ_KERNEL"); return e && !strcmp(e, "general"); }();
     bool fast_params = !no_fast && !abl && weak_ratio == 3 && p->mal == 11 && p->msl == 7 && p->mrd == 40 && p->mqd == 40 && p->reg == 35 && p->aw == 15 && p->am == 7 && p->ar == 3;
@@ -1474,156 +1510,40 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
     // (Building batch b + 1 on a second stream while batch b is parsed was measured: the 160 KiB-LDS build
     // workgroups and the parse waves only split the CUs between them, 321 vs 319 ms at 100 k genomes -- so
     // the batches run back to back on the library stream, as few and as large as the budget allows.)
-    struct lz_batch {
-        int64_t pos = 0, end = 0;            // sorted task range
-        int first_ref = 0, n_refs = 0;       // reference ordinals [first_ref, first_ref + n_refs)
-        std::vector<int64_t> chunk_off{ 0 };
-        std::vector<int> reg_list, mid_list, small_list, large_list; std::vector<int64_t> large_chunks{ 0 };
-        int64_t rr_words = 0, mask_words = 0, stab_tot = 0, sent_n = 0, scratch_words = 0, stride = 0;
-        int nblk_build = 0;
-        double bytes_alg = 0; int64_t q_max = 0, q_sum = 0;          // SURVEY 8(d) bytes of the batch; longest / total query
-    };
-    auto ref_need = [&](uint32_t r, int64_t* chunks_out) {
-        const int64_t n_rr = 2 * g->len[r] + 1;
-        const int64_t chunks = (n_rr + RR_PAD + 31) / 32 + 2;
-        if (chunks_out) *chunks_out = chunks;
-        return chunks * 12 + (stab_n + n_rr) * 4;
-    };
-    // default budget 24 GiB; a set whose indexes all fit in twice that is built in ONE batch (every batch boundary is a
-    // tail of the parse launch with idle CUs: 100 k genomes, 40 GB of indexes, 43.5 vs 44.3 ms of parse)
-    int64_t batch_budget = g_index_budget_bytes;
-    if (!g_index_budget_set && vg_one_shot()) {
-        // a cold one-shot call (the CLI): one small set of index pools reused by every batch -- 6 GiB of device memory to
-        // touch for the first time instead of 40 (vg_core.cpp), for a few batch boundaries (1-3 ms each)
-        static const double gb = [] { const char* e = getenv("VG_ONESHOT_INDEX_GB"); const double v = e ? atof(e) : 0.0; return v >= 0.0625 ? v : 6.0; }();
-        batch_budget = (int64_t)(gb * 1073741824.0);
-    } else if (!g_index_budget_set) {
-        int64_t all = 0;
-        for (size_t ri = 0; ri < ref_ids.size() && all <= 2 * batch_budget; ++ri) all += ref_need(ref_ids[ri], nullptr);
-        if (all <= 2 * batch_budget) batch_budget = std::max(batch_budget, all);
-    }
-    std::vector<lz_batch> batches;
-    std::vector<ref_desc> all_refs(ref_ids.size());           // indexed by the reference ordinal the task records carry
-    for (size_t ri = 0; ri < ref_ids.size();) {
-        batches.emplace_back();
-        lz_batch& B = batches.back();
-        B.first_ref = (int)ri;
-        B.pos = ref_first[ref_ids[ri]];
-        int64_t bytes = 0;
-        while (ri < ref_ids.size()) {
-            const uint32_t r = ref_ids[ri];
-            const int64_t L = g->len[r]; const int64_t n_rr = 2 * L + 1;
-            int64_t chunks = 0; const int64_t need = ref_need(r, &chunks);
-            if (B.n_refs > 0 && bytes + need > batch_budget) break;
-            ref_desc rd; memset(&rd, 0, sizeof rd);
-            rd.rr_w = B.rr_words; rd.mask_w = B.mask_words; rd.stab = B.stab_tot; rd.sent = B.sent_n;
-            rd.L = (int32_t)L; rd.n_rr = (int32_t)n_rr; rd.genome = (int32_t)r; rd.has_n = g->has_n[r];
-            { int pb = 1; while ((1LL << pb) < n_rr) ++pb; rd.pos_bits = pb; }
-            rd.tag_bits = std::max(0, std::min({ 2 * (p->mal - p->msl), 14, 32 - rd.pos_bits }));
-            all_refs[ri] = rd;
-            B.rr_words += chunks * 2; B.mask_words += chunks; B.stab_tot += stab_n; B.sent_n += n_rr;
-            B.chunk_off.push_back(B.chunk_off.back() + chunks);
-            bytes += need; ++B.n_refs; ++ri;
+    // A plan left by vg_lz_prepare for exactly these references (same set, same parameters, same budget) is taken over
+    // with its first batch already built (or being built: same stream).
+    std::unique_ptr<lz_plan> plan;
+    {
+        std::lock_guard<std::mutex> lk(g_prep_mu);
+        if (g_prepared) {
+            lz_plan& Q = *g_prepared;
+            if (Q.g == g && Q.mal == p->mal && Q.msl == p->msl && Q.ref_ids == ref_ids && Q.budget == lz_batch_budget(g, p, ref_ids)) plan = std::move(g_prepared);
+            else g_prepared.reset();                             // (its pools go back to the allocator: one stream, in order)
         }
-        B.end = ri < ref_ids.size() ? ref_first[ref_ids[ri]] : n_tasks;
+    }
+    if (!plan) {
+        plan.reset(new lz_plan);
+        plan->g = g; plan->ref_ids = ref_ids;
+        lz_plan_references(g, p, *plan);
+    }
+    std::vector<lz_batch>& batches = plan->batches;
+    dbuf<ref_desc>& d_refs = plan->d_refs;
+    lz_slot& slot = plan->slot;
+    // the task ranges of the batches (sorted task list: tasks of a reference are contiguous)
+    for (auto& B : batches) {
+        B.pos = ref_first[ref_ids[(size_t)B.first_ref]];
+        const size_t ri_end = (size_t)B.first_ref + (size_t)B.n_refs;
+        B.end = ri_end < ref_ids.size() ? ref_first[ref_ids[ri_end]] : n_tasks;
         B.bytes_alg = bytes_alg_all * (double)(B.end - B.pos) / (double)n_tasks;       // the call's SURVEY 8(d) bytes, by task share
         B.q_max = q_max; B.q_sum = (int64_t)(q_sum * (double)(B.end - B.pos) / (double)n_tasks);
-        const int n_refs = B.n_refs;
-        // split the batch: LDS counting sort for ordinary references, global path for the rest
-        for (int i = 0; i < n_refs; ++i) {
-            const int gi = B.first_ref + i;                      // ordinal = index into all_refs / the device array
-            const bool small = all_refs[(size_t)gi].n_rr <= (1 << 21) && p->msl <= 7;
-            if (small && all_refs[(size_t)gi].n_rr <= REG_MAX_RR && !g_no_reg_build) B.reg_list.push_back(gi);
-            else if (small && all_refs[(size_t)gi].n_rr <= MID_MAX_RR && !g_no_reg_build) B.mid_list.push_back(gi);
-            else if (small) B.small_list.push_back(gi);
-            else { B.large_list.push_back(gi); B.large_chunks.push_back(B.large_chunks.back() + (B.chunk_off[(size_t)i + 1] - B.chunk_off[(size_t)i])); }
-        }
-        // longest references first: the persistent workgroups take them round-robin, so their loads even out
-        // (nothing to even out when the lengths are within 25 % of each other)
-        auto longest_first = [&](std::vector<int>& list) {
-            int32_t mn = INT32_MAX, mx = 0;
-            for (int i : list) { mn = std::min(mn, all_refs[(size_t)i].n_rr); mx = std::max(mx, all_refs[(size_t)i].n_rr); }
-            if (!list.empty() && (int64_t)mx * 4 > (int64_t)mn * 5 && (int64_t)(mx - mn) <= 8 * (int64_t)list.size() + 65536) {
-                // a stable counting sort on the length, descending (10^6 references: a comparison sort costs 40 ms)
-                std::vector<int64_t> at((size_t)(mx - mn) + 2, 0);
-                for (int i : list) at[(size_t)(mx - all_refs[(size_t)i].n_rr) + 1]++;
-                for (size_t b = 1; b < at.size(); ++b) at[b] += at[b - 1];
-                std::vector<int> sorted(list.size());
-                for (int i : list) sorted[(size_t)at[(size_t)(mx - all_refs[(size_t)i].n_rr)]++] = i;
-                list.swap(sorted);
-            } else if (!list.empty() && (int64_t)mx * 4 > (int64_t)mn * 5) {
-                std::vector<uint64_t> keyed(list.size());
-                for (size_t i = 0; i < keyed.size(); ++i) keyed[i] = ((uint64_t)(0x7fffffffu - (uint32_t)all_refs[(size_t)list[i]].n_rr) << 32) | (uint32_t)list[i];
-                std::sort(keyed.begin(), keyed.end());           // length descending, ordinal ascending (= the stable order)
-                for (size_t i = 0; i < keyed.size(); ++i) list[i] = (int)(uint32_t)keyed[i];
-            }
-        };
-        longest_first(B.reg_list); longest_first(B.mid_list); longest_first(B.small_list);
-        if (!B.small_list.empty()) {
-            int64_t max_rr = 0; for (int i : B.small_list) max_rr = std::max<int64_t>(max_rr, all_refs[(size_t)i].n_rr);
-            B.nblk_build = (int)std::min<size_t>(B.small_list.size(), 512);
-            B.stride = (max_rr + 63) / 64 * 64;
-            B.scratch_words = (int64_t)B.nblk_build * B.stride * 3;
-        }
     }
     vg_host_mark("lz: batches planned");
-    // ---- the task records and reference descriptors of the whole call go up once; one set of index buffers,
-    // sized for the largest batch, is reused by every batch
-    dbuf<ref_desc> d_refs(std::max<size_t>(1, all_refs.size()));
-    if (!all_refs.empty()) d_refs.upload(all_refs.data(), all_refs.size(), s);
-    struct lz_slot { dbuf<uint32_t> rr_pool, mask_pool, stab_pool, sent_pool, scratch; dbuf<int> d_reg, d_mid, d_small, d_large; dbuf<int64_t> d_lchunk; };
-    lz_slot slot;
-    {
-        size_t m_rr = 0, m_mask = 0, m_stab = 1, m_sent = 0, m_scr = 1, m_reg = 1, m_mid = 1, m_small = 1, m_large = 1, m_lch = 1;
-        for (auto& B : batches) {
-            m_rr = std::max(m_rr, (size_t)B.rr_words); m_mask = std::max(m_mask, (size_t)B.mask_words);
-            m_stab = std::max(m_stab, (size_t)B.stab_tot); m_sent = std::max(m_sent, (size_t)B.sent_n); m_scr = std::max(m_scr, (size_t)B.scratch_words);
-            m_reg = std::max(m_reg, B.reg_list.size()); m_mid = std::max(m_mid, B.mid_list.size()); m_small = std::max(m_small, B.small_list.size()); m_large = std::max(m_large, B.large_list.size());
-            m_lch = std::max(m_lch, B.large_chunks.size());
-        }
-        lz_slot& L = slot;
-        L.rr_pool.alloc(m_rr + 8); L.mask_pool.alloc(m_mask + 8); L.stab_pool.alloc(m_stab); L.sent_pool.alloc(m_sent + 4);
-        L.scratch.alloc(m_scr); L.d_reg.alloc(m_reg); L.d_mid.alloc(m_mid); L.d_small.alloc(m_small); L.d_large.alloc(m_large); L.d_lchunk.alloc(m_lch);
-    }
     hipStream_t sb = s;
     static const char* seg_env = getenv("VG_LZ_SEGMENTS");
     for (size_t bi = 0; bi < batches.size(); ++bi) {
         lz_batch& B = batches[bi];
         lz_slot& L = slot;
-        if (!B.reg_list.empty()) L.d_reg.upload(B.reg_list.data(), B.reg_list.size(), sb);
-        if (!B.mid_list.empty()) L.d_mid.upload(B.mid_list.data(), B.mid_list.size(), sb);
-        if (!B.small_list.empty()) L.d_small.upload(B.small_list.data(), B.small_list.size(), sb);
-        if (!B.large_list.empty()) { L.d_large.upload(B.large_list.data(), B.large_list.size(), sb); L.d_lchunk.upload(B.large_chunks.data(), B.large_chunks.size(), sb); }
-        const int64_t total_chunks = B.chunk_off.back();
-        {
-            vg_prof_scope ps("lz_build_index", (double)total_chunks * 32 * (0.375 + 0.375 + 4));
-            if (!B.large_list.empty()) VG_HIP(hipMemsetAsync(L.stab_pool.p, 0, (size_t)B.stab_tot * sizeof(uint32_t), sb));
-            if (!B.reg_list.empty()) {
-                hipLaunchKernelGGL(k_build_index_reg, dim3((unsigned)std::min<size_t>(B.reg_list.size(), 512)), dim3(1024), 0, sb, d_refs.p, L.d_reg.p,
-                                   (int)B.reg_list.size(), g->d_packed.p, g->d_nmask.p, g->d_base_off.p, L.rr_pool.p, L.mask_pool.p, p->msl,
-                                   L.stab_pool.p, L.sent_pool.p);
-            }
-            if (!B.mid_list.empty()) {
-                hipLaunchKernelGGL(k_build_index_mid, dim3((unsigned)std::min<size_t>(B.mid_list.size(), 512)), dim3(1024), 0, sb, d_refs.p, L.d_mid.p,
-                                   (int)B.mid_list.size(), g->d_packed.p, g->d_nmask.p, g->d_base_off.p, L.rr_pool.p, L.mask_pool.p, p->msl,
-                                   L.stab_pool.p, L.sent_pool.p);
-            }
-            if (!B.small_list.empty()) {
-                hipLaunchKernelGGL(k_build_index_lds, dim3(B.nblk_build), dim3(1024), 0, sb, d_refs.p, L.d_small.p, (int)B.small_list.size(),
-                                   g->d_packed.p, g->d_nmask.p, g->d_base_off.p, L.rr_pool.p, L.mask_pool.p, p->mal, p->msl,
-                                   L.stab_pool.p, L.sent_pool.p, L.scratch.p, B.stride);
-            }
-            if (!B.large_list.empty()) {
-                const int nl = (int)B.large_list.size(); const int64_t lc = B.large_chunks.back();
-                hipLaunchKernelGGL(k_build_rr, dim3(grid_for(lc)), dim3(256), 0, sb, d_refs.p, L.d_large.p, nl, L.d_lchunk.p, g->d_packed.p,
-                                   g->d_nmask.p, g->d_base_off.p, L.rr_pool.p, L.mask_pool.p);
-                hipLaunchKernelGGL(k_index_pass, dim3(grid_for(lc * 32)), dim3(256), 0, sb, d_refs.p, L.d_large.p, nl, L.d_lchunk.p, L.rr_pool.p,
-                                   L.mask_pool.p, p->mal, p->msl, 0, L.stab_pool.p, L.sent_pool.p);
-                hipLaunchKernelGGL(k_scan_tables, dim3(nl), dim3(256), 0, sb, d_refs.p, L.d_large.p, p->msl, L.stab_pool.p);
-                hipLaunchKernelGGL(k_index_pass, dim3(grid_for(lc * 32)), dim3(256), 0, sb, d_refs.p, L.d_large.p, nl, L.d_lchunk.p, L.rr_pool.p,
-                                   L.mask_pool.p, p->mal, p->msl, 1, L.stab_pool.p, L.sent_pool.p);
-            }
-        }
+        if (!(bi == 0 && plan->batch0_built)) lz_build_batch(g, p, *plan, bi, sb);
         {
             const int64_t nt = B.end - B.pos;
             vg_prof_scope ps("lz_parse", B.bytes_alg);
@@ -1709,6 +1629,186 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
         if (!h_regions.empty()) memcpy(o, h_regions.data(), sizeof(vg_region) * h_regions.size());
         *regions = o; if (n_regions) *n_regions = (int64_t)h_regions.size();
     }
+    VG_API_END
+}
+
+
+// ------------------------------------------------------------------ reference plan (see lz_plan)
+namespace {
+int64_t lz_ref_need(const vg_genomes* g, const vg_lz_params* p, uint32_t r, int64_t* chunks_out) {
+    const int64_t stab_n = 1LL << (2 * p->msl);
+    const int64_t n_rr = 2 * g->len[r] + 1;
+    const int64_t chunks = (n_rr + RR_PAD + 31) / 32 + 2;
+    if (chunks_out) *chunks_out = chunks;
+    return chunks * 12 + (stab_n + n_rr) * 4;
+}
+// default budget 24 GiB; a set whose indexes all fit in twice that is built in ONE batch (every batch boundary is a
+// tail of the parse launch with idle CUs: 100 k genomes, 40 GB of indexes, 43.5 vs 44.3 ms of parse)
+int64_t lz_batch_budget(const vg_genomes* g, const vg_lz_params* p, const std::vector<uint32_t>& ref_ids) {
+    int64_t batch_budget = g_index_budget_bytes;
+    if (!g_index_budget_set && vg_one_shot()) {
+        // a cold one-shot call (the CLI): one small set of index pools reused by every batch -- 6 GiB of device memory to
+        // touch for the first time instead of 40 (vg_core.cpp), for a few batch boundaries (1-3 ms each)
+        static const double gb = [] { const char* e = getenv("VG_ONESHOT_INDEX_GB"); const double v = e ? atof(e) : 0.0; return v >= 0.0625 ? v : 6.0; }();
+        batch_budget = (int64_t)(gb * 1073741824.0);
+    } else if (!g_index_budget_set) {
+        int64_t all = 0;
+        for (size_t ri = 0; ri < ref_ids.size() && all <= 2 * batch_budget; ++ri) all += lz_ref_need(g, p, ref_ids[ri], nullptr);
+        if (all <= 2 * batch_budget) batch_budget = std::max(batch_budget, all);
+    }
+    return batch_budget;
+}
+// batches, descriptors, build lists, pools and the descriptor upload for P.ref_ids
+void lz_plan_references(const vg_genomes* g, const vg_lz_params* p, lz_plan& P) {
+    hipStream_t s = vg_stream();
+    const std::vector<uint32_t>& ref_ids = P.ref_ids;
+    const int64_t stab_n = 1LL << (2 * p->msl);
+    P.mal = p->mal; P.msl = p->msl; P.g = g;
+    const int64_t batch_budget = P.budget = lz_batch_budget(g, p, ref_ids);
+    std::vector<lz_batch>& batches = P.batches;
+    std::vector<ref_desc>& all_refs = P.all_refs;
+    all_refs.assign(ref_ids.size(), ref_desc{});
+    for (size_t ri = 0; ri < ref_ids.size();) {
+        batches.emplace_back();
+        lz_batch& B = batches.back();
+        B.first_ref = (int)ri;
+        int64_t bytes = 0;
+        while (ri < ref_ids.size()) {
+            const uint32_t r = ref_ids[ri];
+            const int64_t L = g->len[r]; const int64_t n_rr = 2 * L + 1;
+            int64_t chunks = 0; const int64_t need = lz_ref_need(g, p, r, &chunks);
+            if (B.n_refs > 0 && bytes + need > batch_budget) break;
+            ref_desc rd; memset(&rd, 0, sizeof rd);
+            rd.rr_w = B.rr_words; rd.mask_w = B.mask_words; rd.stab = B.stab_tot; rd.sent = B.sent_n;
+            rd.L = (int32_t)L; rd.n_rr = (int32_t)n_rr; rd.genome = (int32_t)r; rd.has_n = g->has_n[r];
+            { int pb = 1; while ((1LL << pb) < n_rr) ++pb; rd.pos_bits = pb; }
+            rd.tag_bits = std::max(0, std::min({ 2 * (p->mal - p->msl), 14, 32 - rd.pos_bits }));
+            all_refs[ri] = rd;
+            B.rr_words += chunks * 2; B.mask_words += chunks; B.stab_tot += stab_n; B.sent_n += n_rr;
+            B.chunk_off.push_back(B.chunk_off.back() + chunks);
+            bytes += need; ++B.n_refs; ++ri;
+        }
+        const int n_refs = B.n_refs;
+        // split the batch: LDS counting sort for ordinary references, global path for the rest
+        for (int i = 0; i < n_refs; ++i) {
+            const int gi = B.first_ref + i;                      // ordinal = index into all_refs / the device array
+            const bool small = all_refs[(size_t)gi].n_rr <= (1 << 21) && p->msl <= 7;
+            if (small && all_refs[(size_t)gi].n_rr <= REG_MAX_RR && !g_no_reg_build) B.reg_list.push_back(gi);
+            else if (small && all_refs[(size_t)gi].n_rr <= MID_MAX_RR && !g_no_reg_build) B.mid_list.push_back(gi);
+            else if (small) B.small_list.push_back(gi);
+            else { B.large_list.push_back(gi); B.large_chunks.push_back(B.large_chunks.back() + (B.chunk_off[(size_t)i + 1] - B.chunk_off[(size_t)i])); }
+        }
+        // longest references first: the persistent workgroups take them round-robin, so their loads even out
+        // (nothing to even out when the lengths are within 25 % of each other)
+        auto longest_first = [&](std::vector<int>& list) {
+            int32_t mn = INT32_MAX, mx = 0;
+            for (int i : list) { mn = std::min(mn, all_refs[(size_t)i].n_rr); mx = std::max(mx, all_refs[(size_t)i].n_rr); }
+            if (!list.empty() && (int64_t)mx * 4 > (int64_t)mn * 5 && (int64_t)(mx - mn) <= 8 * (int64_t)list.size() + 65536) {
+                // a stable counting sort on the length, descending (10^6 references: a comparison sort costs 40 ms)
+                std::vector<int64_t> at((size_t)(mx - mn) + 2, 0);
+                for (int i : list) at[(size_t)(mx - all_refs[(size_t)i].n_rr) + 1]++;
+                for (size_t b = 1; b < at.size(); ++b) at[b] += at[b - 1];
+                std::vector<int> sorted(list.size());
+                for (int i : list) sorted[(size_t)at[(size_t)(mx - all_refs[(size_t)i].n_rr)]++] = i;
+                list.swap(sorted);
+            } else if (!list.empty() && (int64_t)mx * 4 > (int64_t)mn * 5) {
+                std::vector<uint64_t> keyed(list.size());
+                for (size_t i = 0; i < keyed.size(); ++i) keyed[i] = ((uint64_t)(0x7fffffffu - (uint32_t)all_refs[(size_t)list[i]].n_rr) << 32) | (uint32_t)list[i];
+                std::sort(keyed.begin(), keyed.end());           // length descending, ordinal ascending (= the stable order)
+                for (size_t i = 0; i < keyed.size(); ++i) list[i] = (int)(uint32_t)keyed[i];
+            }
+        };
+        longest_first(B.reg_list); longest_first(B.mid_list); longest_first(B.small_list);
+        if (!B.small_list.empty()) {
+            int64_t max_rr = 0; for (int i : B.small_list) max_rr = std::max<int64_t>(max_rr, all_refs[(size_t)i].n_rr);
+            B.nblk_build = (int)std::min<size_t>(B.small_list.size(), 512);
+            B.stride = (max_rr + 63) / 64 * 64;
+            B.scratch_words = (int64_t)B.nblk_build * B.stride * 3;
+        }
+    }
+    // ---- the reference descriptors of the whole call go up once; one set of index buffers, sized for the largest
+    // batch, is reused by every batch
+    P.d_refs.alloc(std::max<size_t>(1, all_refs.size()));
+    if (!all_refs.empty()) P.d_refs.upload(all_refs.data(), all_refs.size(), s);
+    size_t m_rr = 0, m_mask = 0, m_stab = 1, m_sent = 0, m_scr = 1, m_reg = 1, m_mid = 1, m_small = 1, m_large = 1, m_lch = 1;
+    for (auto& B : batches) {
+        m_rr = std::max(m_rr, (size_t)B.rr_words); m_mask = std::max(m_mask, (size_t)B.mask_words);
+        m_stab = std::max(m_stab, (size_t)B.stab_tot); m_sent = std::max(m_sent, (size_t)B.sent_n); m_scr = std::max(m_scr, (size_t)B.scratch_words);
+        m_reg = std::max(m_reg, B.reg_list.size()); m_mid = std::max(m_mid, B.mid_list.size()); m_small = std::max(m_small, B.small_list.size()); m_large = std::max(m_large, B.large_list.size());
+        m_lch = std::max(m_lch, B.large_chunks.size());
+    }
+    lz_slot& L = P.slot;
+    L.rr_pool.alloc(m_rr + 8); L.mask_pool.alloc(m_mask + 8); L.stab_pool.alloc(m_stab); L.sent_pool.alloc(m_sent + 4);
+    L.scratch.alloc(m_scr); L.d_reg.alloc(m_reg); L.d_mid.alloc(m_mid); L.d_small.alloc(m_small); L.d_large.alloc(m_large); L.d_lchunk.alloc(m_lch);
+}
+// RR, bucket tables and entries of the references of batch bi into the plan's pools (asynchronous on sb)
+void lz_build_batch(const vg_genomes* g, const vg_lz_params* p, lz_plan& P, size_t bi, hipStream_t sb) {
+    lz_batch& B = P.batches[bi];
+    lz_slot& L = P.slot;
+    dbuf<ref_desc>& d_refs = P.d_refs;
+    if (!B.reg_list.empty()) L.d_reg.upload(B.reg_list.data(), B.reg_list.size(), sb);
+    if (!B.mid_list.empty()) L.d_mid.upload(B.mid_list.data(), B.mid_list.size(), sb);
+    if (!B.small_list.empty()) L.d_small.upload(B.small_list.data(), B.small_list.size(), sb);
+    if (!B.large_list.empty()) { L.d_large.upload(B.large_list.data(), B.large_list.size(), sb); L.d_lchunk.upload(B.large_chunks.data(), B.large_chunks.size(), sb); }
+    const int64_t total_chunks = B.chunk_off.back();
+    vg_prof_scope ps("lz_build_index", (double)total_chunks * 32 * (0.375 + 0.375 + 4));
+    if (!B.large_list.empty()) VG_HIP(hipMemsetAsync(L.stab_pool.p, 0, (size_t)B.stab_tot * sizeof(uint32_t), sb));
+    if (!B.reg_list.empty()) {
+        hipLaunchKernelGGL(k_build_index_reg, dim3((unsigned)std::min<size_t>(B.reg_list.size(), 512)), dim3(1024), 0, sb, d_refs.p, L.d_reg.p,
+                           (int)B.reg_list.size(), g->d_packed.p, g->d_nmask.p, g->d_base_off.p, L.rr_pool.p, L.mask_pool.p, p->msl,
+                           L.stab_pool.p, L.sent_pool.p);
+    }
+    if (!B.mid_list.empty()) {
+        hipLaunchKernelGGL(k_build_index_mid, dim3((unsigned)std::min<size_t>(B.mid_list.size(), 512)), dim3(1024), 0, sb, d_refs.p, L.d_mid.p,
+                           (int)B.mid_list.size(), g->d_packed.p, g->d_nmask.p, g->d_base_off.p, L.rr_pool.p, L.mask_pool.p, p->msl,
+                           L.stab_pool.p, L.sent_pool.p);
+    }
+    if (!B.small_list.empty()) {
+        hipLaunchKernelGGL(k_build_index_lds, dim3(B.nblk_build), dim3(1024), 0, sb, d_refs.p, L.d_small.p, (int)B.small_list.size(),
+                           g->d_packed.p, g->d_nmask.p, g->d_base_off.p, L.rr_pool.p, L.mask_pool.p, p->mal, p->msl,
+                           L.stab_pool.p, L.sent_pool.p, L.scratch.p, B.stride);
+    }
+    if (!B.large_list.empty()) {
+        const int nl = (int)B.large_list.size(); const int64_t lc = B.large_chunks.back();
+        hipLaunchKernelGGL(k_build_rr, dim3(grid_for(lc)), dim3(256), 0, sb, d_refs.p, L.d_large.p, nl, L.d_lchunk.p, g->d_packed.p,
+                           g->d_nmask.p, g->d_base_off.p, L.rr_pool.p, L.mask_pool.p);
+        hipLaunchKernelGGL(k_index_pass, dim3(grid_for(lc * 32)), dim3(256), 0, sb, d_refs.p, L.d_large.p, nl, L.d_lchunk.p, L.rr_pool.p,
+                           L.mask_pool.p, p->mal, p->msl, 0, L.stab_pool.p, L.sent_pool.p);
+        hipLaunchKernelGGL(k_scan_tables, dim3(nl), dim3(256), 0, sb, d_refs.p, L.d_large.p, p->msl, L.stab_pool.p);
+        hipLaunchKernelGGL(k_index_pass, dim3(grid_for(lc * 32)), dim3(256), 0, sb, d_refs.p, L.d_large.p, nl, L.d_lchunk.p, L.rr_pool.p,
+                           L.mask_pool.p, p->mal, p->msl, 1, L.stab_pool.p, L.sent_pool.p);
+    }
+}
+}  // namespace
+
+// Optional head start of vg_lz_align: the reference indexes of the genomes named by the candidate pairs (every genome of
+// a pair is a reference of one of its two tasks) are planned and the first batch is queued on the device NOW, so that
+// the build runs while the caller assembles the canonical task list (vg_align_tasks) and vg_lz_align groups it: host
+// work that otherwise leaves the device idle.  vg_lz_align takes the plan over when its task list names exactly these
+// references under the same parameters; otherwise the plan is dropped and nothing is lost but the build.
+extern "C" int vg_lz_prepare(vg_genomes* g, const vg_pair_count* pairs, int64_t n_pairs, const vg_lz_params* p) {
+    VG_API_BEGIN
+    if (!g || (!pairs && n_pairs) || !p) throw vg_error(VG_EINVAL, "vg_lz_prepare: null argument");
+    if (p->mal < 8 || p->mal > 31 || p->msl < 4 || p->msl > 12 || p->msl > p->mal) throw vg_error(VG_EINVAL, "mal must be 8..31, msl 4..12 and <= mal");
+    vg_require_device();
+    int rc = vg_genomes_to_device(g); if (rc) return rc;
+    vg_lz_drop_prepared(nullptr);
+    if (n_pairs == 0) return VG_OK;
+    for (int i = 0; i < g->n; ++i) if (g->len[i] > (1 << 29)) throw vg_error(VG_EOVERFLOW, "genome longer than 2^29 bases");
+    std::vector<uint8_t> is_ref((size_t)g->n, 0);
+    for (int64_t i = 0; i < n_pairs; ++i) {
+        if (pairs[i].a >= (uint32_t)g->n || pairs[i].b >= (uint32_t)g->n) throw vg_error(VG_EINVAL, "pair id out of range");
+        is_ref[pairs[i].a] = 1; is_ref[pairs[i].b] = 1;
+    }
+    std::unique_ptr<lz_plan> plan(new lz_plan);
+    for (int i = 0; i < g->n; ++i) if (is_ref[(size_t)i]) plan->ref_ids.push_back((uint32_t)i);
+    plan->g = g;
+    lz_plan_references(g, p, *plan);
+    lz_build_batch(g, p, *plan, 0, vg_stream());
+    plan->batch0_built = true;
+    vg_host_mark("lz: first batch of indexes queued");
+    std::lock_guard<std::mutex> lk(g_prep_mu);
+    g_prepared = std::move(plan);
     VG_API_END
 }
 

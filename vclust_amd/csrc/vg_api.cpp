@@ -84,6 +84,7 @@ extern "C" int vg_align(const char* const* fasta_paths, int n_paths, const char*
     free_guard pairs, tasks, regions; int64_t np = 0, nt = 0, nr = 0;
     check(vg_read_filter(gg.g, p->filter_path, p->filter_threshold, (vg_pair_count**)&pairs.p, &np));
     vg_host_mark("filter read");
+    check(vg_lz_prepare(gg.g, (const vg_pair_count*)pairs.p, np, &p->lz));          // (the first index batch is built beside the task list)
     check(vg_align_tasks(gg.g, (const vg_pair_count*)pairs.p, np, (vg_task**)&tasks.p, &nt));
     std::vector<vg_pair_stat> stats((size_t)std::max<int64_t>(1, nt));
     const bool want_aln = p->out_aln_path != nullptr;

@@ -121,6 +121,7 @@ struct vg_genomes {
     mutable std::vector<int32_t> len_order, len_rank;
 };
 void vg_length_order(const vg_genomes* g);        // fills g->len_order / g->len_rank on first use
+void vg_lz_drop_prepared(const vg_genomes* g);    // forget the index plan vg_lz_prepare left for g (nullptr: whatever it left)
 
 // vg_genomes_load with the upload to the library's device overlapped with the packing (vg_genomes.cpp; whole-stage calls)
 int vg_genomes_load_resident(const char* const* paths, int n_paths, int multisample, int n_threads, vg_genomes** out);

@@ -41,6 +41,7 @@ extern "C" int vg_set_device(int device) {
     if (n <= 0) throw vg_error(VG_ENODEV, "no HIP device visible: libvclust_gpu has no CPU fallback");
     if (device < 0 || device >= n) throw vg_error(VG_EINVAL, "device index out of range");
     if (g_device >= 0 && device != g_device) {
+        vg_lz_drop_prepared(nullptr);
         // cached blocks belong to the device they were allocated on: give them back before switching
         // (genome sets re-upload themselves on their next use, vg_genomes_to_device)
         vg_dev_trim();

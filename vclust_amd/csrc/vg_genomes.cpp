@@ -558,7 +558,7 @@ extern "C" int vg_genomes_from_codes(const uint8_t* codes, const int64_t* offset
     VG_API_END
 }
 
-extern "C" void vg_genomes_free(vg_genomes* g) { delete g; }
+extern "C" void vg_genomes_free(vg_genomes* g) { if (g) vg_lz_drop_prepared(g); delete g; }
 extern "C" int vg_genomes_count(const vg_genomes* g) { return g ? g->n : 0; }
 extern "C" int64_t vg_genomes_total_len(const vg_genomes* g) {
     int64_t t = 0; if (g) for (auto l : g->len) t += l; return t;

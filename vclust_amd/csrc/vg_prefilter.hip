@@ -534,10 +534,15 @@ k_spgemm(const uint32_t* __restrict__ rowinfo, const uint32_t* __restrict__ gen,
     __shared__ uint32_t s_used, s_lq, s_fail, s_first;
     // XCD-aware dealing (workgroup b runs on XCD b % 8): consecutive rows -- neighbouring genomes, which share
     // their k-mers' genome lists when they are related -- go to ONE XCD, so the lists are re-read from its L2
-    const int per_xcd = (int)gridDim.x / 8;                    // the grid is a multiple of 8 workgroups
-    const int row = (int)(blockIdx.x % 8) * per_xcd + (int)(blockIdx.x / 8);
-    if (row >= n_rows) return;
+    // A workgroup takes the rows k = its slot, slot + slots, ... of its XCD's share.  (Every launch gives a workgroup ONE
+    // row today: a few thousand persistent one-wave workgroups were measured and were no faster -- 2.7 against 1.9 ms for a
+    // shard of eight at 100 k genomes, the same at 10^6 contigs -- so the dispatch of 10^6 workgroups is not what costs.)
+    const int per_xcd = (n_rows + 7) / 8;                      // the grid is a multiple of 8 workgroups
+    for (int k = (int)(blockIdx.x / 8); k < per_xcd; k += (int)(gridDim.x / 8)) {
+    const int row = (int)(blockIdx.x % 8) * per_xcd + k;
+    if (row >= n_rows) break;
     const uint32_t a = row_list ? row_list[row] : (uint32_t)row;
+    __syncthreads();                                           // (the previous row's table has been read out)
     for (int i = threadIdx.x; i < HT_SIZE; i += blockDim.x) { hk[i] = HT_EMPTY; hc[i] = 0; }
     if (threadIdx.x == 0) { s_used = 0; s_lq = 0; s_fail = 0; }
     __syncthreads();
@@ -628,7 +633,7 @@ k_spgemm(const uint32_t* __restrict__ rowinfo, const uint32_t* __restrict__ gen,
     if (s_fail || s_used > HT_SIZE * 7 / 8) {
         // too many partners for the LDS table: hand the row to the dense fallback
         if (threadIdx.x == 0) { uint32_t o = atomicAdd(n_overflow, 1u); overflow_rows[o] = a; }
-        return;
+        continue;
     }
     // output: the workgroup takes ONE range of the global cursor for all its pairs (threads place themselves inside it
     // through an LDS counter).  One global atomic per PAIR on the one cursor word was the floor of this kernel: ~10 ns
@@ -647,6 +652,7 @@ k_spgemm(const uint32_t* __restrict__ rowinfo, const uint32_t* __restrict__ gen,
             const uint32_t b = hk[i];
             if (b != HT_EMPTY && hc[i] >= min_emit) { if (o < out_cap) { out[o].a = a; out[o].b = b; out[o].shared = hc[i]; } ++o; }
         }
+    }
     }
 }
 
