@@ -855,11 +855,12 @@ __device__ __forceinline__ void decode_tile(const part_src& S, int64_t t0, int64
 // The dense source also counts the kept k-mers per genome (set sizes) on the way.  The raw words of the next
 // tile are requested before the current one is counted (one workgroup per CU: nothing else hides the latency).
 // KC > 0: k = KC, all k-mers kept, one shard -- as compile-time constants (the default k = 25 of a whole set)
-template <int SRC, int KC = 0>
+template <int SRC, int KC = 0, bool RANGE = false>
 __global__ void __launch_bounds__(PT_THREADS)
 k_part_count(part_src S, int B1, int nb /* level-1 buckets of this pass */, int st_tiles, int64_t n_st, uint32_t* __restrict__ T, int* __restrict__ kept_per_genome,
              unsigned long long* __restrict__ wave_mask, uint32_t* __restrict__ wave_cnt /* RANGE shards of the dense source: kept mask and count of every 64 positions */) {
-    if (KC > 0) { S.A.k = KC; S.k2 = 2 * KC; S.A.use_frac = 0; S.A.n_shards = 1; }      // (RANGE shards keep their digits: KC = 25 serves them too)
+    if (KC > 0) { S.A.k = KC; S.k2 = 2 * KC; S.A.use_frac = 0; S.A.n_shards = 1; }
+    if (!RANGE) { S.A.dig_lo = 0; S.A.dig_n = 1u << DIG_BITS; S.bin_lo = 0; wave_mask = nullptr; }      // (the whole pass: the shard tests and the masks fold away)
     __shared__ uint32_t hist[PT_MAXBINS];
     const int lane = threadIdx.x & 63;
     for (int64_t st = blockIdx.x; st < n_st; st += gridDim.x) {
@@ -2144,10 +2145,10 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
             ri->wave_mask.alloc((size_t)W + 1); ri->wave_base.alloc((size_t)W + 1); wave_cnt.alloc((size_t)W + 1);
             VG_HIP(hipMemsetAsync(wave_cnt.p + W, 0, sizeof(uint32_t), s));
         }
-        if (k25) hipLaunchKernelGGL((k_part_count<SRC_DENSE, 25>), dim3(grid_c), dim3(PT_THREADS), 0, s, S, B1, nb1, st_tiles, n_st, T1s.p, d_kept,
-                                    range ? ri->wave_mask.p : no_mask, range ? wave_cnt.p : no_cnt);
-        else if (dense) hipLaunchKernelGGL(k_part_count<SRC_DENSE>, dim3(grid_c), dim3(PT_THREADS), 0, s, S, B1, nb1, st_tiles, n_st, T1s.p, d_kept,
-                                           range ? ri->wave_mask.p : no_mask, range ? wave_cnt.p : no_cnt);
+        if (k25 && range) hipLaunchKernelGGL((k_part_count<SRC_DENSE, 25, true>), dim3(grid_c), dim3(PT_THREADS), 0, s, S, B1, nb1, st_tiles, n_st, T1s.p, d_kept, ri->wave_mask.p, wave_cnt.p);
+        else if (k25) hipLaunchKernelGGL((k_part_count<SRC_DENSE, 25>), dim3(grid_c), dim3(PT_THREADS), 0, s, S, B1, nb1, st_tiles, n_st, T1s.p, d_kept, no_mask, no_cnt);
+        else if (dense && range) hipLaunchKernelGGL((k_part_count<SRC_DENSE, 0, true>), dim3(grid_c), dim3(PT_THREADS), 0, s, S, B1, nb1, st_tiles, n_st, T1s.p, d_kept, ri->wave_mask.p, wave_cnt.p);
+        else if (dense) hipLaunchKernelGGL(k_part_count<SRC_DENSE>, dim3(grid_c), dim3(PT_THREADS), 0, s, S, B1, nb1, st_tiles, n_st, T1s.p, d_kept, no_mask, no_cnt);
         else hipLaunchKernelGGL(k_part_count<SRC_ARRAYS>, dim3(grid_c), dim3(PT_THREADS), 0, s, S, B1, nb1, st_tiles, n_st, T1s.p, (int*)nullptr, no_mask, no_cnt);
         dbuf<char> scan_tmp;
         if (range) {
