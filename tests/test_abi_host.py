@@ -361,7 +361,7 @@ def test_ingest_gzip_through_the_own_decoder(tmp_path, golden_dir):
             "gs = api.GenomeSet.load([%r], multisample=True, n_threads=2); print(sum(int(x) for x in gs.lengths()), len(gs.names()))"
             % (str(__import__('pathlib').Path(__file__).resolve().parent.parent), str(tmp_path / 'l6.fna.gz')))
     import os
-    out = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, VG_GZ='zlib'), stdout=subprocess.PIPE, text=True, check=True).stdout.split()
+    out = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, VG_DEV_SWITCHES='1', VG_GZ='zlib'), stdout=subprocess.PIPE, text=True, check=True).stdout.split()
     assert [int(out[0]), int(out[1])] == [int(sum(plain.lengths())), len(plain.names())]
     bad = bytearray(files['l6.fna.gz']); bad[len(bad) // 3] ^= 0x10
     (tmp_path / 'bad.fna.gz').write_bytes(bytes(bad))

@@ -170,7 +170,7 @@ def test_kernel_variants_write_the_same_files(tmp_path):
 
     def go(tag, **env):
         flt, ani = tmp_path / f'{tag}.flt', tmp_path / f'{tag}.tsv'
-        e = dict(os.environ, **env)
+        e = dict(os.environ, VG_DEV_SWITCHES='1', **env)          # (developer switches are honoured only beside this one)
         for args in (('prefilter', '-i', fa, '-o', flt, '-v', '0'), ('align', '-i', fa, '-o', ani, '--filter', flt, '--outfmt', 'complete', '-v', '0')):
             p = subprocess.run([sys.executable, str(VCLUST), *map(str, args)], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
             assert p.returncode == 0, p.stderr[-2000:]

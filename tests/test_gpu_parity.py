@@ -273,7 +273,7 @@ def test_allocator_cycles_1_to_64_gib(mode):
             'rc = lib.vg_alloc_selftest(sizes, 4, 3)\n'
             'assert rc == 0, lib.vg_last_error()\n'
             'print("ok")\n') % str(ROOT)
-    p = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, VG_ALLOC=mode, VG_ALLOC_TRACE='1'),
+    p = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, VG_DEV_SWITCHES='1', VG_ALLOC=mode, VG_ALLOC_TRACE='1'),
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert p.returncode == 0 and p.stdout.strip().endswith('ok'), p.stderr[-3000:]
     assert (' vmm of ' in p.stderr) == (mode == 'vmm')

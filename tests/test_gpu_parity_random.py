@@ -234,7 +234,7 @@ def test_two_frequent_kmers_in_one_prefix_group(tmp_path):
             "assert np.array_equal(q, np.load(%r)); print('general ok')\n"
             % (str(__import__('pathlib').Path(__file__).resolve().parent.parent), str(tmp_path / 'codes.npy'), str(tmp_path / 'offsets.npy'),
                str(tmp_path / 'pairs.npy')))
-    r = subprocess.run([sys.executable, '-c', code], env=dict(__import__('os').environ, VG_INDEX_PATH='radix'), stdout=subprocess.PIPE,
+    r = subprocess.run([sys.executable, '-c', code], env=dict(__import__('os').environ, VG_DEV_SWITCHES='1', VG_INDEX_PATH='radix'), stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0 and 'general ok' in r.stdout, (r.stdout[-300:], r.stderr[-1500:])
 

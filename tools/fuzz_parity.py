@@ -1,5 +1,8 @@
 """Randomised parity fuzzing of the HIP path against the CPU oracle (longer than the test suite).
-usage: fuzz_parity.py [n_cases] [seed] [big]     (big: sets of 2-30 M positions -- both partition levels of the index pipeline)"""
+usage: fuzz_parity.py [n_cases] [seed] [big|huge]
+  big:  sets of 2-30 M positions -- both partition levels of the index pipeline
+  huge: sets of 70-200 M positions -- the 32 768-position tiles; RANGE shards and the forced sub-shard loop are held to the
+        single pass of the same set (itself held to the oracle at the other sizes), the LZ parse to the oracle on a sample"""
 import sys, pathlib, time
 import numpy as np
 root = pathlib.Path(__file__).resolve().parent.parent
@@ -10,6 +13,8 @@ api.set_device(0)
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 big = len(sys.argv) > 3
+huge = big and sys.argv[3] == 'huge'
+from vclust_amd import _lib
 bad = 0
 t0 = time.time()
 for case in range(n_cases):
@@ -17,6 +22,7 @@ for case in range(n_cases):
     nf = int(rng.integers(1, 5)); mem = int(rng.integers(2, 6))
     if big: nf = int(rng.integers(40, 400))
     lo = int(rng.choice([300, 2000, 9000, 30000])); hi = lo * int(rng.integers(1, 5))
+    if huge: nf = int(rng.integers(300, 700)); mem = int(rng.integers(4, 8)); lo = int(rng.choice([20000, 40000])); hi = lo * 2
     p_hi = float(rng.choice([0.02, 0.12, 0.25, 0.4]))
     codes, offsets, names = synth.make_families(nf, mem, seed=seed0 + case, length_range=(lo, hi), p_hi=p_hi)
     codes = codes.copy()
@@ -24,8 +30,17 @@ for case in range(n_cases):
         p = int(rng.integers(0, max(1, len(codes) - 80))); codes[p:p + int(rng.integers(1, 70))] = 4
     gs = api.GenomeSet.from_codes(codes, offsets, names)
     k = int(rng.choice([15, 21, 25, 30])); frac = float(rng.choice([1.0, 1.0, 0.5, 0.1]))
+    if huge: frac = 1.0
     sizes, pairs = gs.kmer_shared(k=k, fraction=frac)
-    osizes, opairs = orc.shared_all(codes, offsets, k=k, fraction=frac)
+    if huge:
+        osizes, opairs = list(sizes), {(int(p['a']), int(p['b'])): int(p['shared']) for p in pairs}
+        _lib.load().vg_set_subshards(int(rng.choice([2, 5, 8])))
+        try: s8, p8 = gs.kmer_shared(k=k, min_shared=1)
+        finally: _lib.load().vg_set_subshards(0)
+        if list(s8) != osizes or {(int(p['a']), int(p['b'])): int(p['shared']) for p in p8} != opairs:
+            bad += 1; print('SUB-SHARD MISMATCH case', case, 'seed', seed0 + case, flush=True)
+    else:
+        osizes, opairs = orc.shared_all(codes, offsets, k=k, fraction=frac)
     if list(sizes) != list(osizes) or {(int(p['a']), int(p['b'])): int(p['shared']) for p in pairs} != opairs:
         bad += 1; print('PREFILTER MISMATCH case', case, 'seed', seed0 + case, flush=True)
     ns = int(rng.choice([2, 3, 8])); tot = np.zeros_like(sizes); acc = {}
@@ -42,6 +57,10 @@ for case in range(n_cases):
         lz['am'] = min(lz['am'], lz['aw'] - 1)
     tasks = gs.align_tasks(gs.read_filter(None)) if len(gs) <= 8 else gs.align_tasks(synth.family_pairs(nf, mem))
     if big and len(tasks) > 400: tasks = tasks[np.sort(rng.choice(len(tasks) // 2, 200, replace=False))[:, None] * 2 + np.arange(2)].reshape(-1)
+    if rng.random() < 0.5:                                            # the prepared-index path (rows must not depend on it)
+        qq, rr = tasks['q'].astype(np.int64), tasks['r'].astype(np.int64)
+        pr = np.zeros(len(tasks), dtype=api.PAIR_DTYPE); pr['a'] = np.maximum(qq, rr); pr['b'] = np.minimum(qq, rr)
+        gs.lz_prepare(pr[rng.random(len(pr)) < 0.9] if rng.random() < 0.3 else pr, lz=lz)
     stats = gs.lz_align(tasks, lz=lz)
     for t, s in zip(tasks, stats):
         q, r = int(t['q']), int(t['r'])

@@ -19,6 +19,7 @@ nf = sys.argv[1] if len(sys.argv) > 1 else '100'
 import numpy as np
 def run(abl):
     env = dict(os.environ); 
+    env['VG_DEV_SWITCHES'] = '1'
     if abl is not None: env['VG_LZ_ABLATE'] = str(abl)
     p = subprocess.run([sys.executable, '-c', CODE, nf], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     d = json.loads(p.stdout.strip().splitlines()[-1]); return {k: np.array(v) for k, v in d.items()}

@@ -1425,7 +1425,7 @@ void vg_lz_drop_prepared(const vg_genomes* g) {
 
 static int64_t g_segment_task_limit = 32768;
 // VG_LZ_BUILD=lds: the scratch-based LDS build also for short references (tests compare the two)
-static const bool g_no_reg_build = [] { const char* e = getenv("VG_LZ_BUILD"); return e && strcmp(e, "lds") == 0; }();
+static const bool g_no_reg_build = [] { const char* e = vg_dev_getenv("VG_LZ_BUILD"); return e && strcmp(e, "lds") == 0; }();
 
 extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks, const vg_lz_params* p,
                            vg_pair_stat* stats, vg_region** regions, int64_t* n_regions) {
@@ -1484,19 +1484,19 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
     }
     vg_host_mark("lz: tasks grouped");
 #ifdef VG_DEV_KERNELS
-    const char* abl = getenv("VG_LZ_ABLATE");
+    const char* abl = vg_dev_getenv("VG_LZ_ABLATE");
 #else
     const char* abl = nullptr;                                // (the product library has no timing knobs)
 #endif
     // probe widths (speculation only: results do not depend on them): positions probed right after an event, and after a
     // first miss, before the scan goes to 64 per trip
-    static const int pw_after = [] { const char* e = getenv("VG_LZ_PW"); const int v = e ? atoi(e) : PW_AFTER_EVENT; return std::max(1, std::min(v, 64)); }();
-    static const int pw_miss = [] { const char* e = getenv("VG_LZ_PW2"); const int v = e ? atoi(e) : 64; return std::max(1, std::min(v, 64)); }();
+    static const int pw_after = [] { const char* e = vg_dev_getenv("VG_LZ_PW"); const int v = e ? atoi(e) : PW_AFTER_EVENT; return std::max(1, std::min(v, 64)); }();
+    static const int pw_miss = [] { const char* e = vg_dev_getenv("VG_LZ_PW2"); const int v = e ? atoi(e) : 64; return std::max(1, std::min(v, 64)); }();
     // R3's weak-seed ratio (a single-event fit): 3 unless VG_LZ_WEAK_SEED says otherwise (0 = off)
     static const int weak_ratio = [] { const char* e = getenv("VG_LZ_WEAK_SEED"); const int v = e && *e ? atoi(e) : 3; return std::max(0, std::min(v, 1000)); }();
     const lz_dev_params P{ p->mal, p->msl, p->mrd, p->mqd, p->reg, p->aw, p->am, p->ar, abl ? atoi(abl) : 0, pw_after, pw_miss, weak_ratio };
     // default parameters on a set without N: the kernel with those as compile-time constants (VG_LZ_KERNEL=general: never)
-    static const bool no_fast = [] { const char* e = getenv("VG_LZ_KERNEL"); return e && !strcmp(e, "general"); }();
+    static const bool no_fast = [] { const char* e = vg_dev_getenv("VG_LZ_KERNEL"); return e && !strcmp(e, "general"); }();
     bool fast_params = !no_fast && !abl && weak_ratio == 3 && p->mal == 11 && p->msl == 7 && p->mrd == 40 && p->mqd == 40 && p->reg == 35 && p->aw == 15 && p->am == 7 && p->ar == 3;
     for (int i = 0; fast_params && i < g->n; ++i) if (g->has_n[(size_t)i] || g->len[(size_t)i] >= (1 << 22)) fast_params = false;   // (tag: 8 bits beside <= 24 position bits)
 
@@ -1539,7 +1539,7 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
     }
     vg_host_mark("lz: batches planned");
     hipStream_t sb = s;
-    static const char* seg_env = getenv("VG_LZ_SEGMENTS");
+    static const char* seg_env = vg_dev_getenv("VG_LZ_SEGMENTS");
     for (size_t bi = 0; bi < batches.size(); ++bi) {
         lz_batch& B = batches[bi];
         lz_slot& L = slot;

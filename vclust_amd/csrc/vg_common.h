@@ -133,6 +133,7 @@ void vg_kmer_shared_device(vg_genomes* g, int k, double fraction, int shard, int
 // fn(lo, hi, t) over [0, n) cut into contiguous chunks, one per thread (the library's host loops over
 // 10^5..10^6 pairs / tasks: a few threads are enough; an exception in a chunk is rethrown on the caller)
 int vg_host_threads();
+const char* vg_dev_getenv(const char* name);      // a developer switch: read only when VG_DEV_SWITCHES=1 is set
 // developer aid: with VG_HOST_TRACE=1 prints the wall time since the previous mark (host-side phases of a call)
 void vg_host_mark(const char* what);
 double vg_alloc_wait_ms();            // wall time this process has spent inside the driver's device-allocation calls

@@ -194,6 +194,14 @@ void vg_host_mark(const char* what) {
     last = now;
 }
 
+// Developer switches (kernel variants, experiment knobs: DESIGN.md section 5) are honoured only when VG_DEV_SWITCHES=1 is
+// set beside them: a stray VG_INDEX_PATH in a user's environment does not change which kernels run.  The knobs meant for
+// users (VG_HOST_THREADS, VG_WORKSPACE_GB, VG_ONESHOT_INDEX_GB, VG_INDEX_BUDGET_GB, VG_LZ_WEAK_SEED, the traces) are read plainly.
+const char* vg_dev_getenv(const char* name) {
+    static const bool on = [] { const char* e = getenv("VG_DEV_SWITCHES"); return e && *e == '1'; }();
+    return on ? getenv(name) : nullptr;
+}
+
 int vg_host_threads() {
     static int n = [] { const char* e = getenv("VG_HOST_THREADS"); int v = e ? atoi(e) : (int)std::min(8u, std::thread::hardware_concurrency()); return std::max(1, std::min(v, 64)); }();
     return n;
@@ -220,7 +228,7 @@ const bool g_alloc_trace = [] { const char* e = getenv("VG_ALLOC_TRACE"); return
 // The virtual memory management path (one reserved range, 2 GiB physical chunks: hipMemCreate / hipMemMap) remains behind
 // VG_ALLOC=vmm for experiments: round 3 used it for the CLI's large blocks and took its speed on clean memory for a
 // property of the API; two aborts inside a long test process were seen with it on for everything and never explained.
-static int g_vmm_mode = [] { const char* e = getenv("VG_ALLOC"); return !e ? 0 : !strcmp(e, "vmm") ? 1 : !strcmp(e, "malloc") ? -1 : 0; }();
+static int g_vmm_mode = [] { const char* e = vg_dev_getenv("VG_ALLOC"); return !e ? 0 : !strcmp(e, "vmm") ? 1 : !strcmp(e, "malloc") ? -1 : 0; }();
 static bool g_vmm_alloc = g_vmm_mode > 0;
 // one-shot mode: set by the whole-stage calls (vg_prefilter / vg_align) for their duration
 static std::atomic<int> g_one_shot{0};

@@ -209,7 +209,7 @@ void slurp(const std::string& path, filebuf& fb, int n_threads) {
     // every member verified), and by zlib if that one declines the file (VG_GZ=zlib: always zlib)
     bool done = false;
     try { done = slurp_bgzf(path, f, fb, n_threads); } catch (...) { fclose(f); throw; }
-    static const bool zlib_only = [] { const char* e = getenv("VG_GZ"); return e && !strcmp(e, "zlib"); }();
+    static const bool zlib_only = [] { const char* e = vg_dev_getenv("VG_GZ"); return e && !strcmp(e, "zlib"); }();
     if (!done && !zlib_only) {
         fseek(f, 0, SEEK_END); const long long sz = ftell(f);
         void* m = sz > 0 ? mmap(nullptr, (size_t)sz, PROT_READ, MAP_PRIVATE, fileno(f), 0) : MAP_FAILED;

@@ -2054,9 +2054,9 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
     if (range && !ri) throw vg_error(VG_EINVAL, "internal error: a range shard needs its row map");
     hipStream_t s = vg_stream();
     vg_host_mark("buckets: enter");
-    if (g_index_path < 0) { const char* e = getenv("VG_INDEX_PATH"); g_index_path = (e && !strcmp(e, "radix")) ? 0 : 1; }
+    if (g_index_path < 0) { const char* e = vg_dev_getenv("VG_INDEX_PATH"); g_index_path = (e && !strcmp(e, "radix")) ? 0 : 1; }
     if (!g_index_path || n_src < (1 << 16) || n_src >= (1LL << 32)) return false;
-    static const int tb_env = [] { const char* e = getenv("VG_TOTAL_BITS"); return e ? atoi(e) : 0; }();     // developer experiments
+    static const int tb_env = [] { const char* e = vg_dev_getenv("VG_TOTAL_BITS"); return e ? atoi(e) : 0; }();     // developer experiments
     // elements the partition will hold (a RANGE shard holds whole buckets of the set's own partition: the digits follow from n_src)
     const int64_t n_expect = dense && !range ? n_src / std::max<uint32_t>(1u, A.n_shards) : n_src;
     int total_bits = 0; while ((n_expect >> total_bits) > 1024 && total_bits < 22) ++total_bits;
@@ -2064,7 +2064,7 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
     const bool big_buckets = (n_expect >> total_bits) > 1024;
     if ((n_expect >> total_bits) > 4096) return false;
     const int levels = total_bits > 11 ? 2 : 1;
-    static const char* b2_env = getenv("VG_B2");          // developer experiments: level-2 bits
+    static const char* b2_env = vg_dev_getenv("VG_B2");          // developer experiments: level-2 bits
     // level 1 takes 11 bits whenever there are two levels: its segment length does not depend on the digit (tiles of
     // 32 768), level 2's grows as its digit shrinks, and 2k - 11 key bits fit the short records up to k = 25
     const int B2 = levels == 2 ? (b2_env ? atoi(b2_env) : total_bits - 11) : 0;
@@ -2093,7 +2093,7 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
     struct ev_guard { hipEvent_t& e; hipStream_t st; ~ev_guard() { if (e) { (void)hipStreamWaitEvent(st, e, 0); (void)hipEventDestroy(e); } } } ev_g{ ev_rows_zero, s };
     // (dense single-pass sets only, whose whole workspace is a fraction of the HBM: with sub-shards of 10^6 contigs the
     // extra 14 GB block pushed the caching allocator into trims and fresh hipMallocs -- 8.2 s per pass instead of 2.7)
-    static const bool no_prezero = [] { const char* e = getenv("VG_ROWS_PREZERO"); return e && *e == '0'; }();      // developer A/B
+    static const bool no_prezero = [] { const char* e = vg_dev_getenv("VG_ROWS_PREZERO"); return e && *e == '0'; }();      // developer A/B
     if (levels == 2 && dense && !no_prezero && !range) {
         size_t fr = 0, tot = 0;
         if (hipMemGetInfo(&fr, &tot) == hipSuccess && (size_t)n_rows_info * 4 * 8 <= tot / 2) try {
@@ -2122,8 +2122,8 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
     L2.n_u = (int)((n_st + L2.u_st - 1) / L2.u_st);
     L2.kr = 2 * k - B1;
     { int sh = 0; while ((1LL << sh) < st_pos) ++sh; L2.st_shift = sh; }
-    static const bool long_rec = [] { const char* e = getenv("VG_LEVEL1_RECORDS"); return e && !strcmp(e, "long"); }();
-    static const bool old_scatter = [] { const char* e = getenv("VG_DENSE_SCATTER"); return e && !strcmp(e, "staged"); }();
+    static const bool long_rec = [] { const char* e = vg_dev_getenv("VG_LEVEL1_RECORDS"); return e && !strcmp(e, "long"); }();
+    static const bool old_scatter = [] { const char* e = vg_dev_getenv("VG_DENSE_SCATTER"); return e && !strcmp(e, "staged"); }();
     const bool tile32k = dense && st_tiles % 4 == 0 && B1 <= 12 && !old_scatter;          // k_part_scatter_dense applies
     bool short_rec = levels == 2 && tile32k && narrow && B2 <= 11 && L2.kr + SR_POS_BITS <= 64 && L2.kr - B2 >= 1 &&
                      (st_pos & (st_pos - 1)) == 0 && st_pos <= (1LL << SR_POS_BITS) && !long_rec;
@@ -2189,7 +2189,7 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
         const size_t rows_cap = range ? n_cap : (size_t)n_rows_info;
         a_rec.alloc(levels == 2 ? std::max((short_rec ? 2 : 3) * n_cap + 8, rows_cap + n_cap + 16) : 3 * n_cap + 8);
         const int grid_s = (int)std::min<int64_t>(n_st, 256);
-        static const bool range_dense = [] { const char* e = getenv("VG_RANGE_SCATTER"); return e && !strcmp(e, "dense"); }();      // developer A/B
+        static const bool range_dense = [] { const char* e = vg_dev_getenv("VG_RANGE_SCATTER"); return e && !strcmp(e, "dense"); }();      // developer A/B
         if (tile32k && range && nb1 <= RG_MAXBINS && !range_dense)
             if (k == 25 && !A.use_frac) hipLaunchKernelGGL(k_part_scatter_range<25>, dim3(grid_s), dim3(PT_THREADS), 0, s, S, B1, nb1, st_tiles / 4, n_st, (const uint32_t*)T1s.p, a_rec.p,
                                                            short_rec ? L2.kr : 0);
@@ -2223,7 +2223,7 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
             else hipLaunchKernelGGL(k_part_count2<false>, dim3(grid_c2), dim3(PT_THREADS), 0, s, (const uint32_t*)a_rec.p, B1, B2, n_units, L2, T2s.p);
             hipLaunchKernelGGL(k_scan_units, dim3(nb1), dim3(PT_THREADS), 0, s, T2s.p, L2.n_u, nb2, (const uint32_t*)d_off1.p, nb1, boff.p);
             b_rec.alloc((narrow ? 2 : 3) * n_cap + 8);
-            static const bool staged2 = [] { const char* e = getenv("VG_LEVEL2_SCATTER"); return e && !strcmp(e, "staged"); }();
+            static const bool staged2 = [] { const char* e = vg_dev_getenv("VG_LEVEL2_SCATTER"); return e && !strcmp(e, "staged"); }();
             const int grid_s2 = (int)std::min<int64_t>(n_units, 256);
             if (short_rec)
                 hipLaunchKernelGGL(k_part_scatter2_narrow<true>, dim3(grid_s2), dim3(PT_THREADS), 0, s, (const uint32_t*)a_rec.p, B1, B2, n_units,
@@ -2551,7 +2551,7 @@ static void kmer_shared_subshards(vg_genomes* g, int k, double fraction, int sha
     for (int i = 0; i < n; ++i) set_sizes[i] = 0;
     std::vector<dbuf<vg_pair_count>> parts((size_t)sub); std::vector<unsigned long long> counts((size_t)sub, 0ULL);
     std::vector<vg_pair_count> none;
-    static const bool no_overlap = [] { const char* e = getenv("VG_SUBSHARD_OVERLAP"); return e && *e == '0'; }();      // developer A/B
+    static const bool no_overlap = [] { const char* e = vg_dev_getenv("VG_SUBSHARD_OVERLAP"); return e && *e == '0'; }();      // developer A/B
     struct hook_guard { ~hook_guard() { g_after_extract = nullptr; g_precount.drop(); } } hg;
     for (int t = 0; t < sub; ++t) {
         g_after_extract = nullptr;
@@ -2586,7 +2586,7 @@ extern "C" int vg_kmer_shared(vg_genomes* g, int k, double fraction, int shard, 
     const double expect = (double)P * fraction / n_shards;                 // k-mers kept by this shard, at most
     const bool dense = fraction >= 1.0 && n_shards == 1;
     int sub = 1;
-    static const int env_sub = [] { const char* e = getenv("VG_SUBSHARDS"); return e ? atoi(e) : 0; }();      // developer experiments
+    static const int env_sub = [] { const char* e = vg_dev_getenv("VG_SUBSHARDS"); return e ? atoi(e) : 0; }();      // developer experiments
     if (g_force_subshards > 0) sub = g_force_subshards;
     else if (env_sub > 0) sub = env_sub;
     else if (dense ? P >= (1LL << 32) : expect >= 3.9e9) sub = (int)std::ceil(expect / 3.6e9);      // row numbers of one pass are 32 bits
