@@ -92,6 +92,8 @@ def step(nf):
         sizes, pairs = gs.kmer_shared(k=25, min_shared=20); t.append(time.perf_counter())
         k1 = sum(e['total_ms'] for e in api.profile_get()); api.profile_reset()
         cand = gs.filter_pairs(sizes, pairs, k=25, min_kmers=20, min_ident=0.7); t.append(time.perf_counter())
+        if os.environ.get('STEP_PREPARE', '1') == '1':
+            gs.lz_prepare(cand)            # (as the bench step does: the index build runs beside the task list)
         tasks = gs.align_tasks(cand); t.append(time.perf_counter())
         stats = gs.lz_align(tasks); t.append(time.perf_counter())
         k2 = sum(e['total_ms'] for e in api.profile_get())

@@ -670,12 +670,11 @@ constexpr int REG_STAGE = REG_LDS_WORDS / 1024 * 1024;  // entries per staging w
 constexpr int REG_STAGE0 = (REG_LDS_WORDS - LDS_TAB) / 1024 * 1024;   // slots staged while the table is still live
 constexpr int REG_SLOT_BITS = 17;                       // slot < n_rr < 2^17; tag (<= 14 bits) above it
 
-__global__ void __launch_bounds__(1024)
-k_build_index_reg(const ref_desc* __restrict__ refs, const int* __restrict__ slot_list, int n_list,
+// RR, bucket table and entries of ONE reference by the 1 024 threads of a workgroup (lds: REG_LDS_WORDS words)
+__device__ __forceinline__ void build_ref_reg(uint32_t* const lds, const ref_desc rd,
                   const uint32_t* __restrict__ packed, const uint32_t* __restrict__ nmask, const int64_t* __restrict__ base_off,
                   uint32_t* __restrict__ rr_pool, uint32_t* __restrict__ mask_pool, int msl,
                   uint32_t* __restrict__ stab_pool, uint32_t* __restrict__ sent_pool) {
-    __shared__ uint32_t lds[REG_LDS_WORDS];
     uint32_t* const tab = lds;                                   // bucket table
     uint32_t* const gw = lds + LDS_TAB;                          // genome words, mask, scan scratch
     uint32_t* const gm = gw + 3328; uint32_t* const wtot = gw + 8192;
@@ -684,10 +683,9 @@ k_build_index_reg(const ref_desc* __restrict__ refs, const int* __restrict__ slo
     uint32_t* const stage = lds;                                 // the windows use all of it
     const uint64_t smask = (1ULL << (2 * msl)) - 1;
     const int nb = 1 << (2 * msl);
-    for (int li = blockIdx.x; li < n_list; li += gridDim.x) {
+    {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));                            // per-position constants are recomputed per reference, not kept (and spilled) across the loop
-        const ref_desc rd = refs[slot_list[li]];
         const int64_t g0 = base_off[rd.genome];
         const uint32_t* gpk = packed + (g0 >> 4); const uint32_t* gmk = nmask + (g0 >> 5);
         uint32_t* pk = rr_pool + rd.rr_w; uint32_t* mk = mask_pool + rd.mask_w;
@@ -786,6 +784,15 @@ k_build_index_reg(const ref_desc* __restrict__ refs, const int* __restrict__ slo
             lds_sync();
         }
     }
+}
+__global__ void __launch_bounds__(1024)
+k_build_index_reg(const ref_desc* __restrict__ refs, const int* __restrict__ slot_list, int n_list,
+                  const uint32_t* __restrict__ packed, const uint32_t* __restrict__ nmask, const int64_t* __restrict__ base_off,
+                  uint32_t* __restrict__ rr_pool, uint32_t* __restrict__ mask_pool, int msl,
+                  uint32_t* __restrict__ stab_pool, uint32_t* __restrict__ sent_pool) {
+    __shared__ uint32_t lds[REG_LDS_WORDS];
+    for (int li = blockIdx.x; li < n_list; li += gridDim.x)
+        build_ref_reg(lds, refs[slot_list[li]], packed, nmask, base_off, rr_pool, mask_pool, msl, stab_pool, sent_pool);
 }
 
 // ---- path A1 (references of REG_MAX_RR .. MID_MAX_RR symbols -- genomes of 49 .. 262 kb --, msl <= 7): the positions do
@@ -1017,18 +1024,18 @@ struct seg_rec { int i_ev, ev_pos; uint32_t VM, VA, VN; };     // VN: bit 31 = o
 // FAST: the default LZ-ANI parameters and a set without N as compile-time constants (shift counts, loop bounds
 // and the mask paths fold away); the host launches it when both hold.
 template <int S, bool DEV, bool FAST = false>
-__device__ __forceinline__ void lz_parse_body(PARSE_ARGS) {
+__device__ __forceinline__ void lz_parse_body(PARSE_ARGS, int64_t t_given = -1, int w_given = 0) {
     if (FAST) { P.mal = 11; P.msl = 7; P.mrd = 40; P.mqd = 40; P.reg = 35; P.aw = 15; P.am = 7; P.ar = 3; P.ablate = 0; P.weak_ratio = 3; }
     const int ABL = DEV ? P.ablate : 0;           // developer timing knobs: compiled out of the production kernels
     __shared__ seg_rec s_log[S > 1 ? S * SEG_LOG_CAP : 1];
     __shared__ int s_cnt[4], s_sync_v[4], s_sync_idx[4];
     __shared__ uint32_t s_end[4][3];
     const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // wave-uniform: task data lives in SGPRs
+    const int w = t_given >= 0 ? w_given : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // wave-uniform: task data lives in SGPRs
     // XCD-aware dealing: consecutive task groups of one reference stay on one XCD (block b runs on XCD b % 8)
     const int64_t per_xcd = gridDim.x / 8;           // grid is a multiple of 8 workgroups
     const int64_t vblk = (int64_t)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
-    const int64_t t = (S == 1) ? vblk * 4 + w : vblk;
+    const int64_t t = t_given >= 0 ? t_given : ((S == 1) ? vblk * 4 + w : vblk);      // (t_given: the fused kernel names the task)
     if (t >= n_tasks) return;                        // S > 1: the whole workgroup leaves together
     const task_dev tk = tasks[t];
     ref_desc rd = refs[tk.r_slot];
@@ -1332,6 +1339,35 @@ __device__ __forceinline__ void lz_parse_body(PARSE_ARGS) {
 #define PARSE_KERNEL(NAME, S, DEV, WAVES, FAST) \
     __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) NAME(PARSE_ARGS) { \
         lz_parse_body<S, DEV, FAST>(PARSE_ARG_NAMES); }
+// FUSED experiment (round-3 verdict, item 3; developer switch VG_LZ_FUSED=1): one 1 024-thread workgroup OWNS a reference --
+// it builds the reference's index (build_ref_reg: RR, bucket table and entries written once, read back while they are
+// still in the L2 / the Infinity Cache) and its sixteen waves then parse that reference's tasks, one task per wave.
+// No index makes a round trip through HBM between a build launch and a parse launch, and no two launches meet at a
+// tail.  What it costs is occupancy: the build's 151 KiB of LDS allow one workgroup per CU, and a reference with nine
+// tasks keeps nine of its sixteen waves busy -- 2.25 waves per SIMD where the stand-alone parse runs eight
+// (profiles/r04_fused_align_experiment.md has the measurement).
+__global__ void __launch_bounds__(1024)
+k_lz_fused(const ref_desc* __restrict__ refs, const int* __restrict__ slot_list, int n_list, const int64_t* __restrict__ ref_first,
+           const task_dev* __restrict__ tasks, int64_t n_tasks,
+           const uint32_t* __restrict__ packed, const uint32_t* __restrict__ nmask, const int64_t* __restrict__ base_off,
+           const int64_t* __restrict__ glen, const uint8_t* __restrict__ g_has_n,
+           uint32_t* __restrict__ rr_pool, uint32_t* __restrict__ mask_pool, uint32_t* __restrict__ stab_pool, uint32_t* __restrict__ sent_pool,
+           lz_dev_params P, vg_pair_stat* __restrict__ stats) {
+    __shared__ uint32_t lds[REG_LDS_WORDS];
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    for (int li = blockIdx.x; li < n_list; li += gridDim.x) {
+        const ref_desc rd = refs[slot_list[li]];
+        build_ref_reg(lds, rd, packed, nmask, base_off, rr_pool, mask_pool, P.msl, stab_pool, sent_pool);
+        __threadfence();                                           // the index is read back through the L2 by this workgroup's own waves
+        __syncthreads();
+        const int64_t t0 = ref_first[rd.genome], t1 = ref_first[rd.genome + 1];
+        for (int64_t t = t0 + w; t < t1; t += 16)
+            lz_parse_body<1, false, true>(tasks, n_tasks, refs, packed, nmask, base_off, glen, g_has_n, rr_pool, mask_pool, stab_pool, sent_pool,
+                                          P, stats, (vg_region*)nullptr, (const unsigned long long*)nullptr, t, 0);
+        __syncthreads();                                           // (the LDS is the next reference's)
+    }
+}
+
 PARSE_KERNEL(k_lz_parse, 1, false, 8, false)
 PARSE_KERNEL(k_lz_parse_fast, 1, false, 8, true)
 PARSE_KERNEL(k_lz_parse_seg, 4, false, 8, false)
@@ -1543,6 +1579,20 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
     for (size_t bi = 0; bi < batches.size(); ++bi) {
         lz_batch& B = batches[bi];
         lz_slot& L = slot;
+        // developer experiment: build + parse of a reference in one workgroup (k_lz_fused)
+        static const bool fused_env = [] { const char* e = vg_dev_getenv("VG_LZ_FUSED"); return e && *e == '1'; }();
+        const bool fused = fused_env && fast_params && !want_regions && !B.reg_list.empty() && B.mid_list.empty() && B.small_list.empty() && B.large_list.empty() &&
+                           !(bi == 0 && plan->batch0_built);
+        if (fused) {
+            dbuf<int64_t> d_first((size_t)g->n + 1); d_first.upload(ref_first.data(), ref_first.size(), sb);
+            L.d_reg.upload(B.reg_list.data(), B.reg_list.size(), sb);
+            vg_prof_scope ps("lz_fused", B.bytes_alg);
+            hipLaunchKernelGGL(k_lz_fused, dim3((unsigned)std::min<size_t>(B.reg_list.size(), 256)), dim3(1024), 0, s, (const ref_desc*)d_refs.p, (const int*)L.d_reg.p,
+                               (int)B.reg_list.size(), (const int64_t*)d_first.p, (const task_dev*)d_tasks.p, n_tasks, g->d_packed.p, g->d_nmask.p, g->d_base_off.p,
+                               g->d_len.p, g->d_has_n.p, L.rr_pool.p, L.mask_pool.p, L.stab_pool.p, L.sent_pool.p, P, d_stats.p);
+            VG_HIP(hipStreamSynchronize(s));                     // (d_first goes out of scope)
+            continue;
+        }
         if (!(bi == 0 && plan->batch0_built)) lz_build_batch(g, p, *plan, bi, sb);
         {
             const int64_t nt = B.end - B.pos;
@@ -1794,6 +1844,7 @@ extern "C" int vg_lz_prepare(vg_genomes* g, const vg_pair_count* pairs, int64_t 
     int rc = vg_genomes_to_device(g); if (rc) return rc;
     vg_lz_drop_prepared(nullptr);
     if (n_pairs == 0) return VG_OK;
+    { const char* e = vg_dev_getenv("VG_LZ_FUSED"); if (e && *e == '1') return VG_OK; }      // (the fused experiment builds inside its own kernel)
     for (int i = 0; i < g->n; ++i) if (g->len[i] > (1 << 29)) throw vg_error(VG_EOVERFLOW, "genome longer than 2^29 bases");
     std::vector<uint8_t> is_ref((size_t)g->n, 0);
     for (int64_t i = 0; i < n_pairs; ++i) {
