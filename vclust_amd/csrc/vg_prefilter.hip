@@ -2044,6 +2044,10 @@ static void run_extract_sort(vg_genomes* g, int k, double fraction, int shard, i
 // k-mers of a shard / fraction (keys, row numbers).  Fills gen[] and rowinfo[] like k_group_runs; false = the
 // input does not suit it (tiny, skewed, a bucket beyond the LDS): the caller takes the general path.
 static int g_index_path = -1;      // -1 = not read yet; 0 = radix (rocPRIM) path forced; 1 = buckets
+// set by the sub-shard loop (kmer_shared_subshards): the k-mer scan of the NEXT sub-shard, started on the second queue at
+// a point where the library queue is idle
+static std::function<void()> g_after_extract;
+static void run_scan_hook() { if (g_after_extract) { auto hook = std::move(g_after_extract); g_after_extract = nullptr; hook(); } }
 // A RANGE shard of the dense source (A.dig_n < 2^11): `ri` receives the kept masks, the row bases and the row -> genome
 // map of the pass, n_rows_info becomes the number of kept k-mers, and the row pointers are indexed by row number.
 static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_args& A, const uint64_t* keys, const uint32_t* pos, int64_t n_src,
@@ -2240,6 +2244,12 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
         }
         VG_HIP(hipStreamSynchronize(s));                       // the tables and level-1 records go out of scope below
         vg_host_mark("buckets: level 2 done");
+        // (the library queue is idle here too.  Starting the scan of the next HASH sub-shard HERE, beside the bucket kernel,
+        // instead of in front of the SpGEMM was measured at 10^6 contigs once the SpGEMM had dropped to 16 ms and no longer
+        // covered the 52 ms scan: 2 502 against 2 458 ms per step -- the bucket kernel takes 86 ms instead of 55 beside it;
+        // the scan's arithmetic is additive wherever it runs.  VG_SUBSHARD_SCAN=early selects it.)
+        static const bool early_scan = [] { const char* e = vg_dev_getenv("VG_SUBSHARD_SCAN"); return e && !strcmp(e, "early"); }();
+        if (early_scan) run_scan_hook();
         vg_deferred_start();                                  // (the bucket kernel and the SpGEMM are the long waits of the call)
         f_rec = b_rec.p; f_stride = narrow ? 2 : 3;
         arena = std::move(a_rec);
@@ -2304,7 +2314,6 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
 
 // one pass over the k-mers of one shard: per-genome set sizes and (a, b, shared) of every pair
 // dev_out != nullptr: the pairs stay in HBM (*dev_out, *dev_n of them) and host_pairs is left empty
-static std::function<void()> g_after_extract;       // set by the sub-shard loop (kmer_shared_subshards), run once in front of the SpGEMM
 static void kmer_shared_pass(vg_genomes* g, int k, double fraction, int shard, int n_shards, uint32_t min_shared,
                              int64_t* set_sizes, std::vector<vg_pair_count>& host_pairs,
                              dbuf<vg_pair_count>* dev_out = nullptr, unsigned long long* dev_n = nullptr) {
@@ -2397,7 +2406,7 @@ static void kmer_shared_pass(vg_genomes* g, int k, double fraction, int shard, i
     // (the library queue is idle here -- the index stage ended with a synchronisation --: the sub-shard loop starts the
     // k-mer scan of the NEXT sub-shard on the second queue, beside this sub-shard's SpGEMM: arithmetic beside random
     // reads.  Started earlier, beside the partition kernels, the scan only took their CUs: 2.70 against 2.74 s.)
-    if (g_after_extract) { auto hook = std::move(g_after_extract); g_after_extract = nullptr; hook(); }
+    run_scan_hook();
     // SpGEMM with a growing output buffer
     dbuf<unsigned long long> d_cursor(1);
     dbuf<uint32_t> d_over((size_t)n), d_nover(1);
