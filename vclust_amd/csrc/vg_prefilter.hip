@@ -1850,6 +1850,12 @@ struct max_op { __device__ __host__ uint32_t operator()(uint32_t a, uint32_t b) 
 }  // namespace
 
 static int g_force_subshards = 0;
+// k-mers one pass is cut for: its row numbers are 32 bits (4.29e9) and sub-sharding starts at SUB_PASS_START expected
+// k-mers.  The expectation is an upper bound (every padded position counted) and HASH shards are even to a few 10^-5; a
+// pass that overflows all the same throws VG_EOVERFLOW and the loop is retried one cut finer.  (4.2e9 per pass would
+// make 10^6 contigs six passes instead of seven; its record buffers then peak near the device's memory -- ~250 GB are
+// in use at seven -- so the cut stays at 3.6e9.)
+constexpr double SUB_PASS_KMERS = 3.6e9, SUB_PASS_START = 3.9e9;
 
 // RANGE or HASH shards (see kmer_args): a property of the set and the fraction, the same on every rank and in every pass
 static bool range_shards(const vg_genomes* g, double fraction, int n_shards) {
@@ -2598,7 +2604,7 @@ extern "C" int vg_kmer_shared(vg_genomes* g, int k, double fraction, int shard, 
     static const int env_sub = [] { const char* e = vg_dev_getenv("VG_SUBSHARDS"); return e ? atoi(e) : 0; }();      // developer experiments
     if (g_force_subshards > 0) sub = g_force_subshards;
     else if (env_sub > 0) sub = env_sub;
-    else if (dense ? P >= (1LL << 32) : expect >= 3.9e9) sub = (int)std::ceil(expect / 3.6e9);      // row numbers of one pass are 32 bits
+    else if (dense ? P >= (1LL << 32) : expect >= SUB_PASS_START) sub = std::max(2, (int)std::ceil(expect / SUB_PASS_KMERS));      // row numbers of one pass are 32 bits
     else if (dense && vg_one_shot()) {
         // a cold one-shot call (the CLI): RANGE sub-shards under a workspace budget -- 16 bytes of records per kept k-mer
         // and pass.  Eight passes over 100 k genomes cost eight scans of the bases more than one pass (tens of ms) and
@@ -2643,7 +2649,7 @@ void vg_kmer_shared_device(vg_genomes* g, int k, double fraction, int shard, int
     const int64_t P = g->padded_total();
     const double expect = (double)P * fraction / n_shards;
     const bool dense = fraction >= 1.0 && n_shards == 1;
-    const bool one_pass = g_force_subshards <= 1 && !(dense ? P >= (1LL << 32) : expect >= 3.9e9);
+    const bool one_pass = g_force_subshards <= 1 && !(dense ? P >= (1LL << 32) : expect >= SUB_PASS_START);
     hipStream_t s = vg_stream();
     if (one_pass) {
         std::vector<vg_pair_count> none; unsigned long long n = 0;
@@ -2651,7 +2657,7 @@ void vg_kmer_shared_device(vg_genomes* g, int k, double fraction, int shard, int
         *n_pairs = (int64_t)n;
         return;
     }
-    int sub = g_force_subshards > 1 ? g_force_subshards : (int)std::ceil(expect / 3.6e9);
+    int sub = g_force_subshards > 1 ? g_force_subshards : (int)std::ceil(expect / SUB_PASS_KMERS);
     if (sub < 2) sub = 2;
     unsigned long long n = 0;
     for (int attempt = 0;; ++attempt) {
