@@ -226,11 +226,10 @@ def main():
         # -- prefilter: this rank's k-mer hash range; partial counts add up across ranks (RCCL all-gather)
         sizes, pairs = D.prefilter_counts(gs, comm, args.k, 1.0, min_shared=min_kmers)
         cand = gs.filter_pairs(sizes, pairs, k=args.k, min_kmers=min_kmers, min_ident=args.min_ident)
-        # -- align: canonical task list, reference-range share per rank, rows gathered over RCCL
-        if world == 1:
-            gs.lz_prepare(cand)            # the reference indexes are built on the device while the host assembles the task list
-        tasks = gs.align_tasks(cand)
-        stats, _ = D.align_rows(gs, tasks, comm, None, False)
+        # -- align from the candidate pairs: a rank lists ITS tasks (reference-range share) from the pairs and starts its
+        #    index build and parse at once; the canonical task list of the whole set is assembled on the host beside the
+        #    kernels and places the rows (gathered over RCCL when there is more than one rank)
+        tasks, stats = D.align_pairs(gs, cand, comm)
         state.update(n_pairs=len(tasks) // 2, stats=stats, tasks=tasks)
 
     api.profile_enable(False)

@@ -244,6 +244,34 @@ def test_two_ranks_write_the_same_files(tmp_path):
     assert sorted(open(l1).read().splitlines()) == sorted(open(l2).read().splitlines())
 
 
+def test_two_ranks_align_from_pairs(tmp_path):
+    """vg_lz_align_pairs_sharded on two ranks (both on the single GPU, gathers over gloo): every rank receives the canonical
+    task list and exactly the rows of the single-process vg_align_tasks + vg_lz_align."""
+    script = tmp_path / 'two_rank_pairs.py'
+    script.write_text("""
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+from vclust_amd import api, synth, distributed as D
+dist, dev = D.init_process_group()
+api.set_device(0)
+comm = D.make_comm(dist, dev)
+codes, offsets, names = synth.make_families(40, 5, length=9000, seed=21)
+gs = api.GenomeSet.from_codes(codes, offsets, names)
+sizes, pairs = D.prefilter_counts(gs, comm, 25, 1.0, min_shared=20)
+cand = gs.filter_pairs(sizes, pairs)
+tasks, stats = D.align_pairs(gs, cand, comm)
+ref_tasks = gs.align_tasks(cand)
+assert len(cand) > 300 and np.array_equal(tasks, ref_tasks), (len(cand), len(tasks), len(ref_tasks))
+ref = gs.lz_align(ref_tasks)
+assert np.array_equal(stats, ref), int((stats != ref).sum())
+print('pairs ok rank', dist.get_rank(), flush=True)
+comm.close(); dist.destroy_process_group()
+""" % str(ROOT))
+    p = _torchrun(2, script)
+    assert p.returncode == 0 and p.stdout.count('pairs ok rank') == 2, (p.stdout[-500:], p.stderr[:3000])
+
+
 def test_bench_two_ranks_smoke():
     p = _torchrun(2, ROOT / 'bench.py', '--gpus', '2', '--steps', '1', '--warmup', '1', '--workload', 'phage-1k', '--count', '6',
                   '--no-cpu-baseline', '--no-cli-wall')
@@ -324,6 +352,9 @@ s1, p1 = D.prefilter_counts(gs, comm, 25, 1.0, min_shared=20)
 tasks = gs.align_tasks(gs.filter_pairs(s1, p1))
 st0, rg0 = gs.lz_align(tasks, want_regions=True); st1, rg1 = D.align_rows(gs, tasks, comm, None, True)
 assert np.array_equal(st0, st1) and len(rg0) == len(rg1)
+# the align stage from the candidate PAIRS (tasks listed per rank in pair order, canonical list on a helper thread)
+t2, st2 = D.align_pairs(gs, gs.filter_pairs(s1, p1), comm)
+assert np.array_equal(t2, tasks) and np.array_equal(st2, st0)
 print('forced ok', len(calls))
 """ % str(ROOT)
     p = subprocess.run([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)

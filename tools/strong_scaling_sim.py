@@ -1,8 +1,8 @@
 """Developer tool: per-rank work of a strong-scaling run, emulated on ONE GPU: rank 0's shard of the phage-100k set (NF
 families) for world = 1, 2, 4, 8 -- its k-mer RANGE shard of the prefilter and its reference range of the align tasks --
-with the host work every rank repeats (thresholds, canonical task list, task ownership, selection of its tasks) timed
-beside it.  The exchanges themselves are excluded (a few MB per step: set sizes, nominated pair keys, counts, rows)."""
-import os, sys, pathlib, time
+with the host work every rank repeats between the stages timed beside it (thresholds and the listing of its own tasks;
+the canonical task list runs on a helper thread beside the kernels, as in vg_lz_align_pairs_sharded).  The exchanges themselves are excluded (a few MB per step: set sizes, nominated pair keys, counts, rows)."""
+import os, sys, pathlib, time, threading
 import numpy as np
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
 from vclust_amd import api, synth, distributed as D
@@ -20,13 +20,21 @@ for world in (1, 2, 4, 8):
         t0 = time.perf_counter()
         s, p = gs.kmer_shared(k=25, shard=0, n_shards=world, min_shared=1 if world > 1 else 20)
         t1 = time.perf_counter()
-        # host work of every rank between the stages (on the GLOBAL pair list: it is replicated, not sharded)
+        # host work of every rank between the stages, as vg_lz_align_pairs_sharded does it: thresholds on the global pair
+        # list, the rank's own tasks listed from the pairs (reference ranges from the genomes' task counts), and the
+        # canonical task list of the whole set on a helper thread BESIDE the kernels
         cand = gs.filter_pairs(sizes, pairs)
-        tk = gs.align_tasks(cand)
-        owner = D.align_owner(tk, len(gs), world)
-        mine = tk[owner == 0]
+        a, b = cand['a'].astype(np.int64), cand['b'].astype(np.int64)
+        deg = np.bincount(a, minlength=len(gs)) + np.bincount(b, minlength=len(gs))
+        before = np.concatenate([[0], np.cumsum(deg)[:-1]])
+        own_ref = np.minimum(world - 1, before * world // max(1, 2 * len(cand)))
+        ma, mb = own_ref[a] == 0, own_ref[b] == 0
+        mine = np.zeros(int(ma.sum() + mb.sum()), dtype=api.TASK_DTYPE)
+        mine['q'][:ma.sum()] = b[ma]; mine['r'][:ma.sum()] = a[ma]; mine['q'][ma.sum():] = a[mb]; mine['r'][ma.sum():] = b[mb]
         t2 = time.perf_counter()
+        th = threading.Thread(target=lambda: gs.align_tasks(cand)); th.start()
         st = gs.lz_align(mine)
+        th.join()
         t3 = time.perf_counter()
         prof = {e['name']: round(e['total_ms'], 1) for e in api.profile_get()}
         cur = ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, prof, len(p))

@@ -121,6 +121,7 @@ struct vg_genomes {
     mutable std::vector<int32_t> len_order, len_rank;
 };
 void vg_length_order(const vg_genomes* g);        // fills g->len_order / g->len_rank on first use
+int  vg_align_tasks_perm(const vg_genomes* g, const vg_pair_count* pairs, int64_t n_pairs, vg_task** tasks, int64_t* n_tasks, uint32_t* perm /* n_pairs entries, or null */);
 void vg_lz_drop_prepared(const vg_genomes* g);    // forget the index plan vg_lz_prepare left for g (nullptr: whatever it left)
 
 // vg_genomes_load with the upload to the library's device overlapped with the packing (vg_genomes.cpp; whole-stage calls)

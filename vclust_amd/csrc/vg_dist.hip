@@ -44,6 +44,8 @@ ncclResult_t ncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcoun
 #include <algorithm>
 #include <cstring>
 #include <vector>
+#include <thread>
+#include <string>
 
 // ------------------------------------------------------------------ communicator
 struct vg_comm {
@@ -397,6 +399,94 @@ extern "C" int vg_lz_align_sharded(vg_genomes* g, const vg_task* tasks, int64_t 
         for (int r = 0; r < W; ++r) { memcpy(o + w, ra.data() + (size_t)r * rpad, sizeof(vg_region) * (size_t)cnt[(size_t)r]); w += cnt[(size_t)r]; }
         *regions = o; if (n_regions) *n_regions = tot;
     }
+    VG_API_END
+}
+
+// ------------------------------------------------------------------ align, sharded, from the candidate PAIRS
+// vg_align_tasks + vg_lz_align_sharded in one call whose host work is off the critical path: a rank needs only ITS tasks to
+// start its kernels -- the genomes' task counts follow from the pairs (every pair is one task with r = a and one with
+// r = b), the reference ranges from the counts, and the rank's tasks are listed in pair order -- so the canonical task
+// list of the whole set (3 ms per 450 000 pairs, which every rank of vg_lz_align_sharded's caller builds BEFORE anything
+// is launched) is assembled on a helper thread while the kernels run, and is only needed to place the gathered rows.
+// Every rank receives the canonical task list (vg_free) and all rows (vg_free).  No regions (use vg_lz_align_sharded).
+extern "C" int vg_lz_align_pairs_sharded(vg_genomes* g, const vg_pair_count* cand, int64_t n_cand, const vg_lz_params* p, const vg_comm* c,
+                                         vg_task** tasks_out, int64_t* n_tasks_out, vg_pair_stat** stats_out) {
+    VG_API_BEGIN
+    if (!g || !c || (!cand && n_cand) || !p || !tasks_out || !n_tasks_out || !stats_out) throw vg_error(VG_EINVAL, "vg_lz_align_pairs_sharded: null argument");
+    *tasks_out = nullptr; *n_tasks_out = 0; *stats_out = nullptr;
+    const int n = vg_genomes_count(g);
+    const int64_t n_tasks = 2 * n_cand;
+    struct free_guard2 { void* p = nullptr; ~free_guard2() { if (p) free(p); } } tasks_g, stats_g;
+    if (!c->exchanges()) {
+        check(vg_lz_prepare(g, cand, n_cand, p));
+        int64_t nt = 0;
+        check(vg_align_tasks(g, cand, n_cand, (vg_task**)&tasks_g.p, &nt));
+        stats_g.p = malloc(sizeof(vg_pair_stat) * (size_t)std::max<int64_t>(1, nt));
+        if (!stats_g.p) throw vg_error(VG_ENOMEM, "out of host memory");
+        check(vg_lz_align(g, (const vg_task*)tasks_g.p, nt, p, (vg_pair_stat*)stats_g.p, nullptr, nullptr));
+        *tasks_out = (vg_task*)tasks_g.p; *n_tasks_out = nt; *stats_out = (vg_pair_stat*)stats_g.p; tasks_g.p = nullptr; stats_g.p = nullptr;
+        return VG_OK;
+    }
+    const int W = c->world;
+    std::vector<int32_t> own_ref((size_t)n + 1, 0);
+    std::vector<uint32_t> la((size_t)std::max<int64_t>(n_cand, 1)), lb((size_t)std::max<int64_t>(n_cand, 1)), perm((size_t)std::max<int64_t>(n_cand, 1));
+    std::vector<int64_t> per_rank((size_t)W, 0);
+    std::vector<vg_pair_stat> send, all;
+    int64_t pad = 1, nt = 0;
+    vg_host_mark("align pairs: enter");
+    guarded(c, "align shard", [&] {
+        if (n_cand >= (1LL << 31)) throw vg_error(VG_EOVERFLOW, "more than 2^31 candidate pairs in one call");
+        // the canonical list of the whole set: a helper thread, beside everything below
+        int rc_list = VG_OK; std::string err_list;
+        std::thread th([&] { rc_list = vg_align_tasks_perm(g, cand, n_cand, (vg_task**)&tasks_g.p, &nt, perm.data()); if (rc_list != VG_OK) err_list = vg_last_error(); });
+        struct joiner { std::thread& t; ~joiner() { if (t.joinable()) t.join(); } } jn{ th };
+        // reference ranges with about equal task counts (the rule of vg_align_owner), from the pairs
+        std::vector<int64_t> per_ref((size_t)n + 1, 0);
+        for (int64_t i = 0; i < n_cand; ++i) {
+            if (cand[i].a >= (uint32_t)n || cand[i].b >= (uint32_t)n) throw vg_error(VG_EINVAL, "pair id out of range");
+            per_ref[cand[i].a]++; per_ref[cand[i].b]++;
+        }
+        int64_t before = 0;
+        for (int r = 0; r < n; ++r) { own_ref[(size_t)r] = n_tasks ? (int32_t)std::min<int64_t>(W - 1, before * W / n_tasks) : 0; before += per_ref[(size_t)r]; }
+        // every rank's task list in pair order (task r = a, then task r = b of a pair): the local index of both tasks of
+        // every pair on their owners, and this rank's own list
+        std::vector<vg_task> mine;
+        for (int64_t i = 0; i < n_cand; ++i) {
+            const uint32_t a = cand[i].a, b = cand[i].b;
+            const int ra = own_ref[a], rb = own_ref[b];
+            la[(size_t)i] = (uint32_t)per_rank[(size_t)ra]++; if (ra == c->rank) mine.push_back({ b, a });
+            lb[(size_t)i] = (uint32_t)per_rank[(size_t)rb]++; if (rb == c->rank) mine.push_back({ a, b });
+        }
+        vg_host_mark("align pairs: own tasks listed");
+        std::vector<vg_pair_stat> my_stats(std::max<size_t>(1, mine.size()));
+        check(vg_lz_align(g, mine.data(), (int64_t)mine.size(), p, my_stats.data(), nullptr, nullptr));
+        th.join();
+        vg_host_mark("align pairs: canonical list joined");
+        if (rc_list != VG_OK) throw vg_error(rc_list, err_list);
+        for (int r = 0; r < W; ++r) pad = std::max(pad, per_rank[(size_t)r]);
+        send.assign((size_t)pad, vg_pair_stat{}); all.resize((size_t)pad * W);
+        if (!mine.empty()) memcpy(send.data(), my_stats.data(), sizeof(vg_pair_stat) * mine.size());
+        stats_g.p = malloc(sizeof(vg_pair_stat) * (size_t)std::max<int64_t>(1, n_tasks));
+        if (!stats_g.p) throw vg_error(VG_ENOMEM, "out of host memory");
+        reserve_staging(c, pad * (int64_t)sizeof(vg_pair_stat));
+    });
+    gather_host(c, send.data(), all.data(), pad * (int64_t)sizeof(vg_pair_stat));
+    // rows into the canonical order: couple cidx came from pair perm[cidx]; its two tasks are that pair's (r = a) and (r = b) tasks
+    {
+        const vg_task* tk = (const vg_task*)tasks_g.p; vg_pair_stat* st = (vg_pair_stat*)stats_g.p;
+        vg_parallel_chunks(n_cand, n_cand >= (1 << 18) ? std::min(vg_host_threads(), 8) : 1, [&](int64_t lo, int64_t hi, int) {
+            for (int64_t cidx = lo; cidx < hi; ++cidx) {
+                const uint32_t pi = perm[(size_t)cidx]; const uint32_t a = cand[pi].a, b = cand[pi].b;
+                for (int d = 0; d < 2; ++d) {
+                    const uint32_t r = tk[2 * cidx + d].r;
+                    const bool is_a = r == a;
+                    st[2 * cidx + d] = all[(size_t)own_ref[is_a ? a : b] * (size_t)pad + (is_a ? la[pi] : lb[pi])];
+                }
+            }
+        });
+    }
+    vg_host_mark("align pairs: rows placed");
+    *tasks_out = (vg_task*)tasks_g.p; *n_tasks_out = nt; *stats_out = (vg_pair_stat*)stats_g.p; tasks_g.p = nullptr; stats_g.p = nullptr;
     VG_API_END
 }
 

@@ -322,15 +322,22 @@ extern "C" int vg_read_filter(const vg_genomes* g, const char* path, double thr,
 
 extern "C" int vg_align_tasks(const vg_genomes* g, const vg_pair_count* pairs, int64_t n_pairs,
                               vg_task** tasks, int64_t* n_tasks) {
+    return vg_align_tasks_perm(g, pairs, n_pairs, tasks, n_tasks, nullptr);
+}
+// the same, also telling which pair every canonical couple came from (perm[c] = index into `pairs` of the couple whose
+// rows are tasks 2c and 2c + 1): the sharded align stage places gathered rows through it
+int vg_align_tasks_perm(const vg_genomes* g, const vg_pair_count* pairs, int64_t n_pairs,
+                        vg_task** tasks, int64_t* n_tasks, uint32_t* perm) {
     VG_API_BEGIN
     if (!g || (!pairs && n_pairs) || !tasks || !n_tasks) throw vg_error(VG_EINVAL, "vg_align_tasks: null argument");
+    if (perm && n_pairs >= (1LL << 32)) throw vg_error(VG_EOVERFLOW, "more than 2^32 pairs");
     vg_host_mark("align_tasks: enter");
     vg_length_order(g);
     vg_host_mark("align_tasks: length order");
     const std::vector<int32_t>& order = g->len_order; const std::vector<int32_t>& rank = g->len_rank;
     // couples sorted by (lo, hi) of the length ranks: two stable counting passes, on hi and then on lo (LSD order).
     // One thread: 10^5..10^6 couples are a few milliseconds of cache-resident work, less than starting helpers costs.
-    struct rp { int32_t lo, hi; };
+    struct rp { int32_t lo, hi; uint32_t idx; };
     if (n_pairs >= (1 << 21) && vg_host_threads() > 1) {
         // millions of couples (contigs-1M: 3.5 M, 75 ms on one thread): range partition on lo over the threads (counts,
         // offsets, scatter), every range sorted on its own, the task couples written in parallel
@@ -344,7 +351,7 @@ extern "C" int vg_align_tasks(const vg_genomes* g, const vg_pair_count* pairs, i
             for (int64_t i = a; i < b; ++i) {
                 if (pairs[i].a >= (uint32_t)g->n || pairs[i].b >= (uint32_t)g->n) { bad = true; return; }
                 const int32_t x = rank[pairs[i].a], y = rank[pairs[i].b];
-                v[(size_t)i] = { std::min(x, y), std::max(x, y) };
+                v[(size_t)i] = { std::min(x, y), std::max(x, y), (uint32_t)i };
                 cnt[(size_t)t][(size_t)bucket_of(v[(size_t)i].lo)]++;
             }
         });
@@ -358,10 +365,11 @@ extern "C" int vg_align_tasks(const vg_genomes* g, const vg_pair_count* pairs, i
         if (!o) throw vg_error(VG_ENOMEM, "out of host memory");
         auto finish = [&](int64_t a, int64_t b) {
             for (int64_t bk = a; bk < b; ++bk) {
-                std::sort(tmp.begin() + b_first[(size_t)bk], tmp.begin() + b_first[(size_t)bk + 1], [](const rp& x, const rp& y) { return x.lo != y.lo ? x.lo < y.lo : x.hi < y.hi; });
+                std::sort(tmp.begin() + b_first[(size_t)bk], tmp.begin() + b_first[(size_t)bk + 1], [](const rp& x, const rp& y) { return x.lo != y.lo ? x.lo < y.lo : (x.hi != y.hi ? x.hi < y.hi : x.idx < y.idx); });
                 for (int64_t i = b_first[(size_t)bk]; i < b_first[(size_t)bk + 1]; ++i) {
                     o[2 * i] = { (uint32_t)order[(size_t)tmp[(size_t)i].hi], (uint32_t)order[(size_t)tmp[(size_t)i].lo] };
                     o[2 * i + 1] = { (uint32_t)order[(size_t)tmp[(size_t)i].lo], (uint32_t)order[(size_t)tmp[(size_t)i].hi] };
+                    if (perm) perm[i] = tmp[(size_t)i].idx;
                 }
             }
         };
@@ -375,7 +383,7 @@ extern "C" int vg_align_tasks(const vg_genomes* g, const vg_pair_count* pairs, i
     for (int64_t i = 0; i < n_pairs; ++i) {
         if (pairs[i].a >= (uint32_t)g->n || pairs[i].b >= (uint32_t)g->n) throw vg_error(VG_EINVAL, "pair id out of range");
         const int32_t x = rank[pairs[i].a], y = rank[pairs[i].b];
-        v[(size_t)i] = { std::min(x, y), std::max(x, y) };
+        v[(size_t)i] = { std::min(x, y), std::max(x, y), (uint32_t)i };
         at_lo[(size_t)v[(size_t)i].lo + 1]++; at_hi[(size_t)v[(size_t)i].hi + 1]++;
     }
     for (int key = 0; key < g->n; ++key) { at_lo[(size_t)key + 1] += at_lo[(size_t)key]; at_hi[(size_t)key + 1] += at_hi[(size_t)key]; }
@@ -386,6 +394,7 @@ extern "C" int vg_align_tasks(const vg_genomes* g, const vg_pair_count* pairs, i
     for (size_t i = 0; i < v.size(); ++i) {
         o[2 * i] = { (uint32_t)order[(size_t)v[i].hi], (uint32_t)order[(size_t)v[i].lo] };       // row (q = b, r = a)
         o[2 * i + 1] = { (uint32_t)order[(size_t)v[i].lo], (uint32_t)order[(size_t)v[i].hi] };   // row (q = a, r = b)
+        if (perm) perm[i] = v[i].idx;
     }
     vg_host_mark("align_tasks: done");
     *tasks = o; *n_tasks = (int64_t)(2 * v.size());

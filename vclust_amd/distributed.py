@@ -149,6 +149,19 @@ def prefilter_counts(gs, comm, k, fraction, min_shared=1):
     return sizes[:len(gs)], pairs
 
 
+def align_pairs(gs, cand, comm, lz=None):
+    """Canonical task list and rows of the candidate pairs on every rank (vg_lz_align_pairs_sharded): a rank starts its
+    kernels from the pairs alone, the task list of the whole set is assembled beside them."""
+    from . import _lib, api
+    lib = _lib.load()
+    cand = np.ascontiguousarray(cand, dtype=api.PAIR_DTYPE)
+    prm = _lib.LzParams(**{**api.DEFAULT_LZ, **(lz or {})})
+    tp = C.POINTER(_lib.Task)(); nt = C.c_int64(); sp = C.POINTER(_lib.PairStat)()
+    _lib.check(lib.vg_lz_align_pairs_sharded(gs._h, cand.ctypes.data_as(C.POINTER(_lib.PairCount)), len(cand), C.byref(prm), comm.h,
+                                             C.byref(tp), C.byref(nt), C.byref(sp)))
+    return api._take(tp, nt.value, api.TASK_DTYPE), api._take(sp, nt.value, api.STAT_DTYPE)
+
+
 def align_rows(gs, tasks, comm, lz=None, want_regions=False):
     """Rows (and regions) of every task on every rank (vg_lz_align_sharded)."""
     from . import _lib, api
