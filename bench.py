@@ -156,7 +156,8 @@ def cli_wall(codes, offsets, names, n_pairs):
                alloc_wait_s_per_run=[round(r['breakdown_s']['prefilter']['alloc_wait'] + r['breakdown_s']['align']['alloc_wait'], 3) for r in runs],
                breakdown_s=med['breakdown_s'],
                note=f'python vclust.py prefilter + align --filter, FASTA on disk -> ani.tsv on disk, two cold processes, {len(runs)} runs back to back '
-                    '(total_s / breakdown_s = the median run; runs_total_s in run order: the first is the one that meets the device as the '
+                    '(a command returns when its files are complete and closed: the tear-down of its device context runs in a detached child '
+                    'beside the next command; total_s / breakdown_s = the median run; runs_total_s in run order: the first is the one that meets the device as the '
                     'previous tenant left it); breakdown from the library\'s host-side phase marks (VG_HOST_TRACE); alloc_wait = time inside '
                     'the driver\'s allocation calls (device memory it still has to wipe costs 25-32 ms per GiB, profiles/r04_first_touch.txt), '
                     'taken out of device_work')

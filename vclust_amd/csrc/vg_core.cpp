@@ -327,8 +327,17 @@ void* vg_dev_alloc(size_t bytes) {
     if (e != hipSuccess) {
         (void)hipGetLastError();                      // the failure is handled here: do not leave it as the sticky "last error"
         if (g_alloc_trace) fprintf(stderr, "[vg alloc] allocation of %.1f MB failed: trimming %.1f GB of cached blocks (live %.1f GB)\n", want / 1048576.0, g_cached_bytes / 1073741824.0, g_live_bytes / 1073741824.0);
-        vg_dev_trim();                                // give cached blocks back and retry once
+        vg_dev_trim();                                // give cached blocks back and retry
         e = raw_alloc(&p, want);
+        // (another process may be on its way out -- the CLI returns before the driver has torn its context down -- and its
+        // memory comes back within a fraction of a second: wait for it a little before giving up)
+        for (int tries = 0; e != hipSuccess && tries < 40; ++tries) {
+            (void)hipGetLastError();
+            size_t fr = 0, tot = 0;
+            if (hipMemGetInfo(&fr, &tot) != hipSuccess || want > tot) break;
+            std::this_thread::sleep_for(std::chrono::milliseconds(50));
+            e = raw_alloc(&p, want);
+        }
         if (e != hipSuccess) { (void)hipGetLastError(); throw vg_error(VG_ENOMEM, std::string("device allocation: ") + hipGetErrorString(e)); }
     }
     std::lock_guard<std::mutex> lk(g_alloc_mu);
