@@ -12,7 +12,7 @@ value = unordered pairs aligned per second (whole job, all ranks).
 Default workload: `phage-100k` of SURVEY.md 8(d) (BASELINE configs[3]: 10 000 families x 10 members x 40 kb,
 seed 3), which fits one MI355X.  N > 1: the SAME set (strong scaling; `--scaling weak` multiplies the families
 by N instead) through the sharded C-ABI entry points (vg_kmer_shared_sharded / vg_lz_align_sharded): the prefilter
-is sharded by k-mer hash range (partial counts all-gathered over RCCL and summed on the device), the align tasks
+is sharded by k-mer range (partial counts all-gathered over RCCL and summed on the device), the align tasks
 are dealt by reference range (each rank indexes 1/N of the genomes), and the per-pair integer rows are all-gathered.  Other workloads: --workload phage-1k | imgvr-10k | contigs-1M (+ --count).
 """
 import argparse
@@ -224,7 +224,7 @@ def main():
     state = {}
 
     def step():
-        # -- prefilter: this rank's k-mer hash range; partial counts add up across ranks (RCCL all-gather)
+        # -- prefilter: this rank's k-mer range; partial counts add up across ranks (RCCL all-gather)
         sizes, pairs = D.prefilter_counts(gs, comm, args.k, 1.0, min_shared=min_kmers)
         cand = gs.filter_pairs(sizes, pairs, k=args.k, min_kmers=min_kmers, min_ident=args.min_ident)
         # -- align from the candidate pairs: a rank lists ITS tasks (reference-range share) from the pairs and starts its

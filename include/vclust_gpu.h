@@ -86,7 +86,8 @@ typedef struct { uint32_t a, b, shared; } vg_pair_count;   /* a > b (input order
 /* Integer core of the prefilter on the GPU: per-genome distinct canonical k-mer counts and
  * the sparse all-vs-all shared-k-mer counts (K1+K2 of SURVEY §8a).
  *   fraction        --kmers-fraction (vclust.py:241-248); 1.0 = all k-mers
- *   shard/n_shards  k-mer hash range handled by this call (multi-GPU: one shard per rank;
+ *   shard/n_shards  k-mer range handled by this call -- a range of the scrambled key's top bits for sets below 2^32 bases
+ *                   without a fraction, a hash of its low bits otherwise -- (multi-GPU: one shard per rank;
  *                   set sizes and shared counts of the shards ADD UP)
  *   min_shared      pairs with fewer shared k-mers are not emitted (use 1 when n_shards>1)
  * set_sizes: n entries.  pairs: unordered; released with vg_free(). */
@@ -199,7 +200,7 @@ int  vg_comm_world(const vg_comm* c);
 /* exchange self-test: every rank sends a pattern of `bytes` bytes and checks what it receives (no GPU needed
  * for a callback communicator over host memory) */
 int  vg_comm_selftest(const vg_comm* c, int64_t bytes);
-/* vg_kmer_shared over all ranks: rank r counts the k-mers of hash range r and keeps its partial (a, b, count)
+/* vg_kmer_shared over all ranks: rank r counts the k-mers of range r and keeps its partial (a, b, count)
  * list in HBM.  Exchanged: the set sizes, the KEYS of the pairs a rank holds >= ceil(min_shared / world) of (a pair
  * that reaches min_shared in total has that many on some rank), and every rank's count for each pair of the union of
  * those keys; the counts are summed and the threshold is applied to the SUM.  Every rank receives the global result,

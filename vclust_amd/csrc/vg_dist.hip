@@ -3,7 +3,7 @@
 // The reference has no distributed layer (single node, threads); north_star shards the path
 // over the GPUs of one node with a gather of result rows over RCCL/xGMI.  The path shards without any
 // collective inside the kernels:
-//   prefilter  rank r handles the k-mers whose shard hash falls into range r of `world` (vg_kmer_shared's
+//   prefilter  rank r handles the k-mers of range r of `world` (RANGE or HASH shards, vg_prefilter.hip) (vg_kmer_shared's
 //              shard/n_shards): per-genome set sizes and per-pair shared counts of the shards ADD UP.  What travels
 //              is bounded by the RESULT, not by the partial lists: a pair whose total reaches min_shared has at least
 //              ceil(min_shared / world) shared k-mers on SOME rank, so (1) every rank nominates the pairs it holds
