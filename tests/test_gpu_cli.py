@@ -189,6 +189,39 @@ def test_kernel_variants_write_the_same_files(tmp_path):
         assert filecmp.cmp(base[0], other[0], shallow=False) and filecmp.cmp(base[1], other[1], shallow=False), tag
 
 
+def test_cold_cli_calls_keep_a_bounded_device_footprint(tmp_path):
+    """The two whole-stage calls of the CLI touch ~10 GB of device memory whatever one pass over the set would take
+    (a cold process may wait 25-32 ms per GiB for memory the driver has not wiped yet: DESIGN.md section 3).  30 000 x 40 kb
+    genomes: one prefilter pass would hold 20 GB of records and row pointers, one index batch 12 GB; the allocator trace
+    of both processes stays below 12 GB (live + cached), the prefilter runs as sub-shards, and the files equal those of
+    the unbounded run."""
+    import filecmp
+    import os
+    import re
+    sys.path.insert(0, str(ROOT))
+    from vclust_amd import synth
+    codes, offsets, names, _ = synth.make_workload('phage-100k', 3000)
+    fa = tmp_path / 'set.fna'
+    synth.write_fasta(fa, codes, offsets, names)
+
+    def go(tag, **env):
+        flt, ani = tmp_path / f'{tag}.flt', tmp_path / f'{tag}.tsv'
+        e = dict(os.environ, VG_ALLOC_TRACE='1', VG_HOST_TRACE='1', **env)
+        peak, marks = [], []
+        for args in (('prefilter', '-i', fa, '-o', flt, '-v', '0'), ('align', '-i', fa, '-o', ani, '--filter', flt, '-v', '0')):
+            p = subprocess.run([sys.executable, str(VCLUST), *map(str, args)], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+            assert p.returncode == 0, p.stderr[-2000:]
+            gb = [float(a) + float(b) for a, b in re.findall(r'new block [0-9.]+ MB \(live ([0-9.]+) GB, cached ([0-9.]+) GB\)', p.stderr)]
+            peak.append(max(gb)); marks.append(p.stderr)
+        return flt, ani, peak, marks
+    flt, ani, peak, marks = go('bounded')
+    assert peak[0] < 10.0 and peak[1] < 8.0, peak
+    assert marks[0].count('buckets: enter') >= 2            # the prefilter ran as sub-shards
+    flt2, ani2, peak2, _ = go('one_pass', VG_WORKSPACE_GB='1000', VG_ONESHOT_INDEX_GB='64')
+    assert peak2[0] > 15.0 and peak2[1] > 10.0, peak2
+    assert filecmp.cmp(flt, flt2, shallow=False) and filecmp.cmp(ani, ani2, shallow=False)
+
+
 def test_weak_seed_rule_is_exercised_and_switchable(tmp_path):
     """R3's weak-seed margin (`lit > 3 * seed`: the anchor needs msl - 1 instead of msl more symbols) rests on one event
     of the reference's example (profiles/r04_lz_fit_leave_one_out.md).  On strongly diverged synthetic families the branch

@@ -52,6 +52,7 @@ struct kmer_args {
     const uint32_t* packed; const uint32_t* nmask; const uint32_t* blk2g; const int64_t* base_off; const int64_t* len;
     int64_t P; int k; int use_frac; uint64_t frac_thr; uint32_t shard, n_shards; int blk_shift;
     uint32_t dig_lo, dig_n;          // RANGE shards: keep the keys whose top DIG_BITS bits d satisfy d - dig_lo < dig_n (all: 0, 1 << DIG_BITS)
+    uint32_t dig_max;                // RANGE shards: the widest digit range of any shard of this cut (buffers of all passes are sized alike)
 };
 // A k-mer range shard is one of two things (shard_mode, one rule for every rank and pass of a set):
 //  RANGE  whole set below 2^32 padded bases, no --kmers-fraction: shard s of S owns the keys whose top 11 bits -- the
@@ -1864,8 +1865,9 @@ static bool range_shards(const vg_genomes* g, double fraction, int n_shards) {
 static kmer_args make_kmer_args(const vg_genomes* g, int k, double fraction, int shard, int n_shards) {
     const int use_frac = fraction < 1.0;
     kmer_args A{ g->d_packed.p, g->d_nmask.p, g->d_blk2g.p, g->d_base_off.p, g->d_len.p, g->padded_total(), k, use_frac,
-                 use_frac ? (uint64_t)std::ldexp(fraction, 64) : ~0ULL, (uint32_t)shard, (uint32_t)n_shards, g->align_shift, 0u, 1u << DIG_BITS };
+                 use_frac ? (uint64_t)std::ldexp(fraction, 64) : ~0ULL, (uint32_t)shard, (uint32_t)n_shards, g->align_shift, 0u, 1u << DIG_BITS, 1u << DIG_BITS };
     if (range_shards(g, fraction, n_shards)) {
+        A.dig_max = (uint32_t)(((1u << DIG_BITS) + (uint32_t)n_shards - 1u) / (uint32_t)n_shards);
         const uint32_t lo = (uint32_t)(((uint64_t)shard << DIG_BITS) / (uint64_t)n_shards), hi = (uint32_t)(((uint64_t)(shard + 1) << DIG_BITS) / (uint64_t)n_shards);
         A.shard = 0; A.n_shards = 1; A.dig_lo = lo; A.dig_n = hi - lo;
     }
@@ -2195,7 +2197,7 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
         // descriptors are born after that: they take over the same block (48 GB less to allocate at 100 k genomes)
         // (the passes of a RANGE sub-shard loop ask for the same sizes, so that each finds the previous pass's blocks in the
         // allocator's cache: sized for the widest digit range of the loop plus a margin, not for this pass's exact count)
-        if (range) n_cap = std::max<size_t>((size_t)n1, (size_t)((double)n_src * (A.dig_n + 1) / (double)(1u << DIG_BITS) * 1.01) + 65536);
+        if (range) n_cap = std::max<size_t>((size_t)n1, (size_t)((double)n_src * A.dig_max / (double)(1u << DIG_BITS) * 1.01) + 65536);
         const size_t rows_cap = range ? n_cap : (size_t)n_rows_info;
         a_rec.alloc(levels == 2 ? std::max((short_rec ? 2 : 3) * n_cap + 8, rows_cap + n_cap + 16) : 3 * n_cap + 8);
         const int grid_s = (int)std::min<int64_t>(n_st, 256);
