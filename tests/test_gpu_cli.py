@@ -305,6 +305,37 @@ comm.close(); dist.destroy_process_group()
     assert p.returncode == 0 and p.stdout.count('pairs ok rank') == 2, (p.stdout[-500:], p.stderr[:3000])
 
 
+def test_rccl_failure_falls_back_to_the_callback_communicator(tmp_path):
+    """Two ranks on the ONE GPU of the test box ask for the built-in RCCL communicator: RCCL refuses a device twice, every
+    rank agrees on the failure before any further collective, and all fall back to the callback communicator -- the
+    run completes with the right rows instead of leaving a rank inside a collective."""
+    script = tmp_path / 'two_rank_rccl.py'
+    script.write_text("""
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+from vclust_amd import api, synth, distributed as D
+dist, dev = D.init_process_group()
+api.set_device(0)
+comm = D.make_comm(dist, dev, kind='rccl')
+codes, offsets, names = synth.make_families(12, 4, length=6000, seed=22)
+gs = api.GenomeSet.from_codes(codes, offsets, names)
+sizes, pairs = D.prefilter_counts(gs, comm, 25, 1.0, min_shared=20)
+s0, p0 = gs.kmer_shared(k=25, min_shared=20)
+assert np.array_equal(sizes, s0) and len(pairs) == len(p0)
+print('fallback ok rank', dist.get_rank(), flush=True)
+comm.close(); dist.destroy_process_group()
+""" % str(ROOT))
+    import os
+    import socket
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, VCLUST_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    p = subprocess.run(['timeout', '150', sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+                        '--master-port', str(port), str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert p.returncode == 0 and p.stdout.count('fallback ok rank') == 2, (p.stdout[-500:], p.stderr[:3000])
+    assert 'falling back to the callback communicator' in p.stderr
+
+
 def test_bench_two_ranks_smoke():
     p = _torchrun(2, ROOT / 'bench.py', '--gpus', '2', '--steps', '1', '--warmup', '1', '--workload', 'phage-1k', '--count', '6',
                   '--no-cpu-baseline', '--no-cli-wall')

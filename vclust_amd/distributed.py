@@ -91,17 +91,41 @@ def make_comm(dist=None, device=None, kind=None):
     if kind is None:
         kind = os.environ.get('VCLUST_COMM') or ('rccl' if backend == 'nccl' else 'callback')
     if kind == 'rccl':
-        uid = torch.zeros(128, dtype=torch.uint8)
+        # The built-in RCCL communicator, made fail-soft: no step may leave some ranks inside a collective while another
+        # has raised.  Rank 0's id travels with a flag; creation and a first real exchange (vg_comm_selftest) are each
+        # agreed on by all ranks before the next collective; any failure sends EVERY rank to the callback communicator
+        # (all-gathers through torch.distributed) with a line on stderr.
+        import sys
+
+        def agree(ok):
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device if backend == 'nccl' else 'cpu')
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return int(t.item()) == 1
+        uid = torch.zeros(129, dtype=torch.uint8)
         if rank == 0:
             buf = (C.c_uint8 * 128)()
-            _lib.check(lib.vg_rccl_unique_id(buf, 128))
-            uid = torch.from_numpy(np.frombuffer(bytes(buf), dtype=np.uint8).copy())
+            if lib.vg_rccl_unique_id(buf, 128) == 0:
+                uid = torch.from_numpy(np.frombuffer(bytes(buf) + b'\x01', dtype=np.uint8).copy())
+            else:
+                print(f'vclust_amd.distributed: no RCCL unique id ({lib.vg_last_error().decode()}): callback communicator', file=sys.stderr)
         if backend == 'nccl':
             uid = uid.to(device)
         dist.broadcast(uid, src=0)
         raw = bytes(uid.cpu().numpy().tobytes())
-        _lib.check(lib.vg_comm_rccl_create(rank, world, raw, 128, C.byref(h)))
-        return Comm(h, lib)
+        made = raw[128] == 1 and lib.vg_comm_rccl_create(rank, world, raw[:128], 128, C.byref(h)) == 0
+        if raw[128] == 1 and not made:
+            print(f'vclust_amd.distributed: rank {rank}: vg_comm_rccl_create failed ({lib.vg_last_error().decode()})', file=sys.stderr)
+        if agree(made):
+            tested = lib.vg_comm_selftest(h, 1 << 16) == 0
+            if not tested:
+                print(f'vclust_amd.distributed: rank {rank}: RCCL exchange self-test failed ({lib.vg_last_error().decode()})', file=sys.stderr)
+            if agree(tested):
+                return Comm(h, lib)
+        if made:
+            lib.vg_comm_free(h)
+        h = C.c_void_p()
+        if rank == 0:
+            print('vclust_amd.distributed: falling back to the callback communicator (torch.distributed all-gathers)', file=sys.stderr)
 
     def allgather(ctx, send, recv, nbytes, on_device):
         try:
