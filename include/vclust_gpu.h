@@ -212,6 +212,10 @@ int vg_align_owner(const vg_task* tasks, int64_t n_tasks, int n_genomes, int wor
 /* vg_lz_align over all ranks (reference-range partition): every rank receives all rows (and regions) */
 int vg_lz_align_sharded(vg_genomes* g, const vg_task* tasks, int64_t n_tasks, const vg_lz_params* p, const vg_comm* c,
                         vg_pair_stat* stats, vg_region** regions, int64_t* n_regions);
+/* rank `rank`'s share of the align tasks of the candidate pairs under the reference-range partition (a pure function of
+ * the pairs; tasks in pair order, (q = b, r = a) before (q = a, r = b)); *tasks released with vg_free() */
+int vg_align_pairs_share(const vg_genomes* g, const vg_pair_count* pairs, int64_t n_pairs, int world, int rank,
+                         vg_task** tasks, int64_t* n_tasks);
 /* vg_align_tasks + vg_lz_align_sharded from the candidate pairs in one call: a rank derives its own tasks from the pairs
  * and starts its kernels at once, the canonical task list of the whole set is assembled beside them and only places the
  * gathered rows.  *tasks (canonical order, as vg_align_tasks) and *stats (one row per task) are released with vg_free(). */

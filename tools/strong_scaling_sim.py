@@ -24,13 +24,7 @@ for world in (1, 2, 4, 8):
         # list, the rank's own tasks listed from the pairs (reference ranges from the genomes' task counts), and the
         # canonical task list of the whole set on a helper thread BESIDE the kernels
         cand = gs.filter_pairs(sizes, pairs)
-        a, b = cand['a'].astype(np.int64), cand['b'].astype(np.int64)
-        deg = np.bincount(a, minlength=len(gs)) + np.bincount(b, minlength=len(gs))
-        before = np.concatenate([[0], np.cumsum(deg)[:-1]])
-        own_ref = np.minimum(world - 1, before * world // max(1, 2 * len(cand)))
-        ma, mb = own_ref[a] == 0, own_ref[b] == 0
-        mine = np.zeros(int(ma.sum() + mb.sum()), dtype=api.TASK_DTYPE)
-        mine['q'][:ma.sum()] = b[ma]; mine['r'][:ma.sum()] = a[ma]; mine['q'][ma.sum():] = a[mb]; mine['r'][ma.sum():] = b[mb]
+        mine = D.align_pairs_share(gs, cand, world, 0)
         t2 = time.perf_counter()
         th = threading.Thread(target=lambda: gs.align_tasks(cand)); th.start()
         st = gs.lz_align(mine)

@@ -108,6 +108,7 @@ SYMBOLS = {
     'vg_comm_selftest': (C.c_int, [C.c_void_p, C.c_int64]),
     'vg_kmer_shared_sharded': (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_uint32, C.c_void_p, P(C.c_int64), P(P(PairCount)), P(C.c_int64)]),
     'vg_align_owner': (C.c_int, [P(Task), C.c_int64, C.c_int, C.c_int, P(C.c_int32)]),
+    'vg_align_pairs_share': (C.c_int, [C.c_void_p, P(PairCount), C.c_int64, C.c_int, C.c_int, P(P(Task)), P(C.c_int64)]),
     'vg_lz_align_pairs_sharded': (C.c_int, [C.c_void_p, P(PairCount), C.c_int64, P(LzParams), C.c_void_p, P(P(Task)), P(C.c_int64), P(P(PairStat))]),
     'vg_lz_align_sharded': (C.c_int, [C.c_void_p, P(Task), C.c_int64, P(LzParams), C.c_void_p, P(PairStat), P(P(Region)), P(C.c_int64)]),
     'vg_prefilter_sharded': (C.c_int, [P(C.c_char_p), C.c_int, C.c_char_p, P(PrefilterParams), C.c_void_p]),

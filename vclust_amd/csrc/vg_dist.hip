@@ -402,6 +402,48 @@ extern "C" int vg_lz_align_sharded(vg_genomes* g, const vg_task* tasks, int64_t 
     VG_API_END
 }
 
+// reference ranges of `world` ranks from the candidate pairs (every pair is one task with r = a and one with r = b: the
+// rule of vg_align_owner without the task list), the position of both tasks of every pair in their owners' lists (tasks
+// listed in pair order: r = a first), and rank `me`'s own list
+namespace {
+void pairs_share(int n, const vg_pair_count* cand, int64_t n_cand, int W, int me, std::vector<int32_t>& own_ref,
+                 std::vector<uint32_t>* la, std::vector<uint32_t>* lb, std::vector<int64_t>& per_rank, std::vector<vg_task>& mine) {
+    const int64_t n_tasks = 2 * n_cand;
+    own_ref.assign((size_t)n + 1, 0); per_rank.assign((size_t)W, 0); mine.clear();
+    std::vector<int64_t> per_ref((size_t)n + 1, 0);
+    for (int64_t i = 0; i < n_cand; ++i) {
+        if (cand[i].a >= (uint32_t)n || cand[i].b >= (uint32_t)n) throw vg_error(VG_EINVAL, "pair id out of range");
+        per_ref[cand[i].a]++; per_ref[cand[i].b]++;
+    }
+    int64_t before = 0;
+    for (int r = 0; r < n; ++r) { own_ref[(size_t)r] = n_tasks ? (int32_t)std::min<int64_t>(W - 1, before * W / n_tasks) : 0; before += per_ref[(size_t)r]; }
+    for (int64_t i = 0; i < n_cand; ++i) {
+        const uint32_t a = cand[i].a, b = cand[i].b;
+        const int ra = own_ref[a], rb = own_ref[b];
+        const int64_t ia = per_rank[(size_t)ra]++;
+        if (la) (*la)[(size_t)i] = (uint32_t)ia;
+        if (ra == me) mine.push_back({ b, a });
+        const int64_t ib = per_rank[(size_t)rb]++;
+        if (lb) (*lb)[(size_t)i] = (uint32_t)ib;
+        if (rb == me) mine.push_back({ a, b });
+    }
+}
+}
+// rank `rank`'s share of the align tasks of the candidate pairs under the reference-range partition (a pure function of
+// the pairs: what vg_lz_align_pairs_sharded lists before it launches; exported for tools and tests)
+extern "C" int vg_align_pairs_share(const vg_genomes* g, const vg_pair_count* cand, int64_t n_cand, int world, int rank,
+                                    vg_task** tasks_out, int64_t* n_tasks_out) {
+    VG_API_BEGIN
+    if (!g || (!cand && n_cand) || !tasks_out || !n_tasks_out || world < 1 || rank < 0 || rank >= world) throw vg_error(VG_EINVAL, "vg_align_pairs_share: bad arguments");
+    std::vector<int32_t> own_ref; std::vector<int64_t> per_rank; std::vector<vg_task> mine;
+    pairs_share(vg_genomes_count(g), cand, n_cand, world, rank, own_ref, nullptr, nullptr, per_rank, mine);
+    vg_task* o = (vg_task*)malloc(sizeof(vg_task) * std::max<size_t>(1, mine.size()));
+    if (!o) throw vg_error(VG_ENOMEM, "out of host memory");
+    if (!mine.empty()) memcpy(o, mine.data(), sizeof(vg_task) * mine.size());
+    *tasks_out = o; *n_tasks_out = (int64_t)mine.size();
+    VG_API_END
+}
+
 // ------------------------------------------------------------------ align, sharded, from the candidate PAIRS
 // vg_align_tasks + vg_lz_align_sharded in one call whose host work is off the critical path: a rank needs only ITS tasks to
 // start its kernels -- the genomes' task counts follow from the pairs (every pair is one task with r = a and one with
@@ -428,9 +470,9 @@ extern "C" int vg_lz_align_pairs_sharded(vg_genomes* g, const vg_pair_count* can
         return VG_OK;
     }
     const int W = c->world;
-    std::vector<int32_t> own_ref((size_t)n + 1, 0);
+    std::vector<int32_t> own_ref;
     std::vector<uint32_t> la((size_t)std::max<int64_t>(n_cand, 1)), lb((size_t)std::max<int64_t>(n_cand, 1)), perm((size_t)std::max<int64_t>(n_cand, 1));
-    std::vector<int64_t> per_rank((size_t)W, 0);
+    std::vector<int64_t> per_rank;
     std::vector<vg_pair_stat> send, all;
     int64_t pad = 1, nt = 0;
     vg_host_mark("align pairs: enter");
@@ -440,23 +482,8 @@ extern "C" int vg_lz_align_pairs_sharded(vg_genomes* g, const vg_pair_count* can
         int rc_list = VG_OK; std::string err_list;
         std::thread th([&] { rc_list = vg_align_tasks_perm(g, cand, n_cand, (vg_task**)&tasks_g.p, &nt, perm.data()); if (rc_list != VG_OK) err_list = vg_last_error(); });
         struct joiner { std::thread& t; ~joiner() { if (t.joinable()) t.join(); } } jn{ th };
-        // reference ranges with about equal task counts (the rule of vg_align_owner), from the pairs
-        std::vector<int64_t> per_ref((size_t)n + 1, 0);
-        for (int64_t i = 0; i < n_cand; ++i) {
-            if (cand[i].a >= (uint32_t)n || cand[i].b >= (uint32_t)n) throw vg_error(VG_EINVAL, "pair id out of range");
-            per_ref[cand[i].a]++; per_ref[cand[i].b]++;
-        }
-        int64_t before = 0;
-        for (int r = 0; r < n; ++r) { own_ref[(size_t)r] = n_tasks ? (int32_t)std::min<int64_t>(W - 1, before * W / n_tasks) : 0; before += per_ref[(size_t)r]; }
-        // every rank's task list in pair order (task r = a, then task r = b of a pair): the local index of both tasks of
-        // every pair on their owners, and this rank's own list
         std::vector<vg_task> mine;
-        for (int64_t i = 0; i < n_cand; ++i) {
-            const uint32_t a = cand[i].a, b = cand[i].b;
-            const int ra = own_ref[a], rb = own_ref[b];
-            la[(size_t)i] = (uint32_t)per_rank[(size_t)ra]++; if (ra == c->rank) mine.push_back({ b, a });
-            lb[(size_t)i] = (uint32_t)per_rank[(size_t)rb]++; if (rb == c->rank) mine.push_back({ a, b });
-        }
+        pairs_share(n, cand, n_cand, W, c->rank, own_ref, &la, &lb, per_rank, mine);
         vg_host_mark("align pairs: own tasks listed");
         std::vector<vg_pair_stat> my_stats(std::max<size_t>(1, mine.size()));
         check(vg_lz_align(g, mine.data(), (int64_t)mine.size(), p, my_stats.data(), nullptr, nullptr));

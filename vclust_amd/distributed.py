@@ -173,6 +173,16 @@ def prefilter_counts(gs, comm, k, fraction, min_shared=1):
     return sizes[:len(gs)], pairs
 
 
+def align_pairs_share(gs, cand, world, rank):
+    """Rank `rank`'s tasks of the candidate pairs under the reference-range partition (vg_align_pairs_share)."""
+    from . import _lib, api
+    lib = _lib.load()
+    cand = np.ascontiguousarray(cand, dtype=api.PAIR_DTYPE)
+    tp = C.POINTER(_lib.Task)(); nt = C.c_int64()
+    _lib.check(lib.vg_align_pairs_share(gs._h, cand.ctypes.data_as(C.POINTER(_lib.PairCount)), len(cand), int(world), int(rank), C.byref(tp), C.byref(nt)))
+    return api._take(tp, nt.value, api.TASK_DTYPE)
+
+
 def align_pairs(gs, cand, comm, lz=None):
     """Canonical task list and rows of the candidate pairs on every rank (vg_lz_align_pairs_sharded): a rank starts its
     kernels from the pairs alone, the task list of the whole set is assembled beside them."""
