@@ -275,6 +275,15 @@ def test_two_ranks_write_the_same_files(tmp_path):
     assert filecmp.cmp(f1, f2, shallow=False)
     assert filecmp.cmp(a1, a2, shallow=False)
     assert sorted(open(l1).read().splitlines()) == sorted(open(l2).read().splitlines())
+    # without --out-aln the ranks start from the candidate pairs (vg_lz_align_pairs_sharded), with and without a filter
+    a3, a4 = tmp_path / 'a3.tsv', tmp_path / 'a4.tsv'
+    p = _torchrun(2, VCLUST, 'align', '-i', FASTA_FILE, '-o', a3, '-v', '0')
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert filecmp.cmp(a1, a3, shallow=False)
+    assert run('align', '-i', FASTA_FILE, '-o', a4, '--filter', f1, '-v', '0').returncode == 0
+    p = _torchrun(2, VCLUST, 'align', '-i', FASTA_FILE, '-o', tmp_path / 'a5.tsv', '--filter', f2, '-v', '0')
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert filecmp.cmp(a4, tmp_path / 'a5.tsv', shallow=False)
 
 
 def test_two_ranks_align_from_pairs(tmp_path):

@@ -545,15 +545,24 @@ extern "C" int vg_align_sharded(const char* const* fasta_paths, int n_paths, con
     if (!fasta_paths || n_paths <= 0 || !out_path || !p || !c) throw vg_error(VG_EINVAL, "vg_align_sharded: null argument");
     genomes_guard gg;
     int rc = vg_genomes_load(fasta_paths, n_paths, p->is_multifasta, p->num_threads, &gg.g);
-    free_guard pairs, tasks, regions; int64_t np = 0, nt = 0, nr = 0;
-    if (rc == VG_OK) rc = vg_read_filter(gg.g, p->filter_path, p->filter_threshold, (vg_pair_count**)&pairs.p, &np);
-    if (rc == VG_OK) rc = vg_align_tasks(gg.g, (const vg_pair_count*)pairs.p, np, (vg_task**)&tasks.p, &nt);
-    agree(c, rc, "ingest / filter");
-    std::vector<vg_pair_stat> stats((size_t)std::max<int64_t>(1, nt));
+    free_guard pairs, tasks, regions, rows; int64_t np = 0, nt = 0, nr = 0;
     const bool want_aln = p->out_aln_path != nullptr;
-    check(vg_lz_align_sharded(gg.g, (const vg_task*)tasks.p, nt, &p->lz, c, stats.data(), want_aln ? (vg_region**)&regions.p : nullptr, &nr));
+    if (rc == VG_OK) rc = vg_read_filter(gg.g, p->filter_path, p->filter_threshold, (vg_pair_count**)&pairs.p, &np);
+    // without an alignment table the ranks start from the pairs (the canonical list is assembled beside the kernels)
+    if (rc == VG_OK && want_aln) rc = vg_align_tasks(gg.g, (const vg_pair_count*)pairs.p, np, (vg_task**)&tasks.p, &nt);
+    agree(c, rc, "ingest / filter");
+    std::vector<vg_pair_stat> stats_v;
+    const vg_pair_stat* stats = nullptr;
+    if (want_aln) {
+        stats_v.resize((size_t)std::max<int64_t>(1, nt));
+        check(vg_lz_align_sharded(gg.g, (const vg_task*)tasks.p, nt, &p->lz, c, stats_v.data(), (vg_region**)&regions.p, &nr));
+        stats = stats_v.data();
+    } else {
+        check(vg_lz_align_pairs_sharded(gg.g, (const vg_pair_count*)pairs.p, np, &p->lz, c, (vg_task**)&tasks.p, &nt, (vg_pair_stat**)&rows.p));
+        stats = (const vg_pair_stat*)rows.p;
+    }
     rc = VG_OK;
-    if (c->rank == 0) rc = vg_write_ani(gg.g, (const vg_task*)tasks.p, stats.data(), nt, (const vg_region*)regions.p, nr, out_path, p);
+    if (c->rank == 0) rc = vg_write_ani(gg.g, (const vg_task*)tasks.p, stats, nt, (const vg_region*)regions.p, nr, out_path, p);
     agree(c, rc, "ani.tsv writer");
     VG_API_END
 }
