@@ -225,7 +225,7 @@ k_kmer_gather(const uint64_t* __restrict__ stage, int stage_cap, const uint32_t*
         const uint32_t base = wave_base[ch << 2];
         const uint32_t cnt = wave_base[min<int64_t>((ch + 1) << 2, W)] - base;
         const uint64_t* src = stage + (size_t)ch * stage_cap;
-        for (uint32_t t = lane; t < cnt; t += 64) { keys[base + t] = src[t]; pos[base + t] = base + t; }
+        for (uint32_t t = lane; t < cnt; t += 64) { keys[base + t] = src[t]; if (pos) pos[base + t] = base + t; }
     }
 }
 
@@ -238,7 +238,7 @@ k_kmer_emit(kmer_args A, const unsigned long long* __restrict__ wave_mask, const
         uint32_t g;
         const uint64_t key = kmer_at(A, p, &g);
         const uint32_t c = wave_base[p >> 6] + (uint32_t)__popcll(m & ((1ULL << (p & 63)) - 1ULL));
-        keys[c] = key; pos[c] = c;                               // payload = compact index (row number)
+        keys[c] = key; if (pos) pos[c] = c;                      // payload = compact index (row number)
     }
 }
 
@@ -287,7 +287,7 @@ k_kmer_emit_sparse(kmer_args A, const unsigned long long* __restrict__ wave_mask
             uint32_t g;
             const uint64_t key = kmer_at(A, p, &g);
             const uint32_t c = bj + (uint32_t)r;
-            keys[c] = key; pos[c] = c;
+            keys[c] = key; if (pos) pos[c] = c;
         }
     }
 }
@@ -719,7 +719,7 @@ constexpr int BK_THREADS = 256;
 
 struct part_src {                        // where the elements of a partition level come from
     kmer_args A;                         // level 1, dense: padded base positions (k-mers computed on the fly)
-    const uint64_t* keys; const uint32_t* pos;      // level 1, compact: kept k-mers and their row numbers
+    const uint64_t* keys; const uint32_t* pos;      // level 1, compact: kept k-mers and their row numbers (pos == nullptr: the row number of an element is its index)
     const uint32_t* rec;                 // level 2: the level-1 records (w0, w1, pay), 12 bytes each
     int64_t n;                           // number of source slots (positions or elements)
     int k2;                              // key bits = 2k
@@ -788,7 +788,7 @@ __device__ __forceinline__ void load_tile(const part_src& S, int64_t t0, int64_t
             ok[j] = i < t_end;
             w0[j] = 0; w1[j] = 0; pay[j] = 0;
             if (ok[j]) {
-                if (SRC == SRC_ARRAYS) { key_words(S.keys[i], S.k2, &w0[j], &w1[j]); pay[j] = S.pos[i]; }
+                if (SRC == SRC_ARRAYS) { key_words(S.keys[i], S.k2, &w0[j], &w1[j]); pay[j] = S.pos ? S.pos[i] : (uint32_t)i; }
                 else { const uint32_t* r = S.rec + 3 * i; w0[j] = r[0]; w1[j] = r[1]; pay[j] = r[2]; }
             }
         }
@@ -814,7 +814,7 @@ __device__ __forceinline__ void fetch_tile(const part_src& S, int64_t t0, int64_
         for (int j = 0; j < PT_PER; ++j) {
             const int64_t i = t0 + (int64_t)j * PT_THREADS + threadIdx.x;
             if (i < t_end) {
-                if (SRC == SRC_ARRAYS) { __builtin_memcpy(&raw[3 * j], S.keys + i, 8); raw[3 * j + 2] = S.pos[i]; }
+                if (SRC == SRC_ARRAYS) { __builtin_memcpy(&raw[3 * j], S.keys + i, 8); raw[3 * j + 2] = S.pos ? S.pos[i] : (uint32_t)i; }
                 else __builtin_memcpy(&raw[3 * j], S.rec + 3 * i, 12);
             }
         }
@@ -2003,7 +2003,7 @@ static void run_extract_sort(vg_genomes* g, int k, double fraction, int shard, i
         if (total64 >= (1LL << 32) - 1) throw vg_error(VG_EOVERFLOW, "more than 2^32 k-mers in one shard: use more shards");
         nv = total; n_sort = (int64_t)total;
         const size_t na = (size_t)std::max<int64_t>(n_sort, 1);
-        keys_a.alloc(na); pos_a.alloc(na + 4);
+        keys_a.alloc(na); if (do_sort) pos_a.alloc(na + 4);        // (unsorted, a k-mer's row number is its index: the bucket pipeline needs no array for it)
         if (do_sort) { keys_b.alloc(na); pos_b.alloc(na); }         // the sort's outputs (the bucket pipeline sorts nothing)
         vg_host_mark("extract: counted");
         if (n_sort > 0 && !over) {
