@@ -96,6 +96,34 @@ def test_align_owner_partitions_by_reference():
     assert len(D.align_owner(tasks[:0], 300, 4)) == 0
 
 
+def test_align_pairs_share_is_the_owner_partition_of_the_task_list():
+    """vg_align_pairs_share (a rank's tasks straight from the candidate pairs, what vg_lz_align_pairs_sharded lists before
+    it launches) against vg_align_tasks + vg_align_owner: for every world size the ranks' shares are exactly the tasks the
+    canonical list assigns to them (no GPU: host functions on a set made from codes)."""
+    sys.path.insert(0, str(ROOT))
+    from vclust_amd import api, distributed as D
+    rng = np.random.default_rng(5)
+    n = 400
+    lens = rng.integers(30, 90, n)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    gs = api.GenomeSet.from_codes(rng.integers(0, 4, int(offsets[-1])).astype(np.uint8), offsets, ['g%d' % i for i in range(n)])
+    a = rng.integers(1, n, 3000); b = (rng.integers(0, n, 3000) ** 2 // n) % a                      # a > b, skewed partners
+    keys = np.unique(a.astype(np.int64) * n + b)
+    cand = np.zeros(len(keys), dtype=api.PAIR_DTYPE); cand['a'] = keys // n; cand['b'] = keys % n
+    tasks = gs.align_tasks(cand)
+    assert len(tasks) == 2 * len(cand)
+    for world in (1, 2, 3, 8):
+        owner = D.align_owner(tasks, n, world)
+        got_all = 0
+        for rank in range(world):
+            mine = D.align_pairs_share(gs, cand, world, rank)
+            want = tasks[owner == rank]
+            assert sorted(zip(mine['q'].tolist(), mine['r'].tolist())) == sorted(zip(want['q'].tolist(), want['r'].tolist())), (world, rank)
+            got_all += len(mine)
+        assert got_all == len(tasks)
+    assert len(D.align_pairs_share(gs, cand[:0], 4, 1)) == 0
+
+
 def test_single_rank_comm_needs_no_process_group():
     sys.path.insert(0, str(ROOT))
     from vclust_amd import distributed as D
