@@ -195,7 +195,10 @@ def main():
     else:
         dev = torch.device('cuda', local_rank)
     api.set_device(local_rank % api.device_count())
-    comm = D.make_comm(dist, dev)                   # built-in RCCL communicator of libvclust_gpu (callbacks over gloo in tests)
+    # N > 1 measures the RCCL path or nothing: the built-in communicator is created strictly (no silent fall-back to host
+    # all-gathers through torch.distributed; VCLUST_COMM / VCLUST_DIST_BACKEND=gloo override it for tests on one GPU)
+    kind = os.environ.get('VCLUST_COMM') or ('rccl-strict' if world > 1 and dist is not None and dist.get_backend() == 'nccl' else None)
+    comm = D.make_comm(dist, dev, kind=kind)
 
     wl = synth.WORKLOADS[args.workload]
     base_n = args.count if args.count is not None else (wl['n_families'] if wl['kind'] == 'families' else wl['n'])
@@ -253,7 +256,13 @@ def main():
     api.profile_enable(False)
     # every rank reports its own stage times (stderr, one line each) and rank 0 carries them in the JSON line: a
     # scaling run that goes wrong is diagnosable from its tail
+    xch = [e for e in prof if e['name'] == 'exchange']
     mine = dict(rank=rank, s_per_step=round(dt_local / args.steps, 6), pairs=state.get('n_pairs'),
+                comm=comm.kind, rccl_ranks=comm.rccl_ranks,
+                # RCCL collectives of this rank (HIP events around them on the library stream): ms, calls and bytes received per step
+                exchange=dict(ms_per_step=round(sum(e['total_ms'] for e in xch) / args.steps, 3),
+                              collectives_per_step=round(sum(e['launches'] for e in xch) / args.steps, 2),
+                              bytes_per_step=round(sum(e['bytes'] for e in xch) / args.steps)) if world > 1 or xch else None,
                 ms_per_step_by_scope={e['name']: round(e['total_ms'] / args.steps, 3) for e in prof})
     print(f'[bench rank {rank}/{world}] ' + json.dumps(mine), file=sys.stderr, flush=True)
     per_rank = [mine]
@@ -331,11 +340,13 @@ def main():
                 'workload': f'{desc}, k={args.k}, min-kmers={min_kmers}, min-ident={args.min_ident}, lz defaults',
                 'genomes': int(len(gs)), 'pairs_per_step': int(n_pairs), 'total_bases': int(lens.sum()),
                 'sha256': synth.sha256(codes, offsets) if len(codes) <= (1 << 33) else None,      # (the headline set: pinned in tests/golden/synth_sha256.json)
-                'parallelism': f'kmer-range x{world} prefilter, reference-range x{world} align',
+                'parallelism': f'kmer-range x{world} prefilter (bases scanned in {world} slices, kept masks all-to-all), reference-range x{world} align',
             },
             'roofline': roofline,
             'cpu_baseline': cpu,
             'cli_wall': e2e,
+            'comm': dict(kind=comm.kind, rccl_ranks=comm.rccl_ranks, strict=(kind == 'rccl-strict'),
+                         backend=(dist.get_backend() if dist is not None else None)) if world > 1 else None,
             'per_rank': per_rank if world > 1 else None,
         }
         if cpu:

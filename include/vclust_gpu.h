@@ -160,6 +160,12 @@ void vg_set_index_budget(int64_t bytes);
  * into sub-shards of the k-mer range automatically -- the role of `--batch-size` in the
  * reference (vclust.py:229-239, 1403-1442); n > 0 forces that many sub-shards (tests), 0 = automatic. */
 void vg_set_subshards(int n);
+/* How one RANGE shard call of vg_kmer_shared (shard / n_shards, sets below 2^32 bases) obtains its kept k-mers:
+ * 0 (default) = it scans every base of the set itself; 1 = the sliced scan of the multi-GPU path (rank `shard` scans 1/n_shards
+ * of the bases and receives the kept masks and level-1 counts of its k-mer range from the others) with the peers' slices
+ * computed by this process: one GPU stands in for the world (tools/strong_scaling_sim.py, tests).  Results are identical.
+ * vg_kmer_shared_sharded always exchanges when the sliced scan applies; no reference call site (kmer-db is one process). */
+void vg_set_range_scan(int mode);
 
 typedef struct {            /* mirrors the align sub-parser and cmd_lzani, vclust.py:290-421, 1142-1181 */
     vg_lz_params lz;
@@ -195,13 +201,19 @@ int  vg_comm_create(int rank, int world, vg_allgather_fn allgather, void* ctx, v
 int  vg_rccl_unique_id(void* out /* >= 128 bytes */, int64_t bytes);
 int  vg_comm_rccl_create(int rank, int world, const void* unique_id, int64_t id_bytes, vg_comm** out);
 void vg_comm_free(vg_comm* c);
+/* 1 = built-in RCCL communicator, 0 = callback communicator; the number of ranks RCCL itself reports for the communicator
+ * (ncclCommCount; -1 when it is not an RCCL communicator): a scaling record states which exchange it measured */
+int  vg_comm_kind(const vg_comm* c);
+int  vg_comm_rccl_ranks(const vg_comm* c);
 int  vg_comm_rank(const vg_comm* c);
 int  vg_comm_world(const vg_comm* c);
 /* exchange self-test: every rank sends a pattern of `bytes` bytes and checks what it receives (no GPU needed
  * for a callback communicator over host memory) */
 int  vg_comm_selftest(const vg_comm* c, int64_t bytes);
 /* vg_kmer_shared over all ranks: rank r counts the k-mers of range r and keeps its partial (a, b, count)
- * list in HBM.  Exchanged: the set sizes, the KEYS of the pairs a rank holds >= ceil(min_shared / world) of (a pair
+ * list in HBM.  Sets below 2^32 bases (RANGE shards, two partition levels): every rank scans 1/world of the BASES and an
+ * all-to-all (RCCL: grouped ncclSend / ncclRecv, one xGMI link per peer) hands each rank the kept-k-mer masks (one bit per
+ * base) and level-1 counts of its own range -- no rank computes a k-mer it does not keep or forward.  Exchanged after that: the set sizes, the KEYS of the pairs a rank holds >= ceil(min_shared / world) of (a pair
  * that reaches min_shared in total has that many on some rank), and every rank's count for each pair of the union of
  * those keys; the counts are summed and the threshold is applied to the SUM.  Every rank receives the global result,
  * sorted by (a, b); device-to-device all-gathers only. */

@@ -39,6 +39,22 @@ res["nodev_rc"] = rc; res["nodev_msg"] = lib.vg_last_error().decode()
 p = api.align_params(api.ALIGN_FIELDS[:11])
 rc = lib.vg_align_sharded(arr, 1, os.fsencode(os.environ["VOUT"] + ".ani"), C.byref(p), comm.h)
 res["align_rc"] = rc
+# a set large enough for the sliced k-mer scan (two partition levels: the ranks would exchange kept masks): the agreement in
+# front of that exchange is paired by ranks that never reach it (here: both, there is no device), nobody hangs
+import numpy as np
+rng = np.random.default_rng(7)
+lens = np.full(300, 10000); offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+gs = api.GenomeSet.from_codes(rng.integers(0, 4, int(offs[-1])).astype(np.uint8), offs, None)
+try:
+    D.prefilter_counts(gs, comm, 25, 1.0, min_shared=20); res["sliced_rc"] = 0
+except _lib.VclustGpuError as e:
+    res["sliced_rc"] = e.code; res["sliced_msg"] = str(e)
+res["comm"] = comm.describe()
+# the strict form of the built-in RCCL communicator: no device here, so creation fails on every rank and every rank raises
+try:
+    D.make_comm(dist, device, kind="rccl-strict"); res["strict"] = "created"
+except RuntimeError as e:
+    res["strict"] = str(e)
 json.dump(res, open(os.environ["VOUT"] + f".{rank}.json", "w"))
 comm.close()
 dist.barrier()
@@ -65,6 +81,9 @@ def test_two_ranks_comm_and_failure_agreement(tmp_path, golden_dir):
         assert got[r]['ingest_rc'] != 0 and 'rank 1 failed' in got[r]['ingest_msg']     # the same verdict on both ranks
         assert got[r]['nodev_rc'] == -3 and 'no HIP device' in got[r]['nodev_msg'] or got[r]['nodev_rc'] != 0
         assert got[r]['align_rc'] != 0
+        assert got[r]['sliced_rc'] == -3, got[r]
+        assert got[r]['comm'] == dict(comm='callback', rccl_ranks=None, rank=r, world=2)
+        assert 'rccl-strict' in got[r]['strict'] and 'not falling back' in got[r]['strict']
     assert got[0]['ingest_rc'] == got[1]['ingest_rc'] and got[0]['nodev_rc'] == got[1]['nodev_rc']
     assert not os.path.exists(f'{out}.fltr')
 

@@ -314,6 +314,37 @@ comm.close(); dist.destroy_process_group()
     assert p.returncode == 0 and p.stdout.count('pairs ok rank') == 2, (p.stdout[-500:], p.stderr[:3000])
 
 
+@pytest.mark.parametrize('nproc', [2, 3])
+def test_ranks_exchange_kept_masks(tmp_path, nproc):
+    """vg_kmer_shared_sharded on a set with two partition levels (4.5 M bases): every rank scans 1/world of the bases and the
+    kept masks + level-1 counts travel (here: the all-to-all emulated over the callback communicator's all-gather, ranks
+    sharing the one GPU).  Every rank receives the sizes and pairs of the single-process pass."""
+    script = tmp_path / 'mask_exchange.py'
+    script.write_text("""
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+from vclust_amd import api, synth, distributed as D
+dist, dev = D.init_process_group()
+api.set_device(0)
+comm = D.make_comm(dist, dev)
+codes, offsets, names = synth.make_families(100, 5, length=9000, seed=31)
+gs = api.GenomeSet.from_codes(codes, offsets, names)
+api.profile_enable(True); api.profile_reset()
+sizes, pairs = D.prefilter_counts(gs, comm, 25, 1.0, min_shared=20)
+scopes = {e['name'] for e in api.profile_get()}
+api.profile_enable(False)
+s0, p0 = gs.kmer_shared(k=25, min_shared=20)
+p0 = np.sort(p0, order=['a', 'b'])
+assert 'kmer_slice_scan' in scopes, scopes
+assert np.array_equal(sizes, s0) and np.array_equal(pairs, p0) and len(p0) > 500, (len(pairs), len(p0))
+print('masks ok rank', dist.get_rank(), flush=True)
+comm.close(); dist.destroy_process_group()
+""" % str(ROOT))
+    p = _torchrun(nproc, script)
+    assert p.returncode == 0 and p.stdout.count('masks ok rank') == nproc, (p.stdout[-500:], p.stderr[:3000])
+
+
 def test_rccl_failure_falls_back_to_the_callback_communicator(tmp_path):
     """Two ranks on the ONE GPU of the test box ask for the built-in RCCL communicator: RCCL refuses a device twice, every
     rank agrees on the failure before any further collective, and all fall back to the callback communicator -- the

@@ -173,6 +173,34 @@ def test_bucket_pipeline_key_widths(k):
         assert list(tot) == list(osizes) and acc == opairs
 
 
+@pytest.mark.parametrize('world', [2, 3, 8])
+def test_sliced_scan_equals_the_replicated_scan(world):
+    """The multi-GPU form of a RANGE shard (k_slice_scan: rank r scans 1/world of the BASES, the kept masks and level-1
+    counts of every rank's k-mer range travel to it) with the peers' slices computed by this process: the pairs of every
+    rank are exactly those of the replicated scan, and the ranks' partial set sizes and counts add up to the oracle's.
+    4.5 M bases: two partition levels, a last super-tile that is not full, digit ranges that do not divide 2 048 at 3."""
+    codes, offsets, names = synth.make_families(100, 5, length=9000, seed=31)
+    gs = api.GenomeSet.from_codes(codes, offsets, names)
+    osizes, opairs = orc.shared_all(codes, offsets, k=25)
+    tot = np.zeros(len(gs), dtype=np.int64); acc = {}
+    for r in range(world):
+        sz0, pr0 = gs.kmer_shared(k=25, shard=r, n_shards=world)
+        api.set_range_scan(1)
+        try:
+            api.profile_enable(True); api.profile_reset()
+            sz1, pr1 = gs.kmer_shared(k=25, shard=r, n_shards=world)
+            scopes = {e['name']: e for e in api.profile_get()}
+        finally:
+            api.profile_enable(False); api.set_range_scan(0)
+        assert scopes['emulated_peer_scan']['launches'] == world - 1
+        key = lambda pr: sorted((int(p['a']), int(p['b']), int(p['shared'])) for p in pr)
+        assert key(pr0) == key(pr1) and len(pr1) > 0
+        tot += sz1
+        for p in pr1:
+            acc[(int(p['a']), int(p['b']))] = acc.get((int(p['a']), int(p['b'])), 0) + int(p['shared'])
+    assert list(tot) == list(osizes) and acc == opairs
+
+
 def test_bucket_pipeline_large_buckets():
     """200 near-identical genomes: every k-mer is shared by ~200 of them, so some final buckets exceed the 1 536
     entries of the ordinary bucket kernel; exactly those are queued for the 6 144-entry variant (still the own

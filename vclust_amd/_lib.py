@@ -96,6 +96,7 @@ SYMBOLS = {
     'vg_lz_prepare': (C.c_int, [C.c_void_p, P(PairCount), C.c_int64, P(LzParams)]),
     'vg_set_index_budget': (None, [C.c_int64]),
     'vg_set_subshards': (None, [C.c_int]),
+    'vg_set_range_scan': (None, [C.c_int]),
     'vg_write_ani': (C.c_int, [C.c_void_p, P(Task), P(PairStat), C.c_int64, P(Region), C.c_int64,
                                C.c_char_p, P(AlignParams)]),
     'vg_align': (C.c_int, [P(C.c_char_p), C.c_int, C.c_char_p, P(AlignParams)]),
@@ -103,6 +104,8 @@ SYMBOLS = {
     'vg_rccl_unique_id': (C.c_int, [C.c_void_p, C.c_int64]),
     'vg_comm_rccl_create': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int64, P(C.c_void_p)]),
     'vg_comm_free': (None, [C.c_void_p]),
+    'vg_comm_kind': (C.c_int, [C.c_void_p]),
+    'vg_comm_rccl_ranks': (C.c_int, [C.c_void_p]),
     'vg_comm_rank': (C.c_int, [C.c_void_p]),
     'vg_comm_world': (C.c_int, [C.c_void_p]),
     'vg_comm_selftest': (C.c_int, [C.c_void_p, C.c_int64]),

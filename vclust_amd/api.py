@@ -232,6 +232,12 @@ class GenomeSet:
 from .stages import align, align_params, prefilter  # noqa: E402,F401
 
 
+def set_range_scan(mode):
+    """0 = a RANGE shard call scans every base itself; 1 = the sliced scan of the multi-GPU path with the peers' slices
+    computed by this process (vg_set_range_scan)."""
+    _lib.load().vg_set_range_scan(int(mode))
+
+
 def release_device_memory():
     _lib.load().vg_release_device_memory()
 

@@ -126,9 +126,23 @@ void vg_lz_drop_prepared(const vg_genomes* g);    // forget the index plan vg_lz
 
 // vg_genomes_load with the upload to the library's device overlapped with the packing (vg_genomes.cpp; whole-stage calls)
 int vg_genomes_load_resident(const char* const* paths, int n_paths, int multisample, int n_threads, vg_genomes** out);
+// RANGE shards held by several ranks (vg_prefilter.hip, k_slice_scan): every rank scans 1/world of the BASES and the kept
+// masks + level-1 counts of each rank's digit range travel to it.  The exchange is an all-to-all of device memory:
+// for every part, block d of `send` (bytes send_off[d] .. send_off[d + 1]) goes to rank d and block s of `recv` (bytes
+// recv_off[s] .. recv_off[s + 1]) arrives from rank s.  `status` is the caller's status so far: the implementation
+// agrees on it with all ranks BEFORE anything travels and throws on every rank when one of them failed.
+struct vg_xpart { const void* send; const int64_t* send_off; void* recv; const int64_t* recv_off; };
+struct vg_slice_exchange {
+    int rank = 0, world = 1;
+    bool emulate = false;       // developer / tests: no peers -- their slices are scanned by this process (one GPU stands in for `world`)
+    std::function<void(int status, const vg_xpart* parts, int n_parts)> alltoallv;
+    bool agreed = false;        // the agreement in front of the exchange has taken place (the failure handling of the caller pairs it otherwise)
+};
+// whether a shard pass of (g, k, fraction) over `world` ranks takes the sliced scan: a pure function of its arguments
+bool vg_slice_exchange_applies(const vg_genomes* g, int k, double fraction, int world);
 // one k-mer range shard of vg_kmer_shared with the (a, b, shared) records left in HBM (vg_prefilter.hip; used by vg_dist.hip)
 void vg_kmer_shared_device(vg_genomes* g, int k, double fraction, int shard, int n_shards, uint32_t min_shared,
-                           int64_t* set_sizes, dbuf<vg_pair_count>& pairs, int64_t* n_pairs);
+                           int64_t* set_sizes, dbuf<vg_pair_count>& pairs, int64_t* n_pairs, vg_slice_exchange* xs = nullptr);
 
 // ---------------------------------------------------------------- host threads
 // fn(lo, hi, t) over [0, n) cut into contiguous chunks, one per thread (the library's host loops over

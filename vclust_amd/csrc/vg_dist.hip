@@ -38,6 +38,11 @@ ncclResult_t ncclGetUniqueId(ncclUniqueId* uniqueId);
 ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId commId, int rank);
 ncclResult_t ncclCommDestroy(ncclComm_t comm);
 ncclResult_t ncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcount, ncclDataType_t datatype, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclSend(const void* sendbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclRecv(void* recvbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclGroupStart();
+ncclResult_t ncclGroupEnd();
+ncclResult_t ncclCommCount(const ncclComm_t comm, int* count);
 }
 #endif
 #include <dlfcn.h>
@@ -56,6 +61,11 @@ struct vg_comm {
     void* nccl_lib = nullptr; ncclComm_t nccl_comm = nullptr;
     decltype(&ncclAllGather) p_allgather = nullptr;
     decltype(&ncclCommDestroy) p_destroy = nullptr;
+    // the all-to-all of the sliced k-mer scan (vg_slice_exchange): grouped point-to-point transfers, one per peer and
+    // direction -- on xGMI every pair of GPUs has its own link, so the seven transfers of a rank run side by side
+    decltype(&ncclSend) p_send = nullptr; decltype(&ncclRecv) p_recv = nullptr;
+    decltype(&ncclGroupStart) p_group_start = nullptr; decltype(&ncclGroupEnd) p_group_end = nullptr;
+    decltype(&ncclCommCount) p_count = nullptr;
     // HBM staging of host gathers over RCCL: reserved inside guarded sections, so that an allocation failure is
     // agreed on like any other instead of striking between an agreement and its exchange
     mutable dbuf<char> st_send, st_recv;
@@ -115,6 +125,58 @@ template <class F> void guarded(const vg_comm* c, const char* what, F fn) {
     catch (const std::bad_alloc&) { vg_set_error("out of host memory"); rc = VG_ENOMEM; }
     catch (const std::exception& e) { vg_set_error("%s", e.what()); rc = VG_EINVAL; }
     agree(c, rc, what);
+}
+
+// all-to-all of DEVICE memory (vg_xpart: block d of send -> rank d, block s of recv <- rank s), after the agreement on
+// `status`.  RCCL: one group of ncclSend / ncclRecv per peer; a callback communicator has only its all-gather, so every
+// rank contributes its whole send buffer (padded to the largest) and picks its blocks -- world x the traffic, which is
+// what the CPU / one-GPU tests of the protocol can afford and nothing else uses.
+void alltoallv_device(const vg_comm* c, const vg_xpart* parts, int n_parts, bool self_through_rccl_always = false) {
+    hipStream_t s = vg_stream();
+    const int W = c->world, me = c->rank;
+    if (c->p_allgather) {
+        if (!c->p_send || !c->p_recv || !c->p_group_start || !c->p_group_end) throw vg_error(VG_EIO, "librccl lacks ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd");
+        double bytes = 0;
+        for (int i = 0; i < n_parts; ++i) bytes += (double)(parts[i].recv_off[W] - parts[i].recv_off[0]);
+        vg_prof_scope ps("exchange", bytes);
+        const bool self_through_rccl = self_through_rccl_always || (c->force && W == 1);      // (the self-test, VG_DIST_FORCE with one rank: the point-to-point entry points are exercised on a one-GPU box)
+        if (c->p_group_start() != ncclSuccess) throw vg_error(VG_EIO, "ncclGroupStart failed");
+        bool ok = true;
+        for (int i = 0; i < n_parts && ok; ++i) for (int r = 0; r < W && ok; ++r) {
+            const vg_xpart& x = parts[i];
+            const int64_t sb = x.send_off[r + 1] - x.send_off[r], rb = x.recv_off[r + 1] - x.recv_off[r];
+            if (r == me && !self_through_rccl) continue;
+            if (sb > 0) ok = c->p_send((const char*)x.send + x.send_off[r], (size_t)sb, ncclChar, r, c->nccl_comm, s) == ncclSuccess;
+            if (ok && rb > 0) ok = c->p_recv((char*)x.recv + x.recv_off[r], (size_t)rb, ncclChar, r, c->nccl_comm, s) == ncclSuccess;
+        }
+        const bool ended = c->p_group_end() == ncclSuccess;
+        if (!ok || !ended) throw vg_error(VG_EIO, "ncclSend / ncclRecv failed");
+        if (!self_through_rccl) for (int i = 0; i < n_parts; ++i) {
+            const vg_xpart& x = parts[i];
+            const int64_t sb = x.send_off[me + 1] - x.send_off[me];
+            if (sb != x.recv_off[me + 1] - x.recv_off[me]) throw vg_error(VG_EINVAL, "vg_comm: a rank's own block has two sizes");
+            if (sb > 0) VG_HIP(hipMemcpyAsync((char*)x.recv + x.recv_off[me], (const char*)x.send + x.send_off[me], (size_t)sb, hipMemcpyDeviceToDevice, s));
+        }
+        return;
+    }
+    for (int i = 0; i < n_parts; ++i) {
+        const vg_xpart& x = parts[i];
+        // every rank's block layout, then every rank's send buffer
+        std::vector<int64_t> all_off((size_t)(W + 1) * W);
+        gather_host(c, x.send_off, all_off.data(), (int64_t)sizeof(int64_t) * (W + 1));
+        int64_t pad = 64; for (int r = 0; r < W; ++r) pad = std::max(pad, all_off[(size_t)r * (W + 1) + W] - all_off[(size_t)r * (W + 1)]);
+        dbuf<char> d_send((size_t)pad), d_all((size_t)pad * W);
+        const int64_t mine = x.send_off[W] - x.send_off[0];
+        if (mine > 0) VG_HIP(hipMemcpyAsync(d_send.p, (const char*)x.send + x.send_off[0], (size_t)mine, hipMemcpyDeviceToDevice, s));
+        gather_device(c, d_send.p, d_all.p, pad);
+        for (int r = 0; r < W; ++r) {
+            const int64_t* off = &all_off[(size_t)r * (W + 1)];
+            const int64_t b = off[me + 1] - off[me];
+            if (b != x.recv_off[r + 1] - x.recv_off[r]) throw vg_error(VG_EINVAL, "vg_comm: sender and receiver disagree on a block size");
+            if (b > 0) VG_HIP(hipMemcpyAsync((char*)x.recv + x.recv_off[r], d_all.p + (size_t)r * pad + (off[me] - off[0]), (size_t)b, hipMemcpyDeviceToDevice, s));
+        }
+        VG_HIP(hipStreamSynchronize(s));                              // the staging buffers go out of scope
+    }
 }
 
 inline int dgrid(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 4096)); }
@@ -211,6 +273,9 @@ extern "C" int vg_comm_rccl_create(int rank, int world, const void* unique_id, i
     ncclComm_t comm = nullptr;
     if (init(&comm, world, id, rank) != ncclSuccess) throw vg_error(VG_EIO, "ncclCommInitRank failed");
     vg_comm* c = new vg_comm; c->rank = rank; c->world = world; c->nccl_lib = h; c->nccl_comm = comm; c->p_allgather = ag; c->p_destroy = destroy; c->force = env_force();
+    c->p_send = (decltype(&ncclSend))dlsym(h, "ncclSend"); c->p_recv = (decltype(&ncclRecv))dlsym(h, "ncclRecv");
+    c->p_group_start = (decltype(&ncclGroupStart))dlsym(h, "ncclGroupStart"); c->p_group_end = (decltype(&ncclGroupEnd))dlsym(h, "ncclGroupEnd");
+    c->p_count = (decltype(&ncclCommCount))dlsym(h, "ncclCommCount");
     reserve_staging(c, 1 << 16);                    // status words and counts never allocate
     *out = c;
     VG_API_END
@@ -221,6 +286,14 @@ extern "C" void vg_comm_free(vg_comm* c) {
     if (c->nccl_comm && c->p_destroy) { (void)hipDeviceSynchronize(); (void)c->p_destroy(c->nccl_comm); }
     c->st_send.release(); c->st_recv.release();
     delete c;
+}
+// 1 = the built-in RCCL communicator, 0 = a callback communicator; the rank count RCCL itself reports for it (ncclCommCount;
+// -1: not an RCCL communicator, or the query failed): what a scaling record needs to say which exchange it measured
+extern "C" int vg_comm_kind(const vg_comm* c) { return c && c->p_allgather ? 1 : 0; }
+extern "C" int vg_comm_rccl_ranks(const vg_comm* c) {
+    int n = -1;
+    if (!c || !c->nccl_comm || !c->p_count || c->p_count(c->nccl_comm, &n) != ncclSuccess) return -1;
+    return n;
 }
 extern "C" int vg_comm_rank(const vg_comm* c) { return c ? c->rank : 0; }
 extern "C" int vg_comm_world(const vg_comm* c) { return c ? c->world : 1; }
@@ -236,6 +309,28 @@ extern "C" int vg_comm_selftest(const vg_comm* c, int64_t bytes) {
     for (int r = 0; r < c->world; ++r) for (int64_t i = 0; i < bytes; ++i)
         if (recv[(size_t)(r * bytes + i)] != (uint8_t)(i * 131 + r * 17 + 3)) throw vg_error(VG_EIO, "vg_comm_selftest: wrong data from rank " + std::to_string(r));
     agree(c, 0, "vg_comm_selftest");
+    if (c->p_allgather) {
+        // the built-in communicator also carries the all-to-all of the sliced k-mer scan (grouped ncclSend / ncclRecv):
+        // blocks of unequal sizes between every pair of ranks, a rank's own block through RCCL too, checked on arrival
+        const int W = c->world;
+        auto blk = [&](int from, int to) { return (int64_t)(1000 + 37 * from + 11 * to); };
+        std::vector<int64_t> soff((size_t)W + 1, 0), roff((size_t)W + 1, 0);
+        for (int r = 0; r < W; ++r) { soff[(size_t)r + 1] = soff[(size_t)r] + blk(c->rank, r); roff[(size_t)r + 1] = roff[(size_t)r] + blk(r, c->rank); }
+        std::vector<uint8_t> hs((size_t)soff[(size_t)W]), hr((size_t)roff[(size_t)W]);
+        for (int r = 0; r < W; ++r) for (int64_t i = 0; i < blk(c->rank, r); ++i) hs[(size_t)(soff[(size_t)r] + i)] = (uint8_t)(i * 7 + c->rank * 29 + r * 3 + 1);
+        int rc = VG_OK;
+        try {
+            dbuf<uint8_t> ds(hs.size()), dr(hr.size());
+            hipStream_t s = vg_stream();
+            ds.upload(hs.data(), hs.size(), s);
+            const vg_xpart part{ ds.p, soff.data(), dr.p, roff.data() };
+            alltoallv_device(c, &part, 1, true);
+            dr.download(hr.data(), hr.size(), s); VG_HIP(hipStreamSynchronize(s));
+            for (int r = 0; r < W; ++r) for (int64_t i = 0; i < blk(r, c->rank); ++i)
+                if (hr[(size_t)(roff[(size_t)r] + i)] != (uint8_t)(i * 7 + r * 29 + c->rank * 3 + 1)) throw vg_error(VG_EIO, "vg_comm_selftest: wrong all-to-all block from rank " + std::to_string(r));
+        } catch (const vg_error& e) { vg_set_error("%s", e.what()); rc = e.code; }
+        agree(c, rc, "vg_comm_selftest all-to-all");
+    }
     VG_API_END
 }
 
@@ -278,8 +373,22 @@ extern "C" int vg_kmer_shared_sharded(vg_genomes* g, int k, double fraction, uin
     dbuf<uint64_t> d_nom, lk, lk2; dbuf<uint32_t> lv, lv2; dbuf<unsigned long long> d_cur(1);
     unsigned long long n_nom = 0;
     const uint32_t thr = (min_shared + (uint32_t)W - 1) / (uint32_t)W;        // pigeonhole: some rank holds >= ceil(T / W) of a pair that reaches T
+    // RANGE shards: every rank scans 1/W of the bases, kept masks and level-1 counts travel (k_slice_scan); the agreement
+    // in front of that exchange is paired below by a rank that never reaches it
+    vg_slice_exchange xs; xs.rank = c->rank; xs.world = W;
+    const bool sliced = W > 1 && vg_slice_exchange_applies(g, k, fraction, W);
+    xs.alltoallv = [&](int status, const vg_xpart* parts, int n_parts) {
+        xs.agreed = true;
+        agree(c, status, "prefilter scan");
+        alltoallv_device(c, parts, n_parts);
+    };
     guarded(c, "prefilter shard", [&] {
-        vg_kmer_shared_device(g, k, fraction, c->rank, W, 1u, part_sizes.data(), d_loc, &n_loc);
+        try { vg_kmer_shared_device(g, k, fraction, c->rank, W, 1u, part_sizes.data(), d_loc, &n_loc, sliced ? &xs : nullptr); }
+        catch (...) {
+            if (sliced && !xs.agreed) { xs.agreed = true; try { agree(c, VG_EINVAL, "prefilter scan"); } catch (...) {} }
+            throw;
+        }
+        if (sliced && !xs.agreed) { xs.agreed = true; agree(c, VG_OK, "prefilter scan"); }
         // nominations, and this rank's records sorted by key for the lookups of step 3
         d_nom.alloc((size_t)std::max<int64_t>(n_loc, 1)); d_cur.zero(s);
         lk.alloc((size_t)std::max<int64_t>(n_loc, 1)); lk2.alloc(lk.n); lv.alloc(lk.n); lv2.alloc(lk.n);

@@ -11,6 +11,7 @@
 // reads of the short genome lists of shared k-mers in the SpGEMM.
 #include "vg_common.h"
 #include <functional>
+#include <optional>
 #include <rocprim/rocprim.hpp>
 #include <algorithm>
 #include <cmath>
@@ -921,6 +922,115 @@ k_part_count(part_src S, int B1, int nb /* level-1 buckets of this pass */, int 
         for (int b = threadIdx.x; b < nb; b += PT_THREADS) T[st * nb + b] = hist[b];      // [super-tile][bucket]: one contiguous row
         __syncthreads();
     }
+}
+
+// ---- RANGE shards of SEVERAL RANKS: the scan of the bases is cut by POSITION, the kept masks travel.
+// k_part_count<.., RANGE> computes the k-mer of every base of the set on every rank to keep 1/world of them (8.3 of the
+// 27.6 ms of a rank's prefilter at eight ranks over 100 k genomes).  Here rank r scans only the super-tiles
+// [st_lo, st_hi) -- 1/world of the bases -- and sorts what it finds by the rank that OWNS the k-mer's level-1 digit:
+//   * one kept bit per position and owner: mask block d = the 64-position words of this rank's slice with the bits of
+//     the positions whose k-mer belongs to rank d (every valid position has exactly one owner);
+//   * the level-1 counts [super-tile of the slice][digit], cut into the owners' digit ranges: table block d.
+// An all-to-all hands every rank the blocks of its own digit range from all slices (vg_slice_exchange): concatenated in
+// slice order they ARE the wave_mask and the level-1 table k_part_count<.., RANGE> would have produced.  Per rank
+// 1/world of the k-mer arithmetic, and P / 8 bytes of masks + the table received whatever the world is.
+// Needs the level-1 digit to be the shard digit (two partition levels: B1 = DIG_BITS).
+constexpr int SX_MAX_WORLD = 32;
+struct slice_plan {
+    int world;
+    int64_t st_lo, st_hi;                   // this rank's super-tiles
+    int64_t word_lo, words;                 // its 64-position words: first, count (block d of the masks starts at d * words)
+    unsigned long long* mask;               // send masks
+    uint32_t* T;                            // send tables: block d at T + t_off[d], [st - st_lo][dig_lo[d + 1] - dig_lo[d]]
+    int64_t t_off[SX_MAX_WORLD];
+    uint32_t dig_lo[SX_MAX_WORLD + 1];      // first digit of every rank's range, and 1 << DIG_BITS
+};
+// owner of level-1 digit b: the largest d with floor(d * 2^11 / world) <= b
+__device__ __forceinline__ uint32_t digit_owner(uint32_t b, uint32_t world) { return ((b + 1u) * world - 1u) >> DIG_BITS; }
+
+template <int KC>
+__global__ void __launch_bounds__(PT_THREADS)
+k_slice_scan(part_src S, slice_plan X, int st_tiles, int* __restrict__ kept_per_genome) {
+    if (KC > 0) { S.A.k = KC; S.k2 = 2 * KC; S.A.use_frac = 0; }
+    S.A.n_shards = 1; S.A.dig_lo = 0; S.A.dig_n = 1u << DIG_BITS;      // every k-mer of the slice is computed; its owner is found below
+    __shared__ uint32_t hist[1 << DIG_BITS];
+    // per wave and group q of the tile: one 32-position word per owner and eighth of the wave's 256 positions
+    extern __shared__ uint32_t s_m[];                                   // [16 waves][PT_PER / 4][world][8]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t world = (uint32_t)X.world;
+    const int64_t W_total = S.n >> 6;
+    for (int i = threadIdx.x; i < 16 * (PT_PER / 4) * (int)world * 8; i += PT_THREADS) s_m[i] = 0;
+    for (int64_t st = X.st_lo + blockIdx.x; st < X.st_hi; st += gridDim.x) {
+        for (int b = threadIdx.x; b < (1 << DIG_BITS); b += PT_THREADS) hist[b] = 0;
+        __syncthreads();
+        const int64_t s0 = st * st_tiles * PT_TILE, s1 = min(S.n, s0 + (int64_t)st_tiles * PT_TILE);
+        uint32_t raw[PT_RAW], gq[PT_PER / 4];
+#pragma unroll
+        for (int i = 0; i < PT_RAW; ++i) raw[i] = 0;
+        auto fetch_genomes = [&](int64_t t0) {
+#pragma unroll
+            for (int q = 0; q < PT_PER / 4; ++q) {
+                const int64_t p0 = t0 + ((int64_t)q * PT_THREADS + threadIdx.x) * 4;
+                gq[q] = p0 < s1 ? S.A.blk2g[p0 >> S.A.blk_shift] : 0u;
+            }
+        };
+        fetch_tile<SRC_DENSE>(S, s0, s1, raw); fetch_genomes(s0);
+        for (int64_t t0 = s0; t0 < s1; t0 += PT_TILE) {
+            uint32_t w0[PT_PER], w1[PT_PER], pay[PT_PER], g4[PT_PER / 4]; bool ok[PT_PER];
+            decode_tile<SRC_DENSE>(S, t0, s1, raw, w0, w1, pay, ok);
+#pragma unroll
+            for (int q = 0; q < PT_PER / 4; ++q) g4[q] = gq[q];
+            if (t0 + PT_TILE < s1) { fetch_tile<SRC_DENSE>(S, t0 + PT_TILE, s1, raw); fetch_genomes(t0 + PT_TILE); }
+#pragma unroll
+            for (int q = 0; q < PT_PER / 4; ++q) {
+                uint32_t* sm = s_m + (size_t)((wv * (PT_PER / 4) + q) * (int)world) * 8;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (ok[4 * q + j]) {
+                    const uint32_t b = w0[4 * q + j] >> (32 - DIG_BITS);
+                    atomicAdd(&hist[b], 1u);
+                    atomicOr(&sm[digit_owner(b, world) * 8u + (uint32_t)(lane >> 3)], 1u << (4 * (lane & 7) + j));
+                }
+            }
+            // the wave's own words leave (and are cleared) without a workgroup barrier: LDS operations of one wave complete in order
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int q = 0; q < PT_PER / 4; ++q) {
+                uint32_t* sm = s_m + (size_t)((wv * (PT_PER / 4) + q) * (int)world) * 8;
+                const int64_t wfirst = (t0 + ((int64_t)q * PT_THREADS + (threadIdx.x & ~63u)) * 4) >> 6;      // first of the wave's four 64-position words
+                for (int i = lane; i < (int)world * 8; i += 64) {
+                    const uint32_t v = sm[i]; sm[i] = 0u;
+                    const int d = i >> 3, wd = i & 7;
+                    if (wfirst + (wd >> 1) < W_total)
+                        reinterpret_cast<uint32_t*>(X.mask)[((int64_t)d * X.words + (wfirst - X.word_lo)) * 2 + wd] = v;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (kept_per_genome) {
+#pragma unroll
+                for (int q = 0; q < PT_PER / 4; ++q) {
+                    const uint32_t g = g4[q]; const uint32_t g0 = __shfl(g, 0);
+                    if (__all(g == g0)) {
+                        const int tot = __popcll(__ballot(ok[4 * q])) + __popcll(__ballot(ok[4 * q + 1])) + __popcll(__ballot(ok[4 * q + 2])) + __popcll(__ballot(ok[4 * q + 3]));
+                        if (lane == 0 && tot) atomicAdd(&kept_per_genome[g0], tot);
+                    } else {
+                        const int mine = (int)ok[4 * q] + (int)ok[4 * q + 1] + (int)ok[4 * q + 2] + (int)ok[4 * q + 3];
+                        if (mine) atomicAdd(&kept_per_genome[g], mine);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (int b = threadIdx.x; b < (1 << DIG_BITS); b += PT_THREADS) {
+            const uint32_t d = digit_owner((uint32_t)b, world);
+            const uint32_t nbd = X.dig_lo[d + 1] - X.dig_lo[d];
+            X.T[X.t_off[d] + (st - X.st_lo) * nbd + ((uint32_t)b - X.dig_lo[d])] = hist[b];
+        }
+        __syncthreads();
+    }
+}
+// kept k-mers of every 64-position word of a mask (what k_part_count<.., RANGE> writes beside its masks)
+__global__ void k_mask_popc(const unsigned long long* __restrict__ m, int64_t n, uint32_t* __restrict__ cnt) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) cnt[i] = (uint32_t)__popcll(m[i]);
 }
 
 // Level 2 works on UNITS: the records of one level-1 bucket that came from u_st consecutive super-tiles (about
@@ -2048,10 +2158,97 @@ static void run_extract_sort(vg_genomes* g, int k, double fraction, int shard, i
 }
 
 
+// partition digits of the bucket pipeline for n_expect elements: false = the pipeline declines (buckets beyond the LDS sorts)
+static bool bucket_digits(int64_t n_expect, int* total_bits_out, int* B1_out, int* B2_out) {
+    static const int tb_env = [] { const char* e = vg_dev_getenv("VG_TOTAL_BITS"); return e ? atoi(e) : 0; }();     // developer experiments
+    int total_bits = 0; while ((n_expect >> total_bits) > 1024 && total_bits < 22) ++total_bits;
+    if (tb_env > 0 && tb_env < total_bits) total_bits = tb_env;
+    if ((n_expect >> total_bits) > 4096) return false;
+    static const char* b2_env = vg_dev_getenv("VG_B2");          // developer experiments: level-2 bits
+    // level 1 takes 11 bits whenever there are two levels: its segment length does not depend on the digit (tiles of
+    // 32 768), level 2's grows as its digit shrinks, and 2k - 11 key bits fit the short records up to k = 25
+    const int B2 = total_bits > 11 ? (b2_env ? atoi(b2_env) : total_bits - 11) : 0;
+    *total_bits_out = total_bits; *B2_out = B2; *B1_out = total_bits - B2;
+    return true;
+}
+static int g_index_path = -1;      // -1 = not read yet; 0 = radix (rocPRIM) path forced; 1 = buckets
+static bool index_path_buckets() {
+    if (g_index_path < 0) { const char* e = vg_dev_getenv("VG_INDEX_PATH"); g_index_path = (e && !strcmp(e, "radix")) ? 0 : 1; }
+    return g_index_path != 0;
+}
+// 0 = every rank of a RANGE cut scans all bases (k_part_count<.., RANGE>); 1 = sliced scan, the peers emulated by this
+// process (vg_set_range_scan: tools/strong_scaling_sim.py, tests); the sharded entry points always exchange when it applies
+static int g_range_scan_mode = 0;
+bool vg_slice_exchange_applies(const vg_genomes* g, int k, double fraction, int world) {
+    (void)k;
+    static const bool replicated = [] { const char* e = vg_dev_getenv("VG_RANGE_SCAN"); return e && !strcmp(e, "replicated"); }();      // developer A/B
+    if (replicated || world < 2 || world > SX_MAX_WORLD || g_force_subshards > 1 || !range_shards(g, fraction, world)) return false;
+    const int64_t P = g->padded_total();
+    if (!index_path_buckets() || P < (1 << 16) || P >= (1LL << 32)) return false;
+    int total_bits = 0, B1 = 0, B2 = 0;
+    return bucket_digits(P, &total_bits, &B1, &B2) && total_bits > 11 && B1 == DIG_BITS;      // the level-1 digit is the shard digit
+}
+
+// The count pass of the RANGE shard of rank xs->rank by sliced scan + exchange (k_slice_scan): fills T1s ([super-tile][own
+// digit]), wave_mask and wave_cnt exactly as k_part_count<.., RANGE> does; d_kept receives the VALID k-mers of the rank's
+// slice of the bases per genome (all digits): the ranks' (kept - duplicates) still add up to the set sizes.
+static void sliced_count(int k, const part_src& S, vg_slice_exchange* xs, int st_tiles, int64_t n_st, int nb1, uint32_t* T1s,
+                         unsigned long long* wave_mask, uint32_t* wave_cnt, int* d_kept, int n_genomes, hipStream_t s) {
+    const int W = xs->world, me = xs->rank;
+    const int64_t W_total = S.n >> 6, wps = (int64_t)st_tiles * PT_TILE / 64;                  // 64-position words; per super-tile
+    auto st_of = [&](int r) { return n_st * r / W; };
+    auto word_of = [&](int r) { return std::min<int64_t>(W_total, st_of(r) * wps); };
+    uint32_t dig_lo[SX_MAX_WORLD + 1];
+    for (int r = 0; r <= W; ++r) dig_lo[r] = (uint32_t)(((uint64_t)r << DIG_BITS) / (uint64_t)W);
+    if ((int)(dig_lo[me + 1] - dig_lo[me]) != nb1) throw vg_error(VG_EINVAL, "internal error: sliced scan and shard digits disagree");
+    struct sent { dbuf<unsigned long long> mask; dbuf<uint32_t> T; std::vector<int64_t> m_off, t_off; };
+    auto scan = [&](int r, sent& o, int* kept) {
+        slice_plan X; memset(&X, 0, sizeof X);
+        X.world = W; X.st_lo = st_of(r); X.st_hi = st_of(r + 1); X.word_lo = word_of(r); X.words = word_of(r + 1) - word_of(r);
+        const int64_t rows = X.st_hi - X.st_lo;
+        o.m_off.assign((size_t)W + 1, 0); o.t_off.assign((size_t)W + 1, 0);
+        for (int d = 0; d <= W; ++d) { o.m_off[(size_t)d] = (int64_t)d * X.words * 8; o.t_off[(size_t)d] = rows * (int64_t)dig_lo[d] * 4; }
+        o.mask.alloc((size_t)std::max<int64_t>(1, (int64_t)W * X.words)); o.T.alloc((size_t)std::max<int64_t>(1, rows << DIG_BITS));
+        for (int d = 0; d < W; ++d) X.t_off[d] = o.t_off[(size_t)d] / 4;
+        for (int d = 0; d <= W; ++d) X.dig_lo[d] = dig_lo[d];
+        X.mask = o.mask.p; X.T = o.T.p;
+        if (rows <= 0) return;
+        const size_t lds = (size_t)16 * (PT_PER / 4) * W * 8 * sizeof(uint32_t);
+        const int grid = (int)std::min<int64_t>(rows, 512);
+        if (k == 25 && !S.A.use_frac) hipLaunchKernelGGL(k_slice_scan<25>, dim3(grid), dim3(PT_THREADS), lds, s, S, X, st_tiles, kept);
+        else hipLaunchKernelGGL(k_slice_scan<0>, dim3(grid), dim3(PT_THREADS), lds, s, S, X, st_tiles, kept);
+    };
+    sent mine; int status = VG_OK; std::string err;
+    try { vg_prof_scope ps("kmer_slice_scan", (double)S.n / W * (3.0 / 8.0 + 1.0 / 8.0)); scan(me, mine, d_kept); }
+    catch (const vg_error& e) { status = e.code; err = e.what(); }
+    if (xs->emulate) {
+        if (status != VG_OK) throw vg_error(status, err);
+        // one GPU stands in for the world: the peers' slices are scanned here, one after the other, and the blocks of this
+        // rank's digit range are copied out of their send buffers (what the all-to-all delivers)
+        dbuf<int> scratch_kept((size_t)std::max(1, n_genomes));
+        for (int r = 0; r < W; ++r) {
+            sent other; const sent* src = &mine;
+            if (r != me) { vg_prof_scope ps("emulated_peer_scan", 0); scratch_kept.zero(s); scan(r, other, scratch_kept.p); src = &other; }
+            const int64_t mb = src->m_off[(size_t)me + 1] - src->m_off[(size_t)me], tb = src->t_off[(size_t)me + 1] - src->t_off[(size_t)me];
+            if (mb) VG_HIP(hipMemcpyAsync(wave_mask + word_of(r), (const char*)src->mask.p + src->m_off[(size_t)me], (size_t)mb, hipMemcpyDeviceToDevice, s));
+            if (tb) VG_HIP(hipMemcpyAsync(T1s + st_of(r) * nb1, (const char*)src->T.p + src->t_off[(size_t)me], (size_t)tb, hipMemcpyDeviceToDevice, s));
+            if (r != me) VG_HIP(hipStreamSynchronize(s));        // (the peer's buffers go out of scope)
+        }
+    } else {
+        std::vector<int64_t> m_roff((size_t)W + 1), t_roff((size_t)W + 1);
+        for (int r = 0; r <= W; ++r) { m_roff[(size_t)r] = word_of(r) * 8; t_roff[(size_t)r] = st_of(r) * (int64_t)nb1 * 4; }
+        if (mine.m_off.empty()) { mine.m_off.assign((size_t)W + 1, 0); mine.t_off.assign((size_t)W + 1, 0); }      // (the scan failed before its plan: nothing travels anyway)
+        if (status != VG_OK) vg_set_error("%s", err.c_str());
+        const vg_xpart parts[2] = { { mine.mask.p, mine.m_off.data(), wave_mask, m_roff.data() }, { mine.T.p, mine.t_off.data(), T1s, t_roff.data() } };
+        xs->alltoallv(status, parts, 2);
+    }
+    if (W_total > 0) hipLaunchKernelGGL(k_mask_popc, dim3(grid_for(W_total)), dim3(256), 0, s, (const unsigned long long*)wave_mask, W_total, wave_cnt);
+    VG_HIP(hipStreamSynchronize(s));                                 // the send buffers go out of scope
+}
+
 // ---- the bucket pipeline (see the kernels above).  Source: the packed bases themselves (dense) or the kept
 // k-mers of a shard / fraction (keys, row numbers).  Fills gen[] and rowinfo[] like k_group_runs; false = the
 // input does not suit it (tiny, skewed, a bucket beyond the LDS): the caller takes the general path.
-static int g_index_path = -1;      // -1 = not read yet; 0 = radix (rocPRIM) path forced; 1 = buckets
 // set by the sub-shard loop (kmer_shared_subshards): the k-mer scan of the NEXT sub-shard, started on the second queue at
 // a point where the library queue is idle
 static std::function<void()> g_after_extract;
@@ -2060,27 +2257,19 @@ static void run_scan_hook() { if (g_after_extract) { auto hook = std::move(g_aft
 // map of the pass, n_rows_info becomes the number of kept k-mers, and the row pointers are indexed by row number.
 static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_args& A, const uint64_t* keys, const uint32_t* pos, int64_t n_src,
                                 const compact_map& cmap_in, int* d_kept, dbuf<uint32_t>& gen, dbuf<uint32_t>& rowinfo, dbuf<uint32_t>& arena,
-                                int64_t& n_rows_info, int* d_dups, int64_t* n_valid_out, sorted_index* ri = nullptr) {
+                                int64_t& n_rows_info, int* d_dups, int64_t* n_valid_out, sorted_index* ri = nullptr, vg_slice_exchange* xs = nullptr) {
     compact_map cmap = cmap_in;
     const bool range = dense && A.dig_n < (1u << DIG_BITS);
     if (range && !ri) throw vg_error(VG_EINVAL, "internal error: a range shard needs its row map");
     hipStream_t s = vg_stream();
     vg_host_mark("buckets: enter");
-    if (g_index_path < 0) { const char* e = vg_dev_getenv("VG_INDEX_PATH"); g_index_path = (e && !strcmp(e, "radix")) ? 0 : 1; }
-    if (!g_index_path || n_src < (1 << 16) || n_src >= (1LL << 32)) return false;
-    static const int tb_env = [] { const char* e = vg_dev_getenv("VG_TOTAL_BITS"); return e ? atoi(e) : 0; }();     // developer experiments
+    if (!index_path_buckets() || n_src < (1 << 16) || n_src >= (1LL << 32)) return false;
     // elements the partition will hold (a RANGE shard holds whole buckets of the set's own partition: the digits follow from n_src)
     const int64_t n_expect = dense && !range ? n_src / std::max<uint32_t>(1u, A.n_shards) : n_src;
-    int total_bits = 0; while ((n_expect >> total_bits) > 1024 && total_bits < 22) ++total_bits;
-    if (tb_env > 0 && tb_env < total_bits) total_bits = tb_env;
+    int total_bits = 0, B1 = 0, B2 = 0;
+    if (!bucket_digits(n_expect, &total_bits, &B1, &B2)) return false;
     const bool big_buckets = (n_expect >> total_bits) > 1024;
-    if ((n_expect >> total_bits) > 4096) return false;
     const int levels = total_bits > 11 ? 2 : 1;
-    static const char* b2_env = vg_dev_getenv("VG_B2");          // developer experiments: level-2 bits
-    // level 1 takes 11 bits whenever there are two levels: its segment length does not depend on the digit (tiles of
-    // 32 768), level 2's grows as its digit shrinks, and 2k - 11 key bits fit the short records up to k = 25
-    const int B2 = levels == 2 ? (b2_env ? atoi(b2_env) : total_bits - 11) : 0;
-    const int B1 = total_bits - B2;
     if (range && B1 > DIG_BITS) return false;
     // level-1 buckets of this pass: all 2^B1, or those the RANGE shard's digits fall into
     const int bin_lo = range ? (int)(A.dig_lo >> (DIG_BITS - B1)) : 0;
@@ -2146,7 +2335,10 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
         if (L2.g_st < 0) { short_rec = false; L2.g_st = 0; }
     }
     {
-        vg_prof_scope ps("kmer_partition", (double)n_src * (dense ? 2 * 3.0 / 8.0 : 8.0 + 12.0) + (double)n_src * (short_rec ? 8.0 : 12.0));
+        // (a sliced scan and its exchange have scopes of their own: kmer_slice_scan, exchange)
+        const double part_bytes = (double)n_src * (dense ? 2 * 3.0 / 8.0 : 8.0 + 12.0) + (double)n_src * (short_rec ? 8.0 : 12.0);
+        std::optional<vg_prof_scope> ps;
+        if (!(range && xs)) ps.emplace("kmer_partition", part_bytes);
         const int grid_c = (int)std::min<int64_t>(n_st, 512);
         const bool k25 = dense && k == 25 && !A.use_frac && A.n_shards == 1;          // the default: kernels with k as a constant
         unsigned long long* no_mask = nullptr; uint32_t* no_cnt = nullptr;
@@ -2157,7 +2349,12 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
             ri->wave_mask.alloc((size_t)W + 1); ri->wave_base.alloc((size_t)W + 1); wave_cnt.alloc((size_t)W + 1);
             VG_HIP(hipMemsetAsync(wave_cnt.p + W, 0, sizeof(uint32_t), s));
         }
-        if (k25 && range) hipLaunchKernelGGL((k_part_count<SRC_DENSE, 25, true>), dim3(grid_c), dim3(PT_THREADS), 0, s, S, B1, nb1, st_tiles, n_st, T1s.p, d_kept, ri->wave_mask.p, wave_cnt.p);
+        if (range && xs) {
+            if (levels != 2 || B1 != DIG_BITS) throw vg_error(VG_EINVAL, "internal error: sliced scan without the shard digit as level-1 digit");
+            sliced_count(k, S, xs, st_tiles, n_st, nb1, T1s.p, ri->wave_mask.p, wave_cnt.p, d_kept, g->n, s);
+            ps.emplace("kmer_partition", part_bytes / xs->world);
+        }
+        else if (k25 && range) hipLaunchKernelGGL((k_part_count<SRC_DENSE, 25, true>), dim3(grid_c), dim3(PT_THREADS), 0, s, S, B1, nb1, st_tiles, n_st, T1s.p, d_kept, ri->wave_mask.p, wave_cnt.p);
         else if (k25) hipLaunchKernelGGL((k_part_count<SRC_DENSE, 25>), dim3(grid_c), dim3(PT_THREADS), 0, s, S, B1, nb1, st_tiles, n_st, T1s.p, d_kept, no_mask, no_cnt);
         else if (dense && range) hipLaunchKernelGGL((k_part_count<SRC_DENSE, 0, true>), dim3(grid_c), dim3(PT_THREADS), 0, s, S, B1, nb1, st_tiles, n_st, T1s.p, d_kept, ri->wave_mask.p, wave_cnt.p);
         else if (dense) hipLaunchKernelGGL(k_part_count<SRC_DENSE>, dim3(grid_c), dim3(PT_THREADS), 0, s, S, B1, nb1, st_tiles, n_st, T1s.p, d_kept, no_mask, no_cnt);
@@ -2324,7 +2521,7 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
 // dev_out != nullptr: the pairs stay in HBM (*dev_out, *dev_n of them) and host_pairs is left empty
 static void kmer_shared_pass(vg_genomes* g, int k, double fraction, int shard, int n_shards, uint32_t min_shared,
                              int64_t* set_sizes, std::vector<vg_pair_count>& host_pairs,
-                             dbuf<vg_pair_count>* dev_out = nullptr, unsigned long long* dev_n = nullptr) {
+                             dbuf<vg_pair_count>* dev_out = nullptr, unsigned long long* dev_n = nullptr, vg_slice_exchange* xs = nullptr) {
     hipStream_t s = vg_stream();
     const int n = g->n;
     sorted_index si;
@@ -2348,7 +2545,7 @@ static void kmer_shared_pass(vg_genomes* g, int k, double fraction, int shard, i
             if (P < (1LL << 32)) {
                 n_rows_info = P;
                 const compact_map none{ nullptr, nullptr };
-                bucket_ok = build_index_buckets(g, k, true, A, nullptr, nullptr, P, none, kept_b.p, gen, rowinfo, arena, n_rows_info, d_dups.p, &nv, range ? &si : nullptr);
+                bucket_ok = build_index_buckets(g, k, true, A, nullptr, nullptr, P, none, kept_b.p, gen, rowinfo, arena, n_rows_info, d_dups.p, &nv, range ? &si : nullptr, range ? xs : nullptr);
                 if (bucket_ok) kept_b.download(kept.data(), (size_t)n, s);
             }
         } else {
@@ -2426,7 +2623,12 @@ static void kmer_shared_pass(vg_genomes* g, int k, double fraction, int shard, i
     dbuf<uint32_t> d_small, d_large; int n_small = 0, n_large = 0;
     if (n >= (1 << 16)) {
         std::vector<uint32_t> small_rows, large_rows;
-        for (int i = 0; i < n; ++i) ((compact_rows ? (int64_t)kept[(size_t)i] : g->len[(size_t)i]) <= SMALL_ROW ? small_rows : large_rows).push_back((uint32_t)i);
+        // rows of a genome in this pass: its kept k-mers (a sliced scan counted the k-mers of its slice of the BASES instead:
+        // the rows are then read off the row map)
+        std::vector<uint32_t> goff_h;
+        if (xs && range && bucket_ok) { goff_h.resize((size_t)n + 1); si.goff.download(goff_h.data(), (size_t)n + 1, s); VG_HIP(hipStreamSynchronize(s)); }
+        auto rows_of = [&](int i) { return !goff_h.empty() ? (int64_t)(goff_h[(size_t)i + 1] - goff_h[(size_t)i]) : compact_rows ? (int64_t)kept[(size_t)i] : g->len[(size_t)i]; };
+        for (int i = 0; i < n; ++i) (rows_of(i) <= SMALL_ROW ? small_rows : large_rows).push_back((uint32_t)i);
         if (small_rows.size() * 2 >= (size_t)n) {
             n_small = (int)small_rows.size(); n_large = (int)large_rows.size();
             d_small.alloc(small_rows.size()); d_small.upload(small_rows.data(), small_rows.size(), s);
@@ -2618,7 +2820,9 @@ extern "C" int vg_kmer_shared(vg_genomes* g, int k, double fraction, int shard, 
     if (sub < 1) sub = 1;
     std::vector<vg_pair_count> acc;
     if (sub == 1) {
-        kmer_shared_pass(g, k, fraction, shard, n_shards, min_shared, set_sizes, acc);
+        vg_slice_exchange xs; xs.rank = shard; xs.world = n_shards; xs.emulate = true;
+        const bool sliced = g_range_scan_mode == 1 && vg_slice_exchange_applies(g, k, fraction, n_shards);
+        kmer_shared_pass(g, k, fraction, shard, n_shards, min_shared, set_sizes, acc, nullptr, nullptr, sliced ? &xs : nullptr);
     } else {
         // partial (a, b, count) records of every sub-shard stay in HBM and are summed ONCE there: sort on (a, b), reduce
         // by key, threshold on the sum
@@ -2643,7 +2847,7 @@ extern "C" int vg_kmer_shared(vg_genomes* g, int k, double fraction, int shard, 
 
 // internal (vg_dist.hip): one shard's pairs left in HBM (sub-shards included)
 void vg_kmer_shared_device(vg_genomes* g, int k, double fraction, int shard, int n_shards, uint32_t min_shared,
-                           int64_t* set_sizes, dbuf<vg_pair_count>& pairs, int64_t* n_pairs) {
+                           int64_t* set_sizes, dbuf<vg_pair_count>& pairs, int64_t* n_pairs, vg_slice_exchange* xs) {
     vg_require_device();
     int rc = vg_genomes_to_device(g); if (rc) throw vg_error(rc, vg_last_error());
     *n_pairs = 0;
@@ -2655,7 +2859,7 @@ void vg_kmer_shared_device(vg_genomes* g, int k, double fraction, int shard, int
     hipStream_t s = vg_stream();
     if (one_pass) {
         std::vector<vg_pair_count> none; unsigned long long n = 0;
-        kmer_shared_pass(g, k, fraction, shard, n_shards, min_shared, set_sizes, none, &pairs, &n);
+        kmer_shared_pass(g, k, fraction, shard, n_shards, min_shared, set_sizes, none, &pairs, &n, xs);
         *n_pairs = (int64_t)n;
         return;
     }
@@ -2673,6 +2877,7 @@ void vg_kmer_shared_device(vg_genomes* g, int k, double fraction, int shard, int
 // developer/test knob: force the sub-shard loop on small inputs (0 = automatic)
 static_assert(sizeof(vg_pair_count) == 12, "pair record layout");
 extern "C" void vg_set_subshards(int n) { g_force_subshards = n; }
+extern "C" void vg_set_range_scan(int mode) { g_range_scan_mode = mode == 1 ? 1 : 0; }
 
 extern "C" int vg_kmer_set(vg_genomes* g, int idx, int k, double fraction, uint64_t** out, int64_t* n_out) {
     VG_API_BEGIN

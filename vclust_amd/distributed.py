@@ -49,6 +49,20 @@ class Comm:
         self.h, self._lib, self._keep = handle, lib, keep
 
     @property
+    def kind(self):
+        """'rccl' (the library's built-in RCCL communicator) or 'callback' (all-gathers handed to torch.distributed)."""
+        return 'rccl' if self._lib.vg_comm_kind(self.h) == 1 else 'callback'
+
+    @property
+    def rccl_ranks(self):
+        """ncclCommCount of the built-in communicator (None for a callback communicator)."""
+        n = self._lib.vg_comm_rccl_ranks(self.h)
+        return n if n >= 0 else None
+
+    def describe(self):
+        return dict(comm=self.kind, rccl_ranks=self.rccl_ranks, rank=self.rank, world=self.world)
+
+    @property
     def rank(self):
         return self._lib.vg_comm_rank(self.h)
 
@@ -77,8 +91,11 @@ def _host_view(ptr, nbytes):
 
 
 def make_comm(dist=None, device=None, kind=None):
-    """vg_comm for the current process group.  kind: "rccl" (built-in RCCL communicator), "callback"
-    (all-gather through torch.distributed), default: rccl on the nccl backend, callback otherwise."""
+    """vg_comm for the current process group.  kind: "rccl" (built-in RCCL communicator; any failure to create or
+    self-test it sends every rank to the callback communicator with a line on stderr), "rccl-strict" (the same, but a
+    failure raises on every rank instead: what a measurement of the RCCL path must use -- `bench.py --gpus N`),
+    "callback" (all-gather through torch.distributed); default: $VCLUST_COMM, else rccl on the nccl backend, callback
+    otherwise."""
     import torch
     from . import _lib
     lib = _lib.load()
@@ -90,7 +107,8 @@ def make_comm(dist=None, device=None, kind=None):
     backend = dist.get_backend()
     if kind is None:
         kind = os.environ.get('VCLUST_COMM') or ('rccl' if backend == 'nccl' else 'callback')
-    if kind == 'rccl':
+    strict = kind == 'rccl-strict'
+    if kind in ('rccl', 'rccl-strict'):
         # The built-in RCCL communicator, made fail-soft: no step may leave some ranks inside a collective while another
         # has raised.  Rank 0's id travels with a flag; creation and a first real exchange (vg_comm_selftest) are each
         # agreed on by all ranks before the next collective; any failure sends EVERY rank to the callback communicator
@@ -124,6 +142,10 @@ def make_comm(dist=None, device=None, kind=None):
         if made:
             lib.vg_comm_free(h)
         h = C.c_void_p()
+        if strict:
+            # (every rank is here: the failure was agreed on)
+            raise RuntimeError('vclust_amd.distributed: VCLUST_COMM=rccl-strict and the built-in RCCL communicator could not be '
+                               'created or failed its self-test on some rank (see stderr): not falling back')
         if rank == 0:
             print('vclust_amd.distributed: falling back to the callback communicator (torch.distributed all-gathers)', file=sys.stderr)
 
