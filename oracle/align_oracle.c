@@ -12,6 +12,7 @@
  *   L8  alignment table (example/output/ani.aln.tsv), per pair sorted by alnlen desc, qstart asc.
  */
 #include "vclust_oracle.h"
+#include <omp.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -264,12 +265,27 @@ int vo_align(const vo_genome_set* s, const char* out_path, const vo_align_params
  * pair (genomes in memory -> integer rows in memory; no files).  Same scope as the HIP path's device-resident
  * step, so it is what bench.py times as cpu_baseline and what the full-set parity tests compare with.
  * Ids are input-order genome indices; rows come in pair order, (q=a,r=b) then (q=b,r=a) with a > b. ---- */
+static int path_rows_impl(const vo_genome_set* s, int k, int min_kmers, double min_ident, const vo_lz_params* lz,
+                          vo_pair_stat** rows_out, int64_t* n_rows, int mt, double* stage_s, int* threads_used);
 int vo_path_rows(const vo_genome_set* s, int k, int min_kmers, double min_ident, const vo_lz_params* lz,
                  vo_pair_stat** rows_out, int64_t* n_rows) {
+    return path_rows_impl(s, k, min_kmers, min_ident, lz, rows_out, n_rows, 0, NULL, NULL);
+}
+/* the same with every stage on all host threads (vo_shared_all_mt; the LZ loop is OpenMP over references in both):
+ * bench.py's cpu_baseline.  stage_s[4] = wall seconds of {sets, index, pair count, LZ}; rows in an order of its own
+ * (the pair order of the merge): callers compare as sets. */
+int vo_path_rows_mt(const vo_genome_set* s, int k, int min_kmers, double min_ident, const vo_lz_params* lz,
+                    vo_pair_stat** rows_out, int64_t* n_rows, double* stage_s, int* threads_used) {
+    return path_rows_impl(s, k, min_kmers, min_ident, lz, rows_out, n_rows, 1, stage_s, threads_used);
+}
+static int path_rows_impl(const vo_genome_set* s, int k, int min_kmers, double min_ident, const vo_lz_params* lz,
+                          vo_pair_stat** rows_out, int64_t* n_rows, int mt, double* stage_s, int* threads_used) {
     int n = s->n;
     int64_t* sizes = (int64_t*)calloc(n > 0 ? n : 1, sizeof(int64_t));
     vo_pair_count* pairs; int64_t np;
-    vo_shared_all(s, k, 1.0, sizes, &pairs, &np);
+    if (mt) vo_shared_all_mt(s, k, 1.0, sizes, &pairs, &np, stage_s, threads_used);
+    else vo_shared_all(s, k, 1.0, sizes, &pairs, &np);
+    const double t_lz0 = omp_get_wtime();
     int64_t kept = 0;
     for (int64_t i = 0; i < np; ++i) {
         if ((int64_t)pairs[i].shared < min_kmers) continue;
@@ -308,6 +324,7 @@ int vo_path_rows(const vo_genome_set* s, int k, int min_kmers, double min_ident,
         vo_lz_free_index(ix);
     }
     free(roff); free(rtask);
+    if (mt && stage_s) stage_s[3] = omp_get_wtime() - t_lz0;
     *rows_out = st; *n_rows = nt;
     return 0;
 }

@@ -152,6 +152,164 @@ int vo_shared_all(const vo_genome_set* s, int k, double fraction,
     return 0;
 }
 
+/* ---- the same counts on all host threads: what bench.py times as cpu_baseline (kmer-db runs `-t T` end to end,
+ * vclust.py:953-1055).  vo_shared_all above stays the checker (tests/test_oracle_golden.py holds the two equal):
+ *   sets       per genome, OpenMP over genomes (as above);
+ *   index      (k-mer, genome) records scattered into NP partitions by a hash of the k-mer -- per-thread counts, prefix
+ *              sums, per-thread write cursors: no atomics --, every partition sorted by k-mer on its own thread;
+ *   pair count runs of equal k-mers -> increments into per-THREAD open-addressing tables; the tables' (pair, count)
+ *              entries are then dealt by a hash of the pair into one bucket per thread and every bucket is summed on
+ *              its own thread (sort + reduce).
+ * stage_s (may be NULL) receives the wall seconds of {sets, index, pair count}; *threads_used the OpenMP team size. ---- */
+#include <omp.h>
+static double now_s(void) { return omp_get_wtime(); }
+void vo_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+static int cmp_kg(const void* x, const void* y) {
+    const kg_t* a = (const kg_t*)x; const kg_t* b = (const kg_t*)y;
+    return a->kmer < b->kmer ? -1 : (a->kmer > b->kmer);
+}
+static int cmp_pc(const void* x, const void* y) {
+    const pc_t* a = (const pc_t*)x; const pc_t* b = (const pc_t*)y;
+    return a->key < b->key ? -1 : (a->key > b->key);
+}
+typedef struct { pc_t* tab; uint64_t cap, used; } ptab_t;
+static void ptab_add(ptab_t* T, uint64_t key, uint32_t add) {
+    if ((T->used + 1) * 2 > T->cap) {
+        uint64_t nc = T->cap * 2; pc_t* nt = (pc_t*)calloc(nc, sizeof(pc_t));
+        for (uint64_t t = 0; t < T->cap; ++t) if (T->tab[t].cnt) {
+            uint64_t h = vo_mix64(T->tab[t].key) & (nc - 1);
+            while (nt[h].cnt) h = (h + 1) & (nc - 1);
+            nt[h] = T->tab[t];
+        }
+        free(T->tab); T->tab = nt; T->cap = nc;
+    }
+    uint64_t h = vo_mix64(key) & (T->cap - 1);
+    while (T->tab[h].cnt && T->tab[h].key != key) h = (h + 1) & (T->cap - 1);
+    if (!T->tab[h].cnt) { T->tab[h].key = key; ++T->used; }
+    T->tab[h].cnt += add;
+}
+
+int vo_shared_all_mt(const vo_genome_set* s, int k, double fraction, int64_t* set_sizes, vo_pair_count** out_pairs,
+                     int64_t* n_pairs, double* stage_s, int* threads_used) {
+    const int n = s->n;
+    int T = 1;
+    #pragma omp parallel
+    {
+        #pragma omp single
+        T = omp_get_num_threads();
+    }
+    if (threads_used) *threads_used = T;
+    double t0 = now_s();
+    uint64_t** sets = (uint64_t**)calloc(n > 0 ? n : 1, sizeof(uint64_t*));
+    #pragma omp parallel for schedule(dynamic)
+    for (int g = 0; g < n; ++g) set_sizes[g] = vo_kmer_set_f(s->g[g].seq, s->g[g].len, k, fraction, &sets[g]);
+    double t1 = now_s();
+    /* index: partition by hash, then sort every partition */
+    int PB = 6; while ((1 << PB) < 16 * T && PB < 14) ++PB;
+    const int NP = 1 << PB;
+    int64_t* cnt = (int64_t*)calloc((size_t)T * NP + 1, sizeof(int64_t));      /* [thread][partition] */
+    #pragma omp parallel num_threads(T)
+    {
+        const int t = omp_get_thread_num();
+        int64_t* c = cnt + (size_t)t * NP;
+        #pragma omp for schedule(static)
+        for (int g = 0; g < n; ++g) for (int64_t i = 0; i < set_sizes[g]; ++i) c[vo_mix64(sets[g][i]) >> (64 - PB)]++;
+    }
+    int64_t* pstart = (int64_t*)calloc((size_t)NP + 1, sizeof(int64_t));
+    int64_t total = 0;
+    for (int p = 0; p < NP; ++p) {           /* partition-major, thread-minor: a partition is one contiguous stretch */
+        pstart[p] = total;
+        for (int t = 0; t < T; ++t) { int64_t c = cnt[(size_t)t * NP + p]; cnt[(size_t)t * NP + p] = total; total += c; }
+    }
+    pstart[NP] = total;
+    kg_t* a = (kg_t*)malloc(sizeof(kg_t) * (total > 0 ? total : 1));
+    #pragma omp parallel num_threads(T)
+    {
+        const int t = omp_get_thread_num();
+        int64_t* c = cnt + (size_t)t * NP;
+        #pragma omp for schedule(static)                                        /* the same genomes as in the counting loop */
+        for (int g = 0; g < n; ++g) {
+            for (int64_t i = 0; i < set_sizes[g]; ++i) { const uint64_t x = sets[g][i]; kg_t* o = &a[c[vo_mix64(x) >> (64 - PB)]++]; o->kmer = x; o->g = (uint32_t)g; }
+            free(sets[g]);
+        }
+    }
+    free(sets); free(cnt);
+    {
+        /* every partition sorted by k-mer on its own thread (LSD radix over the key bytes, a scratch buffer per thread) */
+        int64_t pmax = 0; for (int p = 0; p < NP; ++p) if (pstart[p + 1] - pstart[p] > pmax) pmax = pstart[p + 1] - pstart[p];
+        const int bits = (2 * k + 7) / 8 * 8, passes = bits / 8;
+        #pragma omp parallel num_threads(T)
+        {
+            kg_t* tmp = (kg_t*)malloc(sizeof(kg_t) * (pmax > 0 ? pmax : 1));
+            #pragma omp for schedule(dynamic, 1)
+            for (int p = 0; p < NP; ++p) {
+                const int64_t m = pstart[p + 1] - pstart[p];
+                sort_kg(a + pstart[p], tmp, m, bits);
+                if (passes & 1) memcpy(a + pstart[p], tmp, sizeof(kg_t) * (size_t)m);      /* an odd number of passes ends in the scratch buffer */
+            }
+            free(tmp);
+        }
+    }
+    double t2 = now_s();
+    /* pair counts: per-thread tables over the partitions */
+    ptab_t* tabs = (ptab_t*)calloc((size_t)T, sizeof(ptab_t));
+    for (int t = 0; t < T; ++t) { tabs[t].cap = 1 << 12; tabs[t].tab = (pc_t*)calloc(tabs[t].cap, sizeof(pc_t)); }
+    #pragma omp parallel num_threads(T)
+    {
+        ptab_t* tb = &tabs[omp_get_thread_num()];
+        #pragma omp for schedule(dynamic, 1)
+        for (int p = 0; p < NP; ++p) {
+            const int64_t e = pstart[p + 1];
+            for (int64_t i = pstart[p]; i < e;) {
+                int64_t j = i + 1;
+                while (j < e && a[j].kmer == a[i].kmer) ++j;
+                for (int64_t x = i; x < j; ++x) for (int64_t y = x + 1; y < j; ++y) {
+                    const uint32_t ga = a[x].g, gb = a[y].g;                 /* distinct: a set holds a k-mer once */
+                    ptab_add(tb, ga > gb ? ((uint64_t)ga << 32) | gb : ((uint64_t)gb << 32) | ga, 1u);
+                }
+                i = j;
+            }
+        }
+    }
+    free(a); free(pstart);
+    /* merge: entries dealt by a hash of the pair into T buckets, every bucket summed on its own thread */
+    int64_t* bc = (int64_t*)calloc((size_t)T * T + 1, sizeof(int64_t));           /* [source thread][bucket] */
+    #pragma omp parallel for schedule(static, 1) num_threads(T)
+    for (int t = 0; t < T; ++t) for (uint64_t h = 0; h < tabs[t].cap; ++h) if (tabs[t].tab[h].cnt) bc[(size_t)t * T + (vo_mix64(tabs[t].tab[h].key ^ 0x9e3779b97f4a7c15ULL) % (uint64_t)T)]++;
+    int64_t* bstart = (int64_t*)calloc((size_t)T + 1, sizeof(int64_t));
+    int64_t ne = 0;
+    for (int b = 0; b < T; ++b) { bstart[b] = ne; for (int t = 0; t < T; ++t) { int64_t c = bc[(size_t)t * T + b]; bc[(size_t)t * T + b] = ne; ne += c; } }
+    bstart[T] = ne;
+    pc_t* ent = (pc_t*)malloc(sizeof(pc_t) * (ne > 0 ? ne : 1));
+    #pragma omp parallel for schedule(static, 1) num_threads(T)
+    for (int t = 0; t < T; ++t) {
+        for (uint64_t h = 0; h < tabs[t].cap; ++h) if (tabs[t].tab[h].cnt) ent[bc[(size_t)t * T + (vo_mix64(tabs[t].tab[h].key ^ 0x9e3779b97f4a7c15ULL) % (uint64_t)T)]++] = tabs[t].tab[h];
+        free(tabs[t].tab);
+    }
+    free(tabs); free(bc);
+    int64_t* bout = (int64_t*)calloc((size_t)T + 1, sizeof(int64_t));             /* distinct pairs of every bucket */
+    #pragma omp parallel for schedule(static, 1) num_threads(T)
+    for (int b = 0; b < T; ++b) {
+        pc_t* e = ent + bstart[b]; const int64_t m = bstart[b + 1] - bstart[b];
+        qsort(e, (size_t)m, sizeof(pc_t), cmp_pc);
+        int64_t u = 0;
+        for (int64_t i = 0; i < m; ++i) { if (u > 0 && e[u - 1].key == e[i].key) e[u - 1].cnt += e[i].cnt; else e[u++] = e[i]; }
+        bout[b] = u;
+    }
+    int64_t np = 0; for (int b = 0; b < T; ++b) np += bout[b];
+    vo_pair_count* pr = (vo_pair_count*)malloc(sizeof(vo_pair_count) * (np > 0 ? np : 1));
+    int64_t m = 0;
+    for (int b = 0; b < T; ++b) for (int64_t i = 0; i < bout[b]; ++i) {
+        const pc_t* e = &ent[bstart[b] + i];
+        pr[m].a = (uint32_t)(e->key >> 32); pr[m].b = (uint32_t)e->key; pr[m].shared = e->cnt; ++m;
+    }
+    free(ent); free(bstart); free(bout);
+    double t3 = now_s();
+    if (stage_s) { stage_s[0] = t1 - t0; stage_s[1] = t2 - t1; stage_s[2] = t3 - t2; }
+    *out_pairs = pr; *n_pairs = np;
+    return 0;
+}
+
 static int cmp_pair(const void* x, const void* y) {
     const vo_pair_count* a = (const vo_pair_count*)x; const vo_pair_count* b = (const vo_pair_count*)y;
     if (a->a != b->a) return a->a < b->a ? -1 : 1;

@@ -62,6 +62,11 @@ typedef struct { uint32_t a, b, shared; } vo_pair_count;   /* a > b (row, column
 /* sparse all-pairs shared k-mer counts (only pairs with shared > 0) and per-genome set sizes */
 int vo_shared_all(const vo_genome_set* s, int k, double fraction,
                   int64_t* set_sizes, vo_pair_count** out_pairs, int64_t* n_pairs);
+/* the same counts with every stage on all OpenMP threads (bench.py's cpu_baseline; vo_shared_all is the checker);
+ * stage_s[3] = seconds of {sets, index, pair count} */
+void vo_set_threads(int n);      /* OpenMP team size of the calls that follow */
+int vo_shared_all_mt(const vo_genome_set* s, int k, double fraction, int64_t* set_sizes, vo_pair_count** out_pairs,
+                     int64_t* n_pairs, double* stage_s, int* threads_used);
 int vo_write_fltr(const vo_genome_set* s, int k, double fraction, int min_kmers, double min_ident,
                   int max_seqs, const int64_t* set_sizes, vo_pair_count* pairs, int64_t n_pairs,
                   const char* out_path);
@@ -139,6 +144,8 @@ int vo_lz_pair_stat(const uint8_t* qry, int64_t qlen, const uint8_t* ref, int64_
  * input order, rows (q=a,r=b),(q=b,r=a) per kept pair a > b; *rows_out is malloc'd.  OpenMP over references. */
 int vo_path_rows(const vo_genome_set* s, int k, int min_kmers, double min_ident, const vo_lz_params* lz,
                  vo_pair_stat** rows_out, int64_t* n_rows);
+int vo_path_rows_mt(const vo_genome_set* s, int k, int min_kmers, double min_ident, const vo_lz_params* lz,
+                    vo_pair_stat** rows_out, int64_t* n_rows, double* stage_s /* 4: sets, index, pair count, LZ */, int* threads_used);
 
 /* ---------- formatting ---------- */
 /* writes the LZ-ANI style number into buf (>= 32 bytes), returns length */

@@ -48,6 +48,9 @@ def lib():
         if not LIB.exists():
             build()
         L = C.CDLL(str(LIB))
+        if not hasattr(L, 'vo_path_rows_mt'):          # a library built from older sources
+            build()
+            L = C.CDLL(str(LIB))
         L.vo_read_fasta.argtypes = [C.c_char_p, C.c_int, C.POINTER(GenomeSet)]
         L.vo_read_fasta.restype = C.c_int
         L.vo_free_genomes.argtypes = [C.POINTER(GenomeSet)]
@@ -62,6 +65,14 @@ def lib():
         L.vo_path_rows.argtypes = [C.POINTER(GenomeSet), C.c_int, C.c_int, C.c_double, C.POINTER(LzParams),
                                    C.POINTER(C.POINTER(PairStat)), C.POINTER(C.c_int64)]
         L.vo_path_rows.restype = C.c_int
+        L.vo_shared_all_mt.argtypes = [C.POINTER(GenomeSet), C.c_int, C.c_double, C.POINTER(C.c_int64),
+                                       C.POINTER(C.POINTER(PairCount)), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        L.vo_shared_all_mt.restype = C.c_int
+        L.vo_path_rows_mt.argtypes = [C.POINTER(GenomeSet), C.c_int, C.c_int, C.c_double, C.POINTER(LzParams),
+                                      C.POINTER(C.POINTER(PairStat)), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        L.vo_path_rows_mt.restype = C.c_int
+        L.vo_set_threads.argtypes = [C.c_int]
+        L.vo_set_threads.restype = None
         L.vo_fmt_num.argtypes = [C.c_double, C.c_char_p]
         L.vo_fmt_num.restype = C.c_int
         L.vo_fmt_len_ratio.argtypes = [C.c_int64, C.c_int64, C.c_char_p]
@@ -119,6 +130,21 @@ def shared_all(codes, offsets, k=25, fraction=1.0):
     return np.array(sizes[:n], dtype=np.int64), d
 
 
+def shared_all_mt(codes, offsets, k=25, fraction=1.0, threads=None):
+    """The multithreaded form (bench.py's cpu_baseline leg) -> (set_sizes, dict, stage seconds [sets, index, pair count], threads)."""
+    gs, keep = _make_set(codes, offsets)
+    n = gs.n
+    if threads:
+        lib().vo_set_threads(int(threads))
+    sizes = (C.c_int64 * max(n, 1))()
+    pp = C.POINTER(PairCount)(); npairs = C.c_int64(); st = (C.c_double * 3)(); thr = C.c_int()
+    lib().vo_shared_all_mt(C.byref(gs), k, float(fraction), sizes, C.byref(pp), C.byref(npairs), st, C.byref(thr))
+    d = {(pp[i].a, pp[i].b): pp[i].shared for i in range(npairs.value)}
+    assert len(d) == npairs.value, 'a pair was emitted twice'
+    lib().free(C.cast(pp, C.c_void_p))
+    return np.array(sizes[:n], dtype=np.int64), d, list(st), thr.value
+
+
 def lz_pair_stat(q, r, lz=None):
     prm = LzParams(**{**DEFAULT_LZ, **(lz or {})})
     q = np.ascontiguousarray(q, dtype=np.uint8)
@@ -164,3 +190,17 @@ def run_cli(*args, env=None):
     if not CLI.exists():
         build()
     subprocess.run([str(CLI), *map(str, args)], check=True, env=env)
+
+
+def path_rows_mt(codes, offsets, k=25, min_kmers=20, min_ident=0.7, lz=None, threads=None):
+    """vo_path_rows_mt: every stage on all host threads -> (rows, {stage: seconds}, threads that ran)."""
+    gs, keep = _make_set(codes, offsets)
+    if threads:
+        lib().vo_set_threads(int(threads))
+    prm = LzParams(**{**DEFAULT_LZ, **(lz or {})})
+    pp = C.POINTER(PairStat)(); n = C.c_int64(); st = (C.c_double * 4)(); thr = C.c_int()
+    lib().vo_path_rows_mt(C.byref(gs), k, min_kmers, float(min_ident), C.byref(prm), C.byref(pp), C.byref(n), st, C.byref(thr))
+    dt = np.dtype([('q', '<u4'), ('r', '<u4'), ('n_match', '<u4'), ('aln_len', '<u4'), ('n_regions', '<u4')])
+    out = np.ctypeslib.as_array(C.cast(pp, C.POINTER(C.c_uint32)), shape=(max(n.value, 1) * 5,))[:n.value * 5].copy().view(dt)
+    lib().free(C.cast(pp, C.c_void_p))
+    return out, dict(zip(('sets', 'index', 'pair_count', 'lz'), (round(float(x), 3) for x in st))), thr.value

@@ -7,6 +7,8 @@ regression floors for the fitted rules (the upstream source is absent, see DESIG
 import collections
 import filecmp
 
+import pathlib
+
 import numpy as np
 import pytest
 
@@ -225,3 +227,38 @@ def test_cluster_handoff_reproduces_golden_clusters(oracle_align, golden_dir):
     want = golden_partition(golden_dir)
     assert single_linkage_partition(golden_dir / 'output' / 'ani.tsv', golden_dir / 'output' / 'ani.ids.tsv') == want
     assert single_linkage_partition(oracle_align / 'ani.tsv', oracle_align / 'ani.ids.tsv') == want
+
+
+@pytest.mark.parametrize('threads', [1, 3, 8])
+def test_multithreaded_prefilter_equals_the_serial_checker(example, threads):
+    """bench.py's cpu_baseline runs the oracle with EVERY stage on all host threads (vo_shared_all_mt: hash partitions of
+    the (k-mer, genome) records sorted per thread, per-thread pair tables merged by pair hash).  The serial vo_shared_all
+    stays the checker: same set sizes, same pairs, same counts -- on the reference's example, on families with many pairs
+    per genome, and on edge sets (one genome, genomes shorter than k, fractions)."""
+    import sys
+    sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
+    from vclust_amd import synth
+    codes, offsets, names = example
+    cases = [(codes, offsets, 25, 1.0), (codes, offsets, 15, 0.3)]
+    fc, fo, _ = synth.make_families(12, 9, length=6000, seed=17)
+    cases += [(fc, fo, 25, 1.0), (fc, fo, 21, 0.5), (fc[:fo[1]], fo[:2], 25, 1.0)]
+    rng = np.random.default_rng(2)
+    tiny = rng.integers(0, 4, 200).astype(np.uint8)
+    cases.append((tiny, np.array([0, 10, 20, 120, 200], dtype=np.int64), 25, 1.0))
+    for c, o, k, f in cases:
+        s0, p0 = orc.shared_all(c, o, k=k, fraction=f)
+        s1, p1, stage_s, thr = orc.shared_all_mt(c, o, k=k, fraction=f, threads=threads)
+        assert thr == threads and len(stage_s) == 3
+        assert list(s0) == list(s1) and p0 == p1
+
+
+def test_multithreaded_path_rows_equal_the_serial_rows():
+    import sys
+    sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
+    from vclust_amd import synth
+    codes, offsets, _ = synth.make_families(6, 5, length=5000, seed=4)
+    r0 = orc.path_rows(codes, offsets)
+    r1, stage_s, thr = orc.path_rows_mt(codes, offsets, threads=4)
+    assert thr == 4 and set(stage_s) == {'sets', 'index', 'pair_count', 'lz'}
+    key = lambda r: sorted(map(tuple, r.tolist()))
+    assert len(r0) > 50 and key(r0) == key(r1)
