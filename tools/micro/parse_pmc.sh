@@ -1,0 +1,37 @@
+#!/bin/bash
+# Developer tool (GPU box): SQ / TCC counters of the parse kernels, one pair per wave against two pairs per wave
+# (tools/micro/parse_ab.py under rocprofv3 --pmc, one counter set per run).  usage: parse_pmc.sh <out-dir> [NF]
+set -u
+REPO=$(pwd); OUT=$REPO/${1:-gpurun_out/r5_parse_pmc}; export NF=${2:-10000} REPS=1 VG_DEV_SWITCHES=1 TMPDIR=/tmp
+mkdir -p "$OUT"; cd /tmp
+for K in one two; do
+  i=0
+  for SET in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
+             "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_SCA SQ_INSTS_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU" \
+             "TCC_HIT_sum TCC_MISS_sum"; do
+    i=$((i+1))
+    VG_LZ_KERNEL=$K rocprofv3 --pmc $SET --kernel-trace --output-format csv -d "$OUT/$K/set$i" -- python $REPO/tools/micro/parse_ab.py > "$OUT/$K.set$i.log" 2>&1
+  done
+done
+cd "$REPO"
+python - "$OUT" <<'PY'
+import csv, glob, json, os, re, sys
+from collections import defaultdict
+out = sys.argv[1]; doc = {}
+for k in ('one', 'two'):
+    per = defaultdict(lambda: defaultdict(list))
+    for f in glob.glob(os.path.join(out, k, '**', '*counter_collection.csv'), recursive=True):
+        for row in csv.DictReader(open(f, newline='')):
+            m = re.search(r'k_lz_parse\w*', row['Kernel_Name']); name = m.group(0) if m else ''
+            if name: per[name][row['Counter_Name']].append(float(row['Counter_Value']))
+    # the LAST launch of each kernel (the timed repetition; the first is the warm-up)
+    doc[k] = {n: {c: v[-1] for c, v in cs.items()} for n, cs in per.items()}
+    for f in glob.glob(os.path.join(out, k, '**', '*kernel_trace.csv'), recursive=True):
+        for row in csv.DictReader(open(f, newline='')):
+            m = re.search(r'k_lz_parse\w*', row['Kernel_Name']); name = m.group(0) if m else ''
+            if name in doc[k]: doc[k][name]['last_launch_ms'] = (int(row['End_Timestamp']) - int(row['Start_Timestamp'])) / 1e6
+        break
+json.dump(doc, open(os.path.join(out, 'parse_pmc.json'), 'w'), indent=1, sort_keys=True)
+print(json.dumps(doc, indent=1, sort_keys=True))
+PY
+find "$OUT" -name '*.csv' -size +4M -delete

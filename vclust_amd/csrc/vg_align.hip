@@ -1376,6 +1376,402 @@ PARSE_KERNEL(k_lz_parse_seg_fast, 4, false, 8, true)
 PARSE_KERNEL(k_lz_parse_dev, 1, true, 3, false)
 #endif
 
+// ------------------------------------------------------------------ the parse, TWO pairs per wave
+// k_lz_parse_fast spends its time issuing VALU instructions (0.8-0.9 of the SIMD issue rate), and right
+// after an event -- 26 of the 30 probe trips of a pair -- only 32 of its 64 lanes probe.  Here the two HALVES of a wave
+// own one pair each: lane 32 h + l of half h probes position i_h + l of ITS pair, the extensions compare 32 x 32 bases
+// per half and round, the gap score ranks 32 split points per half and round, and every instruction of the loop serves
+// two pairs.  What was wave-uniform state in SGPRs (positions, prediction, region sums, the pair's pointers) is uniform
+// per half in VGPRs; the halves diverge only where their pairs do (one in an event while the other found nothing), as
+// ordinary divergent control flow.  Cross-lane traffic stays off the LDS crossbar where the source lane is known from a
+// ballot (two v_readlane + a select); reductions over a half are DPP butterflies with one LDS swizzle for the last step.
+// A wave takes a chunk of P2_CHUNK consecutive tasks (one reference's tasks are consecutive: both halves probe the same
+// index) and a half that finishes its pair pulls the next task of the chunk, so a long pair does not idle its partner.
+// Default parameters, a set without N, rows only (what k_lz_parse_fast covers); results are bit-identical.
+constexpr int P2_CHUNK = 16;
+constexpr bool VG_LZ_TWO_PAIRS_DEFAULT = false;
+// the ballot bits of this lane's half, in the low 32 bits
+__device__ __forceinline__ uint32_t hsel(unsigned long long b, int h) { return h ? (uint32_t)(b >> 32) : (uint32_t)b; }
+// value of lane s0 (half 0) / lane 32 + s1 (half 1) for the lanes of the respective half; s0, s1 wave-uniform
+__device__ __forceinline__ uint32_t hb32(uint32_t v, int s0, int s1, int h) {
+    const uint32_t a0 = lane32(v, s0 & 31), a1 = lane32(v, 32 | (s1 & 31));
+    return h ? a1 : a0;
+}
+__device__ __forceinline__ uint64_t hb64(uint64_t v, int s0, int s1, int h) {
+    return (uint64_t)hb32((uint32_t)v, s0, s1, h) | ((uint64_t)hb32((uint32_t)(v >> 32), s0, s1, h) << 32);
+}
+__device__ __forceinline__ int ctz32z(uint32_t x) { return x ? __builtin_ctz(x) : 0; }
+__device__ __forceinline__ int top32z(uint32_t x) { return x ? 31 - __builtin_clz(x) : 0; }
+// butterfly over the 32 lanes of each half: lane ^ 1, lane ^ 2 (quad permutes), mirror in 8, mirror in 16 (DPP), lane ^ 16
+#define VG_HALF_BUTTERFLY(v, OP) do { \
+        v = OP(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false)); \
+        v = OP(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false)); \
+        v = OP(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false)); \
+        v = OP(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false)); \
+        v = OP(v, __shfl_xor(v, 16)); } while (0)
+__device__ __forceinline__ int op_add(int a, int b) { return a + b; }
+__device__ __forceinline__ int op_max(int a, int b) { return a > b ? a : b; }
+// sum / maximum over the lanes of this lane's half (all lanes of the wave must be active)
+__device__ __forceinline__ int half_sum(int v) { VG_HALF_BUTTERFLY(v, op_add); return v; }
+__device__ __forceinline__ int half_max(int v) { VG_HALF_BUTTERFLY(v, op_max); return v; }
+
+// extend() for one half (32 lanes x 32 bases = 1 024 positions per round), default parameters aw = 15, am = 7, ar = 3.
+// `on` = this lane's half takes part (uniform per half); the function is entered by the WHOLE wave so that the reductions see
+// all lanes, and a half that is off, or has finished, idles through the other's rounds.
+__device__ __forceinline__ int extend_h(const pair_ctx& c, bool on, int qp, int rp, int dir, int bound, int hl, int h,
+                                        int* n_match, uint64_t mm_first, int rlo, int rhi) {
+    constexpr int AW = 15, AM = 7, AR = 3;
+    int accepted = 0, matches_total = 0;
+    int first_mm = -1;
+    uint64_t carry_mm = 0, carry_ok = 0;
+    int base = 0, cum_before = 0;
+    const uint64_t awmask = (1ULL << (2 * AW)) - 1;
+    bool run_me = on && bound > 0;
+    while (__ballot(run_me)) {
+        uint64_t mm = run_me ? mm_first : 0ULL;
+        if (run_me && base > 0) {
+            mm = EVEN;
+            const int e0 = base + 32 * hl;
+            if (e0 < bound) {
+                if (dir > 0) mm = mism32(c, qp + e0, rp + e0, rlo, rhi);
+                else mm = rev2(mism32(c, qp - e0 - 32, rp - e0 - 32, rlo, rhi)) & EVEN;
+                const int rem = bound - e0; if (rem < 32) mm |= EVEN & ~slots(0, rem);
+            }
+        }
+        const unsigned long long anyw = __ballot(run_me && mm != 0);
+        const uint32_t anyb = hsel(anyw, h);
+        {
+            const uint64_t mfl = hb64(mm, ctz32z((uint32_t)anyw), ctz32z((uint32_t)(anyw >> 32)), h);
+            if (run_me && first_mm < 0 && anyb) first_mm = base + 32 * __builtin_ctz(anyb) + (__builtin_ctzll(mfl) >> 1);
+        }
+        uint64_t prev_mm = lane_prev64(mm); const uint64_t okb = (~mm) & EVEN; uint64_t prev_ok = lane_prev64(okb);
+        if (hl == 0) { prev_mm = carry_mm; prev_ok = carry_ok; }
+        int viol = 32;
+        if (run_me) {
+            const uint64_t tail = prev_mm >> (64 - 2 * (AW - 1));
+            if ((int)(__popcll(mm) + __popcll(tail)) > AM) {
+                uint64_t bits = mm;
+                for (int skip = AM - (int)__popcll(tail); skip > 0; --skip) bits &= bits - 1;
+                while (bits) {
+                    const int j = __builtin_ctzll(bits) >> 1;
+                    const int top = 2 * j + 2;
+                    const uint64_t hi = (top == 64) ? mm : (mm & ((1ULL << top) - 1));
+                    int cnt;
+                    if (j + 1 >= AW) cnt = __popcll(hi & (awmask << (2 * (j + 1 - AW))));
+                    else cnt = __popcll(hi) + __popcll(prev_mm >> (64 - 2 * (AW - 1 - j)));
+                    if (cnt > AM) { viol = j; break; }
+                    bits &= bits - 1;
+                }
+            }
+        }
+        const unsigned long long vw = __ballot(run_me && viol < 32);
+        const uint32_t vb = hsel(vw, h);
+        // positions ending a run of >= ar matches, strictly before the violation
+        uint64_t cand = 0;
+        {
+            uint64_t run = okb;
+#pragma unroll
+            for (int t = 1; t < AR; ++t) run &= (okb << (2 * t)) | (prev_ok >> (64 - 2 * t));
+            const int fv = vb ? __builtin_ctz(vb) : 32;
+            const int vj = (int)hb32((uint32_t)viol, ctz32z((uint32_t)vw), ctz32z((uint32_t)(vw >> 32)), h);
+            cand = run;
+            if (hl > fv) cand = 0;
+            else if (hl == fv) cand &= (vj == 0) ? 0ULL : ((1ULL << (2 * vj)) - 1);
+            if (!(run_me && anyb)) cand = 0;
+        }
+        const unsigned long long cw = __ballot(cand != 0);
+        const uint32_t cb = hsel(cw, h);
+        const int c0 = top32z((uint32_t)cw), c1 = top32z((uint32_t)(cw >> 32));
+        const int hlane = top32z(cb);
+        const uint64_t ch = hb64(cand, c0, c1, h), mh = hb64(mm, c0, c1, h);
+        const int ok_cnt = 32 - (int)__popcll(mm);                      // matches of this lane's 32 positions
+        const int tot_below = cw ? half_sum((run_me && cb && hl < hlane) ? ok_cnt : 0) : 0;
+        if (run_me) {
+            if (anyb) {
+                if (cb) {
+                    const int hj = (63 - __builtin_clzll(ch)) >> 1;
+                    accepted = base + 32 * hlane + hj + 1;
+                    const uint64_t upto = (hj == 31) ? ~0ULL : ((1ULL << (2 * hj + 2)) - 1);
+                    matches_total = cum_before + tot_below + (hj + 1) - (int)__popcll(mh & upto);
+                }
+            } else { accepted = base + 1024; matches_total = cum_before + 1024; }
+        }
+        if (run_me && (vb || base + 1024 >= bound)) run_me = false;
+        if (__ballot(run_me)) {
+            // another round for some half: matches so far and the last lane's masks carry over
+            const int tot_all = half_sum(run_me ? ok_cnt : 0);
+            const uint64_t l_mm = hb64(mm, 31, 31, h), l_ok = hb64(okb, 31, 31, h);
+            if (run_me) { cum_before += anyb ? tot_all : 1024; carry_mm = l_mm; carry_ok = l_ok; base += 1024; }
+        }
+    }
+    if (!(on && bound > 0)) { *n_match = 0; return 0; }
+    if (first_mm < 0) first_mm = bound;
+    if (first_mm > bound) first_mm = bound;
+    if (accepted < first_mm) { accepted = first_mm; matches_total = first_mm; }
+    if (accepted > bound) accepted = bound;
+    *n_match = matches_total;
+    return accepted;
+}
+
+// gap_score() for one half; g <= 64 (the default mqd = 40 bounds the literal run of a chained match).  Entered by the whole
+// wave; `on` = this lane's half has a gap to score.
+__device__ __forceinline__ int gap_score_h(const pair_ctx& c, bool on, int i, int g, int pred0, int E, int hl, int h, int rlo, int rhi,
+                                           int* pm_out, int* sm_out) {
+    const int reflen = E - pred0;
+    const int skip = (reflen >= 0 && g > reflen) ? g - reflen : 0;
+    const int q0 = i - g;
+    uint32_t ok_o = 0, ok_n = 0;
+    {
+        const int e0 = 32 * hl;
+        if (on && e0 < g) {
+            const uint32_t in = (g - e0 >= 32) ? 0xffffffffu : ((1u << (g - e0)) - 1u);
+            ok_o = ~squeeze(mism32(c, q0 + e0, pred0 + e0, rlo, rhi)) & in;
+            ok_n = ~squeeze(mism32(c, q0 + e0, E - g + e0, rlo, rhi)) & in;
+        }
+    }
+    // the (at most 64) literals' match bits on the two diagonals, in every lane of the half
+    const uint64_t O = (uint64_t)hb32(ok_o, 0, 0, h) | ((uint64_t)hb32(ok_o, 1, 1, h) << 32);
+    const uint64_t N = (uint64_t)hb32(ok_n, 0, 0, h) | ((uint64_t)hb32(ok_n, 1, 1, h) << 32);
+    const int n_split = g - skip;                 // split points a = 0 .. n_split
+    int best_key = -1, best_pm = 0, best_sm = 0;
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {                 // a = 32 w + hl covers 0 .. 63 >= n_split (g <= mqd = 40)
+        const int a = 32 * w + hl;
+        const int sp = a + skip;                  // suffix start
+        const int pre = (int)__popcll(O & low_bits64(a));
+        const int suf = sp >= 64 ? 0 : (int)__popcll(N >> sp);
+        const bool valid = on && a <= n_split;
+        const int key = valid ? ((pre + suf) << 7) | a : -1;        // maximum of pre + suf, ties -> the largest a
+        const int kmax = half_max(key);
+        if (kmax >= 0 && kmax > best_key) {
+            best_key = kmax;
+            // the winner's prefix / suffix counts: recomputed from its split point (every lane holds O and N)
+            const int wa = kmax & 127, wsp = wa + skip;
+            best_pm = (int)__popcll(O & low_bits64(wa));
+            best_sm = wsp >= 64 ? 0 : (int)__popcll(N >> wsp);
+        }
+    }
+    *pm_out = best_pm; *sm_out = best_sm;
+    return best_pm + best_sm;
+}
+
+// STATS (developer switch VG_LZ_KERNEL=two_stats): a row carries counters instead of sums -- n_match = the pair's events,
+// aln_len = loop iterations of the wave while the pair was resident, n_regions = those in which BOTH halves had an event
+template <bool STATS>
+__device__ __forceinline__ void lz_parse2_body(PARSE_ARGS) {
+    constexpr int MAL = 11, MSL = 7, MRD = 40, MQD = 40, REG = 35, WEAK = 3, TAGB = 8;
+    const int lane = threadIdx.x & 63, h = lane >> 5, hl = lane & 31;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t per_xcd = gridDim.x / 8;
+    const int64_t vblk = (int64_t)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    int64_t t_next = (vblk * 4 + w) * P2_CHUNK;
+    const int64_t t_end = min(n_tasks, t_next + P2_CHUNK);
+    if (t_next >= t_end) return;
+    // ---- state of this lane's half (uniform over its 32 lanes)
+    bool act = false, alive = false, in_region = false;
+    int i = 0, lit = 0, pred = 0, lim = 0;
+    int r_qstart = 0, r_qend = 0, r_match = 0, kept_end = 0;
+    uint32_t M = 0, A = 0, NR = 0, out_idx = 0; int pos_bits = 1;
+    pair_ctx c; c.qpk = packed; c.qmk = nmask; c.qlen = 0; c.q_has_n = 0; c.rpk = rr_pool; c.rmk = mask_pool; c.n_rr = 1; c.L = 0; c.r_has_n = 0;
+    const uint32_t* stab = stab_pool; const uint32_t* sent = sent_pool;
+    const uint64_t smask = (1ULL << (2 * MSL)) - 1;
+    int n_iter = 0, st_it0 = 0, st_ev = 0, st_both = 0;
+    // STATS with P.ablate = 8 + section: n_match = wave clock cycles / 16 spent in that section while the pair was resident
+    const int psel = STATS ? P.ablate - 8 : -1;
+    long long pc_acc = 0, pc_t0 = 0, tp = STATS ? (long long)clock64() : 0;
+#define P2_MARK(k) do { if (STATS && psel >= 0) { const long long tn_ = (long long)clock64(); if (psel == (k)) pc_acc += tn_ - tp; tp = tn_; } } while (0)
+    auto take = [&](int hh) {       // half hh starts the next task of the wave's chunk (scalar loads, selected into its lanes)
+        const task_dev tk = tasks[t_next++];
+        const ref_desc rd = refs[tk.r_slot];
+        const int64_t qb = base_off[tk.q];
+        const int ql = (int)glen[tk.q];
+        if (h == hh) {
+            c.qpk = packed + (qb >> 4); c.qlen = ql;
+            c.rpk = rr_pool + rd.rr_w; c.n_rr = rd.n_rr; c.L = rd.L;
+            stab = stab_pool + rd.stab; sent = sent_pool + rd.sent;
+            pos_bits = rd.pos_bits;                               // (<= 24: the host takes this kernel for genomes below 2^22 bases)
+            out_idx = tk.out_idx; lim = ql - MAL;
+            act = true; alive = false; in_region = false; i = 0; lit = 0; pred = 0; kept_end = 0; M = 0; A = 0; NR = 0;
+            if (STATS) { st_it0 = n_iter; st_ev = 0; st_both = 0; pc_t0 = pc_acc; }
+        }
+    };
+    take(0);
+    if (t_next < t_end) take(1);
+    int n_events = 0;
+    for (;;) {
+        // ---- a half whose pair is parsed writes its row and takes the next task of the chunk
+        {
+            const bool done = act && i >= lim;
+            const unsigned long long dw = __ballot(done);
+            if (dw) {
+                if (done) {
+                    if (in_region) { const int span = r_qend - r_qstart + 1; if (span >= REG) { M += (uint32_t)r_match; A += (uint32_t)span; NR += 1; } in_region = false; }
+                    if (STATS) { M = psel >= 0 ? (uint32_t)((pc_acc - pc_t0) >> 4) : (uint32_t)st_ev; A = (uint32_t)(n_iter - st_it0); NR = (uint32_t)st_both; }
+                    if (hl == 0) { vg_pair_stat st; st.n_match = M; st.aln_len = A; st.n_regions = NR; stats[out_idx] = st; }
+                    act = false;
+                }
+                if ((uint32_t)dw && t_next < t_end) take(0);
+                if ((uint32_t)(dw >> 32) && t_next < t_end) take(1);
+                continue;                                   // (a pair shorter than mal is done at once)
+            }
+            if (!__ballot(act)) break;
+        }
+        P2_MARK(0);
+        // ---- speculative probe of positions i .. i + 31 of each half's pair
+        const int qi = i + hl;
+        int best_len = 0, best_pos = 0; bool hit_close = false;
+        if (act && qi < lim) {
+            const bool alive_l = alive && (lit + hl <= MQD);
+            const int pred_l = pred + hl;
+            const uint64_t xq = load32(c.qpk, qi);
+            const bool q_ok_s = (qi + MSL <= c.qlen);
+            const uint64_t qbad = (c.qlen - qi < 32) ? (EVEN & ~slots(0, c.qlen - qi)) : 0ULL;
+            const bool do_s = alive_l && q_ok_s;
+            uint32_t s_u = 0, s_e = 0;
+            const uint32_t qtag = (uint32_t)((xq >> (2 * MSL)) & ((1u << TAGB) - 1u));
+            const uint32_t posmask = (1u << pos_bits) - 1u;
+            if (q_ok_s) {
+                const uint32_t b = (uint32_t)(xq & smask);
+                uint2 bb; __builtin_memcpy(&bb, stab + (b ? b - 1 : 0u), 8);
+                s_u = b ? bb.x : 0u; s_e = b ? bb.y : bb.x;
+            }
+            const int pred0 = pred - lit;
+            const bool pred_rc = pred0 > c.L;
+            const int win_lo = pred0;
+            const int win_hi = pred_rc ? pred_l + MRD - 1 : min(pred_l + MRD - 1, c.L - 1);
+            int sbest_len = 0, sbest_pos = 0, sbest_ad = 0, ncap_a = 0, ncap_s = 0;
+            const uint32_t win_span = (uint32_t)(win_hi - win_lo);
+            const bool win_any = win_hi >= win_lo;
+            while (s_u < s_e) {
+                uint4 v; __builtin_memcpy(&v, sent + s_u, 16);
+                const uint32_t e4[4] = { v.x, v.y, v.z, v.w };
+                unsigned am = 0, sm = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t ps = e4[j] & posmask;
+                    am |= (uint32_t)((e4[j] >> pos_bits) == qtag) << j;
+                    sm |= (uint32_t)(ps - (uint32_t)win_lo <= win_span) << j;
+                }
+                const uint32_t left = s_e - s_u;
+                const unsigned vm = left >= 4u ? 0xfu : ((1u << left) - 1u);
+                am &= vm; sm &= (do_s && win_any) ? vm : 0u;
+                unsigned cm = am | sm;
+                while (cm) {
+                    const int j = __builtin_ctz(cm); cm &= cm - 1;
+                    const uint32_t ej = j == 0 ? e4[0] : j == 1 ? e4[1] : j == 2 ? e4[2] : e4[3];
+                    const int rp = (int)(ej & posmask);
+                    const int l0 = match_len32_q(c, xq, qbad, rp);
+                    if ((am >> j) & 1u) {
+                        int l = l0;
+                        if (l >= MAL) {
+                            if (l >= 32) {
+                                if (ncap_a++ > 0 || best_len >= 32) {
+                                    l = match_len_lane(c, qi, rp, 1 << 30);
+                                    if (best_len == 32) best_len = match_len_lane(c, qi, best_pos, 1 << 30);
+                                }
+                            }
+                            if (l > best_len || (l == best_len && rp < best_pos)) { best_len = l; best_pos = rp; }
+                        }
+                    }
+                    if ((sm >> j) & 1u) {
+                        int l = l0;
+                        if (l >= MSL) {
+                            if (l >= 32) {
+                                if (ncap_s++ > 0 || sbest_len >= 32) {
+                                    l = match_len_lane(c, qi, rp, 1 << 30);
+                                    if (sbest_len == 32) sbest_len = match_len_lane(c, qi, sbest_pos, 1 << 30);
+                                }
+                            }
+                            const int ad = abs(rp - pred_l);
+                            if (l > sbest_len || (l == sbest_len && (ad < sbest_ad || (ad == sbest_ad && rp < sbest_pos)))) { sbest_len = l; sbest_pos = rp; sbest_ad = ad; }
+                        }
+                    }
+                }
+                s_u += 4;
+                // positions behind the first one of THIS half that already has a match cannot become its event
+                const uint32_t hit = hsel(__ballot(best_len > 0 || sbest_len > 0), h);
+                if (hit && hl > __builtin_ctz(hit)) s_u = s_e;
+            }
+            if (best_len > 0 && sbest_len > 0 && best_pos != sbest_pos && best_len >= 32 && sbest_len + MSL > 32) {
+                if (best_len == 32) best_len = match_len_lane(c, qi, best_pos, 1 << 30);
+                if (sbest_len == 32) sbest_len = match_len_lane(c, qi, sbest_pos, 1 << 30);
+            }
+            if (best_len > 0 && (sbest_len == 0 || best_len >= sbest_len + MSL - ((lit + hl > WEAK * sbest_len) ? 1 : 0))) {
+                const int d = best_pos - pred_l;
+                hit_close = alive_l && ((best_pos > c.L) == pred_rc) && d >= -MRD && d <= MRD;
+            } else if (sbest_len > 0) { best_len = sbest_len; best_pos = sbest_pos; hit_close = true; }
+        }
+        const unsigned long long hw = __ballot(best_len > 0);
+        const uint32_t hb = hsel(hw, h);
+        const bool ev = act && hb != 0;
+        if (act && !hb) {
+            const int n = min(32, lim - i);
+            i += n; lit += n; if (alive) { pred += n; if (lit > MQD) alive = false; }
+        }
+        if (STATS) { ++n_iter; if (ev) { ++st_ev; if ((uint32_t)hw && (uint32_t)(hw >> 32)) ++st_both; } }
+        P2_MARK(1);
+        if (!hw) continue;
+        // ---- the event of each half that has one (the other idles through the shared instructions)
+        n_events += __popcll(hw) ? 1 : 0;
+        if (n_events == 48) __builtin_amdgcn_s_setprio(1);
+        else if (n_events == 128) __builtin_amdgcn_s_setprio(2);
+        else if (n_events == 320) __builtin_amdgcn_s_setprio(3);
+        const int f0 = ctz32z((uint32_t)hw), f1 = ctz32z((uint32_t)(hw >> 32));
+        const int f = ev ? __builtin_ctz(hb) : 0;
+        const int ev_pos = (int)hb32((uint32_t)best_pos, f0, f1, h);
+        const bool ev_close = hb32((uint32_t)hit_close, f0, f1, h) != 0;
+        const int ev_len = (int)hb32((uint32_t)best_len, f0, f1, h);
+        if (ev) { i += f; lit += f; if (alive) { pred += f; if (lit > MQD) alive = false; } }
+        const int rlo = strand_lo(c, ev_pos), rhi = strand_hi(c, ev_pos);
+        const int kept_after = (in_region && r_qend - r_qstart + 1 >= REG) ? r_qend + 1 : kept_end;
+        const bool do_b = ev && !ev_close;
+        const int bwd_bound = do_b ? i - kept_after : 0;
+        const uint64_t mm_b = do_b ? extend_mask0(c, i, ev_pos, -1, bwd_bound, hl, rlo, rhi) : EVEN;
+        const uint64_t mm_f = ev ? extend_mask0(c, i, ev_pos, +1, 1 << 30, hl, rlo, rhi) : EVEN;
+        if (do_b) {
+            // R5: new region (close the open one first)
+            if (in_region) { const int span = r_qend - r_qstart + 1; if (span >= REG) { M += (uint32_t)r_match; A += (uint32_t)span; NR += 1; kept_end = r_qend + 1; } in_region = false; }
+        }
+        P2_MARK(2);
+        if (__ballot(do_b)) {
+            int bm = 0;
+            const int b = extend_h(c, do_b, i, ev_pos, -1, bwd_bound, hl, h, &bm, mm_b, rlo, rhi);
+            if (do_b) { r_qstart = i - b; r_match = bm; in_region = true; }
+        }
+        P2_MARK(3);
+        int fm = 0;
+        const int fe = extend_h(c, ev, i, ev_pos, +1, 1 << 30, hl, h, &fm, mm_f, rlo, rhi);
+        if (ev) r_match += fm;
+        P2_MARK(4);
+        const bool do_g = ev && ev_close && lit > 0;
+        if (__ballot(do_g)) {
+            int xl = ev_len;
+            {
+                // exact length of the match = position of the first mismatch of the forward pass
+                const unsigned long long mw = __ballot(do_g && xl >= 32 && mm_f != 0);
+                const uint64_t mfl = hb64(mm_f, ctz32z((uint32_t)mw), ctz32z((uint32_t)(mw >> 32)), h);
+                const uint32_t mb = hsel(mw, h);
+                if (do_g && xl >= 32) {
+                    xl = mb ? 32 * __builtin_ctz(mb) + (__builtin_ctzll(mfl) >> 1) : 1024;
+                    if (xl >= 1024) xl = match_len_lane(c, i, ev_pos, 1 << 30);
+                }
+            }
+            int pm = 0, sm = 0;
+            const int gs = gap_score_h(c, do_g, i, lit, pred - lit, ev_pos + xl, hl, h, rlo, rhi, &pm, &sm);
+            if (do_g) r_match += gs;
+        }
+        if (ev) {
+            i += fe; pred = ev_pos + fe; lit = 0; alive = true;
+            r_qend = i - 1;
+        }
+        P2_MARK(5);
+    }
+#undef P2_MARK
+}
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) k_lz_parse_fast2(PARSE_ARGS) { lz_parse2_body<false>(PARSE_ARG_NAMES); }
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) k_lz_parse_fast2_stats(PARSE_ARGS) { lz_parse2_body<true>(PARSE_ARG_NAMES); }
+
 inline int grid_for(int64_t n, int block = 256, int max_blocks = 256 * 16) {
     int64_t b = (n + block - 1) / block; if (b < 1) b = 1;
     return (int)std::min<int64_t>(b, max_blocks);
@@ -1621,7 +2017,17 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
                                    L.sent_pool.p, P, d_stats.p, (vg_region*)nullptr, no_off);
                 } else
 #endif
-                if (fast_params) {
+                // two pairs per wave (k_lz_parse_fast2): VG_LZ_KERNEL=two / one (developer A/B)
+                static const int two_env = [] { const char* e = vg_dev_getenv("VG_LZ_KERNEL"); return e && !strcmp(e, "two") ? 1 : (e && !strcmp(e, "two_stats") ? 2 : (e && !strcmp(e, "one") ? 0 : -1)); }();
+                const bool two_pairs = two_env >= 0 ? two_env >= 1 : VG_LZ_TWO_PAIRS_DEFAULT;
+                if (fast_params && two_pairs) {
+                    const int64_t nwave = (nt + P2_CHUNK - 1) / P2_CHUNK, nblk2 = ((nwave + 3) / 4 + 7) / 8 * 8;
+                    lz_dev_params P2 = P;
+                    if (two_env == 2) { static const char* sel = vg_dev_getenv("VG_LZ_P2SEL"); P2.ablate = sel ? 8 + atoi(sel) : 0; }
+                    hipLaunchKernelGGL(two_env == 2 ? k_lz_parse_fast2_stats : k_lz_parse_fast2, dim3((unsigned)nblk2), dim3(256), 0, s, d_tasks.p + B.pos, nt, d_refs.p, g->d_packed.p, g->d_nmask.p,
+                                   g->d_base_off.p, g->d_len.p, g->d_has_n.p, L.rr_pool.p, L.mask_pool.p, L.stab_pool.p,
+                                   L.sent_pool.p, P2, d_stats.p, (vg_region*)nullptr, no_off);
+                } else if (fast_params) {
                     hipLaunchKernelGGL(k_lz_parse_fast, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p + B.pos, nt, d_refs.p, g->d_packed.p, g->d_nmask.p,
                                    g->d_base_off.p, g->d_len.p, g->d_has_n.p, L.rr_pool.p, L.mask_pool.p, L.stab_pool.p,
                                    L.sent_pool.p, P, d_stats.p, (vg_region*)nullptr, no_off);
