@@ -137,7 +137,9 @@ def cli_wall(codes, offsets, names, n_pairs):
     """End-to-end wall of the drop-in CLI: FASTA on disk -> fltr.txt -> ani.tsv on disk,
     two processes (`vclust.py prefilter`, `vclust.py align --filter`), including process start, ingest and writers,
     with the per-process split of where the wall time goes."""
-    with tempfile.TemporaryDirectory(dir=os.environ.get('TMPDIR', '/tmp')) as td:
+    tdo = tempfile.TemporaryDirectory(dir=os.environ.get('TMPDIR', '/tmp'))      # (kept by the caller until the timed step's rows have been compared with ani.tsv)
+    if True:
+        td = tdo.name
         fa = os.path.join(td, 's.fna')
         synth.write_fasta(fa, codes, offsets, names)
         fl, ani = os.path.join(td, 'fltr.txt'), os.path.join(td, 'ani.tsv')
@@ -153,6 +155,7 @@ def cli_wall(codes, offsets, names, n_pairs):
                              breakdown_s=dict(prefilter=_phase_sums(pre), align=_phase_sums(aln))))
         rows = sum(1 for _ in open(ani)) - 1
         size = os.path.getsize(fa)
+        os.unlink(fa)
     order = sorted(range(len(runs)), key=lambda i: runs[i]['total_s'])
     med = runs[order[len(order) // 2]]
     out = dict(prefilter_s=med['prefilter_s'], align_s=med['align_s'], total_s=med['total_s'], rows=rows,
@@ -168,7 +171,7 @@ def cli_wall(codes, offsets, names, n_pairs):
                     'taken out of device_work')
     if runs[order[-1]] is not med:
         out['slowest_run_breakdown_s'] = runs[order[-1]]['breakdown_s']
-    return out
+    return out, tdo, ani
 
 
 def main():
@@ -213,10 +216,10 @@ def main():
     # End-to-end CLI leg FIRST, while this process has not touched the HBM yet: the driver scrubs device memory
     # that moves between processes, so CLI processes started right after this process has used ~150 GB measure
     # the scrub (observed for the same work: 2.7 s on a quiet device, 6.7-8.4 s right after the timed loop)
-    e2e = None
+    e2e = None; cli_td = None; cli_ani = None
     if world == 1 and rank == 0 and not args.no_cli_wall:
         try:
-            e2e = cli_wall(codes, offsets, names, None)
+            e2e, cli_td, cli_ani = cli_wall(codes, offsets, names, None)
         except Exception as exc:      # the device-resident figure stands on its own
             e2e = dict(error=str(exc))
     gs = api.GenomeSet.from_codes(codes, offsets, names)
@@ -275,6 +278,18 @@ def main():
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
 
+    if rank == 0 and cli_ani is not None:
+        # the file the two cold CLI processes wrote against the rows of the timed step: ani.tsv written from the step's
+        # integers by the same writer must be the same bytes (the cold path -- RANGE sub-shards under the workspace budget,
+        # 6 GiB index batches -- and the resident path agree at the benchmark's own size)
+        try:
+            import filecmp
+            mem_ani = os.path.join(cli_td.name, 'step.ani.tsv')
+            gs.write_ani(mem_ani, state['tasks'], state['stats'])
+            e2e['cli_rows_equal_step'] = bool(filecmp.cmp(cli_ani, mem_ani, shallow=False))
+        except Exception as exc:
+            e2e['cli_rows_equal_step'] = f'not compared: {exc}'
+        cli_td.cleanup()
     if rank == 0:
         n_pairs = state['n_pairs']
         tk = state['tasks']

@@ -3,6 +3,8 @@ configs[1] in full against the oracle (every row, files byte-compared); configs[
 (properties + an oracle sample); configs[3] / [4] at a reduced count with their own flag sets
 (size-independent properties, determinism, oracle sample).  Everything calls through the C ABI."""
 import filecmp
+import pathlib
+import sys
 
 import numpy as np
 import pytest
@@ -357,3 +359,67 @@ def test_config4_contigs_1M_full_size():
     ani = stats['n_match'] / np.maximum(stats['aln_len'], 1); qcov = stats['aln_len'] / lens[tasks['q']]
     kept = np.count_nonzero((ani >= 0.95) & (qcov >= 0.85))
     assert 0 < kept < len(stats)
+
+
+@pytest.mark.slow
+def test_config3_phage_100k_full_size(tmp_path):
+    """BASELINE configs[3] AT ITS SIZE on one MI355X, the set bench.py times (100 000 x 40 kb, seed 3; its sha256 is pinned in
+    tests/golden/synth_sha256.json), asserted -- not only counted:
+      * in memory: exactly the 450 000 family pairs (every family's 45), shared >= 20, a second pass bit-identical,
+        set sizes / shared counts of 40 sampled pairs and the LZ rows of 60 sampled tasks equal to the oracle's;
+      * the cold drop-in CLI at this size (two processes: prefilter as eight RANGE sub-shards under the 8 GiB workspace
+        budget, align with 6 GiB index batches -- the only place those paths run at the real size): `fltr.txt` and
+        `ani.tsv` byte-identical to the files written from the in-memory integers."""
+    import filecmp
+    import os
+    import subprocess
+    codes, offsets, names, _ = synth.make_workload('phage-100k', 10000)
+    assert len(names) == 100000
+    import json
+    pinned = json.load(open(pathlib.Path(__file__).parent / 'golden' / 'synth_sha256.json'))
+    assert synth.sha256(codes, offsets) == pinned['phage-100k']['sha256']
+    fam = np.arange(100000) // 10
+    gs = api.GenomeSet.from_codes(codes, offsets, names)
+    sizes, pairs = gs.kmer_shared(k=25, min_shared=20)
+    cand = gs.filter_pairs(sizes, pairs, k=25, min_kmers=20, min_ident=0.7)
+    assert len(cand) == 450000 and np.all(fam[cand['a']] == fam[cand['b']]) and np.all(cand['a'] > cand['b']) and np.all(cand['shared'] >= 20)
+    assert len(np.unique(cand['a'].astype(np.int64) * 100000 + cand['b'])) == 450000
+    tasks = gs.align_tasks(cand)
+    stats = gs.lz_align(tasks)
+    lens = gs.lengths()
+    assert len(stats) == 900000 and np.all(stats['n_match'] <= stats['aln_len']) and np.all(stats['aln_len'] <= lens[tasks['q']]) and np.all(stats['n_regions'] > 0)
+    # determinism
+    sizes2, pairs2 = gs.kmer_shared(k=25, min_shared=20)
+    o1 = np.lexsort((pairs['b'], pairs['a'])); o2 = np.lexsort((pairs2['b'], pairs2['a']))
+    assert np.array_equal(sizes, sizes2) and np.array_equal(pairs[o1], pairs2[o2])
+    assert np.array_equal(stats, gs.lz_align(tasks))
+    # oracle sample
+    rng = np.random.default_rng(33)
+    for i in rng.choice(len(cand), 40, replace=False):
+        a, b = int(cand[i]['a']), int(cand[i]['b'])
+        ka = orc.kmer_set(codes[offsets[a]:offsets[a + 1]], 25); kb = orc.kmer_set(codes[offsets[b]:offsets[b + 1]], 25)
+        assert len(ka) == sizes[a] and len(kb) == sizes[b]
+        assert len(np.intersect1d(ka, kb, assume_unique=True)) == int(cand[i]['shared']), (a, b)
+    for i in rng.choice(len(tasks), 60, replace=False):
+        q, r = int(tasks[i]['q']), int(tasks[i]['r'])
+        assert orc.lz_pair_stat(codes[offsets[q]:offsets[q + 1]], codes[offsets[r]:offsets[r + 1]]) == tuple(int(x) for x in stats[i]), (q, r)
+    # files from the in-memory integers
+    f_mem, a_mem = tmp_path / 'mem.fltr.txt', tmp_path / 'mem.ani.tsv'
+    gs.write_fltr(f_mem, sizes, pairs, k=25, min_kmers=20, min_ident=0.7)
+    gs.write_ani(a_mem, tasks, stats)
+    del gs
+    api.release_device_memory()
+    # the cold CLI: two processes, FASTA on disk
+    fa = tmp_path / 'phage100k.fna'
+    synth.write_fasta(fa, codes, offsets, names)
+    f_cli, a_cli = tmp_path / 'cli.fltr.txt', tmp_path / 'cli.ani.tsv'
+    vclust = pathlib.Path(__file__).resolve().parent.parent / 'vclust.py'
+    env = dict(os.environ, VG_HOST_TRACE='1')
+    p = subprocess.run([sys.executable, str(vclust), 'prefilter', '-i', str(fa), '-o', str(f_cli), '-v', '0'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert p.stderr.count('spgemm done') >= 8, 'the cold prefilter was expected to run as >= 8 sub-shard passes'
+    p = subprocess.run([sys.executable, str(vclust), 'align', '-i', str(fa), '-o', str(a_cli), '--filter', str(f_cli), '-v', '0'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert filecmp.cmp(f_mem, f_cli, shallow=False)
+    assert filecmp.cmp(a_mem, a_cli, shallow=False)
+    assert sum(1 for _ in open(a_cli)) == 900001
