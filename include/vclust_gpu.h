@@ -47,7 +47,8 @@ void        vg_free(void* p);
 int vg_device_count(void);
 int vg_set_device(int device);
 /* the library keeps released device blocks in a cache (no hipMalloc on the hot path); this returns them to
- * the driver, e.g. before another process needs the HBM */
+ * the driver, e.g. before another process needs the HBM -- together with the reference indexes a vg_lz_prepare
+ * may have left behind (that plan is process-global: one per process, replaced by the next vg_lz_prepare / vg_lz_align) */
 void vg_release_device_memory(void);
 /* allocator self-test (no reference call site): `cycles` rounds of allocating blocks of the given byte sizes through the
  * library's device allocator, writing and reading back a pattern at both ends of each, releasing them and returning the
@@ -122,6 +123,10 @@ typedef struct {            /* mirrors the prefilter sub-parser, vclust.py:208-2
 } vg_prefilter_params;
 int vg_prefilter(const char* const* fasta_paths, int n_paths, const char* out_path,
                  const vg_prefilter_params* p);
+/* on != 0: the process ends right after its vg_prefilter / vg_align call, so the call leaves the genome set (GBs of host
+ * and device memory) to the process exit instead of releasing it piece by piece first (vclust.py's one-shot processes;
+ * no reference call site).  Off by default: an embedding process keeps the normal ownership. */
+void vg_set_process_ends_after_call(int on);
 
 /* ------------------------------------------------------------------ align ------------- */
 typedef struct { int mal, msl, mrd, mqd, reg, aw, am, ar; } vg_lz_params;  /* vclust.py:363-418 */
@@ -130,6 +135,19 @@ typedef struct { uint32_t n_match, aln_len, n_regions; } vg_pair_stat;     /* L5
 typedef struct {            /* one local alignment, 0-based inclusive; r* in fwd|N|rc space */
     uint32_t task; int32_t qstart, qend, rstart, rend; int32_t n_match;
 } vg_region;
+
+/* The constants of the LZ restatement that a handful of events of the reference's 12-genome example decide (DESIGN.md
+ * section 2, profiles/r04_lz_fit_leave_one_out.md) -- everything else of the parse is held by dozens to thousands of
+ * golden regions.  Process-wide; NULL restores the fitted values.  No reference call site: lz-ani has no such options;
+ * they exist so that a maintainer with the upstream binaries can re-decide them (tools/compare_with_upstream.py).
+ *   weak_seed_ratio  3   R3: a seed shorter than 1/ratio of the literal run it bridges gives one symbol of the anchor
+ *                        margin away (0 = never)                                                  [one event]
+ *   anchor_margin   -1   R3: a far anchor replaces the seed when longer by MORE than this; -1 = msl - 1 (6 against 7: two pairs)
+ *   seed_choice      3   R3: among seeds 3 = longest, then closest to the prediction; 1 = closest, then longest   [three regions]
+ * (The fourth thin constant, the oracle's strand separator -- two pairs --, has no counterpart here: the kernels keep one
+ * separator symbol and confine every match, extension, window and gap score to its strand by bounds.) */
+typedef struct { int weak_seed_ratio, anchor_margin, seed_choice; } vg_lz_fit;
+void vg_set_lz_fit(const vg_lz_fit* f);
 
 /* LZ parse of every task on the GPU.  stats: n_tasks entries (caller-owned).
  * regions/n_regions may be NULL; otherwise all kept regions (unordered), vg_free(). */

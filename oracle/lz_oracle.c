@@ -73,6 +73,10 @@ void vo_lz_default_variant(vo_lz_variant* v) {
     v->weak_seed_ratio = 3;          /* R3: a seed shorter than lit / 3 gives one symbol of the margin away */
     /* (a single-event fit, profiles/r04_lz_fit_leave_one_out.md: the product reads VG_LZ_WEAK_SEED -- 0 = off --, and so does the checker) */
     { const char* e = getenv("VG_LZ_WEAK_SEED"); if (e && *e) { int r = atoi(e); v->weak_seed_ratio = r < 0 ? 0 : r > 1000 ? 1000 : r; } }
+    /* the other two thin constants (vg_lz_fit of the product: anchor margin 6 against 7 -- two pairs --, seed tie-break --
+     * three regions): the checker follows the same developer variables */
+    { const char* e = getenv("VG_LZ_ANCHOR_MARGIN"); if (e && *e) { int r = atoi(e); v->anchor_margin = r < 0 ? -1 : r > 1000 ? 1000 : r; } }
+    { const char* e = getenv("VG_LZ_SEED_CHOICE"); if (e && *e) { v->seed_choice = atoi(e) == 1 ? 1 : 3; } }
 }
 
 static inline uint64_t mix64(uint64_t x) {

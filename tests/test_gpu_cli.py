@@ -237,7 +237,7 @@ def test_weak_seed_rule_is_exercised_and_switchable(tmp_path):
     fa = tmp_path / 'div.fna'
     synth.write_fasta(fa, codes, offsets, names)
     out = {}
-    for tag, extra in (('on', {}), ('off', dict(VG_LZ_WEAK_SEED='0'))):
+    for tag, extra in (('on', {}), ('off', dict(VG_LZ_WEAK_SEED='0', VG_DEV_SWITCHES='1'))):      # (the product honours the variable only beside VG_DEV_SWITCHES)
         e = dict(os.environ, **extra)
         ani, aln, oani, oaln = (tmp_path / f'{tag}.{x}' for x in ('tsv', 'aln', 'o.tsv', 'o.aln'))
         p = subprocess.run([sys.executable, str(VCLUST), 'align', '-i', str(fa), '-o', str(ani), '--out-aln', str(aln), '--outfmt', 'complete', '-v', '0'],
@@ -248,6 +248,40 @@ def test_weak_seed_rule_is_exercised_and_switchable(tmp_path):
         assert sorted(open(aln).read().splitlines()) == sorted(open(oaln).read().splitlines()), tag
         out[tag] = sorted(open(aln).read().splitlines())
     assert out['on'] != out['off']
+
+
+@pytest.mark.parametrize('knob,alt', [('anchor_margin', 7), ('anchor_margin', 5), ('seed_choice', 1), ('weak_seed_ratio', 0), ('weak_seed_ratio', 2)])
+def test_thin_fit_constants_are_parameters(knob, alt):
+    """The constants of the LZ restatement that <= 3 events of the reference's example decide are parameters of the product
+    (vg_set_lz_fit) and of the checker (the same developer variables), not literals: with the alternative value the HIP rows
+    still equal the oracle's on every ordered pair of strongly diverged families, and the table differs from the default
+    one -- the branch is exercised both ways."""
+    import os
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / 'tests'))
+    import numpy as np
+    import oracle_lib as orc
+    from vclust_amd import api, synth
+    env_name = dict(anchor_margin='VG_LZ_ANCHOR_MARGIN', seed_choice='VG_LZ_SEED_CHOICE', weak_seed_ratio='VG_LZ_WEAK_SEED')[knob]
+    codes, offsets, names = synth.make_families(4, 8, length=24000, seed=7, p_lo=0.12, p_hi=0.30)
+    gs = api.GenomeSet.from_codes(codes, offsets, names)
+    cand = gs.read_filter(None)
+    fam = np.arange(len(gs)) // 8
+    tasks = gs.align_tasks(cand[fam[cand['a']] == fam[cand['b']]])
+    tables = {}
+    try:
+        for tag, val in (('default', None), ('alt', alt)):
+            api.set_lz_fit(**({knob: val} if val is not None else {}))
+            if val is None: os.environ.pop(env_name, None)
+            else: os.environ[env_name] = str(val)
+            stats = gs.lz_align(tasks)
+            for t, st in zip(tasks, stats):
+                q, r = int(t['q']), int(t['r'])
+                assert orc.lz_pair_stat(codes[offsets[q]:offsets[q + 1]], codes[offsets[r]:offsets[r + 1]]) == tuple(int(x) for x in st), (tag, q, r)
+            tables[tag] = stats.copy()
+    finally:
+        api.set_lz_fit(); os.environ.pop(env_name, None)
+    assert len(tasks) == 4 * 56 and not np.array_equal(tables['default'], tables['alt'])
 
 
 def _torchrun(nproc, *cmd):

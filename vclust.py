@@ -14,26 +14,58 @@ if __name__ == '__main__':
     # the child reports that the output files are complete and closed.  What is left then is the kernel driver tearing the
     # child's device context down (~0.25 s): it happens in the background, beside the start of whatever the caller runs
     # next -- in the reference's pipeline `vclust.py align`, whose own HIP start-up waits for that tear-down anyway and
-    # hides it behind its FASTA ingest.  Exit status, stdout and stderr are the child's; VCLUST_DETACH_TEARDOWN=0 keeps
-    # everything in one process.
+    # hides it behind its FASTA ingest.  Exit status, stdout and stderr are the child's; signals sent to this process
+    # reach the child; VCLUST_DETACH_TEARDOWN=0 keeps everything in one process.  (The saving is a process-model
+    # arrangement, not faster work: the GPU context and its memory live ~0.25 s past the command's return.)
     detach = (len(sys.argv) > 1 and sys.argv[1] in ('prefilter', 'align') and os.environ.get('VCLUST_DETACH_TEARDOWN', '1') != '0'
               and int(os.environ.get('WORLD_SIZE', '1')) == 1 and hasattr(os, 'fork'))
     wfd = None
-    if len(sys.argv) > 1 and sys.argv[1] in ('prefilter', 'align') and int(os.environ.get('WORLD_SIZE', '1')) == 1:
-        os.environ.setdefault('VG_LEAK_AT_EXIT', '1')      # this process ends with the stage: nothing is released one piece at a time first
+    one_shot = len(sys.argv) > 1 and sys.argv[1] in ('prefilter', 'align') and int(os.environ.get('WORLD_SIZE', '1')) == 1
     if detach:
         sys.stdout.flush(); sys.stderr.flush()
         rfd, wfd = os.pipe()
+        ppid = os.getpid()
         pid = os.fork()
         if pid > 0:
             os.close(wfd)
-            b = os.read(rfd, 1)
+            # a caller that stops this command by pid (subprocess timeout, p.kill(), a scheduler's SIGTERM) stops the WORK:
+            # catchable signals are forwarded to the child, and the child asks the kernel to kill it should this process
+            # die uncatchably (PR_SET_PDEATHSIG below) -- no orphan keeps computing on the GPU or writes files later
+            import signal
+
+            def _forward(sig, _frame):
+                try:
+                    os.kill(pid, sig)
+                except ProcessLookupError:
+                    pass
+            for _sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP, signal.SIGQUIT):
+                signal.signal(_sig, _forward)
+            while True:
+                try:
+                    b = os.read(rfd, 1)
+                    break
+                except InterruptedError:
+                    continue
             if b:
                 os._exit(b[0])
             _, st = os.waitpid(pid, 0)             # the child went away without reporting (killed): its fate is ours
             os._exit(os.WEXITSTATUS(st) if os.WIFEXITED(st) else 128 + (os.WTERMSIG(st) if os.WIFSIGNALED(st) else 1))
         os.close(rfd)
+        try:
+            import ctypes
+            _libc = ctypes.CDLL(None, use_errno=True)
+            _libc.prctl(1, 9, 0, 0, 0)             # PR_SET_PDEATHSIG = SIGKILL while the work runs
+            if os.getppid() != ppid:               # (the parent died between fork and prctl)
+                os._exit(137)
+        except Exception:
+            _libc = None
     rc = 0
+    if one_shot:
+        try:        # this process ends with the stage: nothing is released one piece at a time first
+            from vclust_amd import _lib
+            _lib.load().vg_set_process_ends_after_call(1)
+        except Exception:
+            pass    # (a missing library is reported by the stage itself, with the reference's error format)
     try:
         main()
     except SystemExit as exc:          # argparse / handlers: same codes as the reference (0, 1, 2)
@@ -47,6 +79,8 @@ if __name__ == '__main__':
         print('[vg host] %-28s +0.000 ms  alloc 0.000 ms  @%.3f' % ('cli: reporting', time.time()), file=sys.stderr, flush=True)
     if wfd is not None:
         # let go of the caller's pipes (a caller that reads them to their end must not wait for the tear-down), then report
+        if _libc is not None:
+            _libc.prctl(1, 0, 0, 0, 0)             # the files are complete: the tear-down may outlive the parent
         dn = os.open(os.devnull, os.O_RDWR)
         for fd in (0, 1, 2):
             os.dup2(dn, fd)

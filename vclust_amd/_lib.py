@@ -37,6 +37,10 @@ class LzParams(C.Structure):
     _fields_ = [(n, C.c_int) for n in ('mal', 'msl', 'mrd', 'mqd', 'reg', 'aw', 'am', 'ar')]
 
 
+class LzFit(C.Structure):
+    _fields_ = [('weak_seed_ratio', C.c_int), ('anchor_margin', C.c_int), ('seed_choice', C.c_int)]
+
+
 class PrefilterParams(C.Structure):
     _fields_ = [('k', C.c_int), ('min_kmers', C.c_int), ('min_ident', C.c_double),
                 ('batch_size', C.c_int), ('kmers_fraction', C.c_double), ('max_seqs', C.c_int),
@@ -88,6 +92,8 @@ SYMBOLS = {
     'vg_write_fltr': (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int,
                                 P(C.c_int64), P(PairCount), C.c_int64, C.c_char_p]),
     'vg_prefilter': (C.c_int, [P(C.c_char_p), C.c_int, C.c_char_p, P(PrefilterParams)]),
+    'vg_set_process_ends_after_call': (None, [C.c_int]),
+    'vg_set_lz_fit': (None, [P(LzFit)]),
     'vg_lz_align': (C.c_int, [C.c_void_p, P(Task), C.c_int64, P(LzParams), P(PairStat),
                               P(P(Region)), P(C.c_int64)]),
     'vg_align_order': (C.c_int, [C.c_void_p, P(C.c_int32)]),

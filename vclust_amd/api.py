@@ -232,6 +232,12 @@ class GenomeSet:
 from .stages import align, align_params, prefilter  # noqa: E402,F401
 
 
+def set_lz_fit(weak_seed_ratio=3, anchor_margin=-1, seed_choice=3):
+    """The three thin constants of the LZ restatement (vg_set_lz_fit); no arguments = the fitted values."""
+    f = _lib.LzFit(int(weak_seed_ratio), int(anchor_margin), int(seed_choice))
+    _lib.load().vg_set_lz_fit(C.byref(f))
+
+
 def set_range_scan(mode):
     """0 = a RANGE shard call scans every base itself; 1 = the sliced scan of the multi-GPU path with the peers' slices
     computed by this process (vg_set_range_scan)."""

@@ -45,7 +45,11 @@ struct ref_desc {
     int32_t tag_bits;  // tag = the first tag_bits / 2 bases behind the msl-mer (<= mal - msl bases, <= 14 bits, <= 32 - pos_bits)
 };
 
-struct lz_dev_params { int mal, msl, mrd, mqd, reg, aw, am, ar; int ablate; int pw_after, pw_miss; int weak_ratio; };   // ablate: developer timing experiments only; pw_*: probe widths; weak_ratio: R3's weak-seed ratio (3; 0 = the rule is off)
+// ablate: developer timing experiments only; pw_*: probe widths; weak_ratio, margin, seed_choice: the constants of the
+// restatement that a handful of events of the reference's example hold (vg_lz_fit, include/vclust_gpu.h): R3's weak-seed
+// ratio (3; 0 = the rule is off), the symbols a far anchor must be longer than the seed by, minus one (msl - 1), and the
+// tie-break of seeds (3 = longest, then closest to the prediction; 1 = closest, then longest)
+struct lz_dev_params { int mal, msl, mrd, mqd, reg, aw, am, ar; int ablate; int pw_after, pw_miss; int weak_ratio; int margin; int seed_choice; };
 
 // ------------------------------------------------------------------ bit helpers
 // 32 bases (2-bit codes, first base in the low bits) starting at base position p (p >= 0)
@@ -1025,7 +1029,7 @@ struct seg_rec { int i_ev, ev_pos; uint32_t VM, VA, VN; };     // VN: bit 31 = o
 // and the mask paths fold away); the host launches it when both hold.
 template <int S, bool DEV, bool FAST = false>
 __device__ __forceinline__ void lz_parse_body(PARSE_ARGS, int64_t t_given = -1, int w_given = 0) {
-    if (FAST) { P.mal = 11; P.msl = 7; P.mrd = 40; P.mqd = 40; P.reg = 35; P.aw = 15; P.am = 7; P.ar = 3; P.ablate = 0; P.weak_ratio = 3; }
+    if (FAST) { P.mal = 11; P.msl = 7; P.mrd = 40; P.mqd = 40; P.reg = 35; P.aw = 15; P.am = 7; P.ar = 3; P.ablate = 0; P.weak_ratio = 3; P.margin = 6; P.seed_choice = 3; }
     const int ABL = DEV ? P.ablate : 0;           // developer timing knobs: compiled out of the production kernels
     __shared__ seg_rec s_log[S > 1 ? S * SEG_LOG_CAP : 1];
     __shared__ int s_cnt[4], s_sync_v[4], s_sync_idx[4];
@@ -1170,9 +1174,11 @@ __device__ __forceinline__ void lz_parse_body(PARSE_ARGS, int64_t t_given = -1, 
                                     if (sbest_len == 32) sbest_len = match_len_lane(c, qi, sbest_pos, 1 << 30);
                                 }
                             }
-                            // longest; ties -> closest to the prediction, then smallest position
+                            // longest; ties -> closest to the prediction, then smallest position (seed_choice 1: closest first, then longest)
                             const int ad = abs(rp - pred_l);
-                            if (l > sbest_len || (l == sbest_len && (ad < sbest_ad || (ad == sbest_ad && rp < sbest_pos)))) { sbest_len = l; sbest_pos = rp; sbest_ad = ad; }
+                            const bool better = P.seed_choice == 1 ? (sbest_len == 0 || ad < sbest_ad || (ad == sbest_ad && (l > sbest_len || (l == sbest_len && rp < sbest_pos))))
+                                                                   : (l > sbest_len || (l == sbest_len && (ad < sbest_ad || (ad == sbest_ad && rp < sbest_pos))));
+                            if (better) { sbest_len = l; sbest_pos = rp; sbest_ad = ad; }
                         }
                     }
                 }
@@ -1183,14 +1189,14 @@ __device__ __forceinline__ void lz_parse_body(PARSE_ARGS, int64_t t_given = -1, 
             }
             // R2/R3 choice: without a prediction the anchor; with one the seed, unless an anchor is longer
             // than the seed by at least msl (a far, long match beats a short close one)
-            if (best_len > 0 && sbest_len > 0 && best_pos != sbest_pos && best_len >= 32 && sbest_len + P.msl > 32) {
+            if (best_len > 0 && sbest_len > 0 && best_pos != sbest_pos && best_len >= 32 && sbest_len + P.margin + 1 > 32) {
                 if (best_len == 32) best_len = match_len_lane(c, qi, best_pos, 1 << 30);
                 if (sbest_len == 32) sbest_len = match_len_lane(c, qi, sbest_pos, 1 << 30);
             }
             // (one symbol less when the seed is weak: shorter than a third of the literal run it would bridge.  This constant
             // rests on ONE event of the reference's example -- profiles/r04_lz_fit_leave_one_out.md --, so it is a parameter:
             // VG_LZ_WEAK_SEED=0 switches the rule off, =n sets the ratio, in the product and, through the variant, in the oracle)
-            if (best_len > 0 && (sbest_len == 0 || best_len >= sbest_len + P.msl - ((P.weak_ratio > 0 && lit + lane > P.weak_ratio * sbest_len) ? 1 : 0))) {
+            if (best_len > 0 && (sbest_len == 0 || best_len > sbest_len + P.margin - ((P.weak_ratio > 0 && lit + lane > P.weak_ratio * sbest_len) ? 1 : 0))) {
                 const int d = best_pos - pred_l;
                 hit_close = alive_l && ((best_pos > c.L) == pred_rc) && d >= -P.mrd && d <= P.mrd;
             } else if (sbest_len > 0) { best_len = sbest_len; best_pos = sbest_pos; hit_close = true; }
@@ -1779,6 +1785,30 @@ inline int grid_for(int64_t n, int block = 256, int max_blocks = 256 * 16) {
 
 }  // namespace
 
+// The constants of the LZ restatement that <= 3 events of the reference's example decide (vg_lz_fit): process-wide, set
+// through vg_set_lz_fit; their initial values may come from developer switches (honoured only beside VG_DEV_SWITCHES=1):
+// VG_LZ_WEAK_SEED, VG_LZ_ANCHOR_MARGIN, VG_LZ_SEED_CHOICE -- what the CLI-level tests use, read by the oracle too.
+static std::mutex g_fit_mu;
+static bool g_fit_set = false;
+static vg_lz_fit g_fit{ 3, -1, 3 };
+static vg_lz_fit lz_fit_now() {
+    std::lock_guard<std::mutex> lk(g_fit_mu);
+    if (!g_fit_set) {
+        g_fit_set = true;
+        if (const char* e = vg_dev_getenv("VG_LZ_WEAK_SEED")) if (*e) g_fit.weak_seed_ratio = atoi(e);
+        if (const char* e = vg_dev_getenv("VG_LZ_ANCHOR_MARGIN")) if (*e) g_fit.anchor_margin = atoi(e);
+        if (const char* e = vg_dev_getenv("VG_LZ_SEED_CHOICE")) if (*e) g_fit.seed_choice = atoi(e);
+        if (g_fit.weak_seed_ratio != 3 || g_fit.anchor_margin >= 0 || g_fit.seed_choice != 3)
+            fprintf(stderr, "libvclust_gpu: LZ fit constants changed by developer switches (weak seed ratio %d, anchor margin %d, seed choice %d): results differ from the reference's\n",
+                    g_fit.weak_seed_ratio, g_fit.anchor_margin, g_fit.seed_choice);
+    }
+    return g_fit;
+}
+extern "C" void vg_set_lz_fit(const vg_lz_fit* f) {
+    std::lock_guard<std::mutex> lk(g_fit_mu);
+    g_fit_set = true;
+    g_fit = f ? *f : vg_lz_fit{ 3, -1, 3 };
+}
 static bool g_index_budget_set = false;          // VG_INDEX_BUDGET_GB / vg_set_index_budget: the caller's figure is taken as it is
 static int64_t g_index_budget_bytes = [] { const char* e = getenv("VG_INDEX_BUDGET_GB"); const double v = e ? atof(e) : 0.0; g_index_budget_set = v >= 0.0625; return v >= 0.0625 ? (int64_t)(v * 1073741824.0) : (24LL << 30); }();
 // ---- task grouping on the device: the caller's (q, r) list is counted per reference, stably sorted on r
@@ -1925,11 +1955,14 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
     static const int pw_after = [] { const char* e = vg_dev_getenv("VG_LZ_PW"); const int v = e ? atoi(e) : PW_AFTER_EVENT; return std::max(1, std::min(v, 64)); }();
     static const int pw_miss = [] { const char* e = vg_dev_getenv("VG_LZ_PW2"); const int v = e ? atoi(e) : 64; return std::max(1, std::min(v, 64)); }();
     // R3's weak-seed ratio (a single-event fit): 3 unless VG_LZ_WEAK_SEED says otherwise (0 = off)
-    static const int weak_ratio = [] { const char* e = getenv("VG_LZ_WEAK_SEED"); const int v = e && *e ? atoi(e) : 3; return std::max(0, std::min(v, 1000)); }();
-    const lz_dev_params P{ p->mal, p->msl, p->mrd, p->mqd, p->reg, p->aw, p->am, p->ar, abl ? atoi(abl) : 0, pw_after, pw_miss, weak_ratio };
+    const vg_lz_fit fit = lz_fit_now();
+    const int weak_ratio = std::max(0, std::min(fit.weak_seed_ratio, 1000));
+    const int margin = fit.anchor_margin >= 0 ? std::min(fit.anchor_margin, 1000) : p->msl - 1;
+    const int seed_choice = fit.seed_choice == 1 ? 1 : 3;
+    const lz_dev_params P{ p->mal, p->msl, p->mrd, p->mqd, p->reg, p->aw, p->am, p->ar, abl ? atoi(abl) : 0, pw_after, pw_miss, weak_ratio, margin, seed_choice };
     // default parameters on a set without N: the kernel with those as compile-time constants (VG_LZ_KERNEL=general: never)
     static const bool no_fast = [] { const char* e = vg_dev_getenv("VG_LZ_KERNEL"); return e && !strcmp(e, "general"); }();
-    bool fast_params = !no_fast && !abl && weak_ratio == 3 && p->mal == 11 && p->msl == 7 && p->mrd == 40 && p->mqd == 40 && p->reg == 35 && p->aw == 15 && p->am == 7 && p->ar == 3;
+    bool fast_params = !no_fast && !abl && weak_ratio == 3 && margin == 6 && seed_choice == 3 && p->mal == 11 && p->msl == 7 && p->mrd == 40 && p->mqd == 40 && p->reg == 35 && p->aw == 15 && p->am == 7 && p->ar == 3;
     for (int i = 0; fast_params && i < g->n; ++i) if (g->has_n[(size_t)i] || g->len[(size_t)i] >= (1 << 22)) fast_params = false;   // (tag: 8 bits beside <= 24 position bits)
 
     dbuf<vg_pair_stat> d_stats((size_t)n_tasks);

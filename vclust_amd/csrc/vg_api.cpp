@@ -8,10 +8,12 @@
 #include <vector>
 
 namespace {
-// VG_LEAK_AT_EXIT=1 (set by vclust.py for its one-shot `prefilter` / `align` processes): the process ends right after the
-// call, so the genome set -- 1.5 GB of host arrays to unmap, 1.4 GB of device blocks to hand back -- is left to the exit
-// instead of being released first (0.1 s that the caller would wait for)
-static bool leak_at_exit() { static const bool on = [] { const char* e = getenv("VG_LEAK_AT_EXIT"); return e && *e == '1'; }(); return on; }
+// vg_set_process_ends_after_call(1) (vclust.py, for its one-shot `prefilter` / `align` processes): the process ends right
+// after the call, so the genome set -- 1.5 GB of host arrays to unmap, 1.4 GB of device blocks to hand back -- is left to
+// the exit instead of being released first (0.1 s that the caller would wait for).  A setter, not an environment variable:
+// an embedding process that merely inherits an environment keeps the library's normal ownership.
+static bool g_leak_at_exit = false;
+static bool leak_at_exit() { return g_leak_at_exit; }
 struct genomes_guard { vg_genomes* g = nullptr; ~genomes_guard() { if (g && !leak_at_exit()) vg_genomes_free(g); } };
 struct free_guard { void* p = nullptr; ~free_guard() { if (p) vg_free(p); } };
 void check(int rc) { if (rc != VG_OK) throw vg_error(rc, vg_last_error()); }
@@ -43,6 +45,7 @@ struct device_warmup {
     ~device_warmup() { join(); }
 };
 }
+extern "C" void vg_set_process_ends_after_call(int on) { g_leak_at_exit = on != 0; }
 
 extern "C" int vg_prefilter(const char* const* fasta_paths, int n_paths, const char* out_path,
                             const vg_prefilter_params* p) {

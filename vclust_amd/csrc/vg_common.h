@@ -32,6 +32,9 @@ hipStream_t vg_stream();         // the library's compute stream on the current 
 hipStream_t vg_side_stream();                     // a second queue of the same device (created on first use)
 void* vg_dev_alloc(size_t bytes); // caching device allocator (throws vg_error)
 void  vg_dev_free(void* p);
+// while one lives, a failing allocation of this thread throws VG_ENOMEM at once: no trim of the cache, no wait for another
+// process's memory (for buffers that are an optimisation only)
+struct vg_dev_try_scope { vg_dev_try_scope(); ~vg_dev_try_scope(); };
 // copies between a caller's (pageable) buffer and the device on stream s, staged through the library's pinned buffers
 // (vg_core.cpp); a download of 32 KiB or more has completed when the call returns
 void  vg_upload_bytes(void* dst, const void* src, size_t bytes, hipStream_t s);
@@ -142,7 +145,8 @@ struct vg_slice_exchange {
 bool vg_slice_exchange_applies(const vg_genomes* g, int k, double fraction, int world);
 // one k-mer range shard of vg_kmer_shared with the (a, b, shared) records left in HBM (vg_prefilter.hip; used by vg_dist.hip)
 void vg_kmer_shared_device(vg_genomes* g, int k, double fraction, int shard, int n_shards, uint32_t min_shared,
-                           int64_t* set_sizes, dbuf<vg_pair_count>& pairs, int64_t* n_pairs, vg_slice_exchange* xs = nullptr);
+                           int64_t* set_sizes, dbuf<vg_pair_count>& pairs, int64_t* n_pairs, vg_slice_exchange* xs = nullptr,
+                           int* mode_out = nullptr /* how the k-mers were cut: 1 = RANGE shards, 2 = HASH shards */);
 
 // ---------------------------------------------------------------- host threads
 // fn(lo, hi, t) over [0, n) cut into contiguous chunks, one per thread (the library's host loops over

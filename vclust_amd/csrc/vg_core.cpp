@@ -311,6 +311,12 @@ static void raw_free(void* p) {
     (void)hipFree(p);
 }
 
+// allocations that are only an optimisation (a second set of scan buffers, pre-zeroed row pointers) must neither wait for
+// another process's memory nor trim the cache: vg_dev_try_scope makes every allocation of its thread fail fast
+static thread_local int t_try_alloc = 0;
+vg_dev_try_scope::vg_dev_try_scope() { ++t_try_alloc; }
+vg_dev_try_scope::~vg_dev_try_scope() { --t_try_alloc; }
+
 void* vg_dev_alloc(size_t bytes) {
     vg_require_device();
     size_t want = (bytes + ALLOC_GRAN - 1) / ALLOC_GRAN * ALLOC_GRAN;
@@ -324,6 +330,7 @@ void* vg_dev_alloc(size_t bytes) {
     }
     void* p = nullptr;
     hipError_t e = raw_alloc(&p, want);
+    if (e != hipSuccess && t_try_alloc > 0) { (void)hipGetLastError(); throw vg_error(VG_ENOMEM, "device allocation (opportunistic): out of memory"); }
     if (e != hipSuccess) {
         (void)hipGetLastError();                      // the failure is handled here: do not leave it as the sticky "last error"
         if (g_alloc_trace) fprintf(stderr, "[vg alloc] allocation of %.1f MB failed: trimming %.1f GB of cached blocks (live %.1f GB)\n", want / 1048576.0, g_cached_bytes / 1073741824.0, g_live_bytes / 1073741824.0);
@@ -331,10 +338,15 @@ void* vg_dev_alloc(size_t bytes) {
         e = raw_alloc(&p, want);
         // (another process may be on its way out -- the CLI returns before the driver has torn its context down -- and its
         // memory comes back within a fraction of a second: wait for it a little before giving up)
+        // -- but only when the shortfall can BE another process's: what the device reports in use beyond this process's own
+        // blocks must cover it; a set that does not fit beside the caller's own live blocks fails at once)
         for (int tries = 0; e != hipSuccess && tries < 40; ++tries) {
             (void)hipGetLastError();
             size_t fr = 0, tot = 0;
             if (hipMemGetInfo(&fr, &tot) != hipSuccess || want > tot) break;
+            size_t mine = 0; { std::lock_guard<std::mutex> lk(g_alloc_mu); mine = g_live_bytes + g_cached_bytes; }
+            const size_t used = tot - fr, foreign = used > mine ? used - mine : 0;
+            if (fr >= want || foreign + fr < want) break;              // (enough is free: fragmentation, waiting does not help; or nobody else holds enough)
             std::this_thread::sleep_for(std::chrono::milliseconds(50));
             e = raw_alloc(&p, want);
         }
@@ -373,7 +385,9 @@ void vg_dev_trim() {
     }
 }
 
-extern "C" void vg_release_device_memory(void) { vg_dev_trim(); }
+// (also the index plan a vg_lz_prepare may have parked -- pools of up to 2 x 24 GiB with kernels queued on them: a caller
+// who prepares and then skips the align hands the HBM back here; the plan is process-global, one per process)
+extern "C" void vg_release_device_memory(void) { vg_lz_drop_prepared(nullptr); vg_dev_trim(); }
 
 // allocator self-test: `cycles` times allocate blocks of the given sizes from the library's allocator (whichever path
 // VG_ALLOC selects), write a pattern into the first and last MiB of each with a copy from the host, read it back,

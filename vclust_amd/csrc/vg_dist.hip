@@ -368,7 +368,8 @@ extern "C" int vg_kmer_shared_sharded(vg_genomes* g, int k, double fraction, uin
     if (min_shared < 1) min_shared = 1;
     hipStream_t s = vg_stream();
     // ---- this rank's shard of the k-mer range: partial sizes (host) and partial counts (left in HBM)
-    std::vector<int64_t> part_sizes((size_t)std::max(n, 1), 0);
+    std::vector<int64_t> part_sizes((size_t)std::max(n, 1) + 1, 0);           // (+ 1: how this rank cut the k-mers, compared below)
+    int my_mode = 0;
     dbuf<vg_pair_count> d_loc; int64_t n_loc = 0;
     dbuf<uint64_t> d_nom, lk, lk2; dbuf<uint32_t> lv, lv2; dbuf<unsigned long long> d_cur(1);
     unsigned long long n_nom = 0;
@@ -383,7 +384,7 @@ extern "C" int vg_kmer_shared_sharded(vg_genomes* g, int k, double fraction, uin
         alltoallv_device(c, parts, n_parts);
     };
     guarded(c, "prefilter shard", [&] {
-        try { vg_kmer_shared_device(g, k, fraction, c->rank, W, 1u, part_sizes.data(), d_loc, &n_loc, sliced ? &xs : nullptr); }
+        try { vg_kmer_shared_device(g, k, fraction, c->rank, W, 1u, part_sizes.data(), d_loc, &n_loc, sliced ? &xs : nullptr, &my_mode); }
         catch (...) {
             if (sliced && !xs.agreed) { xs.agreed = true; try { agree(c, VG_EINVAL, "prefilter scan"); } catch (...) {} }
             throw;
@@ -403,13 +404,18 @@ extern "C" int vg_kmer_shared_sharded(vg_genomes* g, int k, double fraction, uin
         d_cur.download(&n_nom, 1, s);
         VG_HIP(hipStreamSynchronize(s));
         d_loc.release();
-        reserve_staging(c, (int64_t)sizeof(int64_t) * std::max(n, 1));
+        reserve_staging(c, (int64_t)sizeof(int64_t) * (std::max(n, 1) + 1));
     });
-    // ---- set sizes add up (n words per rank)
+    // ---- set sizes add up (n words per rank); the extra word says how the rank cut its k-mers: RANGE and HASH shards do
+    // not tile the key space together, so a run whose ranks disagree (a per-process knob differs) stops here, on every rank
     {
-        std::vector<int64_t> all_sizes((size_t)std::max(n, 1) * W, 0);
-        gather_host(c, part_sizes.data(), all_sizes.data(), (int64_t)sizeof(int64_t) * std::max(n, 1));
-        for (int i = 0; i < n; ++i) { int64_t t = 0; for (int r = 0; r < W; ++r) t += all_sizes[(size_t)r * std::max(n, 1) + i]; set_sizes[i] = t; }
+        const size_t nw = (size_t)std::max(n, 1) + 1;
+        part_sizes[nw - 1] = my_mode;
+        std::vector<int64_t> all_sizes(nw * W, 0);
+        gather_host(c, part_sizes.data(), all_sizes.data(), (int64_t)sizeof(int64_t) * (int64_t)nw);
+        for (int r = 0; r < W; ++r) if (all_sizes[(size_t)r * nw + nw - 1] != all_sizes[nw - 1])
+            throw vg_error(VG_EINVAL, "vg_kmer_shared_sharded: rank " + std::to_string(r) + " cut its k-mers differently from rank 0 (RANGE against HASH shards: do the ranks differ in vg_set_subshards?)");
+        for (int i = 0; i < n; ++i) { int64_t t = 0; for (int r = 0; r < W; ++r) t += all_sizes[(size_t)r * nw + i]; set_sizes[i] = t; }
     }
     // ---- 1: nominations travel (keys only), 2: their union
     std::vector<int64_t> cnt((size_t)W, 0), prefix((size_t)W + 1, 0);

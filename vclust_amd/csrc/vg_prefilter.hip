@@ -2298,7 +2298,7 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
     if (levels == 2 && dense && !no_prezero && !range) {
         size_t fr = 0, tot = 0;
         if (hipMemGetInfo(&fr, &tot) == hipSuccess && (size_t)n_rows_info * 4 * 8 <= tot / 2) try {
-            rowinfo.alloc((size_t)n_rows_info);
+            { vg_dev_try_scope opportunistic; rowinfo.alloc((size_t)n_rows_info); }
             hipStream_t side = vg_side_stream();
             hipEvent_t ev_s = nullptr;
             VG_HIP(hipEventCreateWithFlags(&ev_s, hipEventDisableTiming));
@@ -2777,7 +2777,7 @@ static void kmer_shared_subshards(vg_genomes* g, int k, double fraction, int sha
         if (t + 1 < sub && !(fraction < 1.0) && !no_overlap && !range_shards(g, fraction, n_shards * sub))      // (HASH shards: the compact source scans first)
             g_after_extract = [=] {
                 // (an optimisation only: without room for the second set of scan buffers the next sub-shard scans in line)
-                try { launch_precount(g, k, shard * sub + t + 1, n_shards * sub); } catch (...) { (void)hipGetLastError(); g_precount.drop(); }
+                try { vg_dev_try_scope opportunistic; launch_precount(g, k, shard * sub + t + 1, n_shards * sub); } catch (...) { (void)hipGetLastError(); g_precount.drop(); }
             };
         kmer_shared_pass(g, k, fraction, shard * sub + t, n_shards * sub, 1u, part.data(), none, &parts[(size_t)t], &counts[(size_t)t]);
         for (int i = 0; i < n; ++i) set_sizes[i] += part[i];
@@ -2847,7 +2847,8 @@ extern "C" int vg_kmer_shared(vg_genomes* g, int k, double fraction, int shard, 
 
 // internal (vg_dist.hip): one shard's pairs left in HBM (sub-shards included)
 void vg_kmer_shared_device(vg_genomes* g, int k, double fraction, int shard, int n_shards, uint32_t min_shared,
-                           int64_t* set_sizes, dbuf<vg_pair_count>& pairs, int64_t* n_pairs, vg_slice_exchange* xs) {
+                           int64_t* set_sizes, dbuf<vg_pair_count>& pairs, int64_t* n_pairs, vg_slice_exchange* xs, int* mode_out) {
+    if (mode_out) *mode_out = 0;
     vg_require_device();
     int rc = vg_genomes_to_device(g); if (rc) throw vg_error(rc, vg_last_error());
     *n_pairs = 0;
@@ -2856,6 +2857,10 @@ void vg_kmer_shared_device(vg_genomes* g, int k, double fraction, int shard, int
     const double expect = (double)P * fraction / n_shards;
     const bool dense = fraction >= 1.0 && n_shards == 1;
     const bool one_pass = g_force_subshards <= 1 && !(dense ? P >= (1LL << 32) : expect >= SUB_PASS_START);
+    // how this rank cuts the k-mers (1 = RANGE, 2 = HASH): the two do not tile the key space together, so the ranks of a
+    // sharded call compare notes (a per-process knob -- vg_set_subshards -- can push one rank over the RANGE limit)
+    const int sub_planned = one_pass ? 1 : std::max(2, g_force_subshards > 1 ? g_force_subshards : (int)std::ceil(expect / SUB_PASS_KMERS));
+    if (mode_out) *mode_out = range_shards(g, fraction, n_shards * sub_planned) ? 1 : 2;
     hipStream_t s = vg_stream();
     if (one_pass) {
         std::vector<vg_pair_count> none; unsigned long long n = 0;
