@@ -355,7 +355,7 @@ void* vg_dev_alloc(size_t bytes) {
     std::lock_guard<std::mutex> lk(g_alloc_mu);
     g_block_size[p] = { want, g_device };
     g_live_bytes += want;
-    if (g_alloc_trace && want >= (64u << 20)) fprintf(stderr, "[vg alloc] new block %.1f MB (live %.1f GB, cached %.1f GB)\n", want / 1048576.0, g_live_bytes / 1073741824.0, g_cached_bytes / 1073741824.0);
+    if (g_alloc_trace && want >= (64u << 20)) fprintf(stderr, "[vg alloc] new block %.1f MB at %p (live %.1f GB, cached %.1f GB)\n", want / 1048576.0, p, g_live_bytes / 1073741824.0, g_cached_bytes / 1073741824.0);
     return p;
 }
 
