@@ -423,3 +423,32 @@ def test_config3_phage_100k_full_size(tmp_path):
     assert filecmp.cmp(f_mem, f_cli, shallow=False)
     assert filecmp.cmp(a_mem, a_cli, shallow=False)
     assert sum(1 for _ in open(a_cli)) == 900001
+
+
+@pytest.mark.parametrize('k,fraction,sub', [(25, 0.5, 5), (21, 0.3, 7), (30, 0.9, 3), (25, 0.5, 32)])
+def test_hash_subshards_from_one_scan(k, fraction, sub):
+    """HASH sub-shards (what sets beyond 2^32 bases run as; forced here through a fraction, which always cuts by hash): the
+    kept masks of ALL passes come from one scan of the bases (k_multi_mask) and every pass computes only the k-mers of its
+    kept positions.  Sizes and counts equal the oracle's, alone and under an outer shard of three."""
+    from vclust_amd import _lib
+    codes, offsets, names = synth.make_families(60, 5, length=9000, seed=37)
+    gs = api.GenomeSet.from_codes(codes, offsets, names)
+    osizes, opairs = orc.shared_all(codes, offsets, k=k, fraction=fraction)
+    _lib.load().vg_set_subshards(sub)
+    try:
+        api.profile_enable(True); api.profile_reset()
+        sizes, pairs = gs.kmer_shared(k=k, fraction=fraction)
+        scopes = {e['name']: e for e in api.profile_get()}
+        api.profile_enable(False)
+        assert scopes['kmer_multi_mask']['launches'] == 1 and 'kmer_count' not in scopes
+        assert list(sizes) == list(osizes)
+        assert {(int(p['a']), int(p['b'])): int(p['shared']) for p in pairs} == opairs
+        tot = np.zeros(len(gs), dtype=np.int64); acc = {}
+        for sh in range(3):
+            sz, pr = gs.kmer_shared(k=k, fraction=fraction, shard=sh, n_shards=3)
+            tot += sz
+            for p in pr:
+                acc[(int(p['a']), int(p['b']))] = acc.get((int(p['a']), int(p['b'])), 0) + int(p['shared'])
+        assert list(tot) == list(osizes) and acc == opairs
+    finally:
+        api.profile_enable(False); _lib.load().vg_set_subshards(0)

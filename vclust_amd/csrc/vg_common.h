@@ -43,6 +43,11 @@ void  vg_download_bytes(void* dst, const void* src, size_t bytes, hipStream_t s)
 void  vg_warm_prefilter(hipStream_t s);
 void  vg_warm_align(hipStream_t s);
 void  vg_dev_trim();             // return all cached blocks to the driver
+// placement trials: set the cached blocks aside (the next allocations are fresh ones beside them); then either restore them
+// (the newer cache goes back to the driver) or free them
+void  vg_dev_park_cache();
+void  vg_dev_unpark(bool restore_parked);
+size_t vg_dev_cached_bytes();
 // Clean-up work that takes the address-space lock for long (unmapping GBs of FASTA): a whole-stage call parks it
 // (vg_defer_mode) until the main thread sits in a long wait for the GPU (vg_deferred_start); otherwise it runs at once
 // on a helper thread.

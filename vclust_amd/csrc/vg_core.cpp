@@ -387,7 +387,31 @@ void vg_dev_trim() {
 
 // (also the index plan a vg_lz_prepare may have parked -- pools of up to 2 x 24 GiB with kernels queued on them: a caller
 // who prepares and then skips the align hands the HBM back here; the plan is process-global, one per process)
-extern "C" void vg_release_device_memory(void) { vg_lz_drop_prepared(nullptr); vg_dev_trim(); }
+// Placement trials (vg_prefilter.hip): the cached blocks -- one placement of a workspace -- are set aside so that the next
+// pass allocates afresh beside them; afterwards either the new blocks are kept and the parked ones freed, or the new ones
+// are freed and the parked ones come back.
+static std::multimap<size_t, void*> g_parked;
+void vg_dev_park_cache() {
+    std::lock_guard<std::mutex> lk(g_alloc_mu);
+    for (auto& kv : g_free_blocks) g_parked.emplace(kv.first, kv.second);
+    g_free_blocks.clear(); g_cached_bytes = 0;
+}
+size_t vg_dev_cached_bytes() { std::lock_guard<std::mutex> lk(g_alloc_mu); return g_cached_bytes; }
+void vg_dev_unpark(bool restore_parked) {
+    if (restore_parked) vg_dev_trim();                   // the newer placement goes back to the driver
+    std::vector<void*> drop;
+    {
+        std::lock_guard<std::mutex> lk(g_alloc_mu);
+        for (auto& kv : g_parked) {
+            if (restore_parked) { g_free_blocks.emplace(kv.first, kv.second); g_cached_bytes += kv.first; }
+            else { drop.push_back(kv.second); g_block_size.erase(kv.second); }
+        }
+        g_parked.clear();
+    }
+    if (!drop.empty()) { (void)hipDeviceSynchronize(); for (void* b : drop) raw_free(b); }
+}
+
+extern "C" void vg_release_device_memory(void) { vg_lz_drop_prepared(nullptr); vg_dev_unpark(false); vg_dev_trim(); }
 
 // allocator self-test: `cycles` times allocate blocks of the given sizes from the library's allocator (whichever path
 // VG_ALLOC selects), write a pattern into the first and last MiB of each with a copy from the host, read it back,

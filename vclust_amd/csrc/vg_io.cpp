@@ -102,20 +102,26 @@ extern "C" int vg_filter_pairs(int k, int min_kmers, double min_ident, const int
     vg_pair_count* o = (vg_pair_count*)malloc(sizeof(vg_pair_count) * std::max<size_t>(1, (size_t)n_pairs));
     if (!o) throw vg_error(VG_ENOMEM, "out of host memory");
     size_t total = 0;
+    auto keeps = [&](const vg_pair_count& p) {
+        if ((int64_t)p.a >= n_genomes || (int64_t)p.b >= n_genomes) throw vg_error(VG_EINVAL, "pair id out of range");
+        if ((int64_t)p.shared < min_kmers) return false;
+        const int64_t mn = std::min(set_sizes[p.a], set_sizes[p.b]);
+        if (mn <= 0 || p.shared == 0) return 0.0 >= min_ident;
+        const double j = (double)p.shared / (double)mn;
+        if (std::isfinite(Jstar) && std::fabs(j - Jstar) > 1e-9 * Jstar) return j > Jstar;
+        return vg_ani_shorter(p.shared, set_sizes[p.a], set_sizes[p.b], k) >= min_ident;
+    };
     try {
-        for (int64_t i = 0; i < n_pairs; ++i) {
-            const vg_pair_count& p = pairs[i];
-            if ((int64_t)p.a >= n_genomes || (int64_t)p.b >= n_genomes) throw vg_error(VG_EINVAL, "pair id out of range");
-            if ((int64_t)p.shared < min_kmers) continue;
-            const int64_t mn = std::min(set_sizes[p.a], set_sizes[p.b]);
-            bool keep_it;
-            if (mn <= 0 || p.shared == 0) keep_it = 0.0 >= min_ident;
-            else {
-                const double j = (double)p.shared / (double)mn;
-                if (std::isfinite(Jstar) && std::fabs(j - Jstar) > 1e-9 * Jstar) keep_it = j > Jstar;
-                else keep_it = vg_ani_shorter(p.shared, set_sizes[p.a], set_sizes[p.b], k) >= min_ident;
-            }
-            if (keep_it) o[total++] = p;
+        // (millions of pairs -- 3.5 M at 10^6 contigs -- : chunks over a few threads, kept pairs counted, then written in order)
+        const int T = n_pairs >= (1 << 19) ? std::max(1, std::min(vg_host_threads(), 8)) : 1;
+        if (T == 1) { for (int64_t i = 0; i < n_pairs; ++i) if (keeps(pairs[i])) o[total++] = pairs[i]; }
+        else {
+            std::vector<int64_t> kept((size_t)T + 1, 0);
+            std::vector<uint8_t> flag((size_t)n_pairs);
+            vg_parallel_chunks(n_pairs, T, [&](int64_t a, int64_t b, int t) { int64_t c = 0; for (int64_t i = a; i < b; ++i) { flag[(size_t)i] = keeps(pairs[i]); c += flag[(size_t)i]; } kept[(size_t)t + 1] = c; });
+            for (int t = 0; t < T; ++t) kept[(size_t)t + 1] += kept[(size_t)t];
+            vg_parallel_chunks(n_pairs, T, [&](int64_t a, int64_t b, int t) { int64_t at = kept[(size_t)t]; for (int64_t i = a; i < b; ++i) if (flag[(size_t)i]) o[at++] = pairs[i]; });
+            total = (size_t)kept[(size_t)T];
         }
     } catch (...) { free(o); throw; }
     vg_host_mark("filter_pairs: done");
@@ -343,7 +349,7 @@ int vg_align_tasks_perm(const vg_genomes* g, const vg_pair_count* pairs, int64_t
         // offsets, scatter), every range sorted on its own, the task couples written in parallel
         const int T = std::max(2, std::min(vg_host_threads(), 16));
         const int64_t ng = std::max<int64_t>(1, g->n);
-        std::vector<rp> v((size_t)n_pairs), tmp((size_t)n_pairs);
+        std::vector<rp, no_init_alloc<rp>> v, tmp; v.resize((size_t)n_pairs); tmp.resize((size_t)n_pairs);      // (84 MB at 3.5 M couples: not cleared by one thread first)
         std::vector<std::vector<int64_t>> cnt((size_t)T, std::vector<int64_t>((size_t)T + 1, 0));
         std::atomic<bool> bad(false);
         auto bucket_of = [&](int32_t lo) { return (int)((int64_t)lo * T / ng); };

@@ -11,6 +11,7 @@
 // reads of the short genome lists of shared k-mers in the SpGEMM.
 #include "vg_common.h"
 #include <functional>
+#include <map>
 #include <optional>
 #include <rocprim/rocprim.hpp>
 #include <algorithm>
@@ -258,22 +259,27 @@ __device__ __forceinline__ int nth_set_bit(unsigned long long m, int r) {
 
 __global__ void __launch_bounds__(256)
 k_kmer_emit_sparse(kmer_args A, const unsigned long long* __restrict__ wave_mask, const uint32_t* __restrict__ wave_base,
-                   uint64_t* __restrict__ keys, uint32_t* __restrict__ pos) {
+                   uint64_t* __restrict__ keys, uint32_t* __restrict__ pos, int nw /* 64-position words per wave and trip, 1 .. 8: about 56 kept positions */) {
     const int lane = threadIdx.x & 63;
     const int64_t W = A.P >> 6;
-    const int64_t n_chunks = (W + 7) >> 3;
+    const int64_t n_chunks = (W + nw - 1) / nw;
     const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int k2 = 2 * A.k;
+    const uint32_t km_lo = k2 >= 32 ? 0xffffffffu : ((1u << k2) - 1u), km_hi = k2 > 32 ? ((1u << (k2 - 32)) - 1u) : 0u;
+    // (the masks and row bases of the NEXT chunk travel while this one is worked on: a trip is a chain of dependent loads)
+    unsigned long long mine = 0; uint32_t base = 0;
+    if (wave0 < n_chunks && lane < nw && wave0 * nw + lane < W) { mine = wave_mask[wave0 * nw + lane]; base = wave_base[wave0 * nw + lane]; }
     for (int64_t ch = wave0; ch < n_chunks; ch += n_waves) {
-        const int64_t w0 = ch << 3;
-        unsigned long long mine = 0; uint32_t base = 0;
-        if (lane < 8 && w0 + lane < W) { mine = wave_mask[w0 + lane]; base = wave_base[w0 + lane]; }
+        const int64_t w0 = ch * nw;
+        const unsigned long long cur = mine; const uint32_t cur_base = base;
+        { const int64_t nx = (ch + n_waves) * nw + lane; mine = 0; base = 0; if (ch + n_waves < n_chunks && lane < nw && nx < W) { mine = wave_mask[nx]; base = wave_base[nx]; } }
         unsigned long long m[8]; int pre[9]; uint32_t bs[8]; pre[0] = 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            bs[j] = (uint32_t)__builtin_amdgcn_readlane((int)base, j);
-            m[j] = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, j)
-                 | ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), j) << 32);
+            bs[j] = (uint32_t)__builtin_amdgcn_readlane((int)cur_base, j);
+            m[j] = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)cur, j)
+                 | ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(cur >> 32), j) << 32);
             pre[j + 1] = pre[j] + __popcll(m[j]);
         }
         for (int t = lane; t < pre[8]; t += 64) {
@@ -285,12 +291,54 @@ k_kmer_emit_sparse(kmer_args A, const unsigned long long* __restrict__ wave_mask
             for (int q = 1; q < 8; ++q) if (j == q) { mj = m[q]; pj = pre[q]; bj = bs[q]; }
             const int r = t - pj;
             const int64_t p = ((w0 + j) << 6) + nth_set_bit(mj, r);
-            uint32_t g;
-            const uint64_t key = kmer_at(A, p, &g);
+            // the kept position's k-mer: one 16-byte load of bases (the window spans at most three words and a bit), one
+            // 8-byte load of the mask; the position was kept by this pass's mask, so the shard tests of canon_key pass
+            uint4 wv; __builtin_memcpy(&wv, A.packed + (p >> 4), 16);
+            const uint32_t sh = 2u * (uint32_t)(p & 15);
+            const uint64_t key = canon_key(A, __builtin_amdgcn_alignbit(wv.y, wv.x, sh) & km_lo, __builtin_amdgcn_alignbit(wv.z, wv.y, sh) & km_hi, km_lo, km_hi);
             const uint32_t c = bj + (uint32_t)r;
             keys[c] = key; if (pos) pos[c] = c;
         }
     }
+}
+
+// HASH sub-shards of one call (sets beyond 2^32 bases: 10^6 contigs run as seven): every pass used to scan ALL bases with
+// k_kmer_count to keep 1/sub of the k-mers -- sub x the k-mer arithmetic of the set.  k_multi_mask scans once and leaves the
+// kept mask of EVERY sub-shard (one bit per base and sub-shard: a valid k-mer belongs to exactly one); a pass then lists
+// its kept positions from its mask and computes only their k-mers (k_kmer_emit_sparse).  Masks of sub-shard t at
+// masks + t * mask_stride.  A wave's 256 positions: one 32-position word per sub-shard and eighth, in the wave's own LDS.
+constexpr int MM_MAX_SUB = 32;
+template <int KC>
+__global__ void __launch_bounds__(256)
+k_multi_mask(kmer_args A, uint32_t first_shard, uint32_t n_sub, uint32_t n_total, unsigned long long* __restrict__ masks, int64_t mask_stride) {
+    if (KC > 0) { A.k = KC; A.use_frac = 0; }
+    A.n_shards = 1; A.shard = 0; A.dig_lo = 0; A.dig_n = 1u << DIG_BITS;      // every valid k-mer is computed; its sub-shard is found below
+    extern __shared__ uint32_t s_mm[];                                        // [4 waves][n_sub][8]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t* sm = s_mm + (size_t)wv * n_sub * 8;
+    for (int i = lane; i < (int)n_sub * 8; i += 64) sm[i] = 0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int64_t p0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; p0 < A.P + 252; p0 += (int64_t)gridDim.x * blockDim.x * 4) {
+        uint64_t kk[4] = {SENT, SENT, SENT, SENT}; uint32_t g = 0;
+        if (p0 < A.P) kmers4(A, p0, kk, &g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (kk[j] != SENT) {
+            const uint32_t h2 = (uint32_t)kk[j] * 0x85ebca6bu;                // the HASH shard of canon_key
+            const uint32_t t = (uint32_t)(((uint64_t)h2 * n_total) >> 32) - first_shard;
+            if (t < n_sub) atomicOr(&sm[t * 8u + (uint32_t)(lane >> 3)], 1u << (4 * (lane & 7) + j));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int64_t wbase = (p0 - 4 * lane) >> 6;                           // first of the wave's four 64-position words
+        for (int i = lane; i < (int)n_sub * 8; i += 64) {
+            const uint32_t v = sm[i]; sm[i] = 0u;
+            const int t = i >> 3, wd = i & 7;
+            if (((wbase + (wd >> 1)) << 6) < A.P) reinterpret_cast<uint32_t*>(masks + (int64_t)t * mask_stride)[wbase * 2 + wd] = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+__global__ void k_kept_from_goff(const uint32_t* __restrict__ goff, int n, int* __restrict__ kept) {
+    for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < n; g += gridDim.x * blockDim.x) kept[g] = (int)(goff[g + 1] - goff[g]);
 }
 
 // compact space: genome of compact index c.  cblk[c >> CBLK_SHIFT] is the genome holding the first
@@ -2028,6 +2076,17 @@ struct precount {
     ~precount() { drop(); }
 };
 static precount g_precount;
+// the index stage's milliseconds (level-1 count ... bucket kernels) of the last pass (placement trials of vg_kmer_shared; measured only while they run)
+static bool g_time_bucket_pass = false;
+static float g_last_bucket_ms = 0.f;
+struct pass_timer {
+    float* out; hipStream_t s; hipEvent_t e0 = nullptr, e1 = nullptr;
+    pass_timer(float* o, hipStream_t st) : out(o), s(st) { if (out && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) (void)hipEventRecord(e0, s); else out = nullptr; }
+    ~pass_timer() { if (!out) return; (void)hipEventRecord(e1, s); (void)hipEventSynchronize(e1); float ms = 0; if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) *out = ms; (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
+};
+// the kept mask of the pass that is about to run, left by the sub-shard loop's one scan of all sub-shards (k_multi_mask)
+struct pass_mask { const vg_genomes* g = nullptr; int k = 0, shard = -1, n_shards = 0; const unsigned long long* mask = nullptr; };
+static pass_mask g_pass_mask;
 static int compact_stage_cap(double keep) { return (int)std::min<double>(256.0, std::ceil(1.5 * 256.0 * keep) + 24.0); }
 // to be called while the library queue is idle
 static void launch_precount(vg_genomes* g, int k, int shard, int n_shards) {
@@ -2053,6 +2112,7 @@ static void run_extract_sort(vg_genomes* g, int k, double fraction, int shard, i
     const int64_t P = g->padded_total();
     // the scan of this very sub-shard may already be running (or done) on the second queue
     const bool pre = g_precount.g == g && g_precount.k == k && g_precount.shard == shard && g_precount.n_shards == n_shards && !(fraction < 1.0) && n_shards > 1;
+    const unsigned long long* premask = (g_pass_mask.g == g && g_pass_mask.k == k && g_pass_mask.shard == shard && g_pass_mask.n_shards == n_shards && !pre) ? g_pass_mask.mask : nullptr;
     if (pre) { VG_HIP(hipStreamWaitEvent(s, g_precount.done, 0)); out.kept = std::move(g_precount.kept); }
     else { out.kept.alloc((size_t)std::max(1, g->n)); out.kept.zero(s); }
     const int use_frac = fraction < 1.0;
@@ -2084,13 +2144,19 @@ static void run_extract_sort(vg_genomes* g, int k, double fraction, int shard, i
             out.wave_mask = std::move(g_precount.wave_mask); wave_cnt = std::move(g_precount.wave_cnt);
             stage = std::move(g_precount.stage); d_over = std::move(g_precount.d_over);
             (void)hipEventDestroy(g_precount.done); g_precount.done = nullptr; g_precount.shard = -1; g_precount.g = nullptr;
+        } else if (premask) {
+            // the pass's kept mask exists already (one scan served every sub-shard): count its words; the k-mers are computed
+            // for the kept positions only by the emit pass below
+            out.wave_mask.view(const_cast<unsigned long long*>(premask), (size_t)W + 1); wave_cnt.alloc((size_t)W + 1);
+            VG_HIP(hipMemsetAsync(wave_cnt.p + W, 0, sizeof(uint32_t), s));
+            if (W > 0) hipLaunchKernelGGL(k_mask_popc, dim3(grid_for(W)), dim3(256), 0, s, premask, W, wave_cnt.p);
         } else {
             out.wave_mask.alloc((size_t)W + 1); wave_cnt.alloc((size_t)W + 1);
             VG_HIP(hipMemsetAsync(wave_cnt.p + W, 0, sizeof(uint32_t), s));
             stage.alloc((size_t)n_chunks * stage_cap);
             d_over.alloc(1); d_over.zero(s);
         }
-        if (!pre) {
+        if (!pre && !premask) {
             vg_prof_scope ps("kmer_count", (double)P * (3.0 / 8.0 + 12.0 / 64.0));
             if (A.k == 25 && !A.use_frac)
                 hipLaunchKernelGGL(k_kmer_count<25>, dim3(grid_for((P + 255) / 4)), dim3(256), 0, s, A, out.wave_mask.p, wave_cnt.p, out.kept.p,
@@ -2103,13 +2169,26 @@ static void run_extract_sort(vg_genomes* g, int k, double fraction, int shard, i
         VG_HIP(rocprim::exclusive_scan(nullptr, tb, wave_cnt.p, out.wave_base.p, 0u, (size_t)W + 1, rocprim::plus<uint32_t>(), s));
         dbuf<char> tmp(tb);
         VG_HIP(rocprim::exclusive_scan((void*)tmp.p, tb, wave_cnt.p, out.wave_base.p, 0u, (size_t)W + 1, rocprim::plus<uint32_t>(), s));
-        uint32_t total = 0; unsigned int over = 0;
-        std::vector<int> kept_h((size_t)std::max(1, g->n));
-        VG_HIP(hipMemcpyAsync(&total, out.wave_base.p + W, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        d_over.download(&over, 1, s);
-        out.kept.download(kept_h.data(), (size_t)g->n, s);
-        VG_HIP(hipStreamSynchronize(s));
-        int64_t total64 = 0; for (int i = 0; i < g->n; ++i) total64 += kept_h[i];
+        uint32_t total = 0; unsigned int over = premask ? 1u : 0u;          // (a given mask: no staged k-mers, the emit pass computes them)
+        int64_t total64 = 0;
+        if (premask) {
+            // the words' counts are 32 bits each, their sum may not be: add them up in 64 bits before trusting the scan
+            dbuf<unsigned long long> d_tot(1); size_t tb2 = 0;
+            VG_HIP(rocprim::reduce(nullptr, tb2, wave_cnt.p, d_tot.p, 0ULL, (size_t)W + 1, rocprim::plus<unsigned long long>(), s));
+            dbuf<char> tmp2(tb2);
+            VG_HIP(rocprim::reduce((void*)tmp2.p, tb2, wave_cnt.p, d_tot.p, 0ULL, (size_t)W + 1, rocprim::plus<unsigned long long>(), s));
+            unsigned long long t64 = 0; d_tot.download(&t64, 1, s);
+            VG_HIP(hipMemcpyAsync(&total, out.wave_base.p + W, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            VG_HIP(hipStreamSynchronize(s));
+            total64 = (int64_t)t64;
+        } else {
+            std::vector<int> kept_h((size_t)std::max(1, g->n));
+            VG_HIP(hipMemcpyAsync(&total, out.wave_base.p + W, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            d_over.download(&over, 1, s);
+            out.kept.download(kept_h.data(), (size_t)g->n, s);
+            VG_HIP(hipStreamSynchronize(s));
+            for (int i = 0; i < g->n; ++i) total64 += kept_h[i];
+        }
         if (total64 >= (1LL << 32) - 1) throw vg_error(VG_EOVERFLOW, "more than 2^32 k-mers in one shard: use more shards");
         nv = total; n_sort = (int64_t)total;
         const size_t na = (size_t)std::max<int64_t>(n_sort, 1);
@@ -2121,12 +2200,17 @@ static void run_extract_sort(vg_genomes* g, int k, double fraction, int shard, i
             hipLaunchKernelGGL(k_kmer_gather, dim3(grid_for(n_chunks * 64)), dim3(256), 0, s, stage.p, stage_cap, out.wave_base.p, W, keys_a.p, pos_a.p);
         } else if (n_sort > 0) {
             vg_prof_scope ps("kmer_emit_recompute", (double)P * 3.0 / 8.0 + (double)n_sort * 12.0);
-            if (n_sort * 4 <= P) hipLaunchKernelGGL(k_kmer_emit_sparse, dim3(grid_for(P / 8)), dim3(256), 0, s, A, out.wave_mask.p, out.wave_base.p, keys_a.p, pos_a.p);
+            // (a wave lists the kept positions of nw words and gives every lane one: about 56 of them, so that a second trip
+            // of a few lanes is rare -- eight words at a seventh kept are 73 positions, two trips for every chunk)
+            const int nw = (int)std::max<int64_t>(1, std::min<int64_t>(8, 56 * P / (64 * std::max<int64_t>(n_sort, 1))));
+            if (n_sort * 4 <= P) hipLaunchKernelGGL(k_kmer_emit_sparse, dim3(grid_for(P / 8)), dim3(256), 0, s, A, out.wave_mask.p, out.wave_base.p, keys_a.p, pos_a.p, nw);
             else hipLaunchKernelGGL(k_kmer_emit, dim3(grid_for(P)), dim3(256), 0, s, A, out.wave_mask.p, out.wave_base.p, keys_a.p, pos_a.p);
         }
         out.cblk.alloc((size_t)(n_sort >> CBLK_SHIFT) + 2); out.cblk.zero(s);
         out.goff.alloc((size_t)g->n + 1);
         hipLaunchKernelGGL(k_cblk, dim3(grid_for(g->n)), dim3(256), 0, s, out.wave_base.p, g->d_base_off.p, g->n, out.cblk.p, out.goff.p);
+        // (a given mask: the kept k-mers of a genome are its rows)
+        if (premask && g->n > 0) hipLaunchKernelGGL(k_kept_from_goff, dim3(grid_for(g->n)), dim3(256), 0, s, (const uint32_t*)out.goff.p, g->n, out.kept.p);
     }
     // Stable LSD radix sort on the top key bits only (bit 2k is the sentinel flag, so sentinels end
     // up behind every real k-mer); k_group_runs then orders the small equal-prefix groups.
@@ -2263,6 +2347,7 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
     if (range && !ri) throw vg_error(VG_EINVAL, "internal error: a range shard needs its row map");
     hipStream_t s = vg_stream();
     vg_host_mark("buckets: enter");
+    pass_timer index_timer(g_time_bucket_pass ? &g_last_bucket_ms : nullptr, s);       // (placement trials: count ... bucket kernels of this pass)
     if (!index_path_buckets() || n_src < (1 << 16) || n_src >= (1LL << 32)) return false;
     // elements the partition will hold (a RANGE shard holds whole buckets of the set's own partition: the digits follow from n_src)
     const int64_t n_expect = dense && !range ? n_src / std::max<uint32_t>(1u, A.n_shards) : n_src;
@@ -2479,6 +2564,7 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
     {
         vg_prof_scope ps("bucket_sort_runs", (double)n1 * ((narrow ? 8 : 12) + 4 + 8));
         const int grid_b = (int)std::min<int64_t>(nbk, 256 * 16);
+
         if (big_buckets) { if (narrow) VG_BUCKET_LAUNCH(true, 1024, 11, grid_b, nbk, nullptr, over1.p, d_nover.p); else VG_BUCKET_LAUNCH(false, 1024, 11, grid_b, nbk, nullptr, over1.p, d_nover.p); }
         else { if (narrow) VG_BUCKET_LAUNCH(true, BK_THREADS, 9, grid_b, nbk, nullptr, over1.p, d_nover.p); else VG_BUCKET_LAUNCH(false, BK_THREADS, 9, grid_b, nbk, nullptr, over1.p, d_nover.p); }
         d_nover.download(n_over, 2, s);
@@ -2771,10 +2857,30 @@ static void kmer_shared_subshards(vg_genomes* g, int k, double fraction, int sha
     std::vector<dbuf<vg_pair_count>> parts((size_t)sub); std::vector<unsigned long long> counts((size_t)sub, 0ULL);
     std::vector<vg_pair_count> none;
     static const bool no_overlap = [] { const char* e = vg_dev_getenv("VG_SUBSHARD_OVERLAP"); return e && *e == '0'; }();      // developer A/B
-    struct hook_guard { ~hook_guard() { g_after_extract = nullptr; g_precount.drop(); } } hg;
+    struct hook_guard { ~hook_guard() { g_after_extract = nullptr; g_precount.drop(); g_pass_mask = pass_mask(); } } hg;
+    // HASH sub-shards: ONE scan of the bases leaves the kept masks of all passes (k_multi_mask); a pass then computes the
+    // k-mers of its kept positions only.  (sub x P / 8 bytes of masks -- 22 GB at 10^6 contigs -- replace two sets of
+    // staging buffers of P / 256 x ~80 x 8 bytes each; VG_SUBSHARD_SCAN=each is the scan per pass of round 4)
+    static const bool scan_each = [] { const char* e = vg_dev_getenv("VG_SUBSHARD_SCAN"); return e && !strcmp(e, "each"); }();
+    dbuf<unsigned long long> all_masks;
+    const int64_t Wm = g->padded_total() / 64 + 1;
+    const bool multi = !scan_each && sub >= 2 && sub <= MM_MAX_SUB && !range_shards(g, fraction, n_shards * sub);
+    if (multi) {
+        int rc = vg_genomes_to_device(g); if (rc) throw vg_error(rc, vg_last_error());
+        hipStream_t s = vg_stream();
+        all_masks.alloc((size_t)sub * (size_t)Wm);
+        const kmer_args A = make_kmer_args(g, k, fraction, 0, 1);
+        const int64_t P = g->padded_total();
+        const size_t lds = (size_t)4 * sub * 8 * sizeof(uint32_t);
+        vg_prof_scope ps("kmer_multi_mask", (double)P * (3.0 / 8.0 + sub / 8.0));
+        if (k == 25 && !A.use_frac) hipLaunchKernelGGL(k_multi_mask<25>, dim3(grid_for((P + 255) / 4)), dim3(256), lds, s, A, (uint32_t)(shard * sub), (uint32_t)sub, (uint32_t)(n_shards * sub), all_masks.p, Wm);
+        else hipLaunchKernelGGL(k_multi_mask<0>, dim3(grid_for((P + 255) / 4)), dim3(256), lds, s, A, (uint32_t)(shard * sub), (uint32_t)sub, (uint32_t)(n_shards * sub), all_masks.p, Wm);
+    }
     for (int t = 0; t < sub; ++t) {
         g_after_extract = nullptr;
-        if (t + 1 < sub && !(fraction < 1.0) && !no_overlap && !range_shards(g, fraction, n_shards * sub))      // (HASH shards: the compact source scans first)
+        g_pass_mask = pass_mask();
+        if (multi) { g_pass_mask.g = g; g_pass_mask.k = k; g_pass_mask.shard = shard * sub + t; g_pass_mask.n_shards = n_shards * sub; g_pass_mask.mask = all_masks.p + (size_t)t * (size_t)Wm; }
+        if (!multi && t + 1 < sub && !(fraction < 1.0) && !no_overlap && !range_shards(g, fraction, n_shards * sub))      // (HASH shards: the compact source scans first)
             g_after_extract = [=] {
                 // (an optimisation only: without room for the second set of scan buffers the next sub-shard scans in line)
                 try { vg_dev_try_scope opportunistic; launch_precount(g, k, shard * sub + t + 1, n_shards * sub); } catch (...) { (void)hipGetLastError(); g_precount.drop(); }
@@ -2802,7 +2908,8 @@ extern "C" int vg_kmer_shared(vg_genomes* g, int k, double fraction, int shard, 
     // Sets beyond the 32-bit row numbering of one pass (2^32 padded bases dense, ~2^31 kept k-mers per
     // shard) are cut into sub-shards of this shard's k-mer range; partial counts of a pair add up.
     const int64_t P = g->padded_total();
-    const double expect = (double)P * fraction / n_shards;                 // k-mers kept by this shard, at most
+    int64_t real_bases = 0; for (int i = 0; i < g->n; ++i) real_bases += g->len[(size_t)i];
+    const double expect = (double)real_bases * fraction / n_shards;        // k-mers kept by this shard, at most (padding positions hold none)
     const bool dense = fraction >= 1.0 && n_shards == 1;
     int sub = 1;
     static const int env_sub = [] { const char* e = vg_dev_getenv("VG_SUBSHARDS"); return e ? atoi(e) : 0; }();      // developer experiments
@@ -2823,6 +2930,36 @@ extern "C" int vg_kmer_shared(vg_genomes* g, int k, double fraction, int shard, 
         vg_slice_exchange xs; xs.rank = shard; xs.world = n_shards; xs.emulate = true;
         const bool sliced = g_range_scan_mode == 1 && vg_slice_exchange_applies(g, k, fraction, n_shards);
         kmer_shared_pass(g, k, fraction, shard, n_shards, min_shared, set_sizes, acc, nullptr, nullptr, sliced ? &xs : nullptr);
+        // Placement trials.  Where the driver puts the workspace decides between two states of the scattering kernels (the
+        // bucket kernel 39 against 44 ms at 100 k genomes: same virtual addresses, same requests, same UTCL1 misses, 1.3-2 x
+        // the translation-in-flight and DRAM-credit stalls -- profiles/r05_placement_states.md), and it stays for the
+        // life of the blocks.  The FIRST whole pass of a long-lived process over a large set therefore tries up to three
+        // placements -- the cached blocks of the previous one set aside, the pass repeated on fresh ones -- and keeps the
+        // workspace whose index stage (level-1 count ... bucket kernel) was fastest; the results of the passes are the same, the caller gets the first's.
+        static const int max_trials = [] { const char* e = vg_dev_getenv("VG_PLACEMENT_TRIALS"); return e ? atoi(e) : 3; }();
+        static std::map<std::pair<int64_t, int>, int> tried;       // (padded bases, k) -> done
+        size_t fr = 0, tot = 0;
+        if (dense && !vg_one_shot() && max_trials > 1 && P >= (1LL << 30) && !tried[{ P, k }]++ && hipMemGetInfo(&fr, &tot) == hipSuccess &&
+            fr > 2 * vg_dev_cached_bytes() + (8ULL << 30)) {
+            struct timing_on { timing_on() { g_time_bucket_pass = true; } ~timing_on() { g_time_bucket_pass = false; } } on;
+            std::vector<int64_t> sz2((size_t)n); std::vector<vg_pair_count> acc2;
+            kmer_shared_pass(g, k, fraction, shard, n_shards, min_shared, sz2.data(), acc2);       // (the first pass paid for the allocations: time this placement on a second one)
+            float best = g_last_bucket_ms;
+            for (int trial = 1; trial < max_trials && best > 0.f; ++trial) {
+                const double w0 = vg_alloc_wait_ms();
+                vg_dev_park_cache();
+                bool keep_new = false;
+                try {
+                    kmer_shared_pass(g, k, fraction, shard, n_shards, min_shared, sz2.data(), acc2);
+                    kmer_shared_pass(g, k, fraction, shard, n_shards, min_shared, sz2.data(), acc2);
+                    keep_new = g_last_bucket_ms > 0.f && g_last_bucket_ms < 0.97f * best;
+                    if (getenv("VG_ALLOC_TRACE")) fprintf(stderr, "[vg placement] trial %d: index stage %.2f ms against %.2f ms -> %s\n", trial, g_last_bucket_ms, best, keep_new ? "kept" : "dropped");
+                    if (keep_new) best = g_last_bucket_ms;
+                } catch (...) { (void)hipGetLastError(); keep_new = false; }
+                vg_dev_unpark(!keep_new);
+                if (vg_alloc_wait_ms() - w0 > 500.0) break;          // (memory the driver still has to wipe: a trial costs seconds here)
+            }
+        }
     } else {
         // partial (a, b, count) records of every sub-shard stay in HBM and are summed ONCE there: sort on (a, b), reduce
         // by key, threshold on the sum
@@ -2854,7 +2991,8 @@ void vg_kmer_shared_device(vg_genomes* g, int k, double fraction, int shard, int
     *n_pairs = 0;
     if (g->n == 0) return;
     const int64_t P = g->padded_total();
-    const double expect = (double)P * fraction / n_shards;
+    int64_t real_bases = 0; for (int i = 0; i < g->n; ++i) real_bases += g->len[(size_t)i];
+    const double expect = (double)real_bases * fraction / n_shards;
     const bool dense = fraction >= 1.0 && n_shards == 1;
     const bool one_pass = g_force_subshards <= 1 && !(dense ? P >= (1LL << 32) : expect >= SUB_PASS_START);
     // how this rank cuts the k-mers (1 = RANGE, 2 = HASH): the two do not tile the key space together, so the ranks of a
