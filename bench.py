@@ -11,9 +11,11 @@ value = unordered pairs aligned per second (whole job, all ranks).
 
 Default workload: `phage-100k` of SURVEY.md 8(d) (BASELINE configs[3]: 10 000 families x 10 members x 40 kb,
 seed 3), which fits one MI355X.  N > 1: the SAME set (strong scaling; `--scaling weak` multiplies the families
-by N instead) through the sharded C-ABI entry points (vg_kmer_shared_sharded / vg_lz_align_sharded): the prefilter
-is sharded by k-mer range (partial counts all-gathered over RCCL and summed on the device), the align tasks
-are dealt by reference range (each rank indexes 1/N of the genomes), and the per-pair integer rows are all-gathered.  Other workloads: --workload phage-1k | imgvr-10k | contigs-1M (+ --count).
+by N instead) through the sharded C-ABI entry points (vg_kmer_shared_sharded / vg_lz_align_pairs_sharded): the prefilter
+is sharded by k-mer range -- every rank scans 1/N of the bases and an RCCL all-to-all hands each rank the kept masks of its
+range; the pairs' keys and counts are all-gathered and summed on the device --, the align tasks are dealt by reference
+range (each rank indexes 1/N of the genomes), and the per-pair integer rows are all-gathered.  N > 1 creates the library's
+RCCL communicator strictly (no fall-back to host all-gathers); the line says which communicator ran (`comm`).  Other workloads: --workload phage-1k | imgvr-10k | contigs-1M (+ --count).
 """
 import argparse
 import json
@@ -43,6 +45,11 @@ SCOPES = {
     'radix_sort_pairs': ('rocprim::onesweep_iteration', 'index'),
     'index_runs': ('k_group_runs', 'index'),
     'bucket_sort_runs': ('k_bucket_runs', 'index'),
+    'kmer_count': ('k_kmer_count', 'extract'),
+    'kmer_emit': ('k_kmer_gather', 'extract'),
+    'kmer_emit_recompute': ('k_kmer_emit_sparse', 'extract'),
+    'kmer_multi_mask': ('k_multi_mask', 'extract'),
+    'kmer_slice_scan': ('k_slice_scan', 'index'),
     'spgemm_rows': ('k_spgemm', 'join'),
     'lz_build_index': ('k_build_index_reg', 'align'),
     'lz_parse': ('k_lz_parse', 'align'),
@@ -307,7 +314,7 @@ def main():
         per_step = {e['name']: e['total_ms'] / args.steps for e in prof}
         roofline = None
         if prof:
-            dom = max(prof, key=lambda e: e['total_ms'])
+            dom = max((e for e in prof if e['name'] != 'exchange'), key=lambda e: e['total_ms'])      # (a kernel of this rank, not a collective)
             kern, stage = SCOPES.get(dom['name'], (dom['name'], 'align'))
             launches_per_step = dom['launches'] / args.steps
             avg_ms = dom['total_ms'] / dom['launches']

@@ -12,6 +12,8 @@ NAME=$WL${N:+/$N}
 OUT=$REPO/gpurun_out/prof_${TAG}_${WL}${N:+_$N}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+# (one prefilter pass per step in the traces: the placement trials of a process's first pass -- DESIGN section 4 -- are off)
+export VG_DEV_SWITCHES=1 VG_PLACEMENT_TRIALS=1
 CMD="python $REPO/bench.py --workload $WL ${N:+--count $N} --steps $STEPS --warmup 1 --no-cpu-baseline --no-cli-wall"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $CMD > "$OUT/stats.log" 2>&1
