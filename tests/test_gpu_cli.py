@@ -211,7 +211,7 @@ def test_cold_cli_calls_keep_a_bounded_device_footprint(tmp_path):
         for args in (('prefilter', '-i', fa, '-o', flt, '-v', '0'), ('align', '-i', fa, '-o', ani, '--filter', flt, '-v', '0')):
             p = subprocess.run([sys.executable, str(VCLUST), *map(str, args)], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
             assert p.returncode == 0, p.stderr[-2000:]
-            gb = [float(a) + float(b) for a, b in re.findall(r'new block [0-9.]+ MB \(live ([0-9.]+) GB, cached ([0-9.]+) GB\)', p.stderr)]
+            gb = [float(a) + float(b) for a, b in re.findall(r'new block [0-9.]+ MB (?:at \S+ )?\(live ([0-9.]+) GB, cached ([0-9.]+) GB\)', p.stderr)]
             peak.append(max(gb)); marks.append(p.stderr)
         return flt, ani, peak, marks
     flt, ani, peak, marks = go('bounded')
