@@ -246,6 +246,8 @@ int vg_lz_align_sharded(vg_genomes* g, const vg_task* tasks, int64_t n_tasks, co
  * the pairs; tasks in pair order, (q = b, r = a) before (q = a, r = b)); *tasks released with vg_free() */
 int vg_align_pairs_share(const vg_genomes* g, const vg_pair_count* pairs, int64_t n_pairs, int world, int rank,
                          vg_task** tasks, int64_t* n_tasks);
+/* (every rank passes the SAME pairs in the SAME order -- vg_kmer_shared_sharded returns them sorted; a checksum of the list
+ * is compared across the ranks and a difference is an error on all of them) */
 /* vg_align_tasks + vg_lz_align_sharded from the candidate pairs in one call: a rank derives its own tasks from the pairs
  * and starts its kernels at once, the canonical task list of the whole set is assembled beside them and only places the
  * gathered rows.  *tasks (canonical order, as vg_align_tasks) and *stats (one row per task) are released with vg_free(). */

@@ -141,6 +141,22 @@ def test_align_pairs_share_is_the_owner_partition_of_the_task_list():
             got_all += len(mine)
         assert got_all == len(tasks)
     assert len(D.align_pairs_share(gs, cand[:0], 4, 1)) == 0
+    # more than 2^17 pairs: the listing runs on several threads (per-chunk owner counts become starting positions) and must
+    # give the same tasks IN THE SAME ORDER as one thread would (pair order, r = a before r = b)
+    a = rng.integers(1, n, 400000); b = (rng.integers(0, n, 400000) ** 2 // n) % a
+    keys = np.unique(a.astype(np.int64) * n + b)
+    cand = np.zeros(len(keys), dtype=api.PAIR_DTYPE); cand['a'] = keys // n; cand['b'] = keys % n
+    assert len(cand) >= (1 << 16)
+    big = np.concatenate([cand, cand, cand])[:(1 << 17) + 777]              # (repeated pairs are fine for the listing)
+    tasks_of = lambda c: np.stack([np.stack([c['b'], c['a']], 1), np.stack([c['a'], c['b']], 1)], 1).reshape(-1, 2)      # (q, r): (b, a) then (a, b)
+    per_ref = np.bincount(np.concatenate([big['a'], big['b']]), minlength=n)
+    for world in (3, 8):
+        own = np.minimum(world - 1, (np.cumsum(per_ref) - per_ref) * world // (2 * len(big)))
+        all_t = tasks_of(big)
+        for rank in (0, world - 1):
+            mine = D.align_pairs_share(gs, big, world, rank)
+            want = all_t[own[all_t[:, 1]] == rank]
+            assert np.array_equal(np.stack([mine['q'], mine['r']], 1), want), (world, rank)
 
 
 def test_single_rank_comm_needs_no_process_group():

@@ -379,6 +379,42 @@ comm.close(); dist.destroy_process_group()
     assert p.returncode == 0 and p.stdout.count('masks ok rank') == nproc, (p.stdout[-500:], p.stderr[:3000])
 
 
+def test_two_ranks_align_from_many_pairs(tmp_path):
+    """vg_lz_align_pairs_sharded with more than 2^17 candidate pairs (80 families of 60 short genomes): the listing of a
+    rank's tasks and their positions in the owners' lists runs on several host threads; every rank must still receive
+    exactly the rows of the single-process vg_align_tasks + vg_lz_align, in the canonical order."""
+    script = tmp_path / 'two_rank_many_pairs.py'
+    script.write_text("""
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+from vclust_amd import api, synth, distributed as D
+dist, dev = D.init_process_group()
+api.set_device(0)
+comm = D.make_comm(dist, dev)
+codes, offsets, names = synth.make_families(80, 60, length=3000, seed=29, p_lo=0.005, p_hi=0.05)
+gs = api.GenomeSet.from_codes(codes, offsets, names)
+sizes, pairs = D.prefilter_counts(gs, comm, 25, 1.0, min_shared=20)        # (sorted: the same list on every rank)
+cand = gs.filter_pairs(sizes, pairs)
+assert len(cand) > (1 << 17), len(cand)
+tasks, stats = D.align_pairs(gs, cand, comm)
+ref_tasks = gs.align_tasks(cand)
+assert np.array_equal(tasks, ref_tasks)
+ref = gs.lz_align(ref_tasks)
+assert np.array_equal(stats, ref), int((stats != ref).sum())
+# ranks that pass differently ordered lists are told so, all of them (the rows could not be placed)
+from vclust_amd import _lib
+try:
+    D.align_pairs(gs, cand[::-1] if dist.get_rank() == 1 else cand, comm); raise SystemExit('a different pair order went unnoticed')
+except _lib.VclustGpuError as e:
+    assert 'different candidate pair lists' in str(e), str(e)
+print('many pairs ok rank', dist.get_rank(), len(cand), flush=True)
+comm.close(); dist.destroy_process_group()
+""" % str(ROOT))
+    p = _torchrun(2, script)
+    assert p.returncode == 0 and p.stdout.count('many pairs ok rank') == 2, (p.stdout[-500:], p.stderr[-3000:])
+
+
 def test_rccl_failure_falls_back_to_the_callback_communicator(tmp_path):
     """Two ranks on the ONE GPU of the test box ask for the built-in RCCL communicator: RCCL refuses a device twice, every
     rank agrees on the failure before any further collective, and all fall back to the callback communicator -- the

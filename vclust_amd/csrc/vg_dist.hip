@@ -117,6 +117,15 @@ void agree(const vg_comm* c, int my_rc, const char* what) {
     for (int r = 0; r < c->world; ++r) if (all[(size_t)r] != 0)
         throw vg_error(all[(size_t)r], std::string(what) + ": rank " + std::to_string(r) + " failed" + (r == c->rank ? std::string(": ") + vg_last_error() : std::string()));
 }
+// the same agreement carrying a checksum every rank must hold alike (e.g. of an input list all ranks are to pass identically)
+void agree_same(const vg_comm* c, int my_rc, uint32_t checksum, const char* what, const char* mismatch) {
+    std::vector<uint32_t> all((size_t)c->world * 2, 0); const uint32_t mine[2] = { (uint32_t)my_rc, checksum };
+    gather_host(c, mine, all.data(), sizeof mine);
+    for (int r = 0; r < c->world; ++r) if ((int32_t)all[(size_t)2 * r] != 0)
+        throw vg_error((int32_t)all[(size_t)2 * r], std::string(what) + ": rank " + std::to_string(r) + " failed" + (r == c->rank ? std::string(": ") + vg_last_error() : std::string()));
+    for (int r = 1; r < c->world; ++r) if (all[(size_t)2 * r + 1] != all[1])
+        throw vg_error(VG_EINVAL, std::string(what) + ": rank " + std::to_string(r) + " and rank 0 " + mismatch);
+}
 // a compute section between two exchanges: its failure becomes this rank's status word of the next agreement
 template <class F> void guarded(const vg_comm* c, const char* what, F fn) {
     int rc = VG_OK;
@@ -525,23 +534,61 @@ void pairs_share(int n, const vg_pair_count* cand, int64_t n_cand, int W, int me
                  std::vector<uint32_t>* la, std::vector<uint32_t>* lb, std::vector<int64_t>& per_rank, std::vector<vg_task>& mine) {
     const int64_t n_tasks = 2 * n_cand;
     own_ref.assign((size_t)n + 1, 0); per_rank.assign((size_t)W, 0); mine.clear();
+    // (every rank of a sharded call does this for the whole pair list between the stages: a few threads from 10^5 pairs on)
+    const int T = n_cand >= (1 << 17) ? std::max(1, std::min(vg_host_threads(), 8)) : 1;
     std::vector<int64_t> per_ref((size_t)n + 1, 0);
-    for (int64_t i = 0; i < n_cand; ++i) {
-        if (cand[i].a >= (uint32_t)n || cand[i].b >= (uint32_t)n) throw vg_error(VG_EINVAL, "pair id out of range");
-        per_ref[cand[i].a]++; per_ref[cand[i].b]++;
+    if (T == 1) {
+        for (int64_t i = 0; i < n_cand; ++i) {
+            if (cand[i].a >= (uint32_t)n || cand[i].b >= (uint32_t)n) throw vg_error(VG_EINVAL, "pair id out of range");
+            per_ref[cand[i].a]++; per_ref[cand[i].b]++;
+        }
+    } else {
+        vg_parallel_chunks(n_cand, T, [&](int64_t lo, int64_t hi, int) {
+            for (int64_t i = lo; i < hi; ++i) {
+                if (cand[i].a >= (uint32_t)n || cand[i].b >= (uint32_t)n) throw vg_error(VG_EINVAL, "pair id out of range");
+                __atomic_fetch_add(&per_ref[cand[i].a], 1, __ATOMIC_RELAXED); __atomic_fetch_add(&per_ref[cand[i].b], 1, __ATOMIC_RELAXED);
+            }
+        });
     }
     int64_t before = 0;
     for (int r = 0; r < n; ++r) { own_ref[(size_t)r] = n_tasks ? (int32_t)std::min<int64_t>(W - 1, before * W / n_tasks) : 0; before += per_ref[(size_t)r]; }
-    for (int64_t i = 0; i < n_cand; ++i) {
-        const uint32_t a = cand[i].a, b = cand[i].b;
-        const int ra = own_ref[a], rb = own_ref[b];
-        const int64_t ia = per_rank[(size_t)ra]++;
-        if (la) (*la)[(size_t)i] = (uint32_t)ia;
-        if (ra == me) mine.push_back({ b, a });
-        const int64_t ib = per_rank[(size_t)rb]++;
-        if (lb) (*lb)[(size_t)i] = (uint32_t)ib;
-        if (rb == me) mine.push_back({ a, b });
+    if (T == 1) {
+        for (int64_t i = 0; i < n_cand; ++i) {
+            const uint32_t a = cand[i].a, b = cand[i].b;
+            const int ra = own_ref[a], rb = own_ref[b];
+            const int64_t ia = per_rank[(size_t)ra]++;
+            if (la) (*la)[(size_t)i] = (uint32_t)ia;
+            if (ra == me) mine.push_back({ b, a });
+            const int64_t ib = per_rank[(size_t)rb]++;
+            if (lb) (*lb)[(size_t)i] = (uint32_t)ib;
+            if (rb == me) mine.push_back({ a, b });
+        }
+        return;
     }
+    // positions in the owners' lists are running counts in pair order: per chunk the tasks of every owner are counted,
+    // the chunks' counts become their starting positions, and every chunk then numbers its own pairs
+    std::vector<std::vector<int64_t>> cnt((size_t)T, std::vector<int64_t>((size_t)W, 0));
+    vg_parallel_chunks(n_cand, T, [&](int64_t lo, int64_t hi, int t) {
+        auto& c = cnt[(size_t)t];
+        for (int64_t i = lo; i < hi; ++i) { c[(size_t)own_ref[cand[i].a]]++; c[(size_t)own_ref[cand[i].b]]++; }
+    });
+    std::vector<int64_t> mine_at((size_t)T + 1, 0);
+    for (int r = 0; r < W; ++r) for (int t = 0; t < T; ++t) { const int64_t c = cnt[(size_t)t][(size_t)r]; cnt[(size_t)t][(size_t)r] = per_rank[(size_t)r]; per_rank[(size_t)r] += c; if (r == me) mine_at[(size_t)t + 1] = c; }
+    for (int t = 0; t < T; ++t) mine_at[(size_t)t + 1] += mine_at[(size_t)t];
+    mine.resize((size_t)mine_at[(size_t)T]);
+    vg_parallel_chunks(n_cand, T, [&](int64_t lo, int64_t hi, int t) {
+        auto& c = cnt[(size_t)t]; int64_t at = mine_at[(size_t)t];
+        for (int64_t i = lo; i < hi; ++i) {
+            const uint32_t a = cand[i].a, b = cand[i].b;
+            const int ra = own_ref[a], rb = own_ref[b];
+            const int64_t ia = c[(size_t)ra]++;
+            if (la) (*la)[(size_t)i] = (uint32_t)ia;
+            if (ra == me) mine[(size_t)at++] = { b, a };
+            const int64_t ib = c[(size_t)rb]++;
+            if (lb) (*lb)[(size_t)i] = (uint32_t)ib;
+            if (rb == me) mine[(size_t)at++] = { a, b };
+        }
+    });
 }
 }
 // rank `rank`'s share of the align tasks of the candidate pairs under the reference-range partition (a pure function of
@@ -591,7 +638,22 @@ extern "C" int vg_lz_align_pairs_sharded(vg_genomes* g, const vg_pair_count* can
     std::vector<vg_pair_stat> send, all;
     int64_t pad = 1, nt = 0;
     vg_host_mark("align pairs: enter");
-    guarded(c, "align shard", [&] {
+    // every rank must pass the SAME pairs in the SAME order (the positions of a rank's rows in the gathered blocks follow
+    // from the order): an order-sensitive checksum of the list travels with the section's status word
+    uint32_t cand_ck = 0;
+    {
+        const int T = n_cand >= (1 << 17) ? std::max(1, std::min(vg_host_threads(), 8)) : 1;
+        std::vector<uint64_t> part((size_t)T, 0);
+        vg_parallel_chunks(n_cand, T, [&](int64_t lo, int64_t hi, int t) {
+            uint64_t h = 0;
+            for (int64_t i = lo; i < hi; ++i) { uint64_t x = (((uint64_t)cand[i].a << 32) | cand[i].b) + 0x9E3779B97F4A7C15ULL * (uint64_t)(i + 1); x ^= x >> 31; x *= 0xBF58476D1CE4E5B9ULL; x ^= x >> 29; h += x; }
+            part[(size_t)t] = h;
+        });
+        uint64_t h = (uint64_t)n_cand; for (uint64_t v : part) h += v;
+        cand_ck = (uint32_t)(h ^ (h >> 32));
+    }
+    int rc_shard = VG_OK;
+    try { [&] {
         if (n_cand >= (1LL << 31)) throw vg_error(VG_EOVERFLOW, "more than 2^31 candidate pairs in one call");
         // the canonical list of the whole set: a helper thread, beside everything below
         int rc_list = VG_OK; std::string err_list;
@@ -611,7 +673,11 @@ extern "C" int vg_lz_align_pairs_sharded(vg_genomes* g, const vg_pair_count* can
         stats_g.p = malloc(sizeof(vg_pair_stat) * (size_t)std::max<int64_t>(1, n_tasks));
         if (!stats_g.p) throw vg_error(VG_ENOMEM, "out of host memory");
         reserve_staging(c, pad * (int64_t)sizeof(vg_pair_stat));
-    });
+    }(); }
+    catch (const vg_error& e) { vg_set_error("%s", e.what()); rc_shard = e.code; }
+    catch (const std::bad_alloc&) { vg_set_error("out of host memory"); rc_shard = VG_ENOMEM; }
+    catch (const std::exception& e) { vg_set_error("%s", e.what()); rc_shard = VG_EINVAL; }
+    agree_same(c, rc_shard, cand_ck, "align shard", "were given different candidate pair lists (the same pairs in the same order are required: vg_kmer_shared_sharded returns them sorted)");
     gather_host(c, send.data(), all.data(), pad * (int64_t)sizeof(vg_pair_stat));
     // rows into the canonical order: couple cidx came from pair perm[cidx]; its two tasks are that pair's (r = a) and (r = b) tasks
     {

@@ -112,8 +112,8 @@ extern "C" int vg_filter_pairs(int k, int min_kmers, double min_ident, const int
         return vg_ani_shorter(p.shared, set_sizes[p.a], set_sizes[p.b], k) >= min_ident;
     };
     try {
-        // (millions of pairs -- 3.5 M at 10^6 contigs -- : chunks over a few threads, kept pairs counted, then written in order)
-        const int T = n_pairs >= (1 << 19) ? std::max(1, std::min(vg_host_threads(), 8)) : 1;
+        // (10^5 .. 10^6 pairs -- every rank of a sharded call does this between the stages --: chunks over a few threads, kept pairs counted, then written in order)
+        const int T = n_pairs >= (1 << 17) ? std::max(1, std::min(vg_host_threads(), 8)) : 1;
         if (T == 1) { for (int64_t i = 0; i < n_pairs; ++i) if (keeps(pairs[i])) o[total++] = pairs[i]; }
         else {
             std::vector<int64_t> kept((size_t)T + 1, 0);
