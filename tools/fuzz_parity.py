@@ -49,6 +49,23 @@ for case in range(n_cases):
         for p in pr: acc[(int(p['a']), int(p['b']))] = acc.get((int(p['a']), int(p['b'])), 0) + int(p['shared'])
     if list(tot) != list(osizes) or acc != opairs:
         bad += 1; print('SHARD MISMATCH case', case, 'seed', seed0 + case, flush=True)
+    # the multi-GPU form of the shards: every rank scans 1/ns of the bases, the peers' slices computed in-process (applies from two
+    # partition levels on; smaller sets take the replicated scan again and must agree all the same)
+    api.set_range_scan(1); tot = np.zeros_like(sizes); acc = {}
+    try:
+        for s in range(ns):
+            sz, pr = gs.kmer_shared(k=k, fraction=frac, shard=s, n_shards=ns); tot += sz
+            for p in pr: acc[(int(p['a']), int(p['b']))] = acc.get((int(p['a']), int(p['b'])), 0) + int(p['shared'])
+    finally: api.set_range_scan(0)
+    if list(tot) != list(osizes) or acc != opairs:
+        bad += 1; print('SLICED SHARD MISMATCH case', case, 'seed', seed0 + case, ns, flush=True)
+    # HASH sub-shards from one scan of the bases (a fraction always cuts by hash; 33+ sub-shards scan per pass)
+    if frac < 1.0 and not huge:
+        _lib.load().vg_set_subshards(int(rng.choice([2, 7, 32, 40])))
+        try: s8, p8 = gs.kmer_shared(k=k, fraction=frac, min_shared=1)
+        finally: _lib.load().vg_set_subshards(0)
+        if list(s8) != list(osizes) or {(int(p['a']), int(p['b'])): int(p['shared']) for p in p8} != opairs:
+            bad += 1; print('HASH SUB-SHARD MISMATCH case', case, 'seed', seed0 + case, flush=True)
     lz = None
     if rng.random() < 0.5:
         mal = int(rng.integers(9, 17)); msl = int(rng.integers(5, min(mal, 9) + 1))
@@ -61,10 +78,20 @@ for case in range(n_cases):
         qq, rr = tasks['q'].astype(np.int64), tasks['r'].astype(np.int64)
         pr = np.zeros(len(tasks), dtype=api.PAIR_DTYPE); pr['a'] = np.maximum(qq, rr); pr['b'] = np.minimum(qq, rr)
         gs.lz_prepare(pr[rng.random(len(pr)) < 0.9] if rng.random() < 0.3 else pr, lz=lz)
+    # the thin constants of the fit, at random (product through vg_set_lz_fit, checker through its developer variables)
+    import os
+    fit = {}
+    if rng.random() < 0.4:
+        fit = dict(weak_seed_ratio=int(rng.choice([0, 2, 3, 5])), anchor_margin=int(rng.choice([-1, 4, 6, 8])), seed_choice=int(rng.choice([1, 3])))
+    api.set_lz_fit(**fit)
+    for name, key in (('VG_LZ_WEAK_SEED', 'weak_seed_ratio'), ('VG_LZ_ANCHOR_MARGIN', 'anchor_margin'), ('VG_LZ_SEED_CHOICE', 'seed_choice')):
+        if key in fit: os.environ[name] = str(fit[key])
+        else: os.environ.pop(name, None)
     stats = gs.lz_align(tasks, lz=lz)
+    api.set_lz_fit()
     for t, s in zip(tasks, stats):
         q, r = int(t['q']), int(t['r'])
         ref = orc.lz_pair_stat(codes[offsets[q]:offsets[q + 1]], codes[offsets[r]:offsets[r + 1]], lz=lz)
         if ref != (int(s['n_match']), int(s['aln_len']), int(s['n_regions'])):
-            bad += 1; print('LZ MISMATCH case', case, 'seed', seed0 + case, (q, r), ref, tuple(int(x) for x in s), lz, flush=True); break
+            bad += 1; print('LZ MISMATCH case', case, 'seed', seed0 + case, (q, r), ref, tuple(int(x) for x in s), lz, fit, flush=True); break
 print(f'{n_cases} cases, {bad} mismatches, {time.time() - t0:.0f} s')
