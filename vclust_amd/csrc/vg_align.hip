@@ -2061,7 +2061,9 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
                                    g->d_base_off.p, g->d_len.p, g->d_has_n.p, L.rr_pool.p, L.mask_pool.p, L.stab_pool.p,
                                    L.sent_pool.p, P2, d_stats.p, (vg_region*)nullptr, no_off);
                 } else if (fast_params) {
-                    hipLaunchKernelGGL(k_lz_parse_fast, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p + B.pos, nt, d_refs.p, g->d_packed.p, g->d_nmask.p,
+                    // (developer experiment: VG_LZ_OCC_KB reserves that much unused LDS per workgroup, i.e. caps the resident waves)
+                    static const size_t occ_lds = [] { const char* e = vg_dev_getenv("VG_LZ_OCC_KB"); return e ? (size_t)atoi(e) * 1024 : (size_t)0; }();
+                    hipLaunchKernelGGL(k_lz_parse_fast, dim3((unsigned)nblk), dim3(256), occ_lds, s, d_tasks.p + B.pos, nt, d_refs.p, g->d_packed.p, g->d_nmask.p,
                                    g->d_base_off.p, g->d_len.p, g->d_has_n.p, L.rr_pool.p, L.mask_pool.p, L.stab_pool.p,
                                    L.sent_pool.p, P, d_stats.p, (vg_region*)nullptr, no_off);
                 } else {

@@ -2381,8 +2381,9 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
     // extra 14 GB block pushed the caching allocator into trims and fresh hipMallocs -- 8.2 s per pass instead of 2.7)
     static const bool no_prezero = [] { const char* e = vg_dev_getenv("VG_ROWS_PREZERO"); return e && *e == '0'; }();      // developer A/B
     if (levels == 2 && dense && !no_prezero && !range) {
-        size_t fr = 0, tot = 0;
-        if (hipMemGetInfo(&fr, &tot) == hipSuccess && (size_t)n_rows_info * 4 * 8 <= tot / 2) try {
+        // (the device's total memory: asked once -- hipMemGetInfo is a driver round trip on every pass otherwise)
+        static const size_t tot = [] { size_t fr0 = 0, t0 = 0; return hipMemGetInfo(&fr0, &t0) == hipSuccess ? t0 : (size_t)0; }();
+        if (tot && (size_t)n_rows_info * 4 * 8 <= tot / 2) try {
             { vg_dev_try_scope opportunistic; rowinfo.alloc((size_t)n_rows_info); }
             hipStream_t side = vg_side_stream();
             hipEvent_t ev_s = nullptr;
@@ -2457,6 +2458,7 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
         hipLaunchKernelGGL(k_scan_columns_a, dim3(n_slabs), dim3(PT_THREADS), 0, s, (const uint32_t*)T1s.p, n_st, nb1, slab.p);
         hipLaunchKernelGGL(k_scan_columns_b, dim3(1), dim3(PT_THREADS), 0, s, slab.p, n_slabs, nb1, d_off1.p);
         hipLaunchKernelGGL(k_scan_columns_c, dim3(n_slabs), dim3(PT_THREADS), 0, s, T1s.p, n_st, nb1, (const uint32_t*)slab.p);
+        vg_host_mark("buckets: count+scan queued");
         VG_HIP(hipMemcpyAsync(&n1, d_off1.p + nb1, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         VG_HIP(hipStreamSynchronize(s));
         vg_host_mark("buckets: count+scan done");
