@@ -1873,6 +1873,8 @@ struct lz_plan {
     lz_slot slot;
     int64_t budget = 0; int mal = 0, msl = 0; const vg_genomes* g = nullptr;
     bool batch0_built = false;
+    hipEvent_t built_ev = nullptr;            // batch 0 was queued on another queue than the library's: vg_lz_align waits for it
+    ~lz_plan() { if (built_ev) { (void)hipEventSynchronize(built_ev); (void)hipEventDestroy(built_ev); } }
 };
 int64_t lz_batch_budget(const vg_genomes* g, const vg_lz_params* p, const std::vector<uint32_t>& ref_ids);
 void lz_plan_references(const vg_genomes* g, const vg_lz_params* p, lz_plan& P);
@@ -1991,6 +1993,7 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
         plan->g = g; plan->ref_ids = ref_ids;
         lz_plan_references(g, p, *plan);
     }
+    if (plan->built_ev) VG_HIP(hipStreamWaitEvent(s, plan->built_ev, 0));
     std::vector<lz_batch>& batches = plan->batches;
     dbuf<ref_desc>& d_refs = plan->d_refs;
     lz_slot& slot = plan->slot;
@@ -2242,7 +2245,7 @@ void lz_build_batch(const vg_genomes* g, const vg_lz_params* p, lz_plan& P, size
     if (!B.small_list.empty()) L.d_small.upload(B.small_list.data(), B.small_list.size(), sb);
     if (!B.large_list.empty()) { L.d_large.upload(B.large_list.data(), B.large_list.size(), sb); L.d_lchunk.upload(B.large_chunks.data(), B.large_chunks.size(), sb); }
     const int64_t total_chunks = B.chunk_off.back();
-    vg_prof_scope ps("lz_build_index", (double)total_chunks * 32 * (0.375 + 0.375 + 4));
+    vg_prof_scope ps("lz_build_index", (double)total_chunks * 32 * (0.375 + 0.375 + 4), sb);
     if (!B.large_list.empty()) VG_HIP(hipMemsetAsync(L.stab_pool.p, 0, (size_t)B.stab_tot * sizeof(uint32_t), sb));
     if (!B.reg_list.empty()) {
         hipLaunchKernelGGL(k_build_index_reg, dim3((unsigned)std::min<size_t>(B.reg_list.size(), 512)), dim3(1024), 0, sb, d_refs.p, L.d_reg.p,
@@ -2296,6 +2299,39 @@ extern "C" int vg_lz_prepare(vg_genomes* g, const vg_pair_count* pairs, int64_t 
     for (int i = 0; i < g->n; ++i) if (is_ref[(size_t)i]) plan->ref_ids.push_back((uint32_t)i);
     plan->g = g;
     lz_plan_references(g, p, *plan);
+    // (developer experiment VG_LZ_PREPARE_QUEUE=own: the build runs on a queue of its own, beside whatever the caller
+    // launches next on the library's queue -- a prefilter pass, if the references are known before it)
+    static const bool own_queue = [] { const char* e = vg_dev_getenv("VG_LZ_PREPARE_QUEUE"); return e && !strcmp(e, "own"); }();
+    static const bool at_spgemm = [] { const char* e = vg_dev_getenv("VG_LZ_PREPARE_QUEUE"); return e && !strcmp(e, "spgemm"); }();
+    if (at_spgemm) {
+        // the build is queued (own queue) when the next prefilter pass reaches its SpGEMM: random reads beside LDS-staged writes
+        lz_plan* raw = plan.get(); const vg_lz_params pp = *p;
+        VG_HIP(hipEventCreateWithFlags(&plan->built_ev, hipEventDisableTiming));
+        VG_HIP(hipEventRecord(plan->built_ev, vg_stream()));                   // (a pass that never comes: the event is complete anyway)
+        raw->batch0_built = false;
+        vg_set_spgemm_hook([g, pp, raw] {
+            static hipStream_t q = nullptr;
+            if (!q && hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess) return;
+            hipEvent_t e0 = nullptr; if (hipEventCreateWithFlags(&e0, hipEventDisableTiming) != hipSuccess) return;
+            (void)hipEventRecord(e0, vg_stream()); (void)hipStreamWaitEvent(q, e0, 0); (void)hipEventDestroy(e0);
+            lz_build_batch(g, &pp, *raw, 0, q);
+            (void)hipEventRecord(raw->built_ev, q);
+            raw->batch0_built = true;
+        });
+        vg_host_mark("lz: first batch of indexes deferred to the SpGEMM");
+        std::lock_guard<std::mutex> lk(g_prep_mu);
+        g_prepared = std::move(plan);
+        return VG_OK;
+    }
+    if (own_queue) {
+        static hipStream_t q = nullptr;
+        if (!q) VG_HIP(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+        hipEvent_t e0 = nullptr; VG_HIP(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
+        VG_HIP(hipEventRecord(e0, vg_stream())); VG_HIP(hipStreamWaitEvent(q, e0, 0)); (void)hipEventDestroy(e0);      // (the pools may have work of the library queue pending)
+        lz_build_batch(g, p, *plan, 0, q);
+        VG_HIP(hipEventCreateWithFlags(&plan->built_ev, hipEventDisableTiming));
+        VG_HIP(hipEventRecord(plan->built_ev, q));
+    } else
     lz_build_batch(g, p, *plan, 0, vg_stream());
     plan->batch0_built = true;
     vg_host_mark("lz: first batch of indexes queued");

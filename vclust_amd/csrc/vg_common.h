@@ -147,6 +147,7 @@ struct vg_slice_exchange {
     bool agreed = false;        // the agreement in front of the exchange has taken place (the failure handling of the caller pairs it otherwise)
 };
 // whether a shard pass of (g, k, fraction) over `world` ranks takes the sliced scan: a pure function of its arguments
+void vg_set_spgemm_hook(std::function<void()> fn);      // developer experiment: run once right before the next SpGEMM launch
 bool vg_slice_exchange_applies(const vg_genomes* g, int k, double fraction, int world);
 // one k-mer range shard of vg_kmer_shared with the (a, b, shared) records left in HBM (vg_prefilter.hip; used by vg_dist.hip)
 void vg_kmer_shared_device(vg_genomes* g, int k, double fraction, int shard, int n_shards, uint32_t min_shared,

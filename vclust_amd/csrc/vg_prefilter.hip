@@ -2336,6 +2336,8 @@ static void sliced_count(int k, const part_src& S, vg_slice_exchange* xs, int st
 // set by the sub-shard loop (kmer_shared_subshards): the k-mer scan of the NEXT sub-shard, started on the second queue at
 // a point where the library queue is idle
 static std::function<void()> g_after_extract;
+static std::function<void()> g_spgemm_hook;
+void vg_set_spgemm_hook(std::function<void()> fn) { g_spgemm_hook = std::move(fn); }
 static void run_scan_hook() { if (g_after_extract) { auto hook = std::move(g_after_extract); g_after_extract = nullptr; hook(); } }
 // A RANGE shard of the dense source (A.dig_n < 2^11): `ri` receives the kept masks, the row bases and the row -> genome
 // map of the pass, n_rows_info becomes the number of kept k-mers, and the row pointers are indexed by row number.
@@ -2700,6 +2702,7 @@ static void kmer_shared_pass(vg_genomes* g, int k, double fraction, int shard, i
     // k-mer scan of the NEXT sub-shard on the second queue, beside this sub-shard's SpGEMM: arithmetic beside random
     // reads.  Started earlier, beside the partition kernels, the scan only took their CUs: 2.70 against 2.74 s.)
     run_scan_hook();
+    if (g_spgemm_hook) { auto hook = std::move(g_spgemm_hook); g_spgemm_hook = nullptr; hook(); }      // (developer experiment: work queued beside the SpGEMM)
     // SpGEMM with a growing output buffer
     dbuf<unsigned long long> d_cursor(1);
     dbuf<uint32_t> d_over((size_t)n), d_nover(1);
