@@ -2046,6 +2046,9 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
                                    L.sent_pool.p, P, d_stats.p, (vg_region*)nullptr, no_off);
             } else {
                 const int64_t nblk = ((nt + 3) / 4 + 7) / 8 * 8;
+                // two pairs per wave (k_lz_parse_fast2): VG_LZ_KERNEL=two / one (developer A/B)
+                static const int two_env = [] { const char* e = vg_dev_getenv("VG_LZ_KERNEL"); return e && !strcmp(e, "two") ? 1 : (e && !strcmp(e, "two_stats") ? 2 : (e && !strcmp(e, "one") ? 0 : -1)); }();
+                const bool two_pairs = two_env >= 0 ? two_env >= 1 : VG_LZ_TWO_PAIRS_DEFAULT;
 #ifdef VG_DEV_KERNELS
                 if (P.ablate) {
                     hipLaunchKernelGGL(k_lz_parse_dev, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p + B.pos, nt, d_refs.p, g->d_packed.p, g->d_nmask.p,
@@ -2053,9 +2056,6 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
                                    L.sent_pool.p, P, d_stats.p, (vg_region*)nullptr, no_off);
                 } else
 #endif
-                // two pairs per wave (k_lz_parse_fast2): VG_LZ_KERNEL=two / one (developer A/B)
-                static const int two_env = [] { const char* e = vg_dev_getenv("VG_LZ_KERNEL"); return e && !strcmp(e, "two") ? 1 : (e && !strcmp(e, "two_stats") ? 2 : (e && !strcmp(e, "one") ? 0 : -1)); }();
-                const bool two_pairs = two_env >= 0 ? two_env >= 1 : VG_LZ_TWO_PAIRS_DEFAULT;
                 if (fast_params && two_pairs) {
                     const int64_t nwave = (nt + P2_CHUNK - 1) / P2_CHUNK, nblk2 = ((nwave + 3) / 4 + 7) / 8 * 8;
                     lz_dev_params P2 = P;
