@@ -43,7 +43,7 @@ for case in range(n_cases):
         osizes, opairs = orc.shared_all(codes, offsets, k=k, fraction=frac)
     if list(sizes) != list(osizes) or {(int(p['a']), int(p['b'])): int(p['shared']) for p in pairs} != opairs:
         bad += 1; print('PREFILTER MISMATCH case', case, 'seed', seed0 + case, flush=True)
-    ns = int(rng.choice([2, 3, 8])); tot = np.zeros_like(sizes); acc = {}
+    ns = int(rng.choice([2, 3, 8, 32])); tot = np.zeros_like(sizes); acc = {}
     for s in range(ns):
         sz, pr = gs.kmer_shared(k=k, fraction=frac, shard=s, n_shards=ns); tot += sz
         for p in pr: acc[(int(p['a']), int(p['b']))] = acc.get((int(p['a']), int(p['b'])), 0) + int(p['shared'])

@@ -710,7 +710,9 @@ extern "C" int vg_prefilter_sharded(const char* const* fasta_paths, int n_paths,
     if (p->k < 15 || p->k > 30) throw vg_error(VG_EINVAL, "k must be in 15..30");
     if (!(p->kmers_fraction > 0.0) || p->kmers_fraction > 1.0) throw vg_error(VG_EINVAL, "kmers_fraction must be in (0,1]");
     genomes_guard gg;
-    int rc = vg_genomes_load(fasta_paths, n_paths, p->is_multifasta, p->num_threads, &gg.g);
+    // (every rank reads the whole input on the same host: the ranks share its cores instead of each taking `num_threads`)
+    const int ingest_threads = std::max(1, std::min(p->num_threads, (int)std::max(1u, std::thread::hardware_concurrency() / (unsigned)std::max(1, c->world))));
+    int rc = vg_genomes_load(fasta_paths, n_paths, p->is_multifasta, ingest_threads, &gg.g);
     agree(c, rc, "ingest");
     std::vector<int64_t> sizes((size_t)std::max(1, vg_genomes_count(gg.g)));
     free_guard pairs; int64_t np = 0;
@@ -725,7 +727,8 @@ extern "C" int vg_align_sharded(const char* const* fasta_paths, int n_paths, con
     VG_API_BEGIN
     if (!fasta_paths || n_paths <= 0 || !out_path || !p || !c) throw vg_error(VG_EINVAL, "vg_align_sharded: null argument");
     genomes_guard gg;
-    int rc = vg_genomes_load(fasta_paths, n_paths, p->is_multifasta, p->num_threads, &gg.g);
+    const int ingest_threads = std::max(1, std::min(p->num_threads, (int)std::max(1u, std::thread::hardware_concurrency() / (unsigned)std::max(1, c->world))));
+    int rc = vg_genomes_load(fasta_paths, n_paths, p->is_multifasta, ingest_threads, &gg.g);
     free_guard pairs, tasks, regions, rows; int64_t np = 0, nt = 0, nr = 0;
     const bool want_aln = p->out_aln_path != nullptr;
     if (rc == VG_OK) rc = vg_read_filter(gg.g, p->filter_path, p->filter_threshold, (vg_pair_count**)&pairs.p, &np);

@@ -113,8 +113,12 @@ def _native(plan, seed, p_lo, p_hi, n_indels):
     mem = np.ascontiguousarray([p[1] for p in plan], dtype=np.int32)
     ln = np.ascontiguousarray([p[2] for p in plan], dtype=np.int32)
     codes_p, off_p, ng = C.c_void_p(), C.c_void_p(), C.c_int64()
+    # (0 = all host threads; the ranks of a multi-GPU run generate the same set side by side and share the host's cores)
+    import os
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    n_thr = 0 if world <= 1 else max(1, (os.cpu_count() or 1) // world)
     _lib.check(lib.vg_synth_plan(fam.ctypes.data, mem.ctypes.data, ln.ctypes.data, len(plan), int(seed), float(p_lo), float(p_hi),
-                                 int(n_indels), 0, C.byref(codes_p), C.byref(off_p), C.byref(ng)))
+                                 int(n_indels), n_thr, C.byref(codes_p), C.byref(off_p), C.byref(ng)))
     n = ng.value
     offsets = np.ctypeslib.as_array(C.cast(off_p, C.POINTER(C.c_int64)), shape=(n + 1,)).copy()
     total = int(offsets[-1])
