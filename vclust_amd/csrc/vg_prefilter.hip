@@ -1397,51 +1397,58 @@ k_part_scatter_dense(part_src S, int B1, int nbins /* level-1 buckets of this pa
 constexpr int RG_LIST = 16384;
 constexpr int RG_PER = RG_LIST / PT_THREADS;
 constexpr int RG_MAXBINS = 2048;
-template <int KC>
+// TT: positions per tile -- 32 768, or 65 536 when a shard keeps so little of a tile (a sixth or less: six ranks or passes
+// and more) that two tiles' kept k-mers fit the list: half the per-tile barriers and scans, segments twice as long
+template <int KC, int TT>
 __global__ void __launch_bounds__(PT_THREADS)
 k_part_scatter_range(part_src S, int B1, int nbins /* <= 2048 */, int unit_tiles, int64_t n_units, const uint32_t* __restrict__ Ts,
                      uint32_t* __restrict__ o_rec, int short_kr /* > 0: SHORT 8-byte records keeping this many key bits */) {
     if (KC > 0) { S.A.k = KC; S.k2 = 2 * KC; S.A.use_frac = 0; }
-    __shared__ uint32_t s_pk[RT_TILE / 16 + 8];
+    __shared__ uint32_t s_pk[TT / 16 + 8];
     __shared__ uint16_t s_list[RG_LIST], s_perm[RG_LIST];
     __shared__ uint32_t thist[RG_MAXBINS], tstart[RG_MAXBINS], cursor[RG_MAXBINS];
     __shared__ uint32_t s_wave[16];
-    __shared__ unsigned long long s_wm[RT_TILE / 64]; __shared__ uint32_t s_wb[RT_TILE / 64 + 1];
+    __shared__ unsigned long long s_wm[TT / 64]; __shared__ uint32_t s_wb[TT / 64 + 1];
     const int64_t n_pk = (S.A.P >> 4) + 16;
     const int64_t W = S.n >> 6;
     for (int64_t u = blockIdx.x; u < n_units; u += gridDim.x) {
-        const int64_t s0 = u * unit_tiles * RT_TILE, s1 = min(S.n, s0 + (int64_t)unit_tiles * RT_TILE);
+        const int64_t s0 = u * unit_tiles * TT, s1 = min(S.n, s0 + (int64_t)unit_tiles * TT);
         lds_sync();
         for (int b = threadIdx.x; b < nbins; b += PT_THREADS) cursor[b] = Ts[u * nbins + b];
-        constexpr int NPK = (RT_TILE / 16 + 4 + PT_THREADS - 1) / PT_THREADS;
+        constexpr int NPK = (TT / 16 + 4 + PT_THREADS - 1) / PT_THREADS;
         uint32_t pf_pk[NPK];
         auto fetch_bases = [&](int64_t t0) {
 #pragma unroll
-            for (int v = 0; v < NPK; ++v) { const int i = v * PT_THREADS + (int)threadIdx.x; const int64_t w = (t0 >> 4) + i; pf_pk[v] = (i < RT_TILE / 16 + 4 && w < n_pk) ? S.A.packed[w] : 0u; }
+            for (int v = 0; v < NPK; ++v) { const int i = v * PT_THREADS + (int)threadIdx.x; const int64_t w = (t0 >> 4) + i; pf_pk[v] = (i < TT / 16 + 4 && w < n_pk) ? S.A.packed[w] : 0u; }
         };
         fetch_bases(s0);
-        for (int64_t t0 = s0; t0 < s1; t0 += RT_TILE) {
+        for (int64_t t0 = s0; t0 < s1; t0 += TT) {
 #pragma unroll
-            for (int v = 0; v < NPK; ++v) { const int i = v * PT_THREADS + (int)threadIdx.x; if (i < RT_TILE / 16 + 4) s_pk[i] = pf_pk[v]; }
-            if (threadIdx.x <= RT_TILE / 64) {
-                const int64_t w = (t0 >> 6) + threadIdx.x;
-                if (threadIdx.x < RT_TILE / 64) s_wm[threadIdx.x] = w < W ? S.wmask[w] : 0ULL;
-                s_wb[threadIdx.x] = S.wbase[w < W ? w : W];
+            for (int v = 0; v < NPK; ++v) { const int i = v * PT_THREADS + (int)threadIdx.x; if (i < TT / 16 + 4) s_pk[i] = pf_pk[v]; }
+            for (int i = (int)threadIdx.x; i <= TT / 64; i += PT_THREADS) {
+                const int64_t w = (t0 >> 6) + i;
+                if (i < TT / 64) s_wm[i] = w < W ? S.wmask[w] : 0ULL;
+                s_wb[i] = S.wbase[w < W ? w : W];
             }
             const uint32_t grp_row0 = S.wbase[(t0 >> SR_POS_BITS) << (SR_POS_BITS - 6)];      // first row of the tile's 2^25-position group
             lds_sync();
-            if (t0 + RT_TILE < s1) fetch_bases(t0 + RT_TILE);
-            const int wn = (s_wb[RT_TILE / 64] - s_wb[0]) <= (uint32_t)RG_LIST ? RT_TILE / 64 : RT_TILE / 128;      // words per sub-tile
-            for (int w0 = 0; w0 < RT_TILE / 64; w0 += wn) {
+            if (t0 + TT < s1) fetch_bases(t0 + TT);
+            // words per sub-tile: the whole tile if its kept k-mers fit the list, else halves, else quarters (16 384 positions always fit)
+            int wn = TT / 64;
+            if (s_wb[TT / 64] - s_wb[0] > (uint32_t)RG_LIST) {
+                wn = TT / 128;
+                if (TT > 32768 && (s_wb[TT / 128] - s_wb[0] > (uint32_t)RG_LIST || s_wb[TT / 64] - s_wb[TT / 128] > (uint32_t)RG_LIST)) wn = TT / 256;
+            }
+            for (int w0 = 0; w0 < TT / 64; w0 += wn) {
                 const uint32_t row0 = s_wb[w0], n_sub = s_wb[w0 + wn] - row0;
                 for (int b = threadIdx.x; b < nbins; b += PT_THREADS) thist[b] = 0;
                 // list the kept positions: thread t takes the 32-position half-word t of the sub-tile
-                if ((int)threadIdx.x < 2 * wn) {
-                    const int w = w0 + ((int)threadIdx.x >> 1);
+                for (int hw = (int)threadIdx.x; hw < 2 * wn; hw += PT_THREADS) {
+                    const int w = w0 + (hw >> 1);
                     const unsigned long long m64 = s_wm[w];
-                    uint32_t m = (threadIdx.x & 1) ? (uint32_t)(m64 >> 32) : (uint32_t)m64;
-                    uint32_t at = s_wb[w] - row0 + ((threadIdx.x & 1) ? (uint32_t)__popc((uint32_t)m64) : 0u);
-                    const uint32_t lp_base = (uint32_t)w * 64u + (threadIdx.x & 1) * 32u;
+                    uint32_t m = (hw & 1) ? (uint32_t)(m64 >> 32) : (uint32_t)m64;
+                    uint32_t at = s_wb[w] - row0 + ((hw & 1) ? (uint32_t)__popc((uint32_t)m64) : 0u);
+                    const uint32_t lp_base = (uint32_t)w * 64u + (uint32_t)(hw & 1) * 32u;
                     while (m) { s_list[at++] = (uint16_t)(lp_base + (uint32_t)__builtin_ctz(m)); m &= m - 1u; }
                 }
                 lds_sync();
@@ -2488,11 +2495,19 @@ static bool build_index_buckets(vg_genomes* g, int k, bool dense, const kmer_arg
         a_rec.alloc(levels == 2 ? std::max((short_rec ? 2 : 3) * n_cap + 8, rows_cap + n_cap + 16) : 3 * n_cap + 8);
         const int grid_s = (int)std::min<int64_t>(n_st, 256);
         static const bool range_dense = [] { const char* e = vg_dev_getenv("VG_RANGE_SCATTER"); return e && !strcmp(e, "dense"); }();      // developer A/B
-        if (tile32k && range && nb1 <= RG_MAXBINS && !range_dense)
-            if (k == 25 && !A.use_frac) hipLaunchKernelGGL(k_part_scatter_range<25>, dim3(grid_s), dim3(PT_THREADS), 0, s, S, B1, nb1, st_tiles / 4, n_st, (const uint32_t*)T1s.p, a_rec.p,
-                                                           short_rec ? L2.kr : 0);
-            else hipLaunchKernelGGL(k_part_scatter_range<0>, dim3(grid_s), dim3(PT_THREADS), 0, s, S, B1, nb1, st_tiles / 4, n_st, (const uint32_t*)T1s.p, a_rec.p,
-                                    short_rec ? L2.kr : 0);
+        static const bool range_32k = [] { const char* e = vg_dev_getenv("VG_RANGE_TILE"); return e && !strcmp(e, "32k"); }();      // developer A/B
+        // (two tiles at a time when the shard keeps a sixth of the positions or less: their kept k-mers fit one list)
+        const bool tile64k = st_tiles % 8 == 0 && !range_32k && (uint64_t)A.dig_n * 6 <= (1u << DIG_BITS);
+        if (tile32k && range && nb1 <= RG_MAXBINS && !range_dense) {
+            const int tsh = short_rec ? L2.kr : 0;
+            if (tile64k) {
+                if (k == 25 && !A.use_frac) hipLaunchKernelGGL((k_part_scatter_range<25, 65536>), dim3(grid_s), dim3(PT_THREADS), 0, s, S, B1, nb1, st_tiles / 8, n_st, (const uint32_t*)T1s.p, a_rec.p, tsh);
+                else hipLaunchKernelGGL((k_part_scatter_range<0, 65536>), dim3(grid_s), dim3(PT_THREADS), 0, s, S, B1, nb1, st_tiles / 8, n_st, (const uint32_t*)T1s.p, a_rec.p, tsh);
+            } else {
+                if (k == 25 && !A.use_frac) hipLaunchKernelGGL((k_part_scatter_range<25, 32768>), dim3(grid_s), dim3(PT_THREADS), 0, s, S, B1, nb1, st_tiles / 4, n_st, (const uint32_t*)T1s.p, a_rec.p, tsh);
+                else hipLaunchKernelGGL((k_part_scatter_range<0, 32768>), dim3(grid_s), dim3(PT_THREADS), 0, s, S, B1, nb1, st_tiles / 4, n_st, (const uint32_t*)T1s.p, a_rec.p, tsh);
+            }
+        }
         else if (tile32k)
             if (k25 && !range) hipLaunchKernelGGL(k_part_scatter_dense<25>, dim3(grid_s), dim3(PT_THREADS), 0, s, S, B1, nb1, st_tiles / 4, n_st, (const uint32_t*)T1s.p, a_rec.p,
                                         short_rec ? L2.kr : 0);
