@@ -2956,7 +2956,7 @@ extern "C" int vg_kmer_shared(vg_genomes* g, int k, double fraction, int shard, 
         // life of the blocks.  The FIRST whole pass of a long-lived process over a large set therefore tries up to three
         // placements -- the cached blocks of the previous one set aside, the pass repeated on fresh ones -- and keeps the
         // workspace whose index stage (level-1 count ... bucket kernel) was fastest; the results of the passes are the same, the caller gets the first's.
-        static const int max_trials = [] { const char* e = vg_dev_getenv("VG_PLACEMENT_TRIALS"); return e ? atoi(e) : 3; }();
+        static const int max_trials = [] { const char* e = vg_dev_getenv("VG_PLACEMENT_TRIALS"); return e ? atoi(e) : 4; }();
         static std::map<std::pair<int64_t, int>, int> tried;       // (padded bases, k) -> done
         size_t fr = 0, tot = 0;
         if (dense && !vg_one_shot() && max_trials > 1 && P >= (1LL << 30) && !tried[{ P, k }]++ && hipMemGetInfo(&fr, &tot) == hipSuccess &&
