@@ -4,11 +4,11 @@
 set -u
 REPO=$(pwd); OUT=$REPO/${1:-gpurun_out/r5_parse_pmc}; export NF=${2:-10000} REPS=1 VG_DEV_SWITCHES=1 TMPDIR=/tmp
 mkdir -p "$OUT"; cd /tmp
-for K in one two; do
+for K in ${KERNELS:-one two}; do
   i=0
   for SET in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
              "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_SCA SQ_INSTS_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU" \
-             "TCC_HIT_sum TCC_MISS_sum"; do
+             "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_STALL_sum TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum"; do
     i=$((i+1))
     VG_LZ_KERNEL=$K rocprofv3 --pmc $SET --kernel-trace --output-format csv -d "$OUT/$K/set$i" -- python $REPO/tools/micro/parse_ab.py > "$OUT/$K.set$i.log" 2>&1
   done
@@ -18,17 +18,17 @@ python - "$OUT" <<'PY'
 import csv, glob, json, os, re, sys
 from collections import defaultdict
 out = sys.argv[1]; doc = {}
-for k in ('one', 'two'):
+for k in [d for d in ('one', 'two') if os.path.isdir(os.path.join(out, d))]:
     per = defaultdict(lambda: defaultdict(list))
     for f in glob.glob(os.path.join(out, k, '**', '*counter_collection.csv'), recursive=True):
         for row in csv.DictReader(open(f, newline='')):
-            m = re.search(r'k_lz_parse\w*', row['Kernel_Name']); name = m.group(0) if m else ''
+            m = re.search(r'k_lz_parse\w*|k_build_index\w*', row['Kernel_Name']); name = m.group(0) if m else ''
             if name: per[name][row['Counter_Name']].append(float(row['Counter_Value']))
     # the LAST launch of each kernel (the timed repetition; the first is the warm-up)
     doc[k] = {n: {c: v[-1] for c, v in cs.items()} for n, cs in per.items()}
     for f in glob.glob(os.path.join(out, k, '**', '*kernel_trace.csv'), recursive=True):
         for row in csv.DictReader(open(f, newline='')):
-            m = re.search(r'k_lz_parse\w*', row['Kernel_Name']); name = m.group(0) if m else ''
+            m = re.search(r'k_lz_parse\w*|k_build_index\w*', row['Kernel_Name']); name = m.group(0) if m else ''
             if name in doc[k]: doc[k][name]['last_launch_ms'] = (int(row['End_Timestamp']) - int(row['Start_Timestamp'])) / 1e6
         break
 json.dump(doc, open(os.path.join(out, 'parse_pmc.json'), 'w'), indent=1, sort_keys=True)

@@ -45,6 +45,14 @@ struct device_warmup {
     ~device_warmup() { join(); }
 };
 }
+namespace {
+// vg_release_device_memory on a helper thread for the lifetime of the object (joined at its end, also when the writer throws)
+struct background_release {
+    std::thread th;
+    background_release() { try { th = std::thread([] { vg_release_device_memory(); }); } catch (...) { vg_release_device_memory(); } }
+    ~background_release() { if (th.joinable()) th.join(); }
+};
+}
 extern "C" void vg_set_process_ends_after_call(int on) { g_leak_at_exit = on != 0; }
 
 extern "C" int vg_prefilter(const char* const* fasta_paths, int n_paths, const char* out_path,
@@ -70,9 +78,12 @@ extern "C" int vg_prefilter(const char* const* fasta_paths, int n_paths, const c
     // a one-shot process: the tens of GB of workspace go back to the driver NOW, so that the scrub of that memory
     // runs beside the writer and the start of the next process (`vclust.py align`) instead of in front of its
     // first allocation
-    vg_release_device_memory();
-    check(vg_write_fltr(gg.g, p->k, p->kmers_fraction, p->min_kmers, p->min_ident, p->max_seqs,
-                        sizes.data(), (const vg_pair_count*)pairs.p, np, out_path));
+    // (handing ~10 GB back is tens of milliseconds inside the driver: on a helper thread, beside the writer, which is host work only)
+    {
+        background_release rel;
+        check(vg_write_fltr(gg.g, p->k, p->kmers_fraction, p->min_kmers, p->min_ident, p->max_seqs,
+                            sizes.data(), (const vg_pair_count*)pairs.p, np, out_path));
+    }
     vg_host_mark("fltr.txt written");
     VG_API_END
 }
@@ -96,8 +107,10 @@ extern "C" int vg_align(const char* const* fasta_paths, int n_paths, const char*
     std::vector<vg_pair_stat> stats((size_t)std::max<int64_t>(1, nt));
     const bool want_aln = p->out_aln_path != nullptr;
     check(vg_lz_align(gg.g, (const vg_task*)tasks.p, nt, &p->lz, stats.data(), want_aln ? (vg_region**)&regions.p : nullptr, &nr));
-    vg_release_device_memory();
-    check(vg_write_ani(gg.g, (const vg_task*)tasks.p, stats.data(), nt, (const vg_region*)regions.p, nr, out_path, p));
+    {
+        background_release rel;
+        check(vg_write_ani(gg.g, (const vg_task*)tasks.p, stats.data(), nt, (const vg_region*)regions.p, nr, out_path, p));
+    }
     vg_host_mark("ani.tsv written");
     VG_API_END
 }
