@@ -217,7 +217,16 @@ def main():
     # N > 1 measures the RCCL path or nothing: the built-in communicator is created strictly (no silent fall-back to host
     # all-gathers through torch.distributed; VCLUST_COMM / VCLUST_DIST_BACKEND=gloo override it for tests on one GPU)
     kind = os.environ.get('VCLUST_COMM') or ('rccl-strict' if world > 1 and dist is not None and dist.get_backend() == 'nccl' else None)
-    comm = D.make_comm(dist, dev, kind=kind)
+    rccl_failure = None
+    try:
+        comm = D.make_comm(dist, dev, kind=kind)
+    except RuntimeError as exc:
+        # (strict creation failed on EVERY rank -- make_comm agrees on it first --: the run goes on over the callback
+        # communicator so that the record holds numbers, and says in so many words that they are NOT an RCCL result)
+        if kind != 'rccl-strict':
+            raise
+        rccl_failure = str(exc)
+        comm = D.make_comm(dist, dev, kind='callback')
 
     wl = synth.WORKLOADS[args.workload]
     base_n = args.count if args.count is not None else (wl['n_families'] if wl['kind'] == 'families' else wl['n'])
@@ -377,7 +386,7 @@ def main():
             'cpu_baseline': cpu,
             'cli_wall': e2e,
             'placement_trials': args.warmup > 0 and world == 1,
-            'comm': dict(kind=comm.kind, rccl_ranks=comm.rccl_ranks, strict=(kind == 'rccl-strict'),
+            'comm': dict(kind=comm.kind, rccl_ranks=comm.rccl_ranks, strict=(kind == 'rccl-strict'), rccl_failure=rccl_failure,
                          backend=(dist.get_backend() if dist is not None else None)) if world > 1 else None,
             'per_rank': per_rank if world > 1 else None,
         }
