@@ -178,7 +178,7 @@ def test_kernel_variants_write_the_same_files(tmp_path):
 
     base = go('default')
     assert sum(1 for _ in open(base[1])) > 50000
-    for tag, env in (('general_parse', dict(VG_LZ_KERNEL='general')), ('two_pairs_per_wave', dict(VG_LZ_KERNEL='two')), ('one_pair_per_wave', dict(VG_LZ_KERNEL='one')), ('lds_build', dict(VG_LZ_BUILD='lds')), ('fused_align', dict(VG_LZ_FUSED='1')),
+    for tag, env in (('general_parse', dict(VG_LZ_KERNEL='general')), ('lds_build', dict(VG_LZ_BUILD='lds')),
                      ('long_records', dict(VG_LEVEL1_RECORDS='long')), ('staged', dict(VG_DENSE_SCATTER='staged', VG_LEVEL2_SCATTER='staged')),
                      ('radix', dict(VG_INDEX_PATH='radix')),
                      # the cold CLI's bounded footprint at a budget that bites here: eight RANGE sub-shards of the prefilter

@@ -44,6 +44,8 @@ def build_lib(force: bool = False, verbose: bool = False) -> pathlib.Path:
     hipcc = _hipcc()
     flags = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
              '-Wno-unused-result', f'-I{ROOT / "include"}']
+    if os.environ.get('VG_LINES') == '1':        # developer build: line tables for rocprofv3's PC sampling
+        flags.append('-gline-tables-only')
     if os.environ.get('VG_DEV') == '1':          # developer build: the instrumented parse kernel (tools/micro/lz_stats.py)
         flags.append('-DVG_DEV_KERNELS')
     objs = []

@@ -52,13 +52,20 @@ struct ref_desc {
 struct lz_dev_params { int mal, msl, mrd, mqd, reg, aw, am, ar; int ablate; int pw_after, pw_miss; int weak_ratio; int margin; int seed_choice; };
 
 // ------------------------------------------------------------------ bit helpers
-// 32 bases (2-bit codes, first base in the low bits) starting at base position p (p >= 0)
+// Two layouts of a sequence.  (1) The genome set's 2-bit codes, 16 bases per word (vg_common.h): what the prefilter and
+// the index builds read.  (2) BIT PLANES, what the parse reads -- the query's genome (vg_genomes::d_planes, made once
+// per resident set by k_genome_planes) and the reference's RR: bases 32 w .. 32 w + 31 are the word pair (lo, hi) =
+// (bit 0 of every code, bit 1 of every code) at words 2 w, 2 w + 1.  Two sequences differ at a base iff
+// (lo ^ lo') | (hi ^ hi') has its bit set: the mismatch mask of 32 bases is ONE 32-bit word straight from three
+// logic operations, and everything the parse does with it -- window counts, runs of matches, first / last set bit,
+// lane-to-lane carries -- is 32-bit arithmetic (the 2-bit layout gave a 64-bit mask with every second bit unused:
+// twice the VALU instructions for each of those steps, round 5).
+
+// 32 bases (2-bit codes, first base in the low bits) starting at base position p (p >= 0) of a 2-bit packed array
 __device__ __forceinline__ uint64_t load32(const uint32_t* __restrict__ pk, int64_t p) {
-    // (a 32-bit byte offset: with a wave-uniform base the load takes the SGPR-base + VGPR-offset form, no 64-bit adds)
     const uint32_t off = ((uint32_t)p >> 4) << 2; const int sh = 2 * (int)(p & 15);
     uint4 v; __builtin_memcpy(&v, (const char*)pk + off, 16);          // one 16-byte load (4-byte aligned); every packed array has slack words
     asm volatile("" :: "v"(v.w));                      // keep it one instruction (the narrowed form is two loads)
-    // two funnel shifts (v_alignbit_b32: ({hi, lo} >> s)[31:0], s = 0 .. 30) instead of a 64-bit shift pair and its s = 0 case
     return (uint64_t)__builtin_amdgcn_alignbit(v.y, v.x, (uint32_t)sh) | ((uint64_t)__builtin_amdgcn_alignbit(v.z, v.y, (uint32_t)sh) << 32);
 }
 // 32 mask bits starting at base position p
@@ -77,50 +84,70 @@ __device__ __forceinline__ uint64_t spread(uint32_t v) {
     x = (x | (x << 1)) & EVEN;
     return x;
 }
-// even-bit mask of the base slots j in [0,32) with lo <= j < hi
-__device__ __forceinline__ uint64_t slots(int lo, int hi) {
-    if (lo < 0) lo = 0; if (hi > 32) hi = 32;
-    if (hi <= lo) return 0;
-    uint64_t a = (hi == 32) ? ~0ULL : ((1ULL << (2 * hi)) - 1);
-    uint64_t b = (lo == 0) ? 0ULL : ((1ULL << (2 * lo)) - 1);
-    return (a & ~b) & EVEN;
-}
 __device__ __forceinline__ uint64_t rev2(uint64_t x) {
     x = __brevll(x);
     return ((x >> 1) & EVEN) | ((x & EVEN) << 1);
 }
+// even-bit mask (one base per 2 bits) -> one bit per base
+__device__ __forceinline__ uint32_t squeeze16(uint32_t x) {       // the 16 even bits of x -> its low 16 bits
+    x &= 0x55555555u;
+    x = (x | (x >> 1)) & 0x33333333u;
+    x = (x | (x >> 2)) & 0x0F0F0F0Fu;
+    x = (x | (x >> 4)) & 0x00FF00FFu;
+    return (x | (x >> 8)) & 0x0000FFFFu;
+}
+__device__ __forceinline__ uint32_t squeeze(uint64_t x) {         // per 32-bit half: no 64-bit shifts
+    return squeeze16((uint32_t)x) | (squeeze16((uint32_t)(x >> 32)) << 16);
+}
+// 32 two-bit codes -> their bit planes
+struct planes32 { uint32_t lo, hi; };
+__device__ __forceinline__ planes32 planes_of(uint64_t codes) { return { squeeze(codes), squeeze(codes >> 1) }; }
+
+// 32 bases of a bit-plane array starting at base position p (p >= 0): one 16-byte load (8-byte aligned; every plane
+// array has a word pair of slack), one funnel shift per plane
+__device__ __forceinline__ planes32 loadp(const uint32_t* __restrict__ pl, int64_t p) {
+    const uint32_t off = ((uint32_t)p >> 5) << 3; const uint32_t sh = (uint32_t)p & 31u;
+    uint4 v; __builtin_memcpy(&v, (const char*)pl + off, 16);
+    asm volatile("" :: "v"(v.w));
+    return { __builtin_amdgcn_alignbit(v.z, v.x, sh), __builtin_amdgcn_alignbit(v.w, v.y, sh) };
+}
+__device__ __forceinline__ uint32_t diff32(const planes32 a, const planes32 b) { return (a.lo ^ b.lo) | (a.hi ^ b.hi); }
+// mask of the base slots j in [0, 32) with lo <= j < hi
+__device__ __forceinline__ uint32_t slots(int lo, int hi) {
+    if (lo < 0) lo = 0; if (hi > 32) hi = 32;
+    if (hi <= lo) return 0u;
+    const uint32_t a = (hi == 32) ? ~0u : ((1u << hi) - 1u);
+    return a & ~((1u << lo) - 1u);                       // (lo < hi <= 32)
+}
 
 struct pair_ctx {
-    const uint32_t* qpk; const uint32_t* qmk; int qlen; int q_has_n;
-    const uint32_t* rpk; const uint32_t* rmk; int n_rr; int L; int r_has_n;
+    const uint32_t* qpl; const uint32_t* qmk; int qlen; int q_has_n;       // query: bit planes of its genome, N mask
+    const uint32_t* rpl; const uint32_t* rmk; int n_rr; int L; int r_has_n;    // reference: bit planes of RR, mask
 };
 
-// mismatch mask (even bits) of the 32 positions q[qp+j] vs rr[rp+j]; positions outside the query or
+// mismatch mask of the 32 positions q[qp+j] vs rr[rp+j] (bit j); positions outside the query or
 // outside the reference window [rlo, rhi), and N positions, are mismatches.  qp/rp may be negative or
 // run past the end.  The window is one strand of RR (forward [0, L) or reverse complement
 // [L+1, n_rr)): matches, extensions and gap scores never cross from one strand into the other.
-__device__ __forceinline__ uint64_t mism32(const pair_ctx& c, int qp, int rp, int rlo, int rhi) {
+__device__ __forceinline__ uint32_t mism32(const pair_ctx& c, int qp, int rp, int rlo, int rhi) {
     const int lo = max(-qp, rlo - rp); const int hi = min(c.qlen - qp, rhi - rp);
     if (lo <= 0 && hi >= 32) {
         // fast path: the whole chunk lies inside both sequences
-        const uint64_t d = load32(c.qpk, qp) ^ load32(c.rpk, rp);
-        uint64_t mm = (d | (d >> 1)) & EVEN;
-        if (c.q_has_n) mm |= spread(loadm32(c.qmk, qp));
-        if (c.r_has_n) mm |= spread(loadm32(c.rmk, rp));
+        uint32_t mm = diff32(loadp(c.qpl, qp), loadp(c.rpl, rp));
+        if (c.q_has_n) mm |= loadm32(c.qmk, qp);
+        if (c.r_has_n) mm |= loadm32(c.rmk, rp);
         return mm;
     }
-    const uint64_t ok = slots(lo, hi);
-    if (ok == 0) return EVEN;
-    const uint64_t bad = EVEN & ~ok;
-    const int qs = qp < 0 ? 0 : qp, rs = rp < 0 ? 0 : rp;     // clamp loads; shifted back below
-    uint64_t xq = load32(c.qpk, qs), xr = load32(c.rpk, rs);
-    if (qp < 0) xq <<= 2 * (-qp);
-    if (rp < 0) xr <<= 2 * (-rp);
-    const uint64_t d = xq ^ xr;
-    uint64_t mm = (d | (d >> 1)) & EVEN;
-    if (c.q_has_n) { uint64_t sp = spread(loadm32(c.qmk, qs)); if (qp < 0) sp <<= 2 * (-qp); mm |= sp; }
-    if (c.r_has_n) { uint64_t sp = spread(loadm32(c.rmk, rs)); if (rp < 0) sp <<= 2 * (-rp); mm |= sp; }
-    return (mm | bad) & EVEN;
+    const uint32_t ok = slots(lo, hi);
+    if (ok == 0) return ~0u;
+    const int qs = qp < 0 ? 0 : qp, rs = rp < 0 ? 0 : rp;     // clamp loads; shifted back below (a shift of 32 or more has ok == 0)
+    planes32 xq = loadp(c.qpl, qs), xr = loadp(c.rpl, rs);
+    if (qp < 0) { xq.lo <<= -qp; xq.hi <<= -qp; }
+    if (rp < 0) { xr.lo <<= -rp; xr.hi <<= -rp; }
+    uint32_t mm = diff32(xq, xr);
+    if (c.q_has_n) { uint32_t sp = loadm32(c.qmk, qs); if (qp < 0) sp <<= -qp; mm |= sp; }
+    if (c.r_has_n) { uint32_t sp = loadm32(c.rmk, rs); if (rp < 0) sp <<= -rp; mm |= sp; }
+    return mm | ~ok;
 }
 // the strand of RR that holds position rp
 __device__ __forceinline__ int strand_lo(const pair_ctx& c, int rp) { return rp > c.L ? c.L + 1 : 0; }
@@ -130,36 +157,30 @@ __device__ __forceinline__ int strand_hi(const pair_ctx& c, int rp) { return rp 
 __device__ __forceinline__ int match_len_lane(const pair_ctx& c, int qp, int rp, int cap) {
     int l = 0;
     while (l < cap) {
-        uint64_t mm = mism32(c, qp + l, rp + l, strand_lo(c, rp), strand_hi(c, rp));
-        if (mm) return l + (__builtin_ctzll(mm) >> 1);
+        const uint32_t mm = mism32(c, qp + l, rp + l, strand_lo(c, rp), strand_hi(c, rp));
+        if (mm) return l + __builtin_ctz(mm);
         l += 32;
     }
     return l;
 }
 
-// exact match length (<= 32) of the query chunk already held in registers (xq, qbad = even-bit mask of
+// exact match length (<= 32) of the query chunk already held in registers (xq, qbad = mask of
 // its unusable slots: beyond the query end or N) against rr[rp ..]: only the reference side is loaded
-__device__ __forceinline__ int match_len32_q(const pair_ctx& c, uint64_t xq, uint64_t qbad, int rp) {
-    const uint64_t d = xq ^ load32(c.rpk, rp);
-    uint64_t mm = ((d | (d >> 1)) & EVEN) | qbad;
-    if (c.r_has_n) mm |= spread(loadm32(c.rmk, rp));
-    const int hi = c.n_rr - rp; if (hi < 32) mm |= EVEN & ~slots(0, hi);
-    const int sj = c.L - rp; if ((unsigned)sj < 32u) mm |= 1ULL << (2 * sj);
-    return mm ? (__builtin_ctzll(mm) >> 1) : 32;
+__device__ __forceinline__ int match_len32_q(const pair_ctx& c, const planes32 xq, uint32_t qbad, int rp) {
+    uint32_t mm = diff32(xq, loadp(c.rpl, rp)) | qbad;
+    if (c.r_has_n) mm |= loadm32(c.rmk, rp);
+    const int hi = c.n_rr - rp; if (hi < 32) mm |= ~slots(0, hi);
+    const int sj = c.L - rp; if ((unsigned)sj < 32u) mm |= 1u << sj;
+    return mm ? __builtin_ctz(mm) : 32;
 }
 
 // ---- cross-lane helpers that stay off the LDS crossbar (ds_bpermute costs ~100 cycles of
 // latency each, and a wave that owns a pair runs these in a dependent chain) ----------------
 // value of a wave-uniform lane: v_readlane
 __device__ __forceinline__ uint32_t lane32(uint32_t v, int src_lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src_lane); }
-__device__ __forceinline__ uint64_t lane64(uint64_t v, int src_lane) {
-    return (uint64_t)lane32((uint32_t)v, src_lane) | ((uint64_t)lane32((uint32_t)(v >> 32), src_lane) << 32);
-}
 // lane l receives the value of lane l-1 (lane 0 receives 0): DPP wave_shr:1
-__device__ __forceinline__ uint64_t lane_prev64(uint64_t v) {
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, 0x138, 0xf, 0xf, false);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), 0x138, 0xf, 0xf, false);
-    return (uint64_t)lo | ((uint64_t)hi << 32);
+__device__ __forceinline__ uint32_t lane_prev32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false);
 }
 // sum over the wave of a per-lane value in [0, 63]: six ballots + scalar popcounts
 __device__ __forceinline__ int wave_sum(int v) {
@@ -178,64 +199,63 @@ __device__ __forceinline__ int wave_sum(int v) {
 // symbol that ends the exact run is a mismatch, so window counts and match runs never straddle
 // the two phases, and the whole thing is the window automaton run over the mismatch mask from
 // e = 0, with the exact run as a lower bound of the result.  Bit-parallel: 32 bases per lane
-// (one XOR of 2-bit words), 2 048 per round; only mismatch positions can start a violation.
+// (one word of mismatch bits), 2 048 per round; only mismatch positions can start a violation.
 // mismatch mask of round 0 of extend(), split out so that a caller can issue the loads of several
 // extensions back to back (one memory round trip instead of one per extension)
-__device__ __forceinline__ uint64_t extend_mask0(const pair_ctx& c, int qp, int rp, int dir, int bound, int lane, int rlo, int rhi) {
-    uint64_t mm = EVEN;
+__device__ __forceinline__ uint32_t extend_mask0(const pair_ctx& c, int qp, int rp, int dir, int bound, int lane, int rlo, int rhi) {
+    uint32_t mm = ~0u;
     const int e0 = 32 * lane;
     if (e0 < bound) {
         if (dir > 0) mm = mism32(c, qp + e0, rp + e0, rlo, rhi);
-        else mm = rev2(mism32(c, qp - e0 - 32, rp - e0 - 32, rlo, rhi)) & EVEN;        // slot j <-> position e0 + j
-        const int rem = bound - e0; if (rem < 32) mm |= EVEN & ~slots(0, rem);
+        else mm = __brev(mism32(c, qp - e0 - 32, rp - e0 - 32, rlo, rhi));        // slot j <-> position e0 + j
+        const int rem = bound - e0; if (rem < 32) mm |= ~slots(0, rem);
     }
     return mm;
 }
 
 __device__ __forceinline__ int extend(const pair_ctx& c, const lz_dev_params& P, int qp, int rp, int dir, int bound,
-                                      int lane, int* n_match, uint64_t mm_first, int rlo, int rhi) {
+                                      int lane, int* n_match, uint32_t mm_first, int rlo, int rhi) {
     int accepted = 0, matches_total = 0;
     int first_mm = -1;            // position of the first mismatch (end of the exact run)
-    uint64_t carry_mm = 0;        // mismatch bits of the previous 32 positions (0 before e = 0)
-    uint64_t carry_ok = 0;        // match bits of the previous 32 positions (none before e = 0)
+    uint32_t carry_mm = 0;        // mismatch bits of the previous 32 positions (0 before e = 0)
+    uint32_t carry_ok = 0;        // match bits of the previous 32 positions (none before e = 0)
     int base = 0;                 // first position of this round
     int cum_before = 0;           // matches in [0, base)
-    const uint64_t awmask = (P.aw >= 32) ? ~0ULL : ((1ULL << (2 * P.aw)) - 1);
+    const uint32_t awmask = (P.aw >= 32) ? ~0u : ((1u << P.aw) - 1u);
     if (bound <= 0) { *n_match = 0; return 0; }
     for (;;) {
-        uint64_t mm = mm_first;
+        uint32_t mm = mm_first;
         if (base > 0) {
-            mm = EVEN;
+            mm = ~0u;
             const int e0 = base + 32 * lane;
             if (e0 < bound) {
                 if (dir > 0) mm = mism32(c, qp + e0, rp + e0, rlo, rhi);
-                else mm = rev2(mism32(c, qp - e0 - 32, rp - e0 - 32, rlo, rhi)) & EVEN;    // slot j <-> position e0 + j
-                const int rem = bound - e0; if (rem < 32) mm |= EVEN & ~slots(0, rem);
+                else mm = __brev(mism32(c, qp - e0 - 32, rp - e0 - 32, rlo, rhi));    // slot j <-> position e0 + j
+                const int rem = bound - e0; if (rem < 32) mm |= ~slots(0, rem);
             }
         }
         const unsigned long long anyb = __ballot(mm != 0);
         if (first_mm < 0 && anyb) {
             const int fl = __builtin_ctzll(anyb);
-            first_mm = base + 32 * fl + (__builtin_ctzll(lane64(mm, fl)) >> 1);
+            first_mm = base + 32 * fl + __builtin_ctz(lane32(mm, fl));
         }
-        uint64_t prev_mm = lane_prev64(mm); const uint64_t okb = (~mm) & EVEN; uint64_t prev_ok = lane_prev64(okb);
+        uint32_t prev_mm = lane_prev32(mm); const uint32_t okb = ~mm; uint32_t prev_ok = lane_prev32(okb);
         if (lane == 0) { prev_mm = carry_mm; prev_ok = carry_ok; }
         // first violation in this lane: never if the chunk plus the aw-1 symbols before it hold <= am
         int viol = 32;
         {
-            const uint64_t tail = (P.aw > 1) ? (prev_mm >> (64 - 2 * (P.aw - 1))) : 0ULL;
-            if ((int)(__popcll(mm) + __popcll(tail)) > P.am) {
-                uint64_t bits = mm;
+            const uint32_t tail = (P.aw > 1) ? (prev_mm >> (32 - (P.aw - 1))) : 0u;
+            if ((int)(__popc(mm) + __popc(tail)) > P.am) {
+                uint32_t bits = mm;
                 // a window holds the mismatches of the tail plus those up to the tested one: the first
                 // am - |tail| mismatches of this chunk cannot push any window over am
-                for (int skip = P.am - (int)__popcll(tail); skip > 0; --skip) bits &= bits - 1;
+                for (int skip = P.am - (int)__popc(tail); skip > 0; --skip) bits &= bits - 1;
                 while (bits) {
-                    const int j = __builtin_ctzll(bits) >> 1;
-                    const int top = 2 * j + 2;
-                    const uint64_t hi = (top == 64) ? mm : (mm & ((1ULL << top) - 1));
+                    const int j = __builtin_ctz(bits);
+                    const uint32_t hi = (j == 31) ? mm : (mm & ((2u << j) - 1u));
                     int cnt;
-                    if (j + 1 >= P.aw) cnt = __popcll(hi & (awmask << (2 * (j + 1 - P.aw))));
-                    else cnt = __popcll(hi) + __popcll(prev_mm >> (64 - 2 * (P.aw - 1 - j)));
+                    if (j + 1 >= P.aw) cnt = __popc(hi & (awmask << (j + 1 - P.aw)));
+                    else cnt = __popc(hi) + __popc(prev_mm >> (32 - (P.aw - 1 - j)));
                     if (cnt > P.am) { viol = j; break; }
                     bits &= bits - 1;
                 }
@@ -244,22 +264,22 @@ __device__ __forceinline__ int extend(const pair_ctx& c, const lz_dev_params& P,
         const unsigned long long vb = __ballot(viol < 32);
         if (anyb) {
             // positions ending a run of >= ar matches, strictly before the violation
-            uint64_t run = okb;
-            for (int t = 1; t < P.ar; ++t) run &= (okb << (2 * t)) | (prev_ok >> (64 - 2 * t));
+            uint32_t run = okb;
+            for (int t = 1; t < P.ar; ++t) run &= __builtin_amdgcn_alignbit(okb, prev_ok, (uint32_t)(32 - t));     // ({okb, prev_ok} >> (32 - t)): bit j = ok[j - t]
             const int fv = vb ? __builtin_ctzll(vb) : 64;
             const int vj = (int)lane32((uint32_t)viol, fv & 63);
-            uint64_t cand = run;
+            uint32_t cand = run;
             if (lane > fv) cand = 0;
-            else if (lane == fv) cand &= (vj == 0) ? 0ULL : ((1ULL << (2 * vj)) - 1);
+            else if (lane == fv) cand &= (vj == 0) ? 0u : ((1u << vj) - 1u);
             const unsigned long long cb = __ballot(cand != 0);
             if (cb) {
                 const int hl = 63 - __builtin_clzll(cb);
-                const uint64_t ch = lane64(cand, hl); const uint64_t mh = lane64(mm, hl);
-                const int hj = (63 - __builtin_clzll(ch)) >> 1;
+                const uint32_t ch = lane32(cand, hl); const uint32_t mh = lane32(mm, hl);
+                const int hj = 31 - __builtin_clz(ch);
                 accepted = base + 32 * hl + hj + 1;
-                int tot = wave_sum(lane < hl ? 32 - __popcll(mm) : 0);
-                const uint64_t upto = (hj == 31) ? ~0ULL : ((1ULL << (2 * hj + 2)) - 1);
-                tot += (hj + 1) - __popcll(mh & upto);
+                int tot = wave_sum(lane < hl ? 32 - __popc(mm) : 0);
+                const uint32_t upto = (hj == 31) ? ~0u : ((2u << hj) - 1u);
+                tot += (hj + 1) - __popc(mh & upto);
                 matches_total = cum_before + tot;
             }
         } else {
@@ -268,8 +288,8 @@ __device__ __forceinline__ int extend(const pair_ctx& c, const lz_dev_params& P,
         }
         if (vb) break;
         if (base + 2048 >= bound) break;
-        cum_before += anyb ? wave_sum(32 - __popcll(mm)) : 2048;
-        carry_mm = lane64(mm, 63); carry_ok = lane64(okb, 63);
+        cum_before += anyb ? wave_sum(32 - __popc(mm)) : 2048;
+        carry_mm = lane32(mm, 63); carry_ok = lane32(okb, 63);
         base += 2048;
     }
     if (first_mm < 0) first_mm = bound;                    // the whole range matched
@@ -280,17 +300,6 @@ __device__ __forceinline__ int extend(const pair_ctx& c, const lz_dev_params& P,
     return accepted;
 }
 
-// even-bit mask (one base per 2 bits) -> one bit per base
-__device__ __forceinline__ uint32_t squeeze16(uint32_t x) {       // the 16 even bits of x -> its low 16 bits
-    x &= 0x55555555u;
-    x = (x | (x >> 1)) & 0x33333333u;
-    x = (x | (x >> 2)) & 0x0F0F0F0Fu;
-    x = (x | (x >> 4)) & 0x00FF00FFu;
-    return (x | (x >> 8)) & 0x0000FFFFu;
-}
-__device__ __forceinline__ uint32_t squeeze(uint64_t x) {         // per 32-bit half: no 64-bit shifts
-    return squeeze16((uint32_t)x) | (squeeze16((uint32_t)(x >> 32)) << 16);
-}
 __device__ __forceinline__ uint64_t low_bits64(int n) { return n >= 64 ? ~0ULL : (n <= 0 ? 0ULL : ((1ULL << n) - 1)); }
 
 // Score of the g literals q[i-g .. i) in front of a chained match (ev_pos, len) whose predecessor ended at
@@ -312,8 +321,8 @@ __device__ __forceinline__ int gap_score(const pair_ctx& c, int i, int g, int pr
         const int e0 = 32 * lane;
         if (e0 < g) {
             const uint32_t in = (g - e0 >= 32) ? 0xffffffffu : ((1u << (g - e0)) - 1u);
-            ok_o = ~squeeze(mism32(c, q0 + e0, pred0 + e0, rlo, rhi)) & in;
-            ok_n = ~squeeze(mism32(c, q0 + e0, E - g + e0, rlo, rhi)) & in;
+            ok_o = ~mism32(c, q0 + e0, pred0 + e0, rlo, rhi) & in;
+            ok_n = ~mism32(c, q0 + e0, E - g + e0, rlo, rhi) & in;
         }
     }
     int tot_n = 0;
@@ -396,8 +405,19 @@ __device__ __forceinline__ void rr_chunk(const uint32_t* __restrict__ gpk, const
 // Tag of the index entry of RR position p (x = the bases from p on, first base in the low bits): the bases
 // that follow its msl-mer.  An anchor lookup keeps the entries whose tag equals the query's: they agree with
 // the query on msl + tag_bits / 2 bases without a look at the sequence (the exact length decides the rest).
-__device__ __forceinline__ uint32_t seed_tag(uint64_t x, int msl, int tag_bits) {
-    return tag_bits ? (uint32_t)((x >> (2 * msl)) & ((1u << tag_bits) - 1u)) : 0u;
+// Both are read off the bit planes (xl, xh = the planes of the bases from p on): bucket = the msl low bits of each plane
+// side by side, tag = the next ceil(tag_bits / 2) bits of the low plane and floor(tag_bits / 2) of the high one -- a
+// bijection of the msl-mer and an injection of the (at most mal - msl) bases behind it, which is all build and probe need.
+__device__ __forceinline__ uint32_t bucket_of(uint32_t xl, uint32_t xh, int msl) { const uint32_t m = (1u << msl) - 1u; return (xl & m) | ((xh & m) << msl); }
+__device__ __forceinline__ uint32_t tag_of(uint32_t xl, uint32_t xh, int msl, int tag_bits) {
+    const int tl = (tag_bits + 1) >> 1, th = tag_bits >> 1;
+    return ((xl >> msl) & ((1u << tl) - 1u)) | (((xh >> msl) & ((1u << th) - 1u)) << tl);
+}
+// RR as bit planes: the word pair of chunk ch
+__device__ __forceinline__ void rr_chunk_planes(const uint32_t* __restrict__ gpk, const uint32_t* __restrict__ gmk, int L, int64_t ch,
+                                                uint32_t* lo_out, uint32_t* hi_out, uint32_t* mask_out) {
+    uint64_t bits; rr_chunk(gpk, gmk, L, ch, &bits, mask_out);
+    const planes32 pl = planes_of(bits); *lo_out = pl.lo; *hi_out = pl.hi;
 }
 
 // ---- path A (references up to 2^21 RR symbols, msl <= 7): one 1024-thread workgroup builds RR
@@ -460,7 +480,6 @@ k_build_index_lds(const ref_desc* __restrict__ refs, const int* __restrict__ slo
     // per workgroup: (bucket | tag << 18) per RR position, then the (bucket|tag, position) list by top-level bin
     uint32_t* scratch = scratch_pool + (int64_t)blockIdx.x * scratch_stride * 3;
     uint2* binned = reinterpret_cast<uint2*>(scratch + scratch_stride);
-    const uint64_t smask = (1ULL << (2 * msl)) - 1;
     (void)mal;
     for (int li = blockIdx.x; li < n_list; li += gridDim.x) {
         const ref_desc rd = refs[slot_list[li]];
@@ -469,9 +488,9 @@ k_build_index_lds(const ref_desc* __restrict__ refs, const int* __restrict__ slo
         uint32_t* pk = rr_pool + rd.rr_w; uint32_t* mk = mask_pool + rd.mask_w;
         const int64_t chunks = ((int64_t)rd.n_rr + RR_PAD + 31) / 32 + 2;
         for (int64_t ch = threadIdx.x; ch < chunks; ch += blockDim.x) {
-            uint64_t bits; uint32_t m;
-            rr_chunk(gpk, gmk, rd.L, ch, &bits, &m);
-            pk[2 * ch] = (uint32_t)bits; pk[2 * ch + 1] = (uint32_t)(bits >> 32); mk[ch] = m;
+            uint32_t lo, hi, m;
+            rr_chunk_planes(gpk, gmk, rd.L, ch, &lo, &hi, &m);
+            pk[2 * ch] = lo; pk[2 * ch + 1] = hi; mk[ch] = m;
         }
         __threadfence_block();
         __syncthreads();
@@ -490,29 +509,29 @@ k_build_index_lds(const ref_desc* __restrict__ refs, const int* __restrict__ slo
             const int n4 = (rd.n_rr + 3) & ~3;
             // (the msl + tag bases of a position are <= 32 bits: one funnel shift over two words serves each of four
             // consecutive positions; the loads of four trips are issued together)
-            const uint32_t tagmask = rd.tag_bits ? ((1u << rd.tag_bits) - 1u) : 0u;
             for (int pb = 4 * threadIdx.x; pb < n4; pb += 16 * blockDim.x) {
-                uint32_t w0[4], w1[4], m0[4], m1[4];
+                uint4 w4[4]; uint32_t m0[4], m1[4];              // (lo, hi) of the chunk of p0 and of the next one
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int p0 = pb + u * 4 * (int)blockDim.x;
                     const bool in = p0 < n4;
-                    w0[u] = in ? pk[p0 >> 4] : 0u; w1[u] = in ? pk[(p0 >> 4) + 1] : 0u;
+                    w4[u] = make_uint4(0u, 0u, 0u, 0u);
+                    if (in) __builtin_memcpy(&w4[u], pk + 2 * (p0 >> 5), 16);
                     m0[u] = in ? mk[p0 >> 5] : ~0u; m1[u] = in ? mk[(p0 >> 5) + 1] : ~0u;
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int p0 = pb + u * 4 * (int)blockDim.x;
                     if (p0 >= n4) continue;
-                    const uint32_t sh = 2u * (uint32_t)(p0 & 15);
+                    const uint32_t sh = (uint32_t)(p0 & 31);
                     uint32_t out[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int p = p0 + j;
                         uint32_t bt = 0xffffffffu;
-                        if (p + w <= rd.n_rr && (__builtin_amdgcn_alignbit(m1[u], m0[u], (uint32_t)(p0 & 31) + j) & ((1u << w) - 1u)) == 0) {
-                            const uint32_t x = __builtin_amdgcn_alignbit(w1[u], w0[u], sh + 2 * j);
-                            bt = (x & (uint32_t)smask) | (((x >> (2 * msl)) & tagmask) << 18);
+                        if (p + w <= rd.n_rr && (__builtin_amdgcn_alignbit(m1[u], m0[u], sh + j) & ((1u << w) - 1u)) == 0) {
+                            const uint32_t xl = __builtin_amdgcn_alignbit(w4[u].z, w4[u].x, sh + j), xh = __builtin_amdgcn_alignbit(w4[u].w, w4[u].y, sh + j);
+                            bt = bucket_of(xl, xh, msl) | (tag_of(xl, xh, msl, rd.tag_bits) << 18);
                             atomicAdd(&tab[(bt & 0x3ffffu) >> (big ? tsh : 0)], 1u);
                         }
                         out[j] = bt;
@@ -685,7 +704,6 @@ __device__ __forceinline__ void build_ref_reg(uint32_t* const lds, const ref_des
     uint32_t* const s_rr = gw + REG_GEN_WORDS;                   // RR = fwd | N | rc of the reference
     uint32_t* const s_mk = s_rr + REG_RR_WORDS;
     uint32_t* const stage = lds;                                 // the windows use all of it
-    const uint64_t smask = (1ULL << (2 * msl)) - 1;
     const int nb = 1 << (2 * msl);
     {
         int tid = threadIdx.x;
@@ -701,10 +719,10 @@ __device__ __forceinline__ void build_ref_reg(uint32_t* const lds, const ref_des
         lds_sync();
         const int chunks = (rd.n_rr + RR_PAD + 31) / 32 + 2;
         for (int ch = tid; ch < chunks; ch += 1024) {
-            uint64_t bits; uint32_t m;
-            rr_chunk(gw, gm, rd.L, ch, &bits, &m);
-            pk[2 * ch] = (uint32_t)bits; pk[2 * ch + 1] = (uint32_t)(bits >> 32); mk[ch] = m;
-            s_rr[2 * ch] = (uint32_t)bits; s_rr[2 * ch + 1] = (uint32_t)(bits >> 32); s_mk[ch] = m;
+            uint32_t lo, hi, m;
+            rr_chunk_planes(gw, gm, rd.L, ch, &lo, &hi, &m);
+            pk[2 * ch] = lo; pk[2 * ch + 1] = hi; mk[ch] = m;
+            s_rr[2 * ch] = lo; s_rr[2 * ch + 1] = hi; s_mk[ch] = m;
         }
         lds_sync();
         // pass 0: bucket | tag << 18 of every position (4 consecutive positions out of one 128-bit window), bucket sizes
@@ -717,16 +735,15 @@ __device__ __forceinline__ void build_ref_reg(uint32_t* const lds, const ref_des
             if (p0 < n4) {
                 // the msl + tag bases of a position are <= 32 bits: one funnel shift over two words serves each of the
                 // four positions (p0 is a multiple of 4: their bit offsets 2 * (p0 & 15) + 2 j stay below 32)
-                const int wi = p0 >> 4; const uint32_t sh = 2u * (uint32_t)(p0 & 15);
-                const uint32_t w0 = s_rr[wi], w1 = s_rr[wi + 1];
+                const int wi = 2 * (p0 >> 5); const uint32_t sh = (uint32_t)(p0 & 31);
+                const uint32_t l0 = s_rr[wi], h0 = s_rr[wi + 1], l1 = s_rr[wi + 2], h1 = s_rr[wi + 3];
                 const uint32_t m0 = s_mk[p0 >> 5], m1 = s_mk[(p0 >> 5) + 1];
-                const uint32_t tagmask = rd.tag_bits ? ((1u << rd.tag_bits) - 1u) : 0u;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int p = p0 + j;
-                    if (p + msl <= rd.n_rr && (__builtin_amdgcn_alignbit(m1, m0, (uint32_t)(p0 & 31) + j) & ((1u << msl) - 1u)) == 0) {
-                        const uint32_t x = __builtin_amdgcn_alignbit(w1, w0, sh + 2 * j);
-                        const uint32_t bt = (x & (uint32_t)smask) | (((x >> (2 * msl)) & tagmask) << 18);
+                    if (p + msl <= rd.n_rr && (__builtin_amdgcn_alignbit(m1, m0, sh + j) & ((1u << msl) - 1u)) == 0) {
+                        const uint32_t xl = __builtin_amdgcn_alignbit(l1, l0, sh + j), xh = __builtin_amdgcn_alignbit(h1, h0, sh + j);
+                        const uint32_t bt = bucket_of(xl, xh, msl) | (tag_of(xl, xh, msl, rd.tag_bits) << 18);
                         atomicAdd(&tab[bt & 0x3ffffu], 1u);
                         reg[it][j] = bt;
                     }
@@ -816,7 +833,6 @@ k_build_index_mid(const ref_desc* __restrict__ refs, const int* __restrict__ slo
     __shared__ uint32_t tab[LDS_TAB];
     __shared__ uint32_t stage[MID_STAGE];
     __shared__ uint32_t wtot[16];
-    const uint32_t smask = (1u << (2 * msl)) - 1u;
     const int nb = 1 << (2 * msl);
     const int tid = threadIdx.x;
     for (int li = blockIdx.x; li < n_list; li += gridDim.x) {
@@ -827,20 +843,22 @@ k_build_index_mid(const ref_desc* __restrict__ refs, const int* __restrict__ slo
         uint32_t* gtab = stab_pool + rd.stab; uint32_t* gent = sent_pool + rd.sent;
         const int chunks = (rd.n_rr + RR_PAD + 31) / 32 + 2;
         for (int ch = tid; ch < chunks; ch += 1024) {
-            uint64_t bits; uint32_t m;
-            rr_chunk(gpk, gmk, rd.L, ch, &bits, &m);
-            pk[2 * ch] = (uint32_t)bits; pk[2 * ch + 1] = (uint32_t)(bits >> 32); mk[ch] = m;
+            uint32_t lo, hi, m;
+            rr_chunk_planes(gpk, gmk, rd.L, ch, &lo, &hi, &m);
+            pk[2 * ch] = lo; pk[2 * ch + 1] = hi; mk[ch] = m;
         }
         for (int i = tid; i < nb; i += 1024) tab[i] = 0;
         __threadfence_block();
         __syncthreads();                                          // RR is read back below (this workgroup's own stores)
-        const uint32_t tagmask = rd.tag_bits ? ((1u << rd.tag_bits) - 1u) : 0u;
         const int n16 = (rd.n_rr + 15) & ~15;
         // a thread takes 16 positions per trip: one RR word, its successor and the N mask of the stretch.  The words of
         // the NEXT trip are asked for before this trip's are used (the passes are latency-bound: 16 waves per CU).
-        auto load16 = [&](int p0, uint32_t& w0, uint32_t& w1, uint32_t& ok) {
-            const int wi = p0 >> 4;
-            w0 = pk[wi]; w1 = pk[wi + 1];
+        // (w = the planes (lo, hi) of the chunk of p0 and of the next one, already shifted to p0: p0 & 31 is 0 or 16 and
+        // the sixteen positions need the bits up to 15 + msl + tag <= 15 + 12 + 7 of each plane -- more than 32 for the long
+        // seeds, so the shift by j stays a funnel shift over both words)
+        auto load16 = [&](int p0, uint4& w, uint32_t& ok) {
+            __builtin_memcpy(&w, pk + 2 * (p0 >> 5), 16);
+            if (p0 & 16) { w.x = __builtin_amdgcn_alignbit(w.z, w.x, 16u); w.y = __builtin_amdgcn_alignbit(w.w, w.y, 16u); w.z >>= 16; w.w >>= 16; }
             const uint32_t m = __builtin_amdgcn_alignbit(mk[(p0 >> 5) + 1], mk[p0 >> 5], (uint32_t)(p0 & 31));
             uint32_t bad = m;                                     // bit j: an N among the symbols j .. j + msl - 1
             for (int q = 1; q < msl; ++q) bad |= m >> q;
@@ -850,15 +868,15 @@ k_build_index_mid(const ref_desc* __restrict__ refs, const int* __restrict__ slo
         };
         // pass 0: bucket sizes
         {
-            int p0 = 16 * tid; uint32_t w0 = 0, w1 = 0, ok = 0;
-            if (p0 < n16) load16(p0, w0, w1, ok);
+            int p0 = 16 * tid; uint4 w = make_uint4(0u, 0u, 0u, 0u); uint32_t ok = 0;
+            if (p0 < n16) load16(p0, w, ok);
             while (p0 < n16) {
-                const int pn = p0 + 16384; uint32_t a0 = 0, a1 = 0, aok = 0;
-                if (pn < n16) load16(pn, a0, a1, aok);
+                const int pn = p0 + 16384; uint4 a = make_uint4(0u, 0u, 0u, 0u); uint32_t aok = 0;
+                if (pn < n16) load16(pn, a, aok);
 #pragma unroll
                 for (int j = 0; j < 16; ++j)
-                    if ((ok >> j) & 1u) atomicAdd(&tab[__builtin_amdgcn_alignbit(w1, w0, 2u * j) & smask], 1u);
-                p0 = pn; w0 = a0; w1 = a1; ok = aok;
+                    if ((ok >> j) & 1u) atomicAdd(&tab[bucket_of(__builtin_amdgcn_alignbit(w.z, w.x, (uint32_t)j), __builtin_amdgcn_alignbit(w.w, w.y, (uint32_t)j), msl)], 1u);
+                p0 = pn; w = a; ok = aok;
             }
         }
         lds_sync();
@@ -875,31 +893,34 @@ k_build_index_mid(const ref_desc* __restrict__ refs, const int* __restrict__ slo
             const uint32_t width = (uint32_t)(b_hi - b_lo);
             lds_sync();                                           // (everybody has read the table before its cursors move)
             if (w_end > base) {
-                int p0 = 16 * tid; uint32_t w0 = 0, w1 = 0, ok = 0;
-                if (p0 < n16) load16(p0, w0, w1, ok);
+                int p0 = 16 * tid; uint4 w = make_uint4(0u, 0u, 0u, 0u); uint32_t ok = 0;
+                if (p0 < n16) load16(p0, w, ok);
                 while (p0 < n16) {
-                    const int pn = p0 + 16384; uint32_t a0 = 0, a1 = 0, aok = 0;
-                    if (pn < n16) load16(pn, a0, a1, aok);
+                    const int pn = p0 + 16384; uint4 a = make_uint4(0u, 0u, 0u, 0u); uint32_t aok = 0;
+                    if (pn < n16) load16(pn, a, aok);
                     uint32_t hits = 0;
 #pragma unroll
                     for (int j = 0; j < 16; ++j)
-                        if ((__builtin_amdgcn_alignbit(w1, w0, 2u * j) & smask) - (uint32_t)b_lo < width) hits |= 1u << j;
+                        if (bucket_of(__builtin_amdgcn_alignbit(w.z, w.x, (uint32_t)j), __builtin_amdgcn_alignbit(w.w, w.y, (uint32_t)j), msl) - (uint32_t)b_lo < width) hits |= 1u << j;
                     hits &= ok;
                     while (hits) {                                // two hits per trip: both cursors are asked for before either entry is stored
                         const int j1 = __ffs(hits) - 1; hits &= hits - 1;
                         const int j2 = hits ? __ffs(hits) - 1 : -1; hits &= hits - 1;     // (0 & anything stays 0)
-                        const uint32_t x1 = __builtin_amdgcn_alignbit(w1, w0, 2u * (uint32_t)j1);
-                        const uint32_t s1 = atomicAdd(&tab[x1 & smask], 1u);
-                        uint32_t x2 = 0, s2 = 0;
-                        if (j2 >= 0) { x2 = __builtin_amdgcn_alignbit(w1, w0, 2u * (uint32_t)j2); s2 = atomicAdd(&tab[x2 & smask], 1u); }
-                        const uint32_t e1 = (uint32_t)(p0 + j1) | (((x1 >> (2 * msl)) & tagmask) << rd.pos_bits);
+                        const uint32_t xl1 = __builtin_amdgcn_alignbit(w.z, w.x, (uint32_t)j1), xh1 = __builtin_amdgcn_alignbit(w.w, w.y, (uint32_t)j1);
+                        const uint32_t s1 = atomicAdd(&tab[bucket_of(xl1, xh1, msl)], 1u);
+                        uint32_t xl2 = 0, xh2 = 0, s2 = 0;
+                        if (j2 >= 0) {
+                            xl2 = __builtin_amdgcn_alignbit(w.z, w.x, (uint32_t)j2); xh2 = __builtin_amdgcn_alignbit(w.w, w.y, (uint32_t)j2);
+                            s2 = atomicAdd(&tab[bucket_of(xl2, xh2, msl)], 1u);
+                        }
+                        const uint32_t e1 = (uint32_t)(p0 + j1) | (tag_of(xl1, xh1, msl, rd.tag_bits) << rd.pos_bits);
                         if (direct) gent[s1] = e1; else stage[s1 - base] = e1;
                         if (j2 >= 0) {
-                            const uint32_t e2 = (uint32_t)(p0 + j2) | (((x2 >> (2 * msl)) & tagmask) << rd.pos_bits);
+                            const uint32_t e2 = (uint32_t)(p0 + j2) | (tag_of(xl2, xh2, msl, rd.tag_bits) << rd.pos_bits);
                             if (direct) gent[s2] = e2; else stage[s2 - base] = e2;
                         }
                     }
-                    p0 = pn; w0 = a0; w1 = a1; ok = aok;
+                    p0 = pn; w = a; ok = aok;
                 }
                 lds_sync();
                 if (!direct) {
@@ -932,9 +953,9 @@ k_build_rr(const ref_desc* __restrict__ refs, const int* __restrict__ slot_list,
         const ref_desc rd = refs[slot_list[lo]];
         const int64_t ch = t - chunk_off[lo];
         const int64_t g0 = base_off[rd.genome];
-        uint64_t bits; uint32_t m;
-        rr_chunk(packed + (g0 >> 4), nmask + (g0 >> 5), rd.L, ch, &bits, &m);
-        rr_pool[rd.rr_w + 2 * ch] = (uint32_t)bits; rr_pool[rd.rr_w + 2 * ch + 1] = (uint32_t)(bits >> 32);
+        uint32_t pl_lo, pl_hi, m;
+        rr_chunk_planes(packed + (g0 >> 4), nmask + (g0 >> 5), rd.L, ch, &pl_lo, &pl_hi, &m);
+        rr_pool[rd.rr_w + 2 * ch] = pl_lo; rr_pool[rd.rr_w + 2 * ch + 1] = pl_hi;
         mask_pool[rd.mask_w + ch] = m;
     }
 }
@@ -946,7 +967,6 @@ k_index_pass(const ref_desc* __restrict__ refs, const int* __restrict__ slot_lis
              uint32_t* __restrict__ stab_pool,
              uint32_t* __restrict__ sent_pool) {
     const int64_t total = chunk_off[n_list] * 32;
-    const uint64_t smask = (1ULL << (2 * msl)) - 1;
     (void)mal;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         int64_t chunk = t >> 5;
@@ -956,13 +976,13 @@ k_index_pass(const ref_desc* __restrict__ refs, const int* __restrict__ slot_lis
         const int64_t p = t - chunk_off[lo] * 32;
         if (p >= rd.n_rr) continue;
         const uint32_t* pk = rr_pool + rd.rr_w; const uint32_t* mk = mask_pool + rd.mask_w;
-        uint64_t x = load32(pk, p);
+        const planes32 x = loadp(pk, p);
         uint64_t m = (uint64_t)mk[p >> 5] | ((uint64_t)mk[(p >> 5) + 1] << 32);
         m >>= (p & 31);
         if (p + msl <= rd.n_rr && (m & ((1ULL << msl) - 1)) == 0) {
-            uint32_t b = (uint32_t)(x & smask);
+            uint32_t b = bucket_of(x.lo, x.hi, msl);
             uint32_t slot = atomicAdd(&stab_pool[rd.stab + b], 1u);
-            if (fill) sent_pool[rd.sent + slot] = (uint32_t)p | (seed_tag(x, msl, rd.tag_bits) << rd.pos_bits);
+            if (fill) sent_pool[rd.sent + slot] = (uint32_t)p | (tag_of(x.lo, x.hi, msl, rd.tag_bits) << rd.pos_bits);
         }
     }
 }
@@ -1016,40 +1036,39 @@ struct seg_rec { int i_ev, ev_pos; uint32_t VM, VA, VN; };     // VN: bit 31 = o
 
 #define PARSE_ARGS \
     const task_dev* __restrict__ tasks, int64_t n_tasks, const ref_desc* __restrict__ refs, \
-    const uint32_t* __restrict__ packed, const uint32_t* __restrict__ nmask, const int64_t* __restrict__ base_off, \
+    const uint32_t* __restrict__ planes, const uint32_t* __restrict__ nmask, const int64_t* __restrict__ base_off, \
     const int64_t* __restrict__ glen, const uint8_t* __restrict__ g_has_n, \
     const uint32_t* __restrict__ rr_pool, const uint32_t* __restrict__ mask_pool, \
     const uint32_t* __restrict__ stab_pool, const uint32_t* __restrict__ sent_pool, \
     lz_dev_params P, vg_pair_stat* __restrict__ stats, \
     vg_region* __restrict__ regions, const unsigned long long* __restrict__ region_off
-#define PARSE_ARG_NAMES tasks, n_tasks, refs, packed, nmask, base_off, glen, g_has_n, rr_pool, mask_pool, \
+#define PARSE_ARG_NAMES tasks, n_tasks, refs, planes, nmask, base_off, glen, g_has_n, rr_pool, mask_pool, \
     stab_pool, sent_pool, P, stats, regions, region_off
 
 // FAST: the default LZ-ANI parameters and a set without N as compile-time constants (shift counts, loop bounds
 // and the mask paths fold away); the host launches it when both hold.
 template <int S, bool DEV, bool FAST = false>
-__device__ __forceinline__ void lz_parse_body(PARSE_ARGS, int64_t t_given = -1, int w_given = 0) {
+__device__ __forceinline__ void lz_parse_body(PARSE_ARGS) {
     if (FAST) { P.mal = 11; P.msl = 7; P.mrd = 40; P.mqd = 40; P.reg = 35; P.aw = 15; P.am = 7; P.ar = 3; P.ablate = 0; P.weak_ratio = 3; P.margin = 6; P.seed_choice = 3; }
     const int ABL = DEV ? P.ablate : 0;           // developer timing knobs: compiled out of the production kernels
     __shared__ seg_rec s_log[S > 1 ? S * SEG_LOG_CAP : 1];
     __shared__ int s_cnt[4], s_sync_v[4], s_sync_idx[4];
     __shared__ uint32_t s_end[4][3];
     const int lane = threadIdx.x & 63;
-    const int w = t_given >= 0 ? w_given : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // wave-uniform: task data lives in SGPRs
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // wave-uniform: task data lives in SGPRs
     // XCD-aware dealing: consecutive task groups of one reference stay on one XCD (block b runs on XCD b % 8)
     const int64_t per_xcd = gridDim.x / 8;           // grid is a multiple of 8 workgroups
     const int64_t vblk = (int64_t)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
-    const int64_t t = t_given >= 0 ? t_given : ((S == 1) ? vblk * 4 + w : vblk);      // (t_given: the fused kernel names the task)
+    const int64_t t = (S == 1) ? vblk * 4 + w : vblk;
     if (t >= n_tasks) return;                        // S > 1: the whole workgroup leaves together
     const task_dev tk = tasks[t];
     ref_desc rd = refs[tk.r_slot];
     if (FAST) { rd.tag_bits = 8; rd.has_n = 0; }
     pair_ctx c;
     const int64_t qb = base_off[tk.q];
-    c.qpk = packed + (qb >> 4); c.qmk = nmask + (qb >> 5); c.qlen = (int)glen[tk.q]; c.q_has_n = FAST ? 0 : g_has_n[tk.q];
-    c.rpk = rr_pool + rd.rr_w; c.rmk = mask_pool + rd.mask_w; c.n_rr = rd.n_rr; c.L = rd.L; c.r_has_n = rd.has_n;
+    c.qpl = planes + (qb >> 4); c.qmk = nmask + (qb >> 5); c.qlen = (int)glen[tk.q]; c.q_has_n = FAST ? 0 : g_has_n[tk.q];
+    c.rpl = rr_pool + rd.rr_w; c.rmk = mask_pool + rd.mask_w; c.n_rr = rd.n_rr; c.L = rd.L; c.r_has_n = rd.has_n;
     const uint32_t* stab = stab_pool + rd.stab; const uint32_t* sent = sent_pool + rd.sent;
-    const uint64_t smask = (1ULL << (2 * P.msl)) - 1;
 
     const long long t_start = (ABL & (32 | 1024)) ? (long long)wall_clock64() : 0;
     const int lim = c.qlen - P.mal;
@@ -1095,15 +1114,14 @@ __device__ __forceinline__ void lz_parse_body(PARSE_ARGS, int64_t t_given = -1, 
         if (qi < lim && lane < pw) {
             const bool alive_l = alive && (lit + lane <= P.mqd);
             const int pred_l = pred + lane;
-            uint64_t xq = load32(c.qpk, qi);
+            const planes32 xq = loadp(c.qpl, qi);
             bool q_ok_a = true, q_ok_s = (qi + P.msl <= c.qlen);
-            uint64_t qbad = (c.qlen - qi < 32) ? (EVEN & ~slots(0, c.qlen - qi)) : 0ULL;     // slots past the query end
+            uint32_t qbad = (c.qlen - qi < 32) ? ~slots(0, c.qlen - qi) : 0u;     // slots past the query end
             if (c.q_has_n) {
-                uint64_t m = (uint64_t)c.qmk[qi >> 5] | ((uint64_t)c.qmk[(qi >> 5) + 1] << 32);
-                m >>= (qi & 31);
-                q_ok_a = (m & ((1ULL << P.mal) - 1)) == 0;
-                q_ok_s = q_ok_s && (m & ((1ULL << P.msl) - 1)) == 0;
-                qbad |= spread((uint32_t)m);
+                const uint32_t m = loadm32(c.qmk, qi);
+                q_ok_a = (m & ((1u << P.mal) - 1u)) == 0;                          // (mal <= 31)
+                q_ok_s = q_ok_s && (m & ((1u << P.msl) - 1u)) == 0;
+                qbad |= m;
             }
             // R2 (anchor = longest exact match >= mal over all occurrences of the mal-mer) and R3 (seed >= msl
             // near the prediction) read ONE bucket: the entries of the query's msl-mer, four per trip.  An
@@ -1113,10 +1131,10 @@ __device__ __forceinline__ void lz_parse_body(PARSE_ARGS, int64_t t_given = -1, 
             const bool do_s = alive_l && q_ok_s && !(ABL & 1);
             uint32_t s_u = 0, s_e = 0;
             const uint32_t posmask = (rd.pos_bits >= 32) ? 0xffffffffu : ((1u << rd.pos_bits) - 1u);
-            const uint32_t qtag = rd.tag_bits ? (uint32_t)((xq >> (2 * P.msl)) & ((1u << rd.tag_bits) - 1u)) : 0u;
+            const uint32_t qtag = tag_of(xq.lo, xq.hi, P.msl, rd.tag_bits);
             if ((do_a || do_s) && q_ok_s) {
                 // bucket bounds = two neighbouring table words: one 8-byte load
-                const uint32_t b = (uint32_t)(xq & smask);
+                const uint32_t b = bucket_of(xq.lo, xq.hi, P.msl);
                 uint2 bb; __builtin_memcpy(&bb, stab + (b ? b - 1 : 0u), 8);
                 s_u = b ? bb.x : 0u; s_e = b ? bb.y : bb.x;
             }
@@ -1235,8 +1253,8 @@ __device__ __forceinline__ void lz_parse_body(PARSE_ARGS, int64_t t_given = -1, 
         // (closing the open region may move kept_end: use the value it will have)
         const int kept_after = (in_region && r_qend - r_qstart + 1 >= P.reg) ? r_qend + 1 : kept_end;
         const int bwd_bound = ev_close ? 0 : i - kept_after;
-        const uint64_t mm_b = (!ev_close && !(ABL & 2)) ? extend_mask0(c, i, ev_pos, -1, bwd_bound, lane, rlo, rhi) : EVEN;
-        const uint64_t mm_f = extend_mask0(c, i, ev_pos, +1, 1 << 30, lane, rlo, rhi);
+        const uint32_t mm_b = (!ev_close && !(ABL & 2)) ? extend_mask0(c, i, ev_pos, -1, bwd_bound, lane, rlo, rhi) : ~0u;
+        const uint32_t mm_f = extend_mask0(c, i, ev_pos, +1, 1 << 30, lane, rlo, rhi);
         PROF_MARK(1);
         if (!ev_close) {
             // R5: new region, extended to the left (exact, then approximate), not into the last kept region
@@ -1260,7 +1278,7 @@ __device__ __forceinline__ void lz_parse_body(PARSE_ARGS, int64_t t_given = -1, 
                 int xl = ev_len;
                 if (xl >= 32) {
                     const unsigned long long mb = __ballot(mm_f != 0);
-                    xl = mb ? 32 * __builtin_ctzll(mb) + (__builtin_ctzll(lane64(mm_f, __builtin_ctzll(mb))) >> 1) : 2048;
+                    xl = mb ? 32 * __builtin_ctzll(mb) + __builtin_ctz(lane32(mm_f, __builtin_ctzll(mb))) : 2048;
                     if (xl >= 2048) xl = match_len_lane(c, i, ev_pos, 1 << 30);
                 }
                 r_match += gap_score(c, i, lit, pred - lit, ev_pos + xl, lane, rlo, rhi, &pm, &sm);
@@ -1345,35 +1363,6 @@ __device__ __forceinline__ void lz_parse_body(PARSE_ARGS, int64_t t_given = -1, 
 #define PARSE_KERNEL(NAME, S, DEV, WAVES, FAST) \
     __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) NAME(PARSE_ARGS) { \
         lz_parse_body<S, DEV, FAST>(PARSE_ARG_NAMES); }
-// FUSED experiment (round-3 verdict, item 3; developer switch VG_LZ_FUSED=1): one 1 024-thread workgroup OWNS a reference --
-// it builds the reference's index (build_ref_reg: RR, bucket table and entries written once, read back while they are
-// still in the L2 / the Infinity Cache) and its sixteen waves then parse that reference's tasks, one task per wave.
-// No index makes a round trip through HBM between a build launch and a parse launch, and no two launches meet at a
-// tail.  What it costs is occupancy: the build's 151 KiB of LDS allow one workgroup per CU, and a reference with nine
-// tasks keeps nine of its sixteen waves busy -- 2.25 waves per SIMD where the stand-alone parse runs eight
-// (profiles/r04_fused_align_experiment.md has the measurement).
-__global__ void __launch_bounds__(1024)
-k_lz_fused(const ref_desc* __restrict__ refs, const int* __restrict__ slot_list, int n_list, const int64_t* __restrict__ ref_first,
-           const task_dev* __restrict__ tasks, int64_t n_tasks,
-           const uint32_t* __restrict__ packed, const uint32_t* __restrict__ nmask, const int64_t* __restrict__ base_off,
-           const int64_t* __restrict__ glen, const uint8_t* __restrict__ g_has_n,
-           uint32_t* __restrict__ rr_pool, uint32_t* __restrict__ mask_pool, uint32_t* __restrict__ stab_pool, uint32_t* __restrict__ sent_pool,
-           lz_dev_params P, vg_pair_stat* __restrict__ stats) {
-    __shared__ uint32_t lds[REG_LDS_WORDS];
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    for (int li = blockIdx.x; li < n_list; li += gridDim.x) {
-        const ref_desc rd = refs[slot_list[li]];
-        build_ref_reg(lds, rd, packed, nmask, base_off, rr_pool, mask_pool, P.msl, stab_pool, sent_pool);
-        __threadfence();                                           // the index is read back through the L2 by this workgroup's own waves
-        __syncthreads();
-        const int64_t t0 = ref_first[rd.genome], t1 = ref_first[rd.genome + 1];
-        for (int64_t t = t0 + w; t < t1; t += 16)
-            lz_parse_body<1, false, true>(tasks, n_tasks, refs, packed, nmask, base_off, glen, g_has_n, rr_pool, mask_pool, stab_pool, sent_pool,
-                                          P, stats, (vg_region*)nullptr, (const unsigned long long*)nullptr, t, 0);
-        __syncthreads();                                           // (the LDS is the next reference's)
-    }
-}
-
 PARSE_KERNEL(k_lz_parse, 1, false, 8, false)
 PARSE_KERNEL(k_lz_parse_fast, 1, false, 8, true)
 PARSE_KERNEL(k_lz_parse_seg, 4, false, 8, false)
@@ -1381,402 +1370,6 @@ PARSE_KERNEL(k_lz_parse_seg_fast, 4, false, 8, true)
 #ifdef VG_DEV_KERNELS      // developer build only (VG_DEV=1 python -m vclust_amd.build --force): timing knobs and counters
 PARSE_KERNEL(k_lz_parse_dev, 1, true, 3, false)
 #endif
-
-// ------------------------------------------------------------------ the parse, TWO pairs per wave
-// k_lz_parse_fast spends its time issuing VALU instructions (0.8-0.9 of the SIMD issue rate), and right
-// after an event -- 26 of the 30 probe trips of a pair -- only 32 of its 64 lanes probe.  Here the two HALVES of a wave
-// own one pair each: lane 32 h + l of half h probes position i_h + l of ITS pair, the extensions compare 32 x 32 bases
-// per half and round, the gap score ranks 32 split points per half and round, and every instruction of the loop serves
-// two pairs.  What was wave-uniform state in SGPRs (positions, prediction, region sums, the pair's pointers) is uniform
-// per half in VGPRs; the halves diverge only where their pairs do (one in an event while the other found nothing), as
-// ordinary divergent control flow.  Cross-lane traffic stays off the LDS crossbar where the source lane is known from a
-// ballot (two v_readlane + a select); reductions over a half are DPP butterflies with one LDS swizzle for the last step.
-// A wave takes a chunk of P2_CHUNK consecutive tasks (one reference's tasks are consecutive: both halves probe the same
-// index) and a half that finishes its pair pulls the next task of the chunk, so a long pair does not idle its partner.
-// Default parameters, a set without N, rows only (what k_lz_parse_fast covers); results are bit-identical.
-constexpr int P2_CHUNK = 16;
-constexpr bool VG_LZ_TWO_PAIRS_DEFAULT = false;
-// the ballot bits of this lane's half, in the low 32 bits
-__device__ __forceinline__ uint32_t hsel(unsigned long long b, int h) { return h ? (uint32_t)(b >> 32) : (uint32_t)b; }
-// value of lane s0 (half 0) / lane 32 + s1 (half 1) for the lanes of the respective half; s0, s1 wave-uniform
-__device__ __forceinline__ uint32_t hb32(uint32_t v, int s0, int s1, int h) {
-    const uint32_t a0 = lane32(v, s0 & 31), a1 = lane32(v, 32 | (s1 & 31));
-    return h ? a1 : a0;
-}
-__device__ __forceinline__ uint64_t hb64(uint64_t v, int s0, int s1, int h) {
-    return (uint64_t)hb32((uint32_t)v, s0, s1, h) | ((uint64_t)hb32((uint32_t)(v >> 32), s0, s1, h) << 32);
-}
-__device__ __forceinline__ int ctz32z(uint32_t x) { return x ? __builtin_ctz(x) : 0; }
-__device__ __forceinline__ int top32z(uint32_t x) { return x ? 31 - __builtin_clz(x) : 0; }
-// butterfly over the 32 lanes of each half: lane ^ 1, lane ^ 2 (quad permutes), mirror in 8, mirror in 16 (DPP), lane ^ 16
-#define VG_HALF_BUTTERFLY(v, OP) do { \
-        v = OP(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false)); \
-        v = OP(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false)); \
-        v = OP(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false)); \
-        v = OP(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false)); \
-        v = OP(v, __shfl_xor(v, 16)); } while (0)
-__device__ __forceinline__ int op_add(int a, int b) { return a + b; }
-__device__ __forceinline__ int op_max(int a, int b) { return a > b ? a : b; }
-// sum / maximum over the lanes of this lane's half (all lanes of the wave must be active)
-__device__ __forceinline__ int half_sum(int v) { VG_HALF_BUTTERFLY(v, op_add); return v; }
-__device__ __forceinline__ int half_max(int v) { VG_HALF_BUTTERFLY(v, op_max); return v; }
-
-// extend() for one half (32 lanes x 32 bases = 1 024 positions per round), default parameters aw = 15, am = 7, ar = 3.
-// `on` = this lane's half takes part (uniform per half); the function is entered by the WHOLE wave so that the reductions see
-// all lanes, and a half that is off, or has finished, idles through the other's rounds.
-__device__ __forceinline__ int extend_h(const pair_ctx& c, bool on, int qp, int rp, int dir, int bound, int hl, int h,
-                                        int* n_match, uint64_t mm_first, int rlo, int rhi) {
-    constexpr int AW = 15, AM = 7, AR = 3;
-    int accepted = 0, matches_total = 0;
-    int first_mm = -1;
-    uint64_t carry_mm = 0, carry_ok = 0;
-    int base = 0, cum_before = 0;
-    const uint64_t awmask = (1ULL << (2 * AW)) - 1;
-    bool run_me = on && bound > 0;
-    while (__ballot(run_me)) {
-        uint64_t mm = run_me ? mm_first : 0ULL;
-        if (run_me && base > 0) {
-            mm = EVEN;
-            const int e0 = base + 32 * hl;
-            if (e0 < bound) {
-                if (dir > 0) mm = mism32(c, qp + e0, rp + e0, rlo, rhi);
-                else mm = rev2(mism32(c, qp - e0 - 32, rp - e0 - 32, rlo, rhi)) & EVEN;
-                const int rem = bound - e0; if (rem < 32) mm |= EVEN & ~slots(0, rem);
-            }
-        }
-        const unsigned long long anyw = __ballot(run_me && mm != 0);
-        const uint32_t anyb = hsel(anyw, h);
-        {
-            const uint64_t mfl = hb64(mm, ctz32z((uint32_t)anyw), ctz32z((uint32_t)(anyw >> 32)), h);
-            if (run_me && first_mm < 0 && anyb) first_mm = base + 32 * __builtin_ctz(anyb) + (__builtin_ctzll(mfl) >> 1);
-        }
-        uint64_t prev_mm = lane_prev64(mm); const uint64_t okb = (~mm) & EVEN; uint64_t prev_ok = lane_prev64(okb);
-        if (hl == 0) { prev_mm = carry_mm; prev_ok = carry_ok; }
-        int viol = 32;
-        if (run_me) {
-            const uint64_t tail = prev_mm >> (64 - 2 * (AW - 1));
-            if ((int)(__popcll(mm) + __popcll(tail)) > AM) {
-                uint64_t bits = mm;
-                for (int skip = AM - (int)__popcll(tail); skip > 0; --skip) bits &= bits - 1;
-                while (bits) {
-                    const int j = __builtin_ctzll(bits) >> 1;
-                    const int top = 2 * j + 2;
-                    const uint64_t hi = (top == 64) ? mm : (mm & ((1ULL << top) - 1));
-                    int cnt;
-                    if (j + 1 >= AW) cnt = __popcll(hi & (awmask << (2 * (j + 1 - AW))));
-                    else cnt = __popcll(hi) + __popcll(prev_mm >> (64 - 2 * (AW - 1 - j)));
-                    if (cnt > AM) { viol = j; break; }
-                    bits &= bits - 1;
-                }
-            }
-        }
-        const unsigned long long vw = __ballot(run_me && viol < 32);
-        const uint32_t vb = hsel(vw, h);
-        // positions ending a run of >= ar matches, strictly before the violation
-        uint64_t cand = 0;
-        {
-            uint64_t run = okb;
-#pragma unroll
-            for (int t = 1; t < AR; ++t) run &= (okb << (2 * t)) | (prev_ok >> (64 - 2 * t));
-            const int fv = vb ? __builtin_ctz(vb) : 32;
-            const int vj = (int)hb32((uint32_t)viol, ctz32z((uint32_t)vw), ctz32z((uint32_t)(vw >> 32)), h);
-            cand = run;
-            if (hl > fv) cand = 0;
-            else if (hl == fv) cand &= (vj == 0) ? 0ULL : ((1ULL << (2 * vj)) - 1);
-            if (!(run_me && anyb)) cand = 0;
-        }
-        const unsigned long long cw = __ballot(cand != 0);
-        const uint32_t cb = hsel(cw, h);
-        const int c0 = top32z((uint32_t)cw), c1 = top32z((uint32_t)(cw >> 32));
-        const int hlane = top32z(cb);
-        const uint64_t ch = hb64(cand, c0, c1, h), mh = hb64(mm, c0, c1, h);
-        const int ok_cnt = 32 - (int)__popcll(mm);                      // matches of this lane's 32 positions
-        const int tot_below = cw ? half_sum((run_me && cb && hl < hlane) ? ok_cnt : 0) : 0;
-        if (run_me) {
-            if (anyb) {
-                if (cb) {
-                    const int hj = (63 - __builtin_clzll(ch)) >> 1;
-                    accepted = base + 32 * hlane + hj + 1;
-                    const uint64_t upto = (hj == 31) ? ~0ULL : ((1ULL << (2 * hj + 2)) - 1);
-                    matches_total = cum_before + tot_below + (hj + 1) - (int)__popcll(mh & upto);
-                }
-            } else { accepted = base + 1024; matches_total = cum_before + 1024; }
-        }
-        if (run_me && (vb || base + 1024 >= bound)) run_me = false;
-        if (__ballot(run_me)) {
-            // another round for some half: matches so far and the last lane's masks carry over
-            const int tot_all = half_sum(run_me ? ok_cnt : 0);
-            const uint64_t l_mm = hb64(mm, 31, 31, h), l_ok = hb64(okb, 31, 31, h);
-            if (run_me) { cum_before += anyb ? tot_all : 1024; carry_mm = l_mm; carry_ok = l_ok; base += 1024; }
-        }
-    }
-    if (!(on && bound > 0)) { *n_match = 0; return 0; }
-    if (first_mm < 0) first_mm = bound;
-    if (first_mm > bound) first_mm = bound;
-    if (accepted < first_mm) { accepted = first_mm; matches_total = first_mm; }
-    if (accepted > bound) accepted = bound;
-    *n_match = matches_total;
-    return accepted;
-}
-
-// gap_score() for one half; g <= 64 (the default mqd = 40 bounds the literal run of a chained match).  Entered by the whole
-// wave; `on` = this lane's half has a gap to score.
-__device__ __forceinline__ int gap_score_h(const pair_ctx& c, bool on, int i, int g, int pred0, int E, int hl, int h, int rlo, int rhi,
-                                           int* pm_out, int* sm_out) {
-    const int reflen = E - pred0;
-    const int skip = (reflen >= 0 && g > reflen) ? g - reflen : 0;
-    const int q0 = i - g;
-    uint32_t ok_o = 0, ok_n = 0;
-    {
-        const int e0 = 32 * hl;
-        if (on && e0 < g) {
-            const uint32_t in = (g - e0 >= 32) ? 0xffffffffu : ((1u << (g - e0)) - 1u);
-            ok_o = ~squeeze(mism32(c, q0 + e0, pred0 + e0, rlo, rhi)) & in;
-            ok_n = ~squeeze(mism32(c, q0 + e0, E - g + e0, rlo, rhi)) & in;
-        }
-    }
-    // the (at most 64) literals' match bits on the two diagonals, in every lane of the half
-    const uint64_t O = (uint64_t)hb32(ok_o, 0, 0, h) | ((uint64_t)hb32(ok_o, 1, 1, h) << 32);
-    const uint64_t N = (uint64_t)hb32(ok_n, 0, 0, h) | ((uint64_t)hb32(ok_n, 1, 1, h) << 32);
-    const int n_split = g - skip;                 // split points a = 0 .. n_split
-    int best_key = -1, best_pm = 0, best_sm = 0;
-#pragma unroll
-    for (int w = 0; w < 2; ++w) {                 // a = 32 w + hl covers 0 .. 63 >= n_split (g <= mqd = 40)
-        const int a = 32 * w + hl;
-        const int sp = a + skip;                  // suffix start
-        const int pre = (int)__popcll(O & low_bits64(a));
-        const int suf = sp >= 64 ? 0 : (int)__popcll(N >> sp);
-        const bool valid = on && a <= n_split;
-        const int key = valid ? ((pre + suf) << 7) | a : -1;        // maximum of pre + suf, ties -> the largest a
-        const int kmax = half_max(key);
-        if (kmax >= 0 && kmax > best_key) {
-            best_key = kmax;
-            // the winner's prefix / suffix counts: recomputed from its split point (every lane holds O and N)
-            const int wa = kmax & 127, wsp = wa + skip;
-            best_pm = (int)__popcll(O & low_bits64(wa));
-            best_sm = wsp >= 64 ? 0 : (int)__popcll(N >> wsp);
-        }
-    }
-    *pm_out = best_pm; *sm_out = best_sm;
-    return best_pm + best_sm;
-}
-
-// STATS (developer switch VG_LZ_KERNEL=two_stats): a row carries counters instead of sums -- n_match = the pair's events,
-// aln_len = loop iterations of the wave while the pair was resident, n_regions = those in which BOTH halves had an event
-template <bool STATS>
-__device__ __forceinline__ void lz_parse2_body(PARSE_ARGS) {
-    constexpr int MAL = 11, MSL = 7, MRD = 40, MQD = 40, REG = 35, WEAK = 3, TAGB = 8;
-    const int lane = threadIdx.x & 63, h = lane >> 5, hl = lane & 31;
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t per_xcd = gridDim.x / 8;
-    const int64_t vblk = (int64_t)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
-    int64_t t_next = (vblk * 4 + w) * P2_CHUNK;
-    const int64_t t_end = min(n_tasks, t_next + P2_CHUNK);
-    if (t_next >= t_end) return;
-    // ---- state of this lane's half (uniform over its 32 lanes)
-    bool act = false, alive = false, in_region = false;
-    int i = 0, lit = 0, pred = 0, lim = 0;
-    int r_qstart = 0, r_qend = 0, r_match = 0, kept_end = 0;
-    uint32_t M = 0, A = 0, NR = 0, out_idx = 0; int pos_bits = 1;
-    pair_ctx c; c.qpk = packed; c.qmk = nmask; c.qlen = 0; c.q_has_n = 0; c.rpk = rr_pool; c.rmk = mask_pool; c.n_rr = 1; c.L = 0; c.r_has_n = 0;
-    const uint32_t* stab = stab_pool; const uint32_t* sent = sent_pool;
-    const uint64_t smask = (1ULL << (2 * MSL)) - 1;
-    int n_iter = 0, st_it0 = 0, st_ev = 0, st_both = 0;
-    // STATS with P.ablate = 8 + section: n_match = wave clock cycles / 16 spent in that section while the pair was resident
-    const int psel = STATS ? P.ablate - 8 : -1;
-    long long pc_acc = 0, pc_t0 = 0, tp = STATS ? (long long)clock64() : 0;
-#define P2_MARK(k) do { if (STATS && psel >= 0) { const long long tn_ = (long long)clock64(); if (psel == (k)) pc_acc += tn_ - tp; tp = tn_; } } while (0)
-    auto take = [&](int hh) {       // half hh starts the next task of the wave's chunk (scalar loads, selected into its lanes)
-        const task_dev tk = tasks[t_next++];
-        const ref_desc rd = refs[tk.r_slot];
-        const int64_t qb = base_off[tk.q];
-        const int ql = (int)glen[tk.q];
-        if (h == hh) {
-            c.qpk = packed + (qb >> 4); c.qlen = ql;
-            c.rpk = rr_pool + rd.rr_w; c.n_rr = rd.n_rr; c.L = rd.L;
-            stab = stab_pool + rd.stab; sent = sent_pool + rd.sent;
-            pos_bits = rd.pos_bits;                               // (<= 24: the host takes this kernel for genomes below 2^22 bases)
-            out_idx = tk.out_idx; lim = ql - MAL;
-            act = true; alive = false; in_region = false; i = 0; lit = 0; pred = 0; kept_end = 0; M = 0; A = 0; NR = 0;
-            if (STATS) { st_it0 = n_iter; st_ev = 0; st_both = 0; pc_t0 = pc_acc; }
-        }
-    };
-    take(0);
-    if (t_next < t_end) take(1);
-    int n_events = 0;
-    for (;;) {
-        // ---- a half whose pair is parsed writes its row and takes the next task of the chunk
-        {
-            const bool done = act && i >= lim;
-            const unsigned long long dw = __ballot(done);
-            if (dw) {
-                if (done) {
-                    if (in_region) { const int span = r_qend - r_qstart + 1; if (span >= REG) { M += (uint32_t)r_match; A += (uint32_t)span; NR += 1; } in_region = false; }
-                    if (STATS) { M = psel >= 0 ? (uint32_t)((pc_acc - pc_t0) >> 4) : (uint32_t)st_ev; A = (uint32_t)(n_iter - st_it0); NR = (uint32_t)st_both; }
-                    if (hl == 0) { vg_pair_stat st; st.n_match = M; st.aln_len = A; st.n_regions = NR; stats[out_idx] = st; }
-                    act = false;
-                }
-                if ((uint32_t)dw && t_next < t_end) take(0);
-                if ((uint32_t)(dw >> 32) && t_next < t_end) take(1);
-                continue;                                   // (a pair shorter than mal is done at once)
-            }
-            if (!__ballot(act)) break;
-        }
-        P2_MARK(0);
-        // ---- speculative probe of positions i .. i + 31 of each half's pair
-        const int qi = i + hl;
-        int best_len = 0, best_pos = 0; bool hit_close = false;
-        if (act && qi < lim) {
-            const bool alive_l = alive && (lit + hl <= MQD);
-            const int pred_l = pred + hl;
-            const uint64_t xq = load32(c.qpk, qi);
-            const bool q_ok_s = (qi + MSL <= c.qlen);
-            const uint64_t qbad = (c.qlen - qi < 32) ? (EVEN & ~slots(0, c.qlen - qi)) : 0ULL;
-            const bool do_s = alive_l && q_ok_s;
-            uint32_t s_u = 0, s_e = 0;
-            const uint32_t qtag = (uint32_t)((xq >> (2 * MSL)) & ((1u << TAGB) - 1u));
-            const uint32_t posmask = (1u << pos_bits) - 1u;
-            if (q_ok_s) {
-                const uint32_t b = (uint32_t)(xq & smask);
-                uint2 bb; __builtin_memcpy(&bb, stab + (b ? b - 1 : 0u), 8);
-                s_u = b ? bb.x : 0u; s_e = b ? bb.y : bb.x;
-            }
-            const int pred0 = pred - lit;
-            const bool pred_rc = pred0 > c.L;
-            const int win_lo = pred0;
-            const int win_hi = pred_rc ? pred_l + MRD - 1 : min(pred_l + MRD - 1, c.L - 1);
-            int sbest_len = 0, sbest_pos = 0, sbest_ad = 0, ncap_a = 0, ncap_s = 0;
-            const uint32_t win_span = (uint32_t)(win_hi - win_lo);
-            const bool win_any = win_hi >= win_lo;
-            while (s_u < s_e) {
-                uint4 v; __builtin_memcpy(&v, sent + s_u, 16);
-                const uint32_t e4[4] = { v.x, v.y, v.z, v.w };
-                unsigned am = 0, sm = 0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t ps = e4[j] & posmask;
-                    am |= (uint32_t)((e4[j] >> pos_bits) == qtag) << j;
-                    sm |= (uint32_t)(ps - (uint32_t)win_lo <= win_span) << j;
-                }
-                const uint32_t left = s_e - s_u;
-                const unsigned vm = left >= 4u ? 0xfu : ((1u << left) - 1u);
-                am &= vm; sm &= (do_s && win_any) ? vm : 0u;
-                unsigned cm = am | sm;
-                while (cm) {
-                    const int j = __builtin_ctz(cm); cm &= cm - 1;
-                    const uint32_t ej = j == 0 ? e4[0] : j == 1 ? e4[1] : j == 2 ? e4[2] : e4[3];
-                    const int rp = (int)(ej & posmask);
-                    const int l0 = match_len32_q(c, xq, qbad, rp);
-                    if ((am >> j) & 1u) {
-                        int l = l0;
-                        if (l >= MAL) {
-                            if (l >= 32) {
-                                if (ncap_a++ > 0 || best_len >= 32) {
-                                    l = match_len_lane(c, qi, rp, 1 << 30);
-                                    if (best_len == 32) best_len = match_len_lane(c, qi, best_pos, 1 << 30);
-                                }
-                            }
-                            if (l > best_len || (l == best_len && rp < best_pos)) { best_len = l; best_pos = rp; }
-                        }
-                    }
-                    if ((sm >> j) & 1u) {
-                        int l = l0;
-                        if (l >= MSL) {
-                            if (l >= 32) {
-                                if (ncap_s++ > 0 || sbest_len >= 32) {
-                                    l = match_len_lane(c, qi, rp, 1 << 30);
-                                    if (sbest_len == 32) sbest_len = match_len_lane(c, qi, sbest_pos, 1 << 30);
-                                }
-                            }
-                            const int ad = abs(rp - pred_l);
-                            if (l > sbest_len || (l == sbest_len && (ad < sbest_ad || (ad == sbest_ad && rp < sbest_pos)))) { sbest_len = l; sbest_pos = rp; sbest_ad = ad; }
-                        }
-                    }
-                }
-                s_u += 4;
-                // positions behind the first one of THIS half that already has a match cannot become its event
-                const uint32_t hit = hsel(__ballot(best_len > 0 || sbest_len > 0), h);
-                if (hit && hl > __builtin_ctz(hit)) s_u = s_e;
-            }
-            if (best_len > 0 && sbest_len > 0 && best_pos != sbest_pos && best_len >= 32 && sbest_len + MSL > 32) {
-                if (best_len == 32) best_len = match_len_lane(c, qi, best_pos, 1 << 30);
-                if (sbest_len == 32) sbest_len = match_len_lane(c, qi, sbest_pos, 1 << 30);
-            }
-            if (best_len > 0 && (sbest_len == 0 || best_len >= sbest_len + MSL - ((lit + hl > WEAK * sbest_len) ? 1 : 0))) {
-                const int d = best_pos - pred_l;
-                hit_close = alive_l && ((best_pos > c.L) == pred_rc) && d >= -MRD && d <= MRD;
-            } else if (sbest_len > 0) { best_len = sbest_len; best_pos = sbest_pos; hit_close = true; }
-        }
-        const unsigned long long hw = __ballot(best_len > 0);
-        const uint32_t hb = hsel(hw, h);
-        const bool ev = act && hb != 0;
-        if (act && !hb) {
-            const int n = min(32, lim - i);
-            i += n; lit += n; if (alive) { pred += n; if (lit > MQD) alive = false; }
-        }
-        if (STATS) { ++n_iter; if (ev) { ++st_ev; if ((uint32_t)hw && (uint32_t)(hw >> 32)) ++st_both; } }
-        P2_MARK(1);
-        if (!hw) continue;
-        // ---- the event of each half that has one (the other idles through the shared instructions)
-        n_events += __popcll(hw) ? 1 : 0;
-        if (n_events == 48) __builtin_amdgcn_s_setprio(1);
-        else if (n_events == 128) __builtin_amdgcn_s_setprio(2);
-        else if (n_events == 320) __builtin_amdgcn_s_setprio(3);
-        const int f0 = ctz32z((uint32_t)hw), f1 = ctz32z((uint32_t)(hw >> 32));
-        const int f = ev ? __builtin_ctz(hb) : 0;
-        const int ev_pos = (int)hb32((uint32_t)best_pos, f0, f1, h);
-        const bool ev_close = hb32((uint32_t)hit_close, f0, f1, h) != 0;
-        const int ev_len = (int)hb32((uint32_t)best_len, f0, f1, h);
-        if (ev) { i += f; lit += f; if (alive) { pred += f; if (lit > MQD) alive = false; } }
-        const int rlo = strand_lo(c, ev_pos), rhi = strand_hi(c, ev_pos);
-        const int kept_after = (in_region && r_qend - r_qstart + 1 >= REG) ? r_qend + 1 : kept_end;
-        const bool do_b = ev && !ev_close;
-        const int bwd_bound = do_b ? i - kept_after : 0;
-        const uint64_t mm_b = do_b ? extend_mask0(c, i, ev_pos, -1, bwd_bound, hl, rlo, rhi) : EVEN;
-        const uint64_t mm_f = ev ? extend_mask0(c, i, ev_pos, +1, 1 << 30, hl, rlo, rhi) : EVEN;
-        if (do_b) {
-            // R5: new region (close the open one first)
-            if (in_region) { const int span = r_qend - r_qstart + 1; if (span >= REG) { M += (uint32_t)r_match; A += (uint32_t)span; NR += 1; kept_end = r_qend + 1; } in_region = false; }
-        }
-        P2_MARK(2);
-        if (__ballot(do_b)) {
-            int bm = 0;
-            const int b = extend_h(c, do_b, i, ev_pos, -1, bwd_bound, hl, h, &bm, mm_b, rlo, rhi);
-            if (do_b) { r_qstart = i - b; r_match = bm; in_region = true; }
-        }
-        P2_MARK(3);
-        int fm = 0;
-        const int fe = extend_h(c, ev, i, ev_pos, +1, 1 << 30, hl, h, &fm, mm_f, rlo, rhi);
-        if (ev) r_match += fm;
-        P2_MARK(4);
-        const bool do_g = ev && ev_close && lit > 0;
-        if (__ballot(do_g)) {
-            int xl = ev_len;
-            {
-                // exact length of the match = position of the first mismatch of the forward pass
-                const unsigned long long mw = __ballot(do_g && xl >= 32 && mm_f != 0);
-                const uint64_t mfl = hb64(mm_f, ctz32z((uint32_t)mw), ctz32z((uint32_t)(mw >> 32)), h);
-                const uint32_t mb = hsel(mw, h);
-                if (do_g && xl >= 32) {
-                    xl = mb ? 32 * __builtin_ctz(mb) + (__builtin_ctzll(mfl) >> 1) : 1024;
-                    if (xl >= 1024) xl = match_len_lane(c, i, ev_pos, 1 << 30);
-                }
-            }
-            int pm = 0, sm = 0;
-            const int gs = gap_score_h(c, do_g, i, lit, pred - lit, ev_pos + xl, hl, h, rlo, rhi, &pm, &sm);
-            if (do_g) r_match += gs;
-        }
-        if (ev) {
-            i += fe; pred = ev_pos + fe; lit = 0; alive = true;
-            r_qend = i - 1;
-        }
-        P2_MARK(5);
-    }
-#undef P2_MARK
-}
-
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) k_lz_parse_fast2(PARSE_ARGS) { lz_parse2_body<false>(PARSE_ARG_NAMES); }
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) k_lz_parse_fast2_stats(PARSE_ARGS) { lz_parse2_body<true>(PARSE_ARG_NAMES); }
 
 inline int grid_for(int64_t n, int block = 256, int max_blocks = 256 * 16) {
     int64_t b = (n + block - 1) / block; if (b < 1) b = 1;
@@ -1887,6 +1480,29 @@ void vg_lz_drop_prepared(const vg_genomes* g) {
     if (g_prepared && (!g || g_prepared->g == g)) { (void)hipStreamSynchronize(vg_stream()); g_prepared.reset(); }
 }
 
+// The genome set as bit planes (what the parse reads its queries from): made once per resident set, on the library's
+// stream, from the 2-bit codes (a streaming pass: 0.5 ms per Gbp).
+namespace {
+__global__ void __launch_bounds__(256)
+k_genome_planes(const uint32_t* __restrict__ packed, int64_t n_pairs, uint32_t* __restrict__ planes) {
+    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_pairs; w += (int64_t)gridDim.x * blockDim.x) {
+        uint2 v; __builtin_memcpy(&v, packed + 2 * w, 8);
+        const planes32 pl = planes_of((uint64_t)v.x | ((uint64_t)v.y << 32));
+        const uint2 o = make_uint2(pl.lo, pl.hi); __builtin_memcpy(planes + 2 * w, &o, 8);
+    }
+}
+std::mutex g_planes_mu;
+const uint32_t* lz_genome_planes(const vg_genomes* g, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_planes_mu);
+    if (g->d_planes.n != g->d_packed.n || !g->d_planes.p) {
+        const size_t words = g->d_packed.n & ~(size_t)1;
+        g->d_planes.alloc(g->d_packed.n);
+        hipLaunchKernelGGL(k_genome_planes, dim3(grid_for((int64_t)(words / 2))), dim3(256), 0, s, (const uint32_t*)g->d_packed.p, (int64_t)(words / 2), g->d_planes.p);
+    }
+    return g->d_planes.p;
+}
+}  // namespace
+
 static int64_t g_segment_task_limit = 32768;
 // VG_LZ_BUILD=lds: the scratch-based LDS build also for short references (tests compare the two)
 static const bool g_no_reg_build = [] { const char* e = vg_dev_getenv("VG_LZ_BUILD"); return e && strcmp(e, "lds") == 0; }();
@@ -1903,6 +1519,7 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
     int rc = vg_genomes_to_device(g); if (rc) return rc;
     hipStream_t s = vg_stream();
     vg_host_mark("vg_lz_align: enter");
+    const uint32_t* d_planes = lz_genome_planes(g, s);
 
     if (regions) { *regions = nullptr; if (n_regions) *n_regions = 0; }
     if (n_tasks == 0) return VG_OK;
@@ -2011,20 +1628,6 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
     for (size_t bi = 0; bi < batches.size(); ++bi) {
         lz_batch& B = batches[bi];
         lz_slot& L = slot;
-        // developer experiment: build + parse of a reference in one workgroup (k_lz_fused)
-        static const bool fused_env = [] { const char* e = vg_dev_getenv("VG_LZ_FUSED"); return e && *e == '1'; }();
-        const bool fused = fused_env && fast_params && !want_regions && !B.reg_list.empty() && B.mid_list.empty() && B.small_list.empty() && B.large_list.empty() &&
-                           !(bi == 0 && plan->batch0_built);
-        if (fused) {
-            dbuf<int64_t> d_first((size_t)g->n + 1); d_first.upload(ref_first.data(), ref_first.size(), sb);
-            L.d_reg.upload(B.reg_list.data(), B.reg_list.size(), sb);
-            vg_prof_scope ps("lz_fused", B.bytes_alg);
-            hipLaunchKernelGGL(k_lz_fused, dim3((unsigned)std::min<size_t>(B.reg_list.size(), 256)), dim3(1024), 0, s, (const ref_desc*)d_refs.p, (const int*)L.d_reg.p,
-                               (int)B.reg_list.size(), (const int64_t*)d_first.p, (const task_dev*)d_tasks.p, n_tasks, g->d_packed.p, g->d_nmask.p, g->d_base_off.p,
-                               g->d_len.p, g->d_has_n.p, L.rr_pool.p, L.mask_pool.p, L.stab_pool.p, L.sent_pool.p, P, d_stats.p);
-            VG_HIP(hipStreamSynchronize(s));                     // (d_first goes out of scope)
-            continue;
-        }
         if (!(bi == 0 && plan->batch0_built)) lz_build_batch(g, p, *plan, bi, sb);
         {
             const int64_t nt = B.end - B.pos;
@@ -2038,39 +1641,29 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
             const unsigned long long* no_off = nullptr;
             if (segments && P.ablate == 0 && nt < (1LL << 31)) {
                 const int64_t nblk = (nt + 7) / 8 * 8;
-                if (fast_params) hipLaunchKernelGGL(k_lz_parse_seg_fast, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p + B.pos, nt, d_refs.p, g->d_packed.p, g->d_nmask.p,
+                if (fast_params) hipLaunchKernelGGL(k_lz_parse_seg_fast, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p + B.pos, nt, d_refs.p, d_planes, g->d_nmask.p,
                                    g->d_base_off.p, g->d_len.p, g->d_has_n.p, L.rr_pool.p, L.mask_pool.p, L.stab_pool.p,
                                    L.sent_pool.p, P, d_stats.p, (vg_region*)nullptr, no_off);
-                else hipLaunchKernelGGL(k_lz_parse_seg, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p + B.pos, nt, d_refs.p, g->d_packed.p, g->d_nmask.p,
+                else hipLaunchKernelGGL(k_lz_parse_seg, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p + B.pos, nt, d_refs.p, d_planes, g->d_nmask.p,
                                    g->d_base_off.p, g->d_len.p, g->d_has_n.p, L.rr_pool.p, L.mask_pool.p, L.stab_pool.p,
                                    L.sent_pool.p, P, d_stats.p, (vg_region*)nullptr, no_off);
             } else {
                 const int64_t nblk = ((nt + 3) / 4 + 7) / 8 * 8;
-                // two pairs per wave (k_lz_parse_fast2): VG_LZ_KERNEL=two / one (developer A/B)
-                static const int two_env = [] { const char* e = vg_dev_getenv("VG_LZ_KERNEL"); return e && !strcmp(e, "two") ? 1 : (e && !strcmp(e, "two_stats") ? 2 : (e && !strcmp(e, "one") ? 0 : -1)); }();
-                const bool two_pairs = two_env >= 0 ? two_env >= 1 : VG_LZ_TWO_PAIRS_DEFAULT;
 #ifdef VG_DEV_KERNELS
                 if (P.ablate) {
-                    hipLaunchKernelGGL(k_lz_parse_dev, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p + B.pos, nt, d_refs.p, g->d_packed.p, g->d_nmask.p,
+                    hipLaunchKernelGGL(k_lz_parse_dev, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p + B.pos, nt, d_refs.p, d_planes, g->d_nmask.p,
                                    g->d_base_off.p, g->d_len.p, g->d_has_n.p, L.rr_pool.p, L.mask_pool.p, L.stab_pool.p,
                                    L.sent_pool.p, P, d_stats.p, (vg_region*)nullptr, no_off);
                 } else
 #endif
-                if (fast_params && two_pairs) {
-                    const int64_t nwave = (nt + P2_CHUNK - 1) / P2_CHUNK, nblk2 = ((nwave + 3) / 4 + 7) / 8 * 8;
-                    lz_dev_params P2 = P;
-                    if (two_env == 2) { static const char* sel = vg_dev_getenv("VG_LZ_P2SEL"); P2.ablate = sel ? 8 + atoi(sel) : 0; }
-                    hipLaunchKernelGGL(two_env == 2 ? k_lz_parse_fast2_stats : k_lz_parse_fast2, dim3((unsigned)nblk2), dim3(256), 0, s, d_tasks.p + B.pos, nt, d_refs.p, g->d_packed.p, g->d_nmask.p,
-                                   g->d_base_off.p, g->d_len.p, g->d_has_n.p, L.rr_pool.p, L.mask_pool.p, L.stab_pool.p,
-                                   L.sent_pool.p, P2, d_stats.p, (vg_region*)nullptr, no_off);
-                } else if (fast_params) {
+                if (fast_params) {
                     // (developer experiment: VG_LZ_OCC_KB reserves that much unused LDS per workgroup, i.e. caps the resident waves)
                     static const size_t occ_lds = [] { const char* e = vg_dev_getenv("VG_LZ_OCC_KB"); return e ? (size_t)atoi(e) * 1024 : (size_t)0; }();
-                    hipLaunchKernelGGL(k_lz_parse_fast, dim3((unsigned)nblk), dim3(256), occ_lds, s, d_tasks.p + B.pos, nt, d_refs.p, g->d_packed.p, g->d_nmask.p,
+                    hipLaunchKernelGGL(k_lz_parse_fast, dim3((unsigned)nblk), dim3(256), occ_lds, s, d_tasks.p + B.pos, nt, d_refs.p, d_planes, g->d_nmask.p,
                                    g->d_base_off.p, g->d_len.p, g->d_has_n.p, L.rr_pool.p, L.mask_pool.p, L.stab_pool.p,
                                    L.sent_pool.p, P, d_stats.p, (vg_region*)nullptr, no_off);
                 } else {
-                    hipLaunchKernelGGL(k_lz_parse, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p + B.pos, nt, d_refs.p, g->d_packed.p, g->d_nmask.p,
+                    hipLaunchKernelGGL(k_lz_parse, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p + B.pos, nt, d_refs.p, d_planes, g->d_nmask.p,
                                    g->d_base_off.p, g->d_len.p, g->d_has_n.p, L.rr_pool.p, L.mask_pool.p, L.stab_pool.p,
                                    L.sent_pool.p, P, d_stats.p, (vg_region*)nullptr, no_off);
                 }
@@ -2094,7 +1687,7 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
                     dbuf<unsigned long long> d_off((size_t)nt + 1); d_off.upload(off.data(), off.size(), s);
                     dbuf<vg_region> d_regions((size_t)nr);
                     const int64_t nblk = ((nt + 3) / 4 + 7) / 8 * 8;
-                    hipLaunchKernelGGL(k_lz_parse, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p + B.pos, nt, d_refs.p, g->d_packed.p, g->d_nmask.p,
+                    hipLaunchKernelGGL(k_lz_parse, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p + B.pos, nt, d_refs.p, d_planes, g->d_nmask.p,
                                    g->d_base_off.p, g->d_len.p, g->d_has_n.p, L.rr_pool.p, L.mask_pool.p, L.stab_pool.p,
                                    L.sent_pool.p, P, d_stats.p, d_regions.p, (const unsigned long long*)d_off.p);
                     const size_t at = h_regions.size();
@@ -2288,7 +1881,6 @@ extern "C" int vg_lz_prepare(vg_genomes* g, const vg_pair_count* pairs, int64_t 
     int rc = vg_genomes_to_device(g); if (rc) return rc;
     vg_lz_drop_prepared(nullptr);
     if (n_pairs == 0) return VG_OK;
-    { const char* e = vg_dev_getenv("VG_LZ_FUSED"); if (e && *e == '1') return VG_OK; }      // (the fused experiment builds inside its own kernel)
     for (int i = 0; i < g->n; ++i) if (g->len[i] > (1 << 29)) throw vg_error(VG_EOVERFLOW, "genome longer than 2^29 bases");
     std::vector<uint8_t> is_ref((size_t)g->n, 0);
     for (int64_t i = 0; i < n_pairs; ++i) {

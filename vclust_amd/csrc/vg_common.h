@@ -121,6 +121,7 @@ struct vg_genomes {
     // device residency
     int device = -1;
     dbuf<uint32_t> d_packed, d_nmask;
+    mutable dbuf<uint32_t> d_planes;     // the bases once more as bit planes ((lo, hi) word pair per 32 bases): what the LZ parse reads; made on first use (vg_align.hip)
     dbuf<int64_t> d_base_off, d_len;
     dbuf<uint8_t> d_has_n;
     dbuf<uint32_t> d_blk2g;

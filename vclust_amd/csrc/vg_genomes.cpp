@@ -593,7 +593,7 @@ extern "C" int vg_genomes_to_device(vg_genomes* g) {
     if (g->device >= 0) {
         // resident on another device: the allocator knows every block's device and returns these to THAT device's
         // driver instead of caching them here (vg_dev_free)
-        g->d_packed.release(); g->d_nmask.release(); g->d_base_off.release(); g->d_len.release(); g->d_has_n.release(); g->d_blk2g.release();
+        g->d_packed.release(); g->d_planes.release(); g->d_nmask.release(); g->d_base_off.release(); g->d_len.release(); g->d_has_n.release(); g->d_blk2g.release();
         g->device = -1;
     }
     hipStream_t s = vg_stream();
