@@ -1,10 +1,10 @@
 #!/bin/bash
-# Developer tool (GPU box): SQ / TCC counters of the parse kernels, one pair per wave against two pairs per wave
+# Developer tool (GPU box): SQ / TCC counters of the parse and index-build kernels
 # (tools/micro/parse_ab.py under rocprofv3 --pmc, one counter set per run).  usage: parse_pmc.sh <out-dir> [NF]
 set -u
 REPO=$(pwd); OUT=$REPO/${1:-gpurun_out/r5_parse_pmc}; export NF=${2:-10000} REPS=1 VG_DEV_SWITCHES=1 TMPDIR=/tmp
 mkdir -p "$OUT"; cd /tmp
-for K in ${KERNELS:-one two}; do
+for K in ${KERNELS:-default}; do
   i=0
   for SET in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
              "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_SCA SQ_INSTS_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU" \
@@ -18,7 +18,7 @@ python - "$OUT" <<'PY'
 import csv, glob, json, os, re, sys
 from collections import defaultdict
 out = sys.argv[1]; doc = {}
-for k in [d for d in ('one', 'two') if os.path.isdir(os.path.join(out, d))]:
+for k in [d for d in sorted(os.listdir(out)) if os.path.isdir(os.path.join(out, d))]:
     per = defaultdict(lambda: defaultdict(list))
     for f in glob.glob(os.path.join(out, k, '**', '*counter_collection.csv'), recursive=True):
         for row in csv.DictReader(open(f, newline='')):

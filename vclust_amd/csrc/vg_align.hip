@@ -366,40 +366,35 @@ __device__ __forceinline__ int gap_score(const pair_ctx& c, int i, int g, int pr
 }
 
 // ------------------------------------------------------------------ index construction
-// 32 symbols of RR = forward | N | reverse complement, starting at RR position 32*ch, straight
-// from the genome's packed words (no per-base loop): the reverse-complement part is a
-// 2-bit-group reversal + complement of 32 forward bases.
-__device__ __forceinline__ void rr_chunk(const uint32_t* __restrict__ gpk, const uint32_t* __restrict__ gmk, int L, int64_t ch,
-                                         uint64_t* bits_out, uint32_t* mask_out) {
+// 32 symbols of RR = forward | N | reverse complement, starting at RR position 32*ch, as bit planes, straight
+// from the genome's plane words (no per-base loop): the reverse-complement part is a
+// bit reversal + inversion of the two planes of 32 forward bases.
+__device__ __forceinline__ void rr_chunk_planes(const uint32_t* __restrict__ gpl, const uint32_t* __restrict__ gmk, int L, int64_t ch,
+                                                uint32_t* lo_out, uint32_t* hi_out, uint32_t* mask_out) {
     const int64_t p0 = ch * 32;
-    uint64_t bits = 0; uint32_t mask = 0xffffffffu;
+    uint32_t lo = 0, hi = 0, mask = 0xffffffffu;
     const int64_t nf = (int64_t)L - p0;
     if (nf > 0) {
-        uint64_t x = (uint64_t)gpk[p0 >> 4] | ((uint64_t)gpk[(p0 >> 4) + 1] << 32);
-        uint32_t m = gmk[p0 >> 5];
-        if (nf >= 32) { bits = x; mask = m; }
-        else { bits = x & ((1ULL << (2 * nf)) - 1); uint32_t lowm = (1u << nf) - 1; mask = (m & lowm) | ~lowm; }
+        const uint32_t xl = gpl[2 * ch], xh = gpl[2 * ch + 1], m = gmk[ch];
+        if (nf >= 32) { lo = xl; hi = xh; mask = m; }
+        else { const uint32_t lowm = (1u << nf) - 1u; lo = xl & lowm; hi = xh & lowm; mask = (m & lowm) | ~lowm; }
     }
     const int64_t jlo = (L + 1 - p0) > 0 ? (L + 1 - p0) : 0;
     const int64_t jhi = (2 * (int64_t)L - p0) < 31 ? (2 * (int64_t)L - p0) : 31;
     if (jlo <= jhi) {
-        const int64_t fstart = 2 * (int64_t)L - p0 - 31;
-        uint64_t x; uint32_t m;
-        if (fstart >= 0) { x = load32(gpk, fstart); m = loadm32(gmk, fstart); }
-        else { x = load32(gpk, 0) << (2 * (-fstart)); m = loadm32(gmk, 0) << (-fstart); }
-        const uint64_t r = ~rev2(x);
-        const uint32_t mr = __brev(m);
-        const uint64_t hi2 = (jhi == 31) ? ~0ULL : ((1ULL << (2 * (jhi + 1))) - 1);
-        const uint64_t lo2 = (jlo == 0) ? 0ULL : ((1ULL << (2 * jlo)) - 1);
-        const uint64_t sl2 = hi2 & ~lo2;
+        const int64_t fstart = 2 * (int64_t)L - p0 - 31;          // (>= -31 here)
+        planes32 x; uint32_t m;
+        if (fstart >= 0) { x = loadp(gpl, fstart); m = loadm32(gmk, fstart); }
+        else { x = loadp(gpl, 0); x.lo <<= -fstart; x.hi <<= -fstart; m = loadm32(gmk, 0) << (-fstart); }
+        // reverse complement of 32 bases: the planes bit-reversed and inverted
+        const uint32_t rl = ~__brev(x.lo), rh = ~__brev(x.hi), mr = __brev(m);
         const uint32_t hi1 = (jhi == 31) ? 0xffffffffu : ((1u << (jhi + 1)) - 1);
         const uint32_t lo1 = (jlo == 0) ? 0u : ((1u << jlo) - 1);
         const uint32_t sl1 = hi1 & ~lo1;
-        bits |= r & sl2;
+        lo |= rl & sl1; hi |= rh & sl1;
         mask = (mask & ~sl1) | (mr & sl1);
     }
-    uint64_t sm = spread(mask); sm |= sm << 1;
-    *bits_out = bits & ~sm; *mask_out = mask;
+    *lo_out = lo & ~mask; *hi_out = hi & ~mask; *mask_out = mask;
 }
 
 // Tag of the index entry of RR position p (x = the bases from p on, first base in the low bits): the bases
@@ -412,12 +407,6 @@ __device__ __forceinline__ uint32_t bucket_of(uint32_t xl, uint32_t xh, int msl)
 __device__ __forceinline__ uint32_t tag_of(uint32_t xl, uint32_t xh, int msl, int tag_bits) {
     const int tl = (tag_bits + 1) >> 1, th = tag_bits >> 1;
     return ((xl >> msl) & ((1u << tl) - 1u)) | (((xh >> msl) & ((1u << th) - 1u)) << tl);
-}
-// RR as bit planes: the word pair of chunk ch
-__device__ __forceinline__ void rr_chunk_planes(const uint32_t* __restrict__ gpk, const uint32_t* __restrict__ gmk, int L, int64_t ch,
-                                                uint32_t* lo_out, uint32_t* hi_out, uint32_t* mask_out) {
-    uint64_t bits; rr_chunk(gpk, gmk, L, ch, &bits, mask_out);
-    const planes32 pl = planes_of(bits); *lo_out = pl.lo; *hi_out = pl.hi;
 }
 
 // ---- path A (references up to 2^21 RR symbols, msl <= 7): one 1024-thread workgroup builds RR
@@ -468,7 +457,7 @@ __device__ __forceinline__ uint32_t lds_scan_exclusive_waves(uint32_t* tab, int 
 
 __global__ void __launch_bounds__(1024)
 k_build_index_lds(const ref_desc* __restrict__ refs, const int* __restrict__ slot_list, int n_list,
-                  const uint32_t* __restrict__ packed, const uint32_t* __restrict__ nmask, const int64_t* __restrict__ base_off,
+                  const uint32_t* __restrict__ gplanes, const uint32_t* __restrict__ nmask, const int64_t* __restrict__ base_off,
                   uint32_t* __restrict__ rr_pool, uint32_t* __restrict__ mask_pool, int mal, int msl,
                   uint32_t* __restrict__ stab_pool, uint32_t* __restrict__ sent_pool,
                   uint32_t* __restrict__ scratch_pool, int64_t scratch_stride) {
@@ -484,7 +473,7 @@ k_build_index_lds(const ref_desc* __restrict__ refs, const int* __restrict__ slo
     for (int li = blockIdx.x; li < n_list; li += gridDim.x) {
         const ref_desc rd = refs[slot_list[li]];
         const int64_t g0 = base_off[rd.genome];
-        const uint32_t* gpk = packed + (g0 >> 4); const uint32_t* gmk = nmask + (g0 >> 5);
+        const uint32_t* gpk = gplanes + (g0 >> 4); const uint32_t* gmk = nmask + (g0 >> 5);
         uint32_t* pk = rr_pool + rd.rr_w; uint32_t* mk = mask_pool + rd.mask_w;
         const int64_t chunks = ((int64_t)rd.n_rr + RR_PAD + 31) / 32 + 2;
         for (int64_t ch = threadIdx.x; ch < chunks; ch += blockDim.x) {
@@ -695,7 +684,7 @@ constexpr int REG_SLOT_BITS = 17;                       // slot < n_rr < 2^17; t
 
 // RR, bucket table and entries of ONE reference by the 1 024 threads of a workgroup (lds: REG_LDS_WORDS words)
 __device__ __forceinline__ void build_ref_reg(uint32_t* const lds, const ref_desc rd,
-                  const uint32_t* __restrict__ packed, const uint32_t* __restrict__ nmask, const int64_t* __restrict__ base_off,
+                  const uint32_t* __restrict__ gplanes, const uint32_t* __restrict__ nmask, const int64_t* __restrict__ base_off,
                   uint32_t* __restrict__ rr_pool, uint32_t* __restrict__ mask_pool, int msl,
                   uint32_t* __restrict__ stab_pool, uint32_t* __restrict__ sent_pool) {
     uint32_t* const tab = lds;                                   // bucket table
@@ -709,7 +698,7 @@ __device__ __forceinline__ void build_ref_reg(uint32_t* const lds, const ref_des
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));                            // per-position constants are recomputed per reference, not kept (and spilled) across the loop
         const int64_t g0 = base_off[rd.genome];
-        const uint32_t* gpk = packed + (g0 >> 4); const uint32_t* gmk = nmask + (g0 >> 5);
+        const uint32_t* gpk = gplanes + (g0 >> 4); const uint32_t* gmk = nmask + (g0 >> 5);
         uint32_t* pk = rr_pool + rd.rr_w; uint32_t* mk = mask_pool + rd.mask_w;
         uint32_t* gtab = stab_pool + rd.stab; uint32_t* gent = sent_pool + rd.sent;
         const int n_gw = (rd.L >> 4) + 4, n_gm = (rd.L >> 5) + 3;
@@ -736,13 +725,15 @@ __device__ __forceinline__ void build_ref_reg(uint32_t* const lds, const ref_des
                 // the msl + tag bases of a position are <= 32 bits: one funnel shift over two words serves each of the
                 // four positions (p0 is a multiple of 4: their bit offsets 2 * (p0 & 15) + 2 j stay below 32)
                 const int wi = 2 * (p0 >> 5); const uint32_t sh = (uint32_t)(p0 & 31);
-                const uint32_t l0 = s_rr[wi], h0 = s_rr[wi + 1], l1 = s_rr[wi + 2], h1 = s_rr[wi + 3];
-                const uint32_t m0 = s_mk[p0 >> 5], m1 = s_mk[(p0 >> 5) + 1];
+                // (msl + tag bases of the four positions = bits 0 .. 3 + 7 + 7 of the planes from p0 on: one funnel shift per
+                // plane and one for the mask serve all four)
+                const uint32_t XL = __builtin_amdgcn_alignbit(s_rr[wi + 2], s_rr[wi], sh), XH = __builtin_amdgcn_alignbit(s_rr[wi + 3], s_rr[wi + 1], sh);
+                const uint32_t XM = __builtin_amdgcn_alignbit(s_mk[(p0 >> 5) + 1], s_mk[p0 >> 5], sh);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int p = p0 + j;
-                    if (p + msl <= rd.n_rr && (__builtin_amdgcn_alignbit(m1, m0, sh + j) & ((1u << msl) - 1u)) == 0) {
-                        const uint32_t xl = __builtin_amdgcn_alignbit(l1, l0, sh + j), xh = __builtin_amdgcn_alignbit(h1, h0, sh + j);
+                    if (p + msl <= rd.n_rr && ((XM >> j) & ((1u << msl) - 1u)) == 0) {
+                        const uint32_t xl = XL >> j, xh = XH >> j;
                         const uint32_t bt = bucket_of(xl, xh, msl) | (tag_of(xl, xh, msl, rd.tag_bits) << 18);
                         atomicAdd(&tab[bt & 0x3ffffu], 1u);
                         reg[it][j] = bt;
@@ -808,12 +799,12 @@ __device__ __forceinline__ void build_ref_reg(uint32_t* const lds, const ref_des
 }
 __global__ void __launch_bounds__(1024)
 k_build_index_reg(const ref_desc* __restrict__ refs, const int* __restrict__ slot_list, int n_list,
-                  const uint32_t* __restrict__ packed, const uint32_t* __restrict__ nmask, const int64_t* __restrict__ base_off,
+                  const uint32_t* __restrict__ gplanes, const uint32_t* __restrict__ nmask, const int64_t* __restrict__ base_off,
                   uint32_t* __restrict__ rr_pool, uint32_t* __restrict__ mask_pool, int msl,
                   uint32_t* __restrict__ stab_pool, uint32_t* __restrict__ sent_pool) {
     __shared__ uint32_t lds[REG_LDS_WORDS];
     for (int li = blockIdx.x; li < n_list; li += gridDim.x)
-        build_ref_reg(lds, refs[slot_list[li]], packed, nmask, base_off, rr_pool, mask_pool, msl, stab_pool, sent_pool);
+        build_ref_reg(lds, refs[slot_list[li]], gplanes, nmask, base_off, rr_pool, mask_pool, msl, stab_pool, sent_pool);
 }
 
 // ---- path A1 (references of REG_MAX_RR .. MID_MAX_RR symbols -- genomes of 49 .. 262 kb --, msl <= 7): the positions do
@@ -827,7 +818,7 @@ constexpr int MID_MAX_RR = 1 << 19;
 constexpr int MID_STAGE = 23552;                        // staged entries per window (92 KiB beside the 64 KiB table)
 __global__ void __launch_bounds__(1024)
 k_build_index_mid(const ref_desc* __restrict__ refs, const int* __restrict__ slot_list, int n_list,
-                  const uint32_t* __restrict__ packed, const uint32_t* __restrict__ nmask, const int64_t* __restrict__ base_off,
+                  const uint32_t* __restrict__ gplanes, const uint32_t* __restrict__ nmask, const int64_t* __restrict__ base_off,
                   uint32_t* __restrict__ rr_pool, uint32_t* __restrict__ mask_pool, int msl,
                   uint32_t* __restrict__ stab_pool, uint32_t* __restrict__ sent_pool) {
     __shared__ uint32_t tab[LDS_TAB];
@@ -838,7 +829,7 @@ k_build_index_mid(const ref_desc* __restrict__ refs, const int* __restrict__ slo
     for (int li = blockIdx.x; li < n_list; li += gridDim.x) {
         const ref_desc rd = refs[slot_list[li]];
         const int64_t g0 = base_off[rd.genome];
-        const uint32_t* gpk = packed + (g0 >> 4); const uint32_t* gmk = nmask + (g0 >> 5);
+        const uint32_t* gpk = gplanes + (g0 >> 4); const uint32_t* gmk = nmask + (g0 >> 5);
         uint32_t* pk = rr_pool + rd.rr_w; uint32_t* mk = mask_pool + rd.mask_w;
         uint32_t* gtab = stab_pool + rd.stab; uint32_t* gent = sent_pool + rd.sent;
         const int chunks = (rd.n_rr + RR_PAD + 31) / 32 + 2;
@@ -944,7 +935,7 @@ k_build_index_mid(const ref_desc* __restrict__ refs, const int* __restrict__ slo
 __global__ void __launch_bounds__(256)
 k_build_rr(const ref_desc* __restrict__ refs, const int* __restrict__ slot_list, int n_list,
            const int64_t* __restrict__ chunk_off /* n_list+1, in 32-base chunks */,
-           const uint32_t* __restrict__ packed, const uint32_t* __restrict__ nmask, const int64_t* __restrict__ base_off,
+           const uint32_t* __restrict__ gplanes, const uint32_t* __restrict__ nmask, const int64_t* __restrict__ base_off,
            uint32_t* __restrict__ rr_pool, uint32_t* __restrict__ mask_pool) {
     const int64_t total = chunk_off[n_list];
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
@@ -954,7 +945,7 @@ k_build_rr(const ref_desc* __restrict__ refs, const int* __restrict__ slot_list,
         const int64_t ch = t - chunk_off[lo];
         const int64_t g0 = base_off[rd.genome];
         uint32_t pl_lo, pl_hi, m;
-        rr_chunk_planes(packed + (g0 >> 4), nmask + (g0 >> 5), rd.L, ch, &pl_lo, &pl_hi, &m);
+        rr_chunk_planes(gplanes + (g0 >> 4), nmask + (g0 >> 5), rd.L, ch, &pl_lo, &pl_hi, &m);
         rr_pool[rd.rr_w + 2 * ch] = pl_lo; rr_pool[rd.rr_w + 2 * ch + 1] = pl_hi;
         mask_pool[rd.mask_w + ch] = m;
     }
@@ -1838,26 +1829,27 @@ void lz_build_batch(const vg_genomes* g, const vg_lz_params* p, lz_plan& P, size
     if (!B.small_list.empty()) L.d_small.upload(B.small_list.data(), B.small_list.size(), sb);
     if (!B.large_list.empty()) { L.d_large.upload(B.large_list.data(), B.large_list.size(), sb); L.d_lchunk.upload(B.large_chunks.data(), B.large_chunks.size(), sb); }
     const int64_t total_chunks = B.chunk_off.back();
+    const uint32_t* gpl = lz_genome_planes(g, sb);            // the builds read the genomes as bit planes
     vg_prof_scope ps("lz_build_index", (double)total_chunks * 32 * (0.375 + 0.375 + 4), sb);
     if (!B.large_list.empty()) VG_HIP(hipMemsetAsync(L.stab_pool.p, 0, (size_t)B.stab_tot * sizeof(uint32_t), sb));
     if (!B.reg_list.empty()) {
         hipLaunchKernelGGL(k_build_index_reg, dim3((unsigned)std::min<size_t>(B.reg_list.size(), 512)), dim3(1024), 0, sb, d_refs.p, L.d_reg.p,
-                           (int)B.reg_list.size(), g->d_packed.p, g->d_nmask.p, g->d_base_off.p, L.rr_pool.p, L.mask_pool.p, p->msl,
+                           (int)B.reg_list.size(), gpl, g->d_nmask.p, g->d_base_off.p, L.rr_pool.p, L.mask_pool.p, p->msl,
                            L.stab_pool.p, L.sent_pool.p);
     }
     if (!B.mid_list.empty()) {
         hipLaunchKernelGGL(k_build_index_mid, dim3((unsigned)std::min<size_t>(B.mid_list.size(), 512)), dim3(1024), 0, sb, d_refs.p, L.d_mid.p,
-                           (int)B.mid_list.size(), g->d_packed.p, g->d_nmask.p, g->d_base_off.p, L.rr_pool.p, L.mask_pool.p, p->msl,
+                           (int)B.mid_list.size(), gpl, g->d_nmask.p, g->d_base_off.p, L.rr_pool.p, L.mask_pool.p, p->msl,
                            L.stab_pool.p, L.sent_pool.p);
     }
     if (!B.small_list.empty()) {
         hipLaunchKernelGGL(k_build_index_lds, dim3(B.nblk_build), dim3(1024), 0, sb, d_refs.p, L.d_small.p, (int)B.small_list.size(),
-                           g->d_packed.p, g->d_nmask.p, g->d_base_off.p, L.rr_pool.p, L.mask_pool.p, p->mal, p->msl,
+                           gpl, g->d_nmask.p, g->d_base_off.p, L.rr_pool.p, L.mask_pool.p, p->mal, p->msl,
                            L.stab_pool.p, L.sent_pool.p, L.scratch.p, B.stride);
     }
     if (!B.large_list.empty()) {
         const int nl = (int)B.large_list.size(); const int64_t lc = B.large_chunks.back();
-        hipLaunchKernelGGL(k_build_rr, dim3(grid_for(lc)), dim3(256), 0, sb, d_refs.p, L.d_large.p, nl, L.d_lchunk.p, g->d_packed.p,
+        hipLaunchKernelGGL(k_build_rr, dim3(grid_for(lc)), dim3(256), 0, sb, d_refs.p, L.d_large.p, nl, L.d_lchunk.p, gpl,
                            g->d_nmask.p, g->d_base_off.p, L.rr_pool.p, L.mask_pool.p);
         hipLaunchKernelGGL(k_index_pass, dim3(grid_for(lc * 32)), dim3(256), 0, sb, d_refs.p, L.d_large.p, nl, L.d_lchunk.p, L.rr_pool.p,
                            L.mask_pool.p, p->mal, p->msl, 0, L.stab_pool.p, L.sent_pool.p);
