@@ -1482,8 +1482,9 @@ k_genome_planes(const uint32_t* __restrict__ packed, int64_t n_pairs, uint32_t* 
         const uint2 o = make_uint2(pl.lo, pl.hi); __builtin_memcpy(planes + 2 * w, &o, 8);
     }
 }
-std::mutex g_planes_mu;
-const uint32_t* lz_genome_planes(const vg_genomes* g, hipStream_t s) {
+}  // namespace
+static std::mutex g_planes_mu;
+const uint32_t* vg_genome_planes(const vg_genomes* g, hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_planes_mu);
     if (g->d_planes.n != g->d_packed.n || !g->d_planes.p) {
         const size_t words = g->d_packed.n & ~(size_t)1;
@@ -1492,7 +1493,6 @@ const uint32_t* lz_genome_planes(const vg_genomes* g, hipStream_t s) {
     }
     return g->d_planes.p;
 }
-}  // namespace
 
 static int64_t g_segment_task_limit = 32768;
 // VG_LZ_BUILD=lds: the scratch-based LDS build also for short references (tests compare the two)
@@ -1510,7 +1510,7 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
     int rc = vg_genomes_to_device(g); if (rc) return rc;
     hipStream_t s = vg_stream();
     vg_host_mark("vg_lz_align: enter");
-    const uint32_t* d_planes = lz_genome_planes(g, s);
+    const uint32_t* d_planes = vg_genome_planes(g, s);
 
     if (regions) { *regions = nullptr; if (n_regions) *n_regions = 0; }
     if (n_tasks == 0) return VG_OK;
@@ -1829,7 +1829,7 @@ void lz_build_batch(const vg_genomes* g, const vg_lz_params* p, lz_plan& P, size
     if (!B.small_list.empty()) L.d_small.upload(B.small_list.data(), B.small_list.size(), sb);
     if (!B.large_list.empty()) { L.d_large.upload(B.large_list.data(), B.large_list.size(), sb); L.d_lchunk.upload(B.large_chunks.data(), B.large_chunks.size(), sb); }
     const int64_t total_chunks = B.chunk_off.back();
-    const uint32_t* gpl = lz_genome_planes(g, sb);            // the builds read the genomes as bit planes
+    const uint32_t* gpl = vg_genome_planes(g, sb);            // the builds read the genomes as bit planes
     vg_prof_scope ps("lz_build_index", (double)total_chunks * 32 * (0.375 + 0.375 + 4), sb);
     if (!B.large_list.empty()) VG_HIP(hipMemsetAsync(L.stab_pool.p, 0, (size_t)B.stab_tot * sizeof(uint32_t), sb));
     if (!B.reg_list.empty()) {

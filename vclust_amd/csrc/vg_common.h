@@ -131,6 +131,7 @@ struct vg_genomes {
 };
 void vg_length_order(const vg_genomes* g);        // fills g->len_order / g->len_rank on first use
 int  vg_align_tasks_perm(const vg_genomes* g, const vg_pair_count* pairs, int64_t n_pairs, vg_task** tasks, int64_t* n_tasks, uint32_t* perm /* n_pairs entries, or null */);
+const uint32_t* vg_genome_planes(const vg_genomes* g, hipStream_t s);   // g->d_planes, made from the resident 2-bit codes on first use (queued on s; vg_align.hip)
 void vg_lz_drop_prepared(const vg_genomes* g);    // forget the index plan vg_lz_prepare left for g (nullptr: whatever it left)
 
 // vg_genomes_load with the upload to the library's device overlapped with the packing (vg_genomes.cpp; whole-stage calls)

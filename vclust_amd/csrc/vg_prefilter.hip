@@ -1,4 +1,4 @@
-// vg_prefilter.hip — Kmer-db prefilter on gfx950: canonical k-mer extraction from 2-bit packed genomes, the
+// vg_prefilter.hip — Kmer-db prefilter on gfx950: canonical k-mer extraction from the genomes' bit planes, the
 // inverted index by an own two-level MSD partition + LDS bucket sort (no general radix sort on the hot path), and
 // the sparse genome x genome shared-k-mer matrix as a row-wise SpGEMM (A * A^T) with LDS hash accumulators.
 // Replaces `kmer-db build` + `all2all-sp` (vclust.py:953-1017); restates SURVEY §8a K1/K2, parity-checked against
@@ -51,7 +51,7 @@ __device__ __forceinline__ uint64_t rev2(uint64_t x) {
 
 // ------------------------------------------------------------------ K1: canonical k-mers
 struct kmer_args {
-    const uint32_t* packed; const uint32_t* nmask; const uint32_t* blk2g; const int64_t* base_off; const int64_t* len;
+    const uint32_t* planes; const uint32_t* nmask; const uint32_t* blk2g; const int64_t* base_off; const int64_t* len;
     int64_t P; int k; int use_frac; uint64_t frac_thr; uint32_t shard, n_shards; int blk_shift;
     uint32_t dig_lo, dig_n;          // RANGE shards: keep the keys whose top DIG_BITS bits d satisfy d - dig_lo < dig_n (all: 0, 1 << DIG_BITS)
     uint32_t dig_max;                // RANGE shards: the widest digit range of any shard of this cut (buffers of all passes are sized alike)
@@ -71,20 +71,46 @@ constexpr int DIG_BITS = 11;
 // is followed by at least one masked padding base, so "crosses the end" IS "contains a masked base": the
 // mask is the only validity test (no length / offset lookups behind the genome id).
 //
-// The arithmetic is written on 32-bit halves: the 2k <= 62 bits of a k-mer are cut out of three sequence words
-// with two funnel shifts (v_alignbit_b32), reversed per dword, and scrambled with one 32-bit multiply.
-__device__ __forceinline__ uint32_t rev2_32(uint32_t y) {            // the 16 two-bit groups of y in reverse order
-    y = __brev(y);
-    return ((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1);
+// The bases are read as BIT PLANES (vg_genomes::d_planes: the word pair (lo, hi) of every 32 bases): the k-mer at a
+// position is the k-bit windows (fl, fh) of the two planes, its reverse complement the bit-reversed, inverted windows,
+// and the two k-bit halves the key is made of ARE the planes: canonical = the smaller of (fh : fl) and (rh : rl) as
+// 2k-bit numbers -- a bijection of the sequence, chosen the same way from either strand, which is all the grouping of
+// equal k-mers needs (round 5: the 2-bit codes cost a per-dword reversal of 2-bit groups, 64-bit shifts and a 64-bit
+// compare per k-mer, three times per position of the set).  Only --kmers-fraction sees the k-mer as the NUMBER the
+// oracle hashes (2-bit codes, first base most significant): that path re-assembles it (cano_codes).
+__device__ __forceinline__ uint64_t spread32(uint32_t v) {           // bit i -> bit 2 i
+    uint64_t x = v;
+    x = (x | (x << 16)) & 0x0000FFFF0000FFFFULL;
+    x = (x | (x << 8)) & 0x00FF00FF00FF00FFULL;
+    x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0FULL;
+    x = (x | (x << 2)) & 0x3333333333333333ULL;
+    return (x | (x << 1)) & 0x5555555555555555ULL;
 }
-// x = the k-mer's 2k bits, first base in the low bits (xh:xl, already masked) -> scrambled canonical key or SENT
-__device__ __forceinline__ uint64_t canon_key(const kmer_args& A, uint32_t xl, uint32_t xh, uint32_t km_lo, uint32_t km_hi) {
-    const int k2 = 2 * A.k;
-    const uint64_t fwd = (((uint64_t)rev2_32(xl) << 32) | rev2_32(xh)) >> (64 - k2);     // first base most significant
-    const uint64_t rc = ((uint64_t)(~xh & km_hi) << 32) | (~xl & km_lo);                  // reverse complement, same convention
-    const uint64_t cano = fwd < rc ? fwd : rc;
-    if (A.use_frac && !(mix64(cano) < A.frac_thr)) return SENT;
-    const uint64_t key = scramble_key(cano, A.k);               // bit 2k stays 0; SENT has it set
+// the canonical k-mer as the oracle's number: 2-bit codes, first base most significant, the smaller strand
+__host__ __device__ __forceinline__ uint64_t cano_codes_of(uint64_t x /* 2-bit codes, first base in the low bits */, int k) {
+    uint64_t fwd = 0, rc = 0;
+    for (int i = 0; i < k; ++i) { const uint64_t c = (x >> (2 * i)) & 3ULL; fwd = (fwd << 2) | c; rc |= (3ULL - c) << (2 * i); }
+    return fwd < rc ? fwd : rc;
+}
+__device__ __forceinline__ uint64_t cano_codes(uint32_t fl, uint32_t fh, int k) {
+    const int k2 = 2 * k;
+    const uint64_t x = spread32(fl) | (spread32(fh) << 1);                  // first base in the low bits
+    const uint64_t km = (1ULL << k2) - 1ULL;
+    const uint64_t fwd = rev2(x) >> (64 - k2);                               // first base most significant
+    const uint64_t rc = ~x & km;
+    return fwd < rc ? fwd : rc;
+}
+// fl, fh = the planes of the k-mer in their k low bits (first base = bit 0; the bits above are ignored) -> scrambled
+// canonical key or SENT
+__device__ __forceinline__ uint64_t canon_key(const kmer_args& A, uint32_t fl, uint32_t fh) {
+    const int k = A.k;                                                       // 8 .. 31
+    const uint32_t nk = (1u << k) - 1u;
+    fl &= nk; fh &= nk;
+    const uint32_t rl = __brev(~fl) >> (32 - k), rh = __brev(~fh) >> (32 - k);      // (the ones above bit k - 1 of ~f leave at the low end)
+    const bool f = fh < rh || (fh == rh && fl < rl);
+    const uint32_t H = f ? fh : rh, L = f ? fl : rl;
+    if (A.use_frac && !(mix64(cano_codes(fl, fh, k)) < A.frac_thr)) return SENT;
+    const uint64_t key = ((uint64_t)(H ^ ((L * SCRAMBLE32) >> (32 - k))) << k) | L;      // = scramble_key((H << k) | L): bit 2k stays 0; SENT has it set
     if (A.dig_n < (1u << DIG_BITS)) {
         if ((uint32_t)(key >> (2 * A.k - DIG_BITS)) - A.dig_lo >= A.dig_n) return SENT;     // RANGE shard
     } else if (A.n_shards > 1) {
@@ -95,21 +121,22 @@ __device__ __forceinline__ uint64_t canon_key(const kmer_args& A, uint32_t xl, u
     }
     return key;
 }
-// the four k-mers starting at padded positions p0 .. p0+3 (p0 a multiple of 4) from w0..w2 = the 48 bases from
-// the 16-base word that holds p0 and m0, m1 = the N-mask words from the 32-base word that holds p0
-__device__ __forceinline__ void kmers4_words(const kmer_args& A, uint32_t p0_low, uint32_t w0, uint32_t w1, uint32_t w2,
+// the k-mer at base position p of a plane array (global or LDS): the word pairs of its 32-base chunk and of the next one
+__device__ __forceinline__ uint64_t canon_key_at(const kmer_args& A, const uint32_t* pl, uint32_t pair /* p >> 5 */, uint32_t sh /* p & 31 */) {
+    const uint32_t* w = pl + 2 * (size_t)pair;
+    return canon_key(A, __builtin_amdgcn_alignbit(w[2], w[0], sh), __builtin_amdgcn_alignbit(w[3], w[1], sh));
+}
+// the four k-mers starting at padded positions p0 .. p0+3 (p0 a multiple of 4) from (l0, h0, l1, h1) = the planes of the
+// 32-base chunk that holds p0 and of the next one, and m0, m1 = the N-mask words of the same chunks
+__device__ __forceinline__ void kmers4_words(const kmer_args& A, uint32_t p0_low, uint32_t l0, uint32_t h0, uint32_t l1, uint32_t h1,
                                              uint32_t m0, uint32_t m1, uint64_t out[4]) {
-    const int k2 = 2 * A.k;                                               // 16 .. 62
-    const uint32_t sh = 2u * (p0_low & 15u), msh = p0_low & 31u;         // sh in {0, 8, 16, 24}, msh <= 28
+    const uint32_t sh = p0_low & 31u;                                     // <= 28
     const uint32_t nk = (1u << A.k) - 1u;
-    const uint32_t km_lo = k2 >= 32 ? 0xffffffffu : ((1u << k2) - 1u), km_hi = k2 > 32 ? ((1u << (k2 - 32)) - 1u) : 0u;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         uint64_t key = SENT;
-        if ((__builtin_amdgcn_alignbit(m1, m0, msh + j) & nk) == 0) {
-            const uint32_t s2 = sh + 2 * j;                               // <= 30
-            key = canon_key(A, __builtin_amdgcn_alignbit(w1, w0, s2) & km_lo, __builtin_amdgcn_alignbit(w2, w1, s2) & km_hi, km_lo, km_hi);
-        }
+        if ((__builtin_amdgcn_alignbit(m1, m0, sh + j) & nk) == 0)
+            key = canon_key(A, __builtin_amdgcn_alignbit(l1, l0, sh + j), __builtin_amdgcn_alignbit(h1, h0, sh + j));
         out[j] = key;
     }
 }
@@ -118,19 +145,17 @@ __device__ __forceinline__ uint64_t kmer_at(const kmer_args& A, int64_t p, uint3
     const int64_t mw = p >> 5; const uint32_t msh = (uint32_t)(p & 31);
     const uint64_t m = ((uint64_t)A.nmask[mw] | ((uint64_t)A.nmask[mw + 1] << 32)) >> msh;
     if ((m & ((1ULL << A.k) - 1)) != 0) return SENT;
-    const int k2 = 2 * A.k;
-    const uint32_t km_lo = k2 >= 32 ? 0xffffffffu : ((1u << k2) - 1u), km_hi = k2 > 32 ? ((1u << (k2 - 32)) - 1u) : 0u;
-    const int64_t w = p >> 4; const uint32_t sh = 2u * (uint32_t)(p & 15);
-    const uint32_t w0 = A.packed[w], w1 = A.packed[w + 1], w2 = A.packed[w + 2];
-    return canon_key(A, __builtin_amdgcn_alignbit(w1, w0, sh) & km_lo, __builtin_amdgcn_alignbit(w2, w1, sh) & km_hi, km_lo, km_hi);
+    uint4 w; __builtin_memcpy(&w, A.planes + 2 * (p >> 5), 16);
+    return canon_key(A, __builtin_amdgcn_alignbit(w.z, w.x, msh), __builtin_amdgcn_alignbit(w.w, w.y, msh));
 }
 
 // the four k-mers starting at padded positions p0 .. p0+3 (p0 a multiple of 4): one genome lookup,
-// one 96-bit sequence window and one 64-bit N window serve all four
+// the planes of two chunks and one 64-bit N window serve all four
 __device__ __forceinline__ void kmers4(const kmer_args& A, int64_t p0, uint64_t out[4], uint32_t* genome) {
     *genome = A.blk2g[p0 >> A.blk_shift];
-    const int64_t mw = p0 >> 5, w = p0 >> 4;
-    kmers4_words(A, (uint32_t)(p0 & 31), A.packed[w], A.packed[w + 1], A.packed[w + 2], A.nmask[mw], A.nmask[mw + 1], out);
+    const int64_t mw = p0 >> 5;
+    uint4 w; __builtin_memcpy(&w, A.planes + 2 * mw, 16);
+    kmers4_words(A, (uint32_t)(p0 & 31), w.x, w.y, w.z, w.w, A.nmask[mw], A.nmask[mw + 1], out);
 }
 
 // Dense form (all k-mers kept: one shard, fraction 1): four consecutive padded base positions per
@@ -265,8 +290,6 @@ k_kmer_emit_sparse(kmer_args A, const unsigned long long* __restrict__ wave_mask
     const int64_t n_chunks = (W + nw - 1) / nw;
     const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    const int k2 = 2 * A.k;
-    const uint32_t km_lo = k2 >= 32 ? 0xffffffffu : ((1u << k2) - 1u), km_hi = k2 > 32 ? ((1u << (k2 - 32)) - 1u) : 0u;
     // (the masks and row bases of the NEXT chunk travel while this one is worked on: a trip is a chain of dependent loads)
     unsigned long long mine = 0; uint32_t base = 0;
     if (wave0 < n_chunks && lane < nw && wave0 * nw + lane < W) { mine = wave_mask[wave0 * nw + lane]; base = wave_base[wave0 * nw + lane]; }
@@ -293,9 +316,9 @@ k_kmer_emit_sparse(kmer_args A, const unsigned long long* __restrict__ wave_mask
             const int64_t p = ((w0 + j) << 6) + nth_set_bit(mj, r);
             // the kept position's k-mer: one 16-byte load of bases (the window spans at most three words and a bit), one
             // 8-byte load of the mask; the position was kept by this pass's mask, so the shard tests of canon_key pass
-            uint4 wv; __builtin_memcpy(&wv, A.packed + (p >> 4), 16);
-            const uint32_t sh = 2u * (uint32_t)(p & 15);
-            const uint64_t key = canon_key(A, __builtin_amdgcn_alignbit(wv.y, wv.x, sh) & km_lo, __builtin_amdgcn_alignbit(wv.z, wv.y, sh) & km_hi, km_lo, km_hi);
+            uint4 wv; __builtin_memcpy(&wv, A.planes + 2 * (p >> 5), 16);
+            const uint32_t sh = (uint32_t)(p & 31);
+            const uint64_t key = canon_key(A, __builtin_amdgcn_alignbit(wv.z, wv.x, sh), __builtin_amdgcn_alignbit(wv.w, wv.y, sh));
             const uint32_t c = bj + (uint32_t)r;
             keys[c] = key; if (pos) pos[c] = c;
         }
@@ -854,7 +877,7 @@ __device__ __forceinline__ void fetch_tile(const part_src& S, int64_t t0, int64_
         for (int q = 0; q < PT_PER / 4; ++q) {
             const int64_t p0 = t0 + ((int64_t)q * PT_THREADS + threadIdx.x) * 4;
             if (p0 < t_end) {
-                __builtin_memcpy(&raw[6 * q], S.A.packed + (p0 >> 4), 16);
+                __builtin_memcpy(&raw[6 * q], S.A.planes + 2 * (p0 >> 5), 16);
                 raw[6 * q + 4] = S.A.nmask[p0 >> 5]; raw[6 * q + 5] = S.A.nmask[(p0 >> 5) + 1];
             }
         }
@@ -878,7 +901,7 @@ __device__ __forceinline__ void decode_tile(const part_src& S, int64_t t0, int64
             const int64_t p0 = t0 + ((int64_t)q * PT_THREADS + threadIdx.x) * 4;
             uint64_t kk[4] = {SENT, SENT, SENT, SENT};
             if (p0 < t_end) {
-                kmers4_words(S.A, (uint32_t)(p0 & 31), raw[6 * q], raw[6 * q + 1], raw[6 * q + 2], raw[6 * q + 4], raw[6 * q + 5], kk);
+                kmers4_words(S.A, (uint32_t)(p0 & 31), raw[6 * q], raw[6 * q + 1], raw[6 * q + 2], raw[6 * q + 3], raw[6 * q + 4], raw[6 * q + 5], kk);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -1269,14 +1292,14 @@ k_part_scatter(part_src S, int B1, int B2, int unit_tiles, int64_t n_units, cons
 constexpr int RT_TILE = 32768;
 constexpr int RT_PER = RT_TILE / PT_THREADS;
 __device__ __forceinline__ uint64_t kmer_key_lds(const kmer_args& A, const uint32_t* s_pk, uint32_t lp) {
-    const int k2 = 2 * A.k;
-    const uint32_t km_lo = k2 >= 32 ? 0xffffffffu : ((1u << k2) - 1u), km_hi = k2 > 32 ? ((1u << (k2 - 32)) - 1u) : 0u;
-    const uint32_t wi = lp >> 4, sh = 2u * (lp & 15u);
-    const uint32_t w0 = s_pk[wi], w1 = s_pk[wi + 1], w2 = s_pk[wi + 2];
-    const uint32_t xl = __builtin_amdgcn_alignbit(w1, w0, sh) & km_lo, xh = __builtin_amdgcn_alignbit(w2, w1, sh) & km_hi;
-    const uint64_t fwd = (((uint64_t)rev2_32(xl) << 32) | rev2_32(xh)) >> (64 - k2);
-    const uint64_t rc = ((uint64_t)(~xh & km_hi) << 32) | (~xl & km_lo);
-    return scramble_key(fwd < rc ? fwd : rc, A.k);
+    // (the position is a kept one: no validity, fraction or shard test -- the count pass made them)
+    const uint32_t k = (uint32_t)A.k, nk = (1u << k) - 1u;
+    const uint32_t* w = s_pk + 2 * (lp >> 5); const uint32_t sh = lp & 31u;
+    const uint32_t fl = __builtin_amdgcn_alignbit(w[2], w[0], sh) & nk, fh = __builtin_amdgcn_alignbit(w[3], w[1], sh) & nk;
+    const uint32_t rl = __brev(~fl) >> (32 - k), rh = __brev(~fh) >> (32 - k);
+    const bool f = fh < rh || (fh == rh && fl < rl);
+    const uint32_t H = f ? fh : rh, L = f ? fl : rl;
+    return ((uint64_t)(H ^ ((L * SCRAMBLE32) >> (32 - k))) << k) | L;
 }
 template <int KC>
 __global__ void __launch_bounds__(PT_THREADS)
@@ -1299,7 +1322,7 @@ k_part_scatter_dense(part_src S, int B1, int nbins /* level-1 buckets of this pa
         uint32_t pf_pk[NPK], pf_mk[NMK];
         auto fetch_bases = [&](int64_t t0) {
 #pragma unroll
-            for (int v = 0; v < NPK; ++v) { const int i = v * PT_THREADS + (int)threadIdx.x; const int64_t w = (t0 >> 4) + i; pf_pk[v] = (i < RT_TILE / 16 + 4 && w < n_pk) ? S.A.packed[w] : 0u; }
+            for (int v = 0; v < NPK; ++v) { const int i = v * PT_THREADS + (int)threadIdx.x; const int64_t w = (t0 >> 4) + i; pf_pk[v] = (i < RT_TILE / 16 + 4 && w < n_pk) ? S.A.planes[w] : 0u; }
 #pragma unroll
             for (int v = 0; v < NMK; ++v) { const int i = v * PT_THREADS + (int)threadIdx.x; const int64_t w = (t0 >> 5) + i; pf_mk[v] = (i < RT_TILE / 32 + 2 && w < n_mk) ? S.A.nmask[w] : 0xffffffffu; }
         };
@@ -1327,8 +1350,8 @@ k_part_scatter_dense(part_src S, int B1, int nbins /* level-1 buckets of this pa
                 const uint32_t lp0 = ((uint32_t)q * PT_THREADS + threadIdx.x) * 4;
                 uint64_t kk[4] = {SENT, SENT, SENT, SENT};
                 if (t0 + lp0 < s1) {
-                    const uint32_t wi = lp0 >> 4;
-                    kmers4_words(S.A, lp0 & 31u, s_pk[wi], s_pk[wi + 1], s_pk[wi + 2], s_mk[lp0 >> 5], s_mk[(lp0 >> 5) + 1], kk);
+                    const uint32_t wi = 2u * (lp0 >> 5);
+                    kmers4_words(S.A, lp0 & 31u, s_pk[wi], s_pk[wi + 1], s_pk[wi + 2], s_pk[wi + 3], s_mk[lp0 >> 5], s_mk[(lp0 >> 5) + 1], kk);
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -1419,7 +1442,7 @@ k_part_scatter_range(part_src S, int B1, int nbins /* <= 2048 */, int unit_tiles
         uint32_t pf_pk[NPK];
         auto fetch_bases = [&](int64_t t0) {
 #pragma unroll
-            for (int v = 0; v < NPK; ++v) { const int i = v * PT_THREADS + (int)threadIdx.x; const int64_t w = (t0 >> 4) + i; pf_pk[v] = (i < TT / 16 + 4 && w < n_pk) ? S.A.packed[w] : 0u; }
+            for (int v = 0; v < NPK; ++v) { const int i = v * PT_THREADS + (int)threadIdx.x; const int64_t w = (t0 >> 4) + i; pf_pk[v] = (i < TT / 16 + 4 && w < n_pk) ? S.A.planes[w] : 0u; }
         };
         fetch_bases(s0);
         for (int64_t t0 = s0; t0 < s1; t0 += TT) {
@@ -2029,7 +2052,7 @@ static bool range_shards(const vg_genomes* g, double fraction, int n_shards) {
 }
 static kmer_args make_kmer_args(const vg_genomes* g, int k, double fraction, int shard, int n_shards) {
     const int use_frac = fraction < 1.0;
-    kmer_args A{ g->d_packed.p, g->d_nmask.p, g->d_blk2g.p, g->d_base_off.p, g->d_len.p, g->padded_total(), k, use_frac,
+    kmer_args A{ vg_genome_planes(g, vg_stream()), g->d_nmask.p, g->d_blk2g.p, g->d_base_off.p, g->d_len.p, g->padded_total(), k, use_frac,
                  use_frac ? (uint64_t)std::ldexp(fraction, 64) : ~0ULL, (uint32_t)shard, (uint32_t)n_shards, g->align_shift, 0u, 1u << DIG_BITS, 1u << DIG_BITS };
     if (range_shards(g, fraction, n_shards)) {
         A.dig_max = (uint32_t)(((1u << DIG_BITS) + (uint32_t)n_shards - 1u) / (uint32_t)n_shards);
@@ -3065,7 +3088,14 @@ extern "C" int vg_kmer_set(vg_genomes* g, int idx, int k, double fraction, uint6
         lo = c[0]; hi = c[1];
     }
     for (size_t i = 0; i < keys.size(); ++i)
-        if ((int64_t)pos[i] >= lo && (int64_t)pos[i] < hi) mine.push_back(unscramble_key(keys[i], k));
+        if ((int64_t)pos[i] >= lo && (int64_t)pos[i] < hi) {
+            // the key's two halves are the bit planes of the canonical strand: back to the number the caller knows (2-bit
+            // codes, first base most significant, the smaller strand)
+            const uint64_t hl = unscramble_key(keys[i], k), H = hl >> k, L = hl & ((1ULL << k) - 1ULL);
+            uint64_t x = 0;
+            for (int b = 0; b < k; ++b) x |= ((((H >> b) & 1ULL) << 1) | ((L >> b) & 1ULL)) << (2 * b);
+            mine.push_back(cano_codes_of(x, k));
+        }
     std::sort(mine.begin(), mine.end());
     mine.erase(std::unique(mine.begin(), mine.end()), mine.end());
     uint64_t* o = (uint64_t*)malloc(sizeof(uint64_t) * std::max<size_t>(1, mine.size()));
