@@ -1733,6 +1733,7 @@ k_bucket_runs(const uint32_t* __restrict__ rec, int stride /* 3: (w0, w1, pay); 
               const uint32_t* __restrict__ bucket_list /* null: all buckets; else the n_buckets listed ones */,
               uint32_t* __restrict__ over_list, unsigned int* __restrict__ n_over) {
     constexpr int BK_SUB = 1 << SUBBITS, CAP = THREADS * BK_PER;
+    static_assert(CAP <= 8192 && BK_MAXBIN <= 1024, "slot | rank << 13 of the run members");
     __shared__ uint32_t s_big;
     __shared__ uint64_t sk[CAP];                  // NARROW: key << 32 | pos; else (w0 << 32) | w1 -- in sub-bin order
     __shared__ uint32_t sp[NARROW ? 1 : CAP];
@@ -1816,16 +1817,21 @@ k_bucket_runs(const uint32_t* __restrict__ rec, int stride /* 3: (w0, w1, pay); 
             sk[slot] = key[q]; if (!NARROW) sp[slot] = pj[q];
         }
         lds_sync();
+        // Every entry of a run of >= 2 learns its place in the sorted list (start of the run + rank by position) and puts
+        // its genome there.  Whether it repeats a k-mer of its OWN genome is read off that list afterwards: the entry in
+        // front of it in the run is the slot in front of it (the loop carries three counters, no predecessor, and the
+        // predecessor's genome is an LDS word instead of a second look-up in global memory).
+        uint32_t at[BK_PER], gq[BK_PER];                       // slot in the bucket | rank in the run << 13 (CAP <= 8192, rank < BK_MAXBIN), genome; ~0: nothing to do
 #pragma unroll
         for (int q = 0; q < BK_PER; ++q) {
+            at[q] = 0xffffffffu; gq[q] = 0;
             if (rec_of(q) >= n) continue;
             const uint32_t s0 = start[sb[q]], s1 = start[sb[q] + 1];
             if (s1 - s0 < 2) continue;                           // alone in its sub-bin: a singleton k-mer
             const uint64_t kq = key[q]; const uint32_t pq = pj[q];
-            uint32_t lt = 0, eq = 0, before = 0; uint32_t prev_pay = 0; bool has_prev = false;
+            uint32_t lt = 0, eq = 0, before = 0;
             if (NARROW) {
                 const uint32_t kh = (uint32_t)(kq >> 32);
-                uint32_t best = 0;                               // largest position of the same k-mer below this one (+ 1)
 #pragma unroll 4
                 for (uint32_t t = s0; t < s1; ++t) {
                     const uint64_t vt = sk[t];
@@ -1833,30 +1839,27 @@ k_bucket_runs(const uint32_t* __restrict__ rec, int stride /* 3: (w0, w1, pay); 
                     lt += th < kh;
                     const bool same = th == kh;
                     eq += same;
-                    const bool below = same && pt < pq;          // same key: the order of the entries is that of the positions
-                    before += below;
-                    best = max(best, below ? pt + 1u : 0u);
+                    before += same && pt < pq;                   // same key: the order of the entries is that of the positions
                 }
-                has_prev = before > 0; prev_pay = best - 1u;
             } else {
                 for (uint32_t t = s0; t < s1; ++t) {
                     const uint64_t kt = sk[t];
                     lt += kt < kq;
-                    if (kt == kq) {
-                        ++eq;
-                        const uint32_t pt = sp[t];
-                        if (pt < pq) { ++before; if (!has_prev || pt > prev_pay) { prev_pay = pt; has_prev = true; } }
-                    }
+                    if (kt == kq) { ++eq; before += sp[t] < pq; }
                 }
             }
             if (eq < 2) continue;                                // singleton k-mer: no partner, nobody reads its gen[] slot
             const uint32_t g = M.cblk ? genome_of_compact(M, pq) : blk2g[pq >> blk_shift];
-            const bool dup = has_prev && (M.cblk ? genome_of_compact(M, prev_pay) : blk2g[prev_pay >> blk_shift]) == g;
-            const uint32_t rs = b0 + s0 + lt;                    // first entry of this k-mer's run in the sorted list
-            sgen[s0 + lt + before] = g | (dup ? DUP_BIT : 0u);
-            if (dup) { atomicAdd(&dup_per_genome[g], 1); continue; }
-            if (before == 0) continue;                           // the run's smallest genome: no partner b < a
-            rowinfo[pq] = rs + 1u;
+            sgen[s0 + lt + before] = g;
+            if (before) { at[q] = (s0 + lt + before) | (before << 13); gq[q] = g; }      // (the run's smallest position: no partner b < a, not a repeat)
+        }
+        lds_sync();
+#pragma unroll
+        for (int q = 0; q < BK_PER; ++q) {
+            if (at[q] == 0xffffffffu) continue;
+            const uint32_t slot = at[q] & 0x1fffu, g = gq[q];
+            if ((sgen[slot - 1] & ~DUP_BIT) == g) { sgen[slot] = g | DUP_BIT; atomicAdd(&dup_per_genome[g], 1); continue; }
+            rowinfo[pj[q]] = b0 + (slot - (at[q] >> 13)) + 1u;   // 1 + the first entry of this k-mer's run in the sorted list
         }
         lds_sync();
         // (the slots of singleton k-mers carry whatever the LDS held: nobody reads them)
