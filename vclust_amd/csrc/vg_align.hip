@@ -513,13 +513,16 @@ k_build_index_lds(const ref_desc* __restrict__ refs, const int* __restrict__ slo
                     const int p0 = pb + u * 4 * (int)blockDim.x;
                     if (p0 >= n4) continue;
                     const uint32_t sh = (uint32_t)(p0 & 31);
+                    // (one funnel shift per plane and mask serves the four positions: bits 0 .. 3 + 7 + 7 from p0 on)
+                    const uint32_t XL = __builtin_amdgcn_alignbit(w4[u].z, w4[u].x, sh), XH = __builtin_amdgcn_alignbit(w4[u].w, w4[u].y, sh);
+                    const uint32_t XM = __builtin_amdgcn_alignbit(m1[u], m0[u], sh);
                     uint32_t out[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int p = p0 + j;
                         uint32_t bt = 0xffffffffu;
-                        if (p + w <= rd.n_rr && (__builtin_amdgcn_alignbit(m1[u], m0[u], sh + j) & ((1u << w) - 1u)) == 0) {
-                            const uint32_t xl = __builtin_amdgcn_alignbit(w4[u].z, w4[u].x, sh + j), xh = __builtin_amdgcn_alignbit(w4[u].w, w4[u].y, sh + j);
+                        if (p + w <= rd.n_rr && ((XM >> j) & ((1u << w) - 1u)) == 0) {
+                            const uint32_t xl = XL >> j, xh = XH >> j;
                             bt = bucket_of(xl, xh, msl) | (tag_of(xl, xh, msl, rd.tag_bits) << 18);
                             atomicAdd(&tab[(bt & 0x3ffffu) >> (big ? tsh : 0)], 1u);
                         }
@@ -844,12 +847,11 @@ k_build_index_mid(const ref_desc* __restrict__ refs, const int* __restrict__ slo
         const int n16 = (rd.n_rr + 15) & ~15;
         // a thread takes 16 positions per trip: one RR word, its successor and the N mask of the stretch.  The words of
         // the NEXT trip are asked for before this trip's are used (the passes are latency-bound: 16 waves per CU).
-        // (w = the planes (lo, hi) of the chunk of p0 and of the next one, already shifted to p0: p0 & 31 is 0 or 16 and
-        // the sixteen positions need the bits up to 15 + msl + tag <= 15 + 12 + 7 of each plane -- more than 32 for the long
-        // seeds, so the shift by j stays a funnel shift over both words)
+        // (w.x, w.y = the planes (lo, hi) from p0 on: p0 & 31 is 0 or 16, and the sixteen positions need the bits up to
+        // 15 + msl + tag <= 15 + 7 + 7 of each plane -- one word each, so position j's fields are plain bit fields at j)
         auto load16 = [&](int p0, uint4& w, uint32_t& ok) {
             __builtin_memcpy(&w, pk + 2 * (p0 >> 5), 16);
-            if (p0 & 16) { w.x = __builtin_amdgcn_alignbit(w.z, w.x, 16u); w.y = __builtin_amdgcn_alignbit(w.w, w.y, 16u); w.z >>= 16; w.w >>= 16; }
+            if (p0 & 16) { w.x = __builtin_amdgcn_alignbit(w.z, w.x, 16u); w.y = __builtin_amdgcn_alignbit(w.w, w.y, 16u); }
             const uint32_t m = __builtin_amdgcn_alignbit(mk[(p0 >> 5) + 1], mk[p0 >> 5], (uint32_t)(p0 & 31));
             uint32_t bad = m;                                     // bit j: an N among the symbols j .. j + msl - 1
             for (int q = 1; q < msl; ++q) bad |= m >> q;
@@ -866,7 +868,7 @@ k_build_index_mid(const ref_desc* __restrict__ refs, const int* __restrict__ slo
                 if (pn < n16) load16(pn, a, aok);
 #pragma unroll
                 for (int j = 0; j < 16; ++j)
-                    if ((ok >> j) & 1u) atomicAdd(&tab[bucket_of(__builtin_amdgcn_alignbit(w.z, w.x, (uint32_t)j), __builtin_amdgcn_alignbit(w.w, w.y, (uint32_t)j), msl)], 1u);
+                    if ((ok >> j) & 1u) atomicAdd(&tab[bucket_of(w.x >> j, w.y >> j, msl)], 1u);
                 p0 = pn; w = a; ok = aok;
             }
         }
@@ -892,16 +894,16 @@ k_build_index_mid(const ref_desc* __restrict__ refs, const int* __restrict__ slo
                     uint32_t hits = 0;
 #pragma unroll
                     for (int j = 0; j < 16; ++j)
-                        if (bucket_of(__builtin_amdgcn_alignbit(w.z, w.x, (uint32_t)j), __builtin_amdgcn_alignbit(w.w, w.y, (uint32_t)j), msl) - (uint32_t)b_lo < width) hits |= 1u << j;
+                        if (bucket_of(w.x >> j, w.y >> j, msl) - (uint32_t)b_lo < width) hits |= 1u << j;
                     hits &= ok;
                     while (hits) {                                // two hits per trip: both cursors are asked for before either entry is stored
                         const int j1 = __ffs(hits) - 1; hits &= hits - 1;
                         const int j2 = hits ? __ffs(hits) - 1 : -1; hits &= hits - 1;     // (0 & anything stays 0)
-                        const uint32_t xl1 = __builtin_amdgcn_alignbit(w.z, w.x, (uint32_t)j1), xh1 = __builtin_amdgcn_alignbit(w.w, w.y, (uint32_t)j1);
+                        const uint32_t xl1 = w.x >> j1, xh1 = w.y >> j1;
                         const uint32_t s1 = atomicAdd(&tab[bucket_of(xl1, xh1, msl)], 1u);
                         uint32_t xl2 = 0, xh2 = 0, s2 = 0;
                         if (j2 >= 0) {
-                            xl2 = __builtin_amdgcn_alignbit(w.z, w.x, (uint32_t)j2); xh2 = __builtin_amdgcn_alignbit(w.w, w.y, (uint32_t)j2);
+                            xl2 = w.x >> j2; xh2 = w.y >> j2;
                             s2 = atomicAdd(&tab[bucket_of(xl2, xh2, msl)], 1u);
                         }
                         const uint32_t e1 = (uint32_t)(p0 + j1) | (tag_of(xl1, xh1, msl, rd.tag_bits) << rd.pos_bits);
