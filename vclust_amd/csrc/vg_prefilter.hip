@@ -132,6 +132,21 @@ __device__ __forceinline__ void kmers4_words(const kmer_args& A, uint32_t p0_low
                                              uint32_t m0, uint32_t m1, uint64_t out[4]) {
     const uint32_t sh = p0_low & 31u;                                     // <= 28
     const uint32_t nk = (1u << A.k) - 1u;
+    if (A.k <= 29) {
+        // the four windows are bits j .. j + k - 1 <= 31 of the 32 bases from p0 on: one funnel shift per plane and one
+        // for the mask serve all four, and a wave whose positions are all valid (every wave but the few that touch a
+        // genome end or an N) runs the four k-mers as straight-line code
+        const uint32_t XL = __builtin_amdgcn_alignbit(l1, l0, sh), XH = __builtin_amdgcn_alignbit(h1, h0, sh);
+        const uint32_t XM = __builtin_amdgcn_alignbit(m1, m0, sh);
+        if (__all((XM & ((8u << A.k) - 1u)) == 0)) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out[j] = canon_key(A, XL >> j, XH >> j);
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[j] = (((XM >> j) & nk) == 0) ? canon_key(A, XL >> j, XH >> j) : SENT;
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         uint64_t key = SENT;
