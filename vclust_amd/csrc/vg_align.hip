@@ -881,7 +881,18 @@ k_build_index_mid(const ref_desc* __restrict__ refs, const int* __restrict__ slo
             int lo = b_lo, hi = nb;                               // invariant: the buckets [b_lo, lo) fit
             while (lo < hi) { const int mid = (lo + hi + 1) >> 1; const uint32_t e = mid < nb ? tab[mid] : total; if (e - base <= (uint32_t)MID_STAGE) lo = mid; else hi = mid - 1; }
             const bool direct = lo == b_lo;                       // ONE bucket beyond the staging window: its entries go straight out
-            const int b_hi = direct ? b_lo + 1 : lo;
+            // A window that starts and ends where the HIGH plane's field changes (bucket = lo field | hi field << msl) is
+            // tested on that field alone -- three instructions per position and pass instead of five.  From an aligned
+            // start the window is cut back to the last such boundary it reaches; a group of 2^msl buckets too large
+            // for one window is taken bucket by bucket up to its end, which is a boundary again.
+            const int gmask = (1 << msl) - 1;
+            int b_hi = direct ? b_lo + 1 : lo;
+            if (!direct) {
+                if ((b_lo & gmask) == 0) { if ((b_hi & ~gmask) > b_lo) b_hi &= ~gmask; }
+                else b_hi = min(b_hi, (b_lo | gmask) + 1);
+            }
+            const bool by_hi = ((b_lo | b_hi) & gmask) == 0;
+            const uint32_t h_lo = (uint32_t)(b_lo >> msl), h_w = (uint32_t)((b_hi - b_lo) >> msl);
             const uint32_t w_end = b_hi < nb ? tab[b_hi] : total;
             const uint32_t width = (uint32_t)(b_hi - b_lo);
             lds_sync();                                           // (everybody has read the table before its cursors move)
@@ -892,9 +903,15 @@ k_build_index_mid(const ref_desc* __restrict__ refs, const int* __restrict__ slo
                     const int pn = p0 + 16384; uint4 a = make_uint4(0u, 0u, 0u, 0u); uint32_t aok = 0;
                     if (pn < n16) load16(pn, a, aok);
                     uint32_t hits = 0;
+                    if (by_hi) {
 #pragma unroll
-                    for (int j = 0; j < 16; ++j)
-                        if (bucket_of(w.x >> j, w.y >> j, msl) - (uint32_t)b_lo < width) hits |= 1u << j;
+                        for (int j = 0; j < 16; ++j)
+                            if (((w.y >> j) & (uint32_t)gmask) - h_lo < h_w) hits |= 1u << j;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 16; ++j)
+                            if (bucket_of(w.x >> j, w.y >> j, msl) - (uint32_t)b_lo < width) hits |= 1u << j;
+                    }
                     hits &= ok;
                     while (hits) {                                // two hits per trip: both cursors are asked for before either entry is stored
                         const int j1 = __ffs(hits) - 1; hits &= hits - 1;
