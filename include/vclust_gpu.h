@@ -78,7 +78,8 @@ const char* vg_genomes_name(const vg_genomes* g, int idx);
 /* the bases of genome idx as the set holds them on the host (codes 0..3 = ACGT, 4 = N), out = len[idx] bytes:
  * the inverse of the packing, for checks of the reader (no reference call site) */
 int         vg_genomes_codes(const vg_genomes* g, int idx, uint8_t* out);
-/* 2-bit packed bases + N mask -> HBM of the current device (idempotent) */
+/* 2-bit packed bases + N mask -> HBM of the current device (idempotent); the kernels' own copy of the bases -- bit planes,
+ * DESIGN.md section 3 -- is made from them on the device at the first prefilter / align call */
 int vg_genomes_to_device(vg_genomes* g);
 
 /* ------------------------------------------------------------------ prefilter --------- */
