@@ -38,6 +38,21 @@ def test_kmer_sets_example(example):
         assert np.array_equal(mine, ref)
 
 
+@pytest.mark.parametrize('k', [12, 28, 29, 30, 31])
+def test_kmer_sets_from_bit_planes(example, k):
+    """The kernels read k-mers off the bit planes and keep (hi plane : lo plane) of the smaller strand as the key; what
+    leaves through vg_kmer_set is the oracle's number again (2-bit codes, first base most significant).  k = 29 is the
+    last k whose four windows come out of one funnel shift per plane, 30 and 31 take one per position."""
+    codes, offsets, names, gs = example
+    for idx in (1, 7):
+        mine = gs.kmer_set(idx, k)
+        ref = orc.kmer_set(codes[offsets[idx]:offsets[idx + 1]], k)
+        assert np.array_equal(mine, ref), k
+    sizes, pairs = gs.kmer_shared(k=k)
+    osizes, opairs = orc.shared_all(codes, offsets, k=k)
+    assert list(sizes) == list(osizes) and _pairs_dict(pairs) == opairs
+
+
 @pytest.mark.parametrize('k', [25, 20, 30, 15])
 def test_kmer_shared_example(example, k):
     codes, offsets, names, gs = example
