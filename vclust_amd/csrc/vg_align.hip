@@ -1040,7 +1040,7 @@ struct task_dev { uint32_t q, r_slot, out_idx, pad; };
 // the two parses are the same parse.  The chain of such hand-overs is followed from wave 0 and the
 // partial sums are added up; the result is identical to the single-wave parse, only the critical
 // path is ~S times shorter.
-constexpr int SEG_LOG_CAP = 256;
+constexpr int SEG_LOG_CAP = 250;          // (4 x 250 records + the hand-over words: 20 KiB of LDS per workgroup, eight workgroups per CU)
 constexpr int PW_AFTER_EVENT = 32;
 struct seg_rec { int i_ev, ev_pos; uint32_t VM, VA, VN; };     // VN: bit 31 = open region already spans >= reg
 
