@@ -1770,17 +1770,18 @@ void lz_plan_references(const vg_genomes* g, const vg_lz_params* p, lz_plan& P) 
         lz_batch& B = batches.back();
         B.first_ref = (int)ri;
         int64_t bytes = 0;
+        B.chunk_off.reserve(ref_ids.size() - ri + 1); B.reg_list.reserve(ref_ids.size() - ri);
+        const int tag_want = 2 * (p->mal - p->msl);
         while (ri < ref_ids.size()) {
             const uint32_t r = ref_ids[ri];
             const int64_t L = g->len[r]; const int64_t n_rr = 2 * L + 1;
             int64_t chunks = 0; const int64_t need = lz_ref_need(g, p, r, &chunks);
             if (B.n_refs > 0 && bytes + need > batch_budget) break;
-            ref_desc rd; memset(&rd, 0, sizeof rd);
+            ref_desc& rd = all_refs[ri];                         // (zeroed by the assign above)
             rd.rr_w = B.rr_words; rd.mask_w = B.mask_words; rd.stab = B.stab_tot; rd.sent = B.sent_n;
             rd.L = (int32_t)L; rd.n_rr = (int32_t)n_rr; rd.genome = (int32_t)r; rd.has_n = g->has_n[r];
-            { int pb = 1; while ((1LL << pb) < n_rr) ++pb; rd.pos_bits = pb; }
-            rd.tag_bits = std::max(0, std::min({ 2 * (p->mal - p->msl), 14, 32 - rd.pos_bits }));
-            all_refs[ri] = rd;
+            rd.pos_bits = n_rr <= 2 ? 1 : 64 - __builtin_clzll((unsigned long long)(n_rr - 1));       // the smallest pb >= 1 with 2^pb >= n_rr
+            rd.tag_bits = std::max(0, std::min({ tag_want, 14, 32 - rd.pos_bits }));
             B.rr_words += chunks * 2; B.mask_words += chunks; B.stab_tot += stab_n; B.sent_n += n_rr;
             B.chunk_off.push_back(B.chunk_off.back() + chunks);
             bytes += need; ++B.n_refs; ++ri;
@@ -1823,10 +1824,12 @@ void lz_plan_references(const vg_genomes* g, const vg_lz_params* p, lz_plan& P) 
             B.scratch_words = (int64_t)B.nblk_build * B.stride * 3;
         }
     }
+    vg_host_mark("lz plan: batches cut");
     // ---- the reference descriptors of the whole call go up once; one set of index buffers, sized for the largest
     // batch, is reused by every batch
     P.d_refs.alloc(std::max<size_t>(1, all_refs.size()));
     if (!all_refs.empty()) P.d_refs.upload(all_refs.data(), all_refs.size(), s);
+    vg_host_mark("lz plan: descriptors queued");
     size_t m_rr = 0, m_mask = 0, m_stab = 1, m_sent = 0, m_scr = 1, m_reg = 1, m_mid = 1, m_small = 1, m_large = 1, m_lch = 1;
     for (auto& B : batches) {
         m_rr = std::max(m_rr, (size_t)B.rr_words); m_mask = std::max(m_mask, (size_t)B.mask_words);
@@ -1901,7 +1904,9 @@ extern "C" int vg_lz_prepare(vg_genomes* g, const vg_pair_count* pairs, int64_t 
     std::unique_ptr<lz_plan> plan(new lz_plan);
     for (int i = 0; i < g->n; ++i) if (is_ref[(size_t)i]) plan->ref_ids.push_back((uint32_t)i);
     plan->g = g;
+    vg_host_mark("lz prepare: references listed");
     lz_plan_references(g, p, *plan);
+    vg_host_mark("lz prepare: planned");
     // (developer experiment VG_LZ_PREPARE_QUEUE=own: the build runs on a queue of its own, beside whatever the caller
     // launches next on the library's queue -- a prefilter pass, if the references are known before it)
     static const bool own_queue = [] { const char* e = vg_dev_getenv("VG_LZ_PREPARE_QUEUE"); return e && !strcmp(e, "own"); }();
