@@ -685,7 +685,10 @@ constexpr int REG_STAGE = REG_LDS_WORDS / 1024 * 1024;  // entries per staging w
 constexpr int REG_STAGE0 = (REG_LDS_WORDS - LDS_TAB) / 1024 * 1024;   // slots staged while the table is still live
 constexpr int REG_SLOT_BITS = 17;                       // slot < n_rr < 2^17; tag (<= 14 bits) above it
 
-// RR, bucket table and entries of ONE reference by the 1 024 threads of a workgroup (lds: REG_LDS_WORDS words)
+// RR, bucket table and entries of ONE reference by the 1 024 threads of a workgroup (lds: REG_LDS_WORDS words).
+// IT: trips of 4 positions x 1 024 threads the registers hold -- 24 (references up to REG_MAX_RR symbols), 20 (the 40 kb
+// genomes of the benchmark sets: 16 registers and a sixth of every pass less), 16, 12, 8 or 4 (contigs of a few kb).
+template <int IT>
 __device__ __forceinline__ void build_ref_reg(uint32_t* const lds, const ref_desc rd,
                   const uint32_t* __restrict__ gplanes, const uint32_t* __restrict__ nmask, const int64_t* __restrict__ base_off,
                   uint32_t* __restrict__ rr_pool, uint32_t* __restrict__ mask_pool, int msl,
@@ -718,10 +721,10 @@ __device__ __forceinline__ void build_ref_reg(uint32_t* const lds, const ref_des
         }
         lds_sync();
         // pass 0: bucket | tag << 18 of every position (4 consecutive positions out of one 128-bit window), bucket sizes
-        uint32_t reg[REG_IT][4];
+        uint32_t reg[IT][4];
         const int n4 = (rd.n_rr + 3) & ~3;
 #pragma unroll
-        for (int it = 0; it < REG_IT; ++it) {
+        for (int it = 0; it < IT; ++it) {
             const int p0 = 4 * (tid + 1024 * it);
             reg[it][0] = reg[it][1] = reg[it][2] = reg[it][3] = 0xffffffffu;
             if (p0 < n4) {
@@ -755,7 +758,7 @@ __device__ __forceinline__ void build_ref_reg(uint32_t* const lds, const ref_des
             uint32_t t4 = 4u * (uint32_t)tid;
             asm volatile("" : "+v"(t4));
 #pragma unroll
-            for (int it = 0; it < REG_IT; ++it) {
+            for (int it = 0; it < IT; ++it) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const uint32_t bt = reg[it][j];
@@ -783,7 +786,7 @@ __device__ __forceinline__ void build_ref_reg(uint32_t* const lds, const ref_des
             uint32_t t4 = 4u * (uint32_t)tid;
             asm volatile("" : "+v"(t4));                         // nothing below is hoisted out of the window loop (it would triple the live registers)
 #pragma unroll
-            for (int it = 0; it < REG_IT; ++it) {
+            for (int it = 0; it < IT; ++it) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     uint32_t v = reg[it][j];
@@ -800,6 +803,7 @@ __device__ __forceinline__ void build_ref_reg(uint32_t* const lds, const ref_des
         }
     }
 }
+template <int IT>
 __global__ void __launch_bounds__(1024)
 k_build_index_reg(const ref_desc* __restrict__ refs, const int* __restrict__ slot_list, int n_list,
                   const uint32_t* __restrict__ gplanes, const uint32_t* __restrict__ nmask, const int64_t* __restrict__ base_off,
@@ -807,7 +811,7 @@ k_build_index_reg(const ref_desc* __restrict__ refs, const int* __restrict__ slo
                   uint32_t* __restrict__ stab_pool, uint32_t* __restrict__ sent_pool) {
     __shared__ uint32_t lds[REG_LDS_WORDS];
     for (int li = blockIdx.x; li < n_list; li += gridDim.x)
-        build_ref_reg(lds, refs[slot_list[li]], gplanes, nmask, base_off, rr_pool, mask_pool, msl, stab_pool, sent_pool);
+        build_ref_reg<IT>(lds, refs[slot_list[li]], gplanes, nmask, base_off, rr_pool, mask_pool, msl, stab_pool, sent_pool);
 }
 
 // ---- path A1 (references of REG_MAX_RR .. MID_MAX_RR symbols -- genomes of 49 .. 262 kb --, msl <= 7): the positions do
@@ -1463,6 +1467,7 @@ struct lz_batch {
     int first_ref = 0, n_refs = 0;       // reference ordinals [first_ref, first_ref + n_refs)
     std::vector<int64_t> chunk_off{ 0 };
     std::vector<int> reg_list, mid_list, small_list, large_list; std::vector<int64_t> large_chunks{ 0 };
+    int reg_class_end[6] = {0, 0, 0, 0, 0, 0};      // reg_list is ordered by register class (24, 20, 16, 12, 8, 4 trips): end of each class
     int64_t rr_words = 0, mask_words = 0, stab_tot = 0, sent_n = 0, scratch_words = 0, stride = 0;
     int nblk_build = 0;
     double bytes_alg = 0; int64_t q_max = 0, q_sum = 0;          // SURVEY 8(d) bytes of the batch; longest / total query
@@ -1817,6 +1822,17 @@ void lz_plan_references(const vg_genomes* g, const vg_lz_params* p, lz_plan& P) 
             }
         };
         longest_first(B.reg_list); longest_first(B.mid_list); longest_first(B.small_list);
+        {   // the register build comes in six sizes (24 .. 4 trips of 4 096 positions): a reference takes the smallest that
+            // holds it, so a 4 kb contig does not pay the register passes of a 49 kb genome; classes are contiguous in the list
+            std::vector<int> by_class[6];
+            for (int i : B.reg_list) {
+                const int trips = (all_refs[(size_t)i].n_rr + 256 + 4095) / 4096;        // (REG_MAX_RR leaves 256 symbols of slack)
+                const int cls = trips > 20 ? 0 : trips > 16 ? 1 : trips > 12 ? 2 : trips > 8 ? 3 : trips > 4 ? 4 : 5;
+                by_class[cls].push_back(i);
+            }
+            B.reg_list.clear();
+            for (int c = 0; c < 6; ++c) { B.reg_list.insert(B.reg_list.end(), by_class[c].begin(), by_class[c].end()); B.reg_class_end[c] = (int)B.reg_list.size(); }
+        }
         if (!B.small_list.empty()) {
             int64_t max_rr = 0; for (int i : B.small_list) max_rr = std::max<int64_t>(max_rr, all_refs[(size_t)i].n_rr);
             B.nblk_build = (int)std::min<size_t>(B.small_list.size(), 512);
@@ -1855,9 +1871,13 @@ void lz_build_batch(const vg_genomes* g, const vg_lz_params* p, lz_plan& P, size
     vg_prof_scope ps("lz_build_index", (double)total_chunks * 32 * (0.375 + 0.375 + 4), sb);
     if (!B.large_list.empty()) VG_HIP(hipMemsetAsync(L.stab_pool.p, 0, (size_t)B.stab_tot * sizeof(uint32_t), sb));
     if (!B.reg_list.empty()) {
-        hipLaunchKernelGGL(k_build_index_reg, dim3((unsigned)std::min<size_t>(B.reg_list.size(), 512)), dim3(1024), 0, sb, d_refs.p, L.d_reg.p,
-                           (int)B.reg_list.size(), gpl, g->d_nmask.p, g->d_base_off.p, L.rr_pool.p, L.mask_pool.p, p->msl,
-                           L.stab_pool.p, L.sent_pool.p);
+        auto launch = [&](auto kern, int first, int end) {
+            if (end > first) hipLaunchKernelGGL(kern, dim3((unsigned)std::min(end - first, 512)), dim3(1024), 0, sb, d_refs.p, L.d_reg.p + first,
+                                                end - first, gpl, g->d_nmask.p, g->d_base_off.p, L.rr_pool.p, L.mask_pool.p, p->msl, L.stab_pool.p, L.sent_pool.p);
+        };
+        const int* ce = B.reg_class_end;
+        launch(k_build_index_reg<24>, 0, ce[0]); launch(k_build_index_reg<20>, ce[0], ce[1]); launch(k_build_index_reg<16>, ce[1], ce[2]);
+        launch(k_build_index_reg<12>, ce[2], ce[3]); launch(k_build_index_reg<8>, ce[3], ce[4]); launch(k_build_index_reg<4>, ce[4], ce[5]);
     }
     if (!B.mid_list.empty()) {
         hipLaunchKernelGGL(k_build_index_mid, dim3((unsigned)std::min<size_t>(B.mid_list.size(), 512)), dim3(1024), 0, sb, d_refs.p, L.d_mid.p,
