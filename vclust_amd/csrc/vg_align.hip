@@ -1554,7 +1554,8 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
         dbuf<uint32_t> d_cnt((size_t)g->n), d_keys((size_t)n_tasks), d_vals((size_t)n_tasks), d_keys2((size_t)n_tasks), d_vals2((size_t)n_tasks);
         dbuf<unsigned long long> d_sums(4);
         d_cnt.zero(s); d_sums.zero(s);
-        hipLaunchKernelGGL(k_task_count, dim3(grid_for(n_tasks)), dim3(256), 0, s, (const vg_task*)d_raw.p, n_tasks, g->n, g->d_len.p, d_cnt.p,
+        hipLaunchKernelGGL(k_task_count, dim3(grid_for(n_tasks, 256, 512)), dim3(256), 0, s,   // (few workgroups: every wave ends in three atomics on the same words)
+                           (const vg_task*)d_raw.p, n_tasks, g->n, g->d_len.p, d_cnt.p,
                            d_keys.p, d_vals.p, d_sums.p);
         std::vector<uint32_t> cnt((size_t)g->n); unsigned long long sums[4];
         d_cnt.download(cnt.data(), cnt.size(), s); d_sums.download(sums, 4, s);
