@@ -55,6 +55,11 @@ def test_ragged_families_with_n(seed):
     dict(mal=14, msl=7, mrd=60, mqd=70, reg=50, aw=25, am=12, ar=4),
     dict(mal=11, msl=7, mrd=40, mqd=40, reg=35, aw=32, am=15, ar=1),
     dict(mal=16, msl=5, mrd=10, mqd=5, reg=1, aw=3, am=0, ar=3),
+    # the ends of the ranges the library takes: long seeds (bucket = 12 bits of each bit plane, the global index build),
+    # the longest anchors (a 31-bit validity mask of the query), the shortest of both
+    dict(mal=31, msl=12, mrd=40, mqd=40, reg=35, aw=15, am=7, ar=3),
+    dict(mal=20, msl=9, mrd=40, mqd=100, reg=35, aw=15, am=7, ar=16),
+    dict(mal=8, msl=4, mrd=40, mqd=40, reg=10, aw=15, am=7, ar=3),
 ])
 def test_non_default_lz_parameters(lz):
     codes, offsets, names = synth.make_families(5, 4, seed=11, length=8000, p_hi=0.25)
