@@ -9,11 +9,12 @@
 // the prediction and the anchor lookup, and the lane makes the R2/R3 choice between them); a
 // ballot + find-first picks the first hit, which is exactly the sequential result.  Exact
 // extension, the (aw, am, ar) approximate extension and the gap score (best placement of one
-// indel, R7) are bit-parallel: every lane compares 32 bases (one u64 of 2-bit codes), window rule
-// and split points are evaluated on match / mismatch bit masks with ballots.  Only integers leave.
+// indel, R7) are bit-parallel: every lane compares 32 bases (their two bit planes: three logic operations give the
+// 32-bit mismatch mask), window rule and split points are evaluated on match / mismatch bit masks with ballots.
+// Only integers leave.
 //
 // Reference side: per reference genome, RR = forward | N | reverse complement is materialised
-// 2-bit packed (+ N mask) with ONE direct-address index built on the device: 4^msl buckets of
+// as bit planes (+ N mask) with ONE direct-address index built on the device: 4^msl buckets of
 // entries pos | tag, tag = the bases behind the msl-mer (an anchor candidate is an entry whose tag
 // equals the query's).  The strands are separate worlds: every extension, window and gap score is
 // clipped to the strand of its match (the oracle's long separator).  Integer, latency-bound work:
@@ -30,7 +31,6 @@
 namespace {
 
 constexpr int RR_PAD = 128;     // mask=1 padding bases behind RR
-constexpr uint64_t EVEN = 0x5555555555555555ULL;
 
 struct ref_desc {
     int64_t rr_w;      // word offset of packed RR
@@ -61,32 +61,11 @@ struct lz_dev_params { int mal, msl, mrd, mqd, reg, aw, am, ar; int ablate; int 
 // lane-to-lane carries -- is 32-bit arithmetic (the 2-bit layout gave a 64-bit mask with every second bit unused:
 // twice the VALU instructions for each of those steps, round 5).
 
-// 32 bases (2-bit codes, first base in the low bits) starting at base position p (p >= 0) of a 2-bit packed array
-__device__ __forceinline__ uint64_t load32(const uint32_t* __restrict__ pk, int64_t p) {
-    const uint32_t off = ((uint32_t)p >> 4) << 2; const int sh = 2 * (int)(p & 15);
-    uint4 v; __builtin_memcpy(&v, (const char*)pk + off, 16);          // one 16-byte load (4-byte aligned); every packed array has slack words
-    asm volatile("" :: "v"(v.w));                      // keep it one instruction (the narrowed form is two loads)
-    return (uint64_t)__builtin_amdgcn_alignbit(v.y, v.x, (uint32_t)sh) | ((uint64_t)__builtin_amdgcn_alignbit(v.z, v.y, (uint32_t)sh) << 32);
-}
 // 32 mask bits starting at base position p
 __device__ __forceinline__ uint32_t loadm32(const uint32_t* __restrict__ mk, int64_t p) {
     int64_t w = p >> 5; int sh = (int)(p & 31);
     uint64_t m = (uint64_t)mk[w] | ((uint64_t)mk[w + 1] << 32);
     return (uint32_t)(m >> sh);
-}
-// spread 32 bits to the even bit positions of a u64
-__device__ __forceinline__ uint64_t spread(uint32_t v) {
-    uint64_t x = v;
-    x = (x | (x << 16)) & 0x0000FFFF0000FFFFULL;
-    x = (x | (x << 8)) & 0x00FF00FF00FF00FFULL;
-    x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0FULL;
-    x = (x | (x << 2)) & 0x3333333333333333ULL;
-    x = (x | (x << 1)) & EVEN;
-    return x;
-}
-__device__ __forceinline__ uint64_t rev2(uint64_t x) {
-    x = __brevll(x);
-    return ((x >> 1) & EVEN) | ((x & EVEN) << 1);
 }
 // even-bit mask (one base per 2 bits) -> one bit per base
 __device__ __forceinline__ uint32_t squeeze16(uint32_t x) {       // the 16 even bits of x -> its low 16 bits
