@@ -185,6 +185,12 @@ void vg_set_subshards(int n);
  * computed by this process: one GPU stands in for the world (tools/strong_scaling_sim.py, tests).  Results are identical.
  * vg_kmer_shared_sharded always exchanges when the sliced scan applies; no reference call site (kmer-db is one process). */
 void vg_set_range_scan(int mode);
+/* Placement trials: the first dense whole-set pass of vg_kmer_shared in a long-lived process may
+ * repeat itself on up to n freshly allocated workspaces and keep the fastest placement (same results; ~0.25 s per
+ * placement at 100 k genomes, once).  n <= 1 = none, THE DEFAULT: an embedding application opts in (bench.py does, and
+ * says so in its line).  Any failure inside a trial pass is swallowed: the call returns what its first pass computed.
+ * No reference call site (kmer-db is one process per call). */
+void vg_set_placement_trials(int n);
 
 typedef struct {            /* mirrors the align sub-parser and cmd_lzani, vclust.py:290-421, 1142-1181 */
     vg_lz_params lz;

@@ -103,6 +103,7 @@ SYMBOLS = {
     'vg_set_index_budget': (None, [C.c_int64]),
     'vg_set_subshards': (None, [C.c_int]),
     'vg_set_range_scan': (None, [C.c_int]),
+    'vg_set_placement_trials': (None, [C.c_int]),
     'vg_write_ani': (C.c_int, [C.c_void_p, P(Task), P(PairStat), C.c_int64, P(Region), C.c_int64,
                                C.c_char_p, P(AlignParams)]),
     'vg_align': (C.c_int, [P(C.c_char_p), C.c_int, C.c_char_p, P(AlignParams)]),

@@ -244,6 +244,11 @@ def set_range_scan(mode):
     _lib.load().vg_set_range_scan(int(mode))
 
 
+def set_placement_trials(n):
+    """Placements of the prefilter workspace the first dense pass of this process may try (vg_set_placement_trials; 1 = none, the default)."""
+    _lib.load().vg_set_placement_trials(int(n))
+
+
 def release_device_memory():
     _lib.load().vg_release_device_memory()
 

@@ -1471,7 +1471,8 @@ std::unique_ptr<lz_plan> g_prepared;          // left by vg_lz_prepare for the n
 }
 void vg_lz_drop_prepared(const vg_genomes* g) {
     std::lock_guard<std::mutex> lk(g_prep_mu);
-    if (g_prepared && (!g || g_prepared->g == g)) { (void)hipStreamSynchronize(vg_stream()); g_prepared.reset(); }
+    // (a build deferred to the next SpGEMM -- developer experiment -- holds a raw pointer to the plan: it goes with it)
+    if (g_prepared && (!g || g_prepared->g == g)) { vg_set_spgemm_hook(nullptr); (void)hipStreamSynchronize(vg_stream()); g_prepared.reset(); }
 }
 
 // The genome set as bit planes (what the parse reads its queries from): made once per resident set, on the library's
@@ -1489,10 +1490,20 @@ k_genome_planes(const uint32_t* __restrict__ packed, int64_t n_pairs, uint32_t* 
 static std::mutex g_planes_mu;
 const uint32_t* vg_genome_planes(const vg_genomes* g, hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_planes_mu);
+    // The planes are always MADE on the library's stream; a caller on another queue (the developer experiments that build
+    // indexes on a queue of their own) waits for that stream's work up to here, whether this call launched the kernel or an
+    // earlier one did -- a pointer returned to a second queue never names planes that are still being written.
+    hipStream_t lib = vg_stream();
     if (g->d_planes.n != g->d_packed.n || !g->d_planes.p) {
         const size_t words = g->d_packed.n & ~(size_t)1;
         g->d_planes.alloc(g->d_packed.n);
-        hipLaunchKernelGGL(k_genome_planes, dim3(grid_for((int64_t)(words / 2))), dim3(256), 0, s, (const uint32_t*)g->d_packed.p, (int64_t)(words / 2), g->d_planes.p);
+        hipLaunchKernelGGL(k_genome_planes, dim3(grid_for((int64_t)(words / 2))), dim3(256), 0, lib, (const uint32_t*)g->d_packed.p, (int64_t)(words / 2), g->d_planes.p);
+    }
+    if (s != lib) {
+        hipEvent_t e = nullptr;
+        VG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        VG_HIP(hipEventRecord(e, lib)); VG_HIP(hipStreamWaitEvent(s, e, 0));
+        (void)hipEventDestroy(e);
     }
     return g->d_planes.p;
 }
@@ -1595,6 +1606,7 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
     {
         std::lock_guard<std::mutex> lk(g_prep_mu);
         if (g_prepared) {
+            vg_set_spgemm_hook(nullptr);                          // (a deferred build that has not run yet never will: the plan changes hands or goes)
             lz_plan& Q = *g_prepared;
             if (Q.g == g && Q.mal == p->mal && Q.msl == p->msl && Q.ref_ids == ref_ids && Q.budget == lz_batch_budget(g, p, ref_ids)) plan = std::move(g_prepared);
             else g_prepared.reset();                             // (its pools go back to the allocator: one stream, in order)

@@ -49,7 +49,10 @@ namespace {
 // vg_release_device_memory on a helper thread for the lifetime of the object (joined at its end, also when the writer throws)
 struct background_release {
     std::thread th;
-    background_release() { try { th = std::thread([] { vg_release_device_memory(); }); } catch (...) { vg_release_device_memory(); } }
+    // (best effort: the thread selects the library's device first -- a fresh thread starts on device 0 --, and nothing it
+    // throws may leave it: a failure only means the blocks stay cached until the next release)
+    static void release() noexcept { try { vg_require_device(); vg_release_device_memory(); } catch (...) { (void)hipGetLastError(); } }
+    background_release() { try { th = std::thread([] { release(); }); } catch (...) { release(); } }
     ~background_release() { if (th.joinable()) th.join(); }
 };
 }

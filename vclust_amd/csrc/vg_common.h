@@ -151,6 +151,7 @@ struct vg_slice_exchange {
 // whether a shard pass of (g, k, fraction) over `world` ranks takes the sliced scan: a pure function of its arguments
 void vg_set_spgemm_hook(std::function<void()> fn);      // developer experiment: run once right before the next SpGEMM launch
 bool vg_slice_exchange_applies(const vg_genomes* g, int k, double fraction, int world);
+int vg_kmer_shard_mode(const vg_genomes* g, double fraction, int n_shards);      // 1 = RANGE shards, 2 = HASH shards (what a rank of an n_shards-way call would do)
 // one k-mer range shard of vg_kmer_shared with the (a, b, shared) records left in HBM (vg_prefilter.hip; used by vg_dist.hip)
 void vg_kmer_shared_device(vg_genomes* g, int k, double fraction, int shard, int n_shards, uint32_t min_shared,
                            int64_t* set_sizes, dbuf<vg_pair_count>& pairs, int64_t* n_pairs, vg_slice_exchange* xs = nullptr,

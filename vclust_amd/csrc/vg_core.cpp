@@ -212,6 +212,7 @@ namespace {
 struct block_info { size_t size; int device; };
 std::mutex g_alloc_mu;
 std::multimap<size_t, void*> g_free_blocks;          // size -> block (blocks of the current device only)
+static size_t g_parked_bytes = 0;                    // blocks set aside by vg_dev_park_cache (under g_alloc_mu): the process's own memory, like live and cached ones
 std::map<void*, block_info> g_block_size;            // every live or cached block and the device that owns it
 size_t g_cached_bytes = 0, g_live_bytes = 0;
 constexpr size_t ALLOC_GRAN = 1 << 12;
@@ -344,7 +345,7 @@ void* vg_dev_alloc(size_t bytes) {
             (void)hipGetLastError();
             size_t fr = 0, tot = 0;
             if (hipMemGetInfo(&fr, &tot) != hipSuccess || want > tot) break;
-            size_t mine = 0; { std::lock_guard<std::mutex> lk(g_alloc_mu); mine = g_live_bytes + g_cached_bytes; }
+            size_t mine = 0; { std::lock_guard<std::mutex> lk(g_alloc_mu); mine = g_live_bytes + g_cached_bytes + g_parked_bytes; }
             const size_t used = tot - fr, foreign = used > mine ? used - mine : 0;
             if (fr >= want || foreign + fr < want) break;              // (enough is free: fragmentation, waiting does not help; or nobody else holds enough)
             std::this_thread::sleep_for(std::chrono::milliseconds(50));
@@ -393,7 +394,7 @@ void vg_dev_trim() {
 static std::multimap<size_t, void*> g_parked;
 void vg_dev_park_cache() {
     std::lock_guard<std::mutex> lk(g_alloc_mu);
-    for (auto& kv : g_free_blocks) g_parked.emplace(kv.first, kv.second);
+    for (auto& kv : g_free_blocks) { g_parked.emplace(kv.first, kv.second); g_parked_bytes += kv.first; }
     g_free_blocks.clear(); g_cached_bytes = 0;
 }
 size_t vg_dev_cached_bytes() { std::lock_guard<std::mutex> lk(g_alloc_mu); return g_cached_bytes; }
@@ -406,12 +407,17 @@ void vg_dev_unpark(bool restore_parked) {
             if (restore_parked) { g_free_blocks.emplace(kv.first, kv.second); g_cached_bytes += kv.first; }
             else { drop.push_back(kv.second); g_block_size.erase(kv.second); }
         }
-        g_parked.clear();
+        g_parked.clear(); g_parked_bytes = 0;
     }
     if (!drop.empty()) { (void)hipDeviceSynchronize(); for (void* b : drop) raw_free(b); }
 }
 
-extern "C" void vg_release_device_memory(void) { vg_lz_drop_prepared(nullptr); vg_dev_unpark(false); vg_dev_trim(); }
+extern "C" void vg_release_device_memory(void) {
+    // (callable from any thread: the calling thread is put on the library's device first, so that the synchronisation in
+    // front of the frees waits for THAT device's queues; no exception crosses the C boundary)
+    try { vg_require_device(); vg_lz_drop_prepared(nullptr); vg_dev_unpark(false); vg_dev_trim(); }
+    catch (...) { (void)hipGetLastError(); }
+}
 
 // allocator self-test: `cycles` times allocate blocks of the given sizes from the library's allocator (whichever path
 // VG_ALLOC selects), write a pattern into the first and last MiB of each with a copy from the host, read it back,

@@ -66,6 +66,7 @@ struct vg_comm {
     decltype(&ncclSend) p_send = nullptr; decltype(&ncclRecv) p_recv = nullptr;
     decltype(&ncclGroupStart) p_group_start = nullptr; decltype(&ncclGroupEnd) p_group_end = nullptr;
     decltype(&ncclCommCount) p_count = nullptr;
+    decltype(&ncclCommAbort) p_abort = nullptr;
     // HBM staging of host gathers over RCCL: reserved inside guarded sections, so that an allocation failure is
     // agreed on like any other instead of striking between an agreement and its exchange
     mutable dbuf<char> st_send, st_recv;
@@ -126,6 +127,33 @@ void agree_same(const vg_comm* c, int my_rc, uint32_t checksum, const char* what
     for (int r = 1; r < c->world; ++r) if (all[(size_t)2 * r + 1] != all[1])
         throw vg_error(VG_EINVAL, std::string(what) + ": rank " + std::to_string(r) + " and rank 0 " + mismatch);
 }
+// the agreement in front of an all-to-all: status and plan word as in agree_same, plus every rank's block sizes in both
+// directions -- each rank holds the whole (sender, receiver) matrix afterwards and all reach the same verdict: a layout two
+// ranks computed differently (word_of / st_of from different tile counts) stops every rank HERE instead of hanging or
+// writing past a block inside grouped ncclSend / ncclRecv
+void agree_exchange(const vg_comm* c, int my_rc, uint32_t plan, const vg_xpart* parts, int n_parts, const char* what, const char* mismatch) {
+    // (the message has ONE size whatever the rank has to say -- a rank that failed before it knew its blocks, or that does
+    // not slice at all, pairs the collective with n_parts = 0)
+    constexpr int MAX_XPARTS = 4;
+    if (n_parts > MAX_XPARTS) throw vg_error(VG_EINVAL, "internal error: more exchange parts than the agreement carries");
+    const int W = c->world;
+    const size_t nw = 3 + (size_t)MAX_XPARTS * 2 * (size_t)W;
+    std::vector<int64_t> mine(nw, 0), all(nw * (size_t)W, 0);
+    mine[0] = my_rc; mine[1] = plan; mine[2] = n_parts;
+    for (int i = 0; i < n_parts; ++i) for (int r = 0; r < W; ++r) {
+        mine[3 + ((size_t)i * 2 + 0) * W + r] = parts[i].send_off[r + 1] - parts[i].send_off[r];
+        mine[3 + ((size_t)i * 2 + 1) * W + r] = parts[i].recv_off[r + 1] - parts[i].recv_off[r];
+    }
+    gather_host(c, mine.data(), all.data(), (int64_t)(nw * sizeof(int64_t)));
+    for (int r = 0; r < W; ++r) if (all[(size_t)r * nw] != 0)
+        throw vg_error((int)all[(size_t)r * nw], std::string(what) + ": rank " + std::to_string(r) + " failed" + (r == c->rank ? std::string(": ") + vg_last_error() : std::string()));
+    for (int r = 1; r < W; ++r) if (all[(size_t)r * nw + 1] != all[1] || all[(size_t)r * nw + 2] != all[2])
+        throw vg_error(VG_EINVAL, std::string(what) + ": rank " + std::to_string(r) + " and rank 0 " + mismatch);
+    for (int i = 0; i < n_parts; ++i) for (int a = 0; a < W; ++a) for (int b = 0; b < W; ++b)
+        if (all[(size_t)a * nw + 3 + ((size_t)i * 2 + 0) * W + b] != all[(size_t)b * nw + 3 + ((size_t)i * 2 + 1) * W + a])
+            throw vg_error(VG_EINVAL, std::string(what) + ": rank " + std::to_string(a) + " sends a block of part " + std::to_string(i) + " to rank " + std::to_string(b) +
+                           " whose size the receiver computed differently (the ranks disagree on the exchange layout)");
+}
 // a compute section between two exchanges: its failure becomes this rank's status word of the next agreement
 template <class F> void guarded(const vg_comm* c, const char* what, F fn) {
     int rc = VG_OK;
@@ -159,7 +187,12 @@ void alltoallv_device(const vg_comm* c, const vg_xpart* parts, int n_parts, bool
             if (ok && rb > 0) ok = c->p_recv((char*)x.recv + x.recv_off[r], (size_t)rb, ncclChar, r, c->nccl_comm, s) == ncclSuccess;
         }
         const bool ended = c->p_group_end() == ncclSuccess;
-        if (!ok || !ended) throw vg_error(VG_EIO, "ncclSend / ncclRecv failed");
+        if (!ok || !ended) {
+            // (the peers are inside their group call, behind an agreement that said everybody was fine: aborting the
+            // communicator is what gets them out with an error instead of a hang; every later collective of it fails)
+            if (c->p_abort && c->nccl_comm) (void)c->p_abort(c->nccl_comm);
+            throw vg_error(VG_EIO, "ncclSend / ncclRecv failed after the agreement: communicator aborted");
+        }
         if (!self_through_rccl) for (int i = 0; i < n_parts; ++i) {
             const vg_xpart& x = parts[i];
             const int64_t sb = x.send_off[me + 1] - x.send_off[me];
@@ -285,6 +318,7 @@ extern "C" int vg_comm_rccl_create(int rank, int world, const void* unique_id, i
     c->p_send = (decltype(&ncclSend))dlsym(h, "ncclSend"); c->p_recv = (decltype(&ncclRecv))dlsym(h, "ncclRecv");
     c->p_group_start = (decltype(&ncclGroupStart))dlsym(h, "ncclGroupStart"); c->p_group_end = (decltype(&ncclGroupEnd))dlsym(h, "ncclGroupEnd");
     c->p_count = (decltype(&ncclCommCount))dlsym(h, "ncclCommCount");
+    c->p_abort = (decltype(&ncclCommAbort))dlsym(h, "ncclCommAbort");
     reserve_staging(c, 1 << 16);                    // status words and counts never allocate
     *out = c;
     VG_API_END
@@ -387,18 +421,26 @@ extern "C" int vg_kmer_shared_sharded(vg_genomes* g, int k, double fraction, uin
     // in front of that exchange is paired below by a rank that never reaches it
     vg_slice_exchange xs; xs.rank = c->rank; xs.world = W;
     const bool sliced = W > 1 && vg_slice_exchange_applies(g, k, fraction, W);
+    // EVERY rank of a world > 1 goes through ONE "prefilter scan" agreement in front of its shard's exchanges, sliced or
+    // not, and the agreement carries how the rank is about to work: (sliced scan?, RANGE / HASH cut).  Both are decided from
+    // process-local knobs (vg_set_subshards, VG_RANGE_SCAN, VG_INDEX_PATH); a rank that decided differently would otherwise
+    // skip or add a collective and leave its peers inside grouped ncclSend / ncclRecv.  A mismatch throws on every rank.
+    const uint32_t my_plan = W > 1 ? (uint32_t)(sliced ? 1 : 0) | ((uint32_t)vg_kmer_shard_mode(g, fraction, W) << 1) : 0u;
+    const char* plan_mismatch = "plan the prefilter shard differently (sliced scan / RANGE against HASH shards: do the ranks differ in vg_set_subshards, VG_RANGE_SCAN or VG_INDEX_PATH?)";
     xs.alltoallv = [&](int status, const vg_xpart* parts, int n_parts) {
         xs.agreed = true;
-        agree(c, status, "prefilter scan");
+        agree_exchange(c, status, my_plan, parts, n_parts, "prefilter scan", plan_mismatch);
         alltoallv_device(c, parts, n_parts);
     };
     guarded(c, "prefilter shard", [&] {
+        // (a rank that does not slice pairs the agreement here, in front of its pass)
+        if (W > 1 && !sliced) { xs.agreed = true; agree_exchange(c, VG_OK, my_plan, nullptr, 0, "prefilter scan", plan_mismatch); }
         try { vg_kmer_shared_device(g, k, fraction, c->rank, W, 1u, part_sizes.data(), d_loc, &n_loc, sliced ? &xs : nullptr, &my_mode); }
         catch (...) {
-            if (sliced && !xs.agreed) { xs.agreed = true; try { agree(c, VG_EINVAL, "prefilter scan"); } catch (...) {} }
+            if (W > 1 && !xs.agreed) { xs.agreed = true; try { agree_exchange(c, VG_EINVAL, my_plan, nullptr, 0, "prefilter scan", plan_mismatch); } catch (...) {} }
             throw;
         }
-        if (sliced && !xs.agreed) { xs.agreed = true; agree(c, VG_OK, "prefilter scan"); }
+        if (W > 1 && !xs.agreed) { xs.agreed = true; agree_exchange(c, VG_OK, my_plan, nullptr, 0, "prefilter scan", plan_mismatch); }
         // nominations, and this rank's records sorted by key for the lookups of step 3
         d_nom.alloc((size_t)std::max<int64_t>(n_loc, 1)); d_cur.zero(s);
         lk.alloc((size_t)std::max<int64_t>(n_loc, 1)); lk2.alloc(lk.n); lv.alloc(lk.n); lv2.alloc(lk.n);

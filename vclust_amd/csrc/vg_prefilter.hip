@@ -12,6 +12,7 @@
 #include "vg_common.h"
 #include <functional>
 #include <map>
+#include <mutex>
 #include <optional>
 #include <rocprim/rocprim.hpp>
 #include <algorithm>
@@ -2953,6 +2954,21 @@ static void kmer_shared_subshards(vg_genomes* g, int k, double fraction, int sha
     sum_partial_pairs(parts, counts, min_shared, out, n_out);
 }
 
+// Placement trials (below): how many placements of the workspace the first dense pass of a long-lived process may try.
+// 1 = none, the default: an embedder opts in (vg_set_placement_trials); the developer switch VG_PLACEMENT_TRIALS overrides.
+static std::mutex g_trials_mu;
+static int g_placement_trials = 1;
+static std::map<std::pair<int64_t, int>, int> g_trials_done;       // (padded bases, k) -> tried (under g_trials_mu)
+static int placement_trials_now() {
+    static const int env = [] { const char* e = vg_dev_getenv("VG_PLACEMENT_TRIALS"); return e && *e ? atoi(e) : 0; }();
+    std::lock_guard<std::mutex> lk(g_trials_mu);
+    return env > 0 ? env : g_placement_trials;
+}
+extern "C" void vg_set_placement_trials(int n) {
+    std::lock_guard<std::mutex> lk(g_trials_mu);
+    g_placement_trials = n < 1 ? 1 : (n > 8 ? 8 : n);
+    g_trials_done.clear();                                          // (a caller who asks again gets trials again)
+}
 extern "C" int vg_kmer_shared(vg_genomes* g, int k, double fraction, int shard, int n_shards, uint32_t min_shared,
                               int64_t* set_sizes, vg_pair_count** pairs, int64_t* n_pairs) {
     VG_API_BEGIN
@@ -2997,15 +3013,24 @@ extern "C" int vg_kmer_shared(vg_genomes* g, int k, double fraction, int shard, 
         // life of the blocks.  The FIRST whole pass of a long-lived process over a large set therefore tries up to three
         // placements -- the cached blocks of the previous one set aside, the pass repeated on fresh ones -- and keeps the
         // workspace whose index stage (level-1 count ... bucket kernel) was fastest; the results of the passes are the same, the caller gets the first's.
-        static const int max_trials = [] { const char* e = vg_dev_getenv("VG_PLACEMENT_TRIALS"); return e ? atoi(e) : 4; }();
-        static std::map<std::pair<int64_t, int>, int> tried;       // (padded bases, k) -> done
+        // OPT-IN (vg_set_placement_trials; bench.py asks for 4 and says so in its line): an embedder's first call does no hidden
+        // extra passes.  The caller's result is already in `acc`: whatever happens in a trial pass -- out of memory beside the
+        // parked blocks, a HIP error -- is swallowed here, the parked workspace comes back and the call returns what it computed.
+        const int max_trials = placement_trials_now();
         size_t fr = 0, tot = 0;
-        if (dense && !vg_one_shot() && max_trials > 1 && P >= (1LL << 30) && !tried[{ P, k }]++ && hipMemGetInfo(&fr, &tot) == hipSuccess &&
-            fr > 2 * vg_dev_cached_bytes() + (8ULL << 30)) {
+        bool first_time = false;
+        if (dense && !vg_one_shot() && max_trials > 1 && P >= (1LL << 30)) {
+            std::lock_guard<std::mutex> lk(g_trials_mu);
+            first_time = !g_trials_done[{ P, k }]++;
+        }
+        if (first_time && hipMemGetInfo(&fr, &tot) == hipSuccess && fr > 2 * vg_dev_cached_bytes() + (8ULL << 30)) {
             struct timing_on { timing_on() { g_time_bucket_pass = true; } ~timing_on() { g_time_bucket_pass = false; } } on;
             std::vector<int64_t> sz2((size_t)n); std::vector<vg_pair_count> acc2;
-            kmer_shared_pass(g, k, fraction, shard, n_shards, min_shared, sz2.data(), acc2);       // (the first pass paid for the allocations: time this placement on a second one)
-            float best = g_last_bucket_ms;
+            float best = 0.f;
+            try {
+                kmer_shared_pass(g, k, fraction, shard, n_shards, min_shared, sz2.data(), acc2);       // (the first pass paid for the allocations: time this placement on a second one)
+                best = g_last_bucket_ms;
+            } catch (...) { (void)hipGetLastError(); best = 0.f; }
             for (int trial = 1; trial < max_trials && best > 0.f; ++trial) {
                 const double w0 = vg_alloc_wait_ms();
                 vg_dev_park_cache();
@@ -3043,6 +3068,18 @@ extern "C" int vg_kmer_shared(vg_genomes* g, int k, double fraction, int shard, 
     VG_API_END
 }
 
+// how a rank of an n_shards-way call cuts the k-mers (1 = RANGE, 2 = HASH): the two do not tile the key space together, so
+// the ranks of a sharded call compare notes BEFORE anything is exchanged (a per-process knob -- vg_set_subshards,
+// VG_RANGE_SCAN, VG_INDEX_PATH -- can differ between processes).  A pure function of the set and the process's knobs.
+int vg_kmer_shard_mode(const vg_genomes* g, double fraction, int n_shards) {
+    const int64_t P = g->padded_total();
+    int64_t real_bases = 0; for (int i = 0; i < g->n; ++i) real_bases += g->len[(size_t)i];
+    const double expect = (double)real_bases * fraction / n_shards;
+    const bool dense = fraction >= 1.0 && n_shards == 1;
+    const bool one_pass = g_force_subshards <= 1 && !(dense ? P >= (1LL << 32) : expect >= SUB_PASS_START);
+    const int sub_planned = one_pass ? 1 : std::max(2, g_force_subshards > 1 ? g_force_subshards : (int)std::ceil(expect / SUB_PASS_KMERS));
+    return range_shards(g, fraction, n_shards * sub_planned) ? 1 : 2;
+}
 // internal (vg_dist.hip): one shard's pairs left in HBM (sub-shards included)
 void vg_kmer_shared_device(vg_genomes* g, int k, double fraction, int shard, int n_shards, uint32_t min_shared,
                            int64_t* set_sizes, dbuf<vg_pair_count>& pairs, int64_t* n_pairs, vg_slice_exchange* xs, int* mode_out) {
@@ -3056,10 +3093,7 @@ void vg_kmer_shared_device(vg_genomes* g, int k, double fraction, int shard, int
     const double expect = (double)real_bases * fraction / n_shards;
     const bool dense = fraction >= 1.0 && n_shards == 1;
     const bool one_pass = g_force_subshards <= 1 && !(dense ? P >= (1LL << 32) : expect >= SUB_PASS_START);
-    // how this rank cuts the k-mers (1 = RANGE, 2 = HASH): the two do not tile the key space together, so the ranks of a
-    // sharded call compare notes (a per-process knob -- vg_set_subshards -- can push one rank over the RANGE limit)
-    const int sub_planned = one_pass ? 1 : std::max(2, g_force_subshards > 1 ? g_force_subshards : (int)std::ceil(expect / SUB_PASS_KMERS));
-    if (mode_out) *mode_out = range_shards(g, fraction, n_shards * sub_planned) ? 1 : 2;
+    if (mode_out) *mode_out = vg_kmer_shard_mode(g, fraction, n_shards);
     hipStream_t s = vg_stream();
     if (one_pass) {
         std::vector<vg_pair_count> none; unsigned long long n = 0;
