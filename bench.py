@@ -75,24 +75,40 @@ def pmc_traffic(workload, kernel, launches_per_step):
     return None, None
 
 
-def cpu_baseline(sample_families, members, length, seed, threads, k, min_kmers, min_ident, total_families):
+def cpu_baseline(sample_families, members, length, seed, threads, k, min_kmers, min_ident, total_families, reps=3):
     """The CPU oracle (own restatement of the reference path: the reference's native binaries are absent from
     its checkout) on a bounded sample of the same workload, SAME SCOPE as `value`: genomes in memory ->
     integer rows in memory, EVERY stage on all host threads (oracle/align_oracle.c: vo_path_rows_mt -- k-mer sets per
     genome, hash-partitioned index sorted per thread, per-thread pair tables merged by pair hash, LZ parse over
-    references; tests/test_oracle_golden.py holds it equal to the serial checker)."""
+    references; tests/test_oracle_golden.py holds it equal to the serial checker).  `reps` repetitions: value = the MEDIAN
+    run, with the spread and every run's stage seconds beside it; busy_threads = CPU seconds / wall seconds of a stage
+    (clock of the whole process): the threads that actually worked in it."""
     sys.path.insert(0, str(ROOT / 'tests'))
     import oracle_lib as orc
     codes, offsets, names = synth.make_families(sample_families, members, length=length, seed=seed)
-    t0 = time.perf_counter()
-    rows, stage_s, ran = orc.path_rows_mt(codes, offsets, k=k, min_kmers=min_kmers, min_ident=min_ident, threads=threads)
-    dt = time.perf_counter() - t0
-    pairs = len(rows) // 2
-    return dict(value=round(pairs / dt, 3), unit='pairs/s', cores=ran, kind='port',
-                seconds=round(dt, 3), stage_seconds=stage_s, threads_per_stage={k_: ran for k_ in stage_s},
+    runs = []
+    pairs = 0; ran = threads
+    for _ in range(max(1, reps)):
+        t0 = time.perf_counter()
+        rows, stage_s, ran = orc.path_rows_mt(codes, offsets, k=k, min_kmers=min_kmers, min_ident=min_ident, threads=threads)
+        dt = time.perf_counter() - t0
+        cpu_s = orc.last_stage_cpu()
+        pairs = len(rows) // 2
+        runs.append(dict(seconds=round(dt, 3), pairs_per_s=round(pairs / dt, 1), stage_seconds=stage_s,
+                         busy_threads={k_: round(cpu_s[k_] / stage_s[k_], 1) if stage_s[k_] > 0 else None for k_ in stage_s}))
+    order = sorted(range(len(runs)), key=lambda i: runs[i]['seconds'])
+    med = runs[order[len(order) // 2]]
+    rates = [r['pairs_per_s'] for r in runs]
+    total_s = sum(r['seconds'] for r in runs)
+    return dict(value=med['pairs_per_s'], unit='pairs/s', cores=ran, kind='port',
+                seconds=med['seconds'], stage_seconds=med['stage_seconds'], busy_threads_per_stage=med['busy_threads'],
+                threads_per_stage={k_: ran for k_ in med['stage_seconds']},
+                repetitions=len(runs), runs_pairs_per_s=rates, spread=round((max(rates) - min(rates)) / med['pairs_per_s'], 3),
+                runs=runs, total_seconds=round(total_s, 1),
                 sample_genomes=sample_families * members, extrapolation=round(total_families / sample_families, 2),
                 sample=f'first {sample_families} families ({sample_families * members} genomes x {length} bp) of the same set = '
-                       f'{pairs} pairs; genomes in memory -> integer rows in memory (same scope as value), {dt:.1f} s on {ran} OpenMP threads in every stage; '
+                       f'{pairs} pairs; genomes in memory -> integer rows in memory (same scope as value), {len(runs)} repetitions of {med["seconds"]:.1f} s (median) on {ran} OpenMP threads '
+                       'in every stage (value = the median run; the first run also pays the first touch of its GBs of records); '
                        'pairs/s of the sample stands for the whole set (the work per family is the same: families do not share k-mers); '
                        'own CPU restatement (oracle/), not upstream: kmer-db / lz-ani sources are absent from the reference checkout')
 
@@ -181,6 +197,119 @@ def cli_wall(codes, offsets, names, n_pairs):
     return out, tdo, ani
 
 
+def stage_bytes_of(lens, tasks, n_pairs, k):
+    """SURVEY 8(d) algorithmic bytes by stage, B_pre and B_aln."""
+    n_pos = float(np.sum(np.maximum(lens - k + 1, 0)))
+    sb = {
+        'extract': float(np.sum(lens)) / 4.0 + 8.0 * n_pos,        # read the packed bases, write each position's u64 k-mer
+        'index': 16.0 * n_pos,                                    # the join's key stream: written once, read once
+        'join': 8.0 * n_pos + 16.0 * n_pairs,                     # read each k-mer once for the join, 16 B per emitted pair
+        'align': float(np.sum((lens[tasks['q']] + lens[tasks['r']]) / 4.0 + 20.0)),
+    }
+    b_pre = float(np.sum(lens / 4.0 + 16.0 * np.maximum(lens - k + 1, 0))) + 16.0 * n_pairs
+    return sb, b_pre, sb['align']
+
+
+def roofline_of(prof, steps, step_s, stage_bytes, b_pre, b_aln, world, workload_key):
+    """The `roofline` object of a run: the dominant kernel of the profile scopes priced on its stage's SURVEY 8(d) bytes."""
+    if not prof:
+        return None
+    per_step = {e['name']: e['total_ms'] / steps for e in prof}
+    dom = max((e for e in prof if e['name'] != 'exchange'), key=lambda e: e['total_ms'])      # (a kernel of this rank, not a collective)
+    kern, stage = SCOPES.get(dom['name'], (dom['name'], 'align'))
+    launches_per_step = dom['launches'] / steps
+    avg_ms = dom['total_ms'] / dom['launches']
+    stage_ms = sum(v for k, v in per_step.items() if SCOPES.get(k, (k, 'align'))[1] == stage)
+    stage_frac = stage_bytes[stage] / max(world, 1) / (stage_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    if stage == 'index':
+        # the inverted index is ONE logical pass of SURVEY 8(d) (16 B per position) implemented as several
+        # kernels (partition levels + bucket sort): a kernel of it is priced with its time share of the stage
+        alg = stage_bytes[stage] / max(world, 1) * (dom['total_ms'] / steps / stage_ms) / launches_per_step
+        basis = ('SURVEY 8(d) bytes of the "index" stage (16 B per position) x this kernel\'s share of the stage time, per launch, '
+                 '/ its HIP-event time on the library stream: equals the stage\'s fraction')
+    else:
+        alg = stage_bytes[stage] / launches_per_step / max(world, 1)
+        basis = f'SURVEY 8(d) bytes of the "{stage}" stage, per launch, / this kernel\'s HIP-event time on the library stream'
+    achieved = alg / (avg_ms * 1e-3) / 1e9
+    impl = dom['bytes'] / dom['launches']
+    traffic, src = pmc_traffic(workload_key, kern, launches_per_step) if world == 1 else (None, None)
+    return dict(
+        bound='hbm', kernel=kern, scope=dom['name'], achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit='GB/s',
+        frac=round(achieved / HBM_PEAK_GBS, 6), traffic=traffic, traffic_source=src,
+        avg_launch_ms=round(avg_ms, 4), launches_per_step=round(launches_per_step, 3),
+        algorithmic_bytes_per_launch=round(alg), basis=basis,
+        stage=dict(name=stage, ms_per_step=round(stage_ms, 3), algorithmic_bytes_per_step=round(stage_bytes[stage] / max(world, 1)),
+                   frac=round(stage_frac, 6)),
+        implementation_bytes_per_launch=round(impl),
+        implementation_frac=round(impl / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+        ms_per_step_by_scope={k: round(v, 3) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
+        host_ms_per_step=round(step_s * 1e3 - sum(per_step.values()), 3),
+        path=dict(algorithmic_bytes_per_step=round(b_pre + b_aln), achieved=round((b_pre + b_aln) / step_s / 1e9, 3),
+                  frac=round((b_pre + b_aln) / step_s / 1e9 / HBM_PEAK_GBS, 6),
+                  note='B_pre + B_aln of SURVEY 8(d) / whole step incl. host time' + (', all ranks' if world > 1 else '')))
+
+
+def side_workload(name, comm, k, min_ident, steps=8, warmup=3):
+    """BASELINE.json configs[1] / [2] in the driver-run record: the same step (prefilter -> thresholds -> align, inputs resident
+    in HBM) on another workload, a few steps behind the headline's, with its own roofline object."""
+    import torch
+    wl = synth.WORKLOADS[name]
+    codes, offsets, names, desc = synth.make_workload(name)
+    gs = api.GenomeSet.from_codes(codes, offsets, names)
+    gs.to_device()
+    lens = gs.lengths()
+    st = {}
+
+    def step():
+        sizes, pairs = D.prefilter_counts(gs, comm, k, 1.0, min_shared=20)
+        cand = gs.filter_pairs(sizes, pairs, k=k, min_kmers=20, min_ident=min_ident)
+        tasks, stats = D.align_pairs(gs, cand, comm)
+        st.update(tasks=tasks, n_pairs=len(tasks) // 2)
+    api.profile_enable(False)
+    for _ in range(warmup):
+        step()
+    api.profile_enable(True); api.profile_reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = api.profile_get(); api.profile_enable(False)
+    sb, b_pre, b_aln = stage_bytes_of(lens, st['tasks'], st['n_pairs'], k)
+    rf = roofline_of(prof, steps, dt / steps, sb, b_pre, b_aln, 1, name)
+    out = dict(workload=f'{desc}, k={k}, min-kmers=20, min-ident={min_ident}, lz defaults', genomes=int(len(gs)), total_bases=int(lens.sum()),
+               pairs_per_step=int(st['n_pairs']), steps=steps, warmup=warmup, ms_per_step=round(dt / steps * 1e3, 3),
+               value=round(st['n_pairs'] * steps / dt, 1), unit='pairs/s', roofline=rf)
+    gs.close()
+    return out
+
+
+def out_aln_leg(gs, tasks, plain_parse_ms):
+    """--out-aln (SURVEY 8(f)1) at the headline's size: rows AND regions of all tasks from ONE parse (vg_lz_align with regions);
+    kernel times from the library's HIP-event scopes, against the stats-only parse of the timed steps."""
+    res = {}
+    for rep in range(2):              # (the first call pays for the arena's allocation)
+        api.profile_enable(True); api.profile_reset()
+        t0 = time.perf_counter()
+        stats, regions = gs.lz_align(tasks, want_regions=True)
+        wall = time.perf_counter() - t0
+        prof = {e['name']: e for e in api.profile_get()}
+        api.profile_enable(False)
+        parse = prof.get('lz_parse', {}).get('total_ms', 0.0)
+        place = prof.get('lz_regions_place', {}).get('total_ms', 0.0)
+        res = dict(regions=int(len(regions)), regions_per_task=round(len(regions) / max(1, len(tasks)), 2),
+                   parse_with_regions_ms=round(parse, 3), place_ms=round(place, 3), parse_launches=prof.get('lz_parse', {}).get('launches'),
+                   stats_only_parse_ms=round(plain_parse_ms, 3), ratio_parse=round(parse / plain_parse_ms, 3) if plain_parse_ms else None,
+                   ratio_parse_and_place=round((parse + place) / plain_parse_ms, 3) if plain_parse_ms else None,
+                   call_wall_ms=round(wall * 1e3, 1),
+                   note='vg_lz_align(..., regions): ONE parse launch writes rows and regions (chunks behind a cursor, placed by k_regions_place once '
+                        'the rows are known); call_wall_ms includes the index build, the download of the regions (24 B each) and the host copy')
+        assert int(stats['n_regions'].sum()) == len(regions)
+        del regions
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -194,14 +323,14 @@ def main():
     ap.add_argument('--min-kmers', type=int, default=None, help='default 20 (30 for contigs-1M, large.yml:65-72)')
     ap.add_argument('--min-ident', type=float, default=0.7)
     ap.add_argument('--cpu-sample-families', type=int, default=2000, help='families of the set the CPU baseline runs on (2 000 = 20 000 genomes: a fifth of phage-100k)')
+    ap.add_argument('--cpu-reps', type=int, default=3, help='repetitions of the CPU baseline (value = the median run)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-cli-wall', action='store_true')
+    ap.add_argument('--no-other-workloads', action='store_true', help='skip configs[1] / [2] (phage-1k, imgvr-10k) behind the headline step')
+    ap.add_argument('--no-out-aln', action='store_true', help='skip the --out-aln leg (rows + regions from one parse)')
+    ap.add_argument('--placement-trials', type=int, default=4, help='placements of the prefilter workspace the first pass may try (vg_set_placement_trials; 1 = none)')
     args = ap.parse_args()
 
-    if args.warmup == 0:
-        # the first pass of a long-lived process tries up to three placements of its workspace (~0.8 s, once);
-        # without a warm-up step that would fall into the timed region, so it is switched off and the line says so
-        os.environ['VG_DEV_SWITCHES'] = '1'; os.environ['VG_PLACEMENT_TRIALS'] = '1'
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -214,6 +343,11 @@ def main():
     else:
         dev = torch.device('cuda', local_rank)
     api.set_device(local_rank % api.device_count())
+    # Placement trials are OPT-IN in the library (vg_set_placement_trials): the first pass of this long-lived process may try
+    # up to --placement-trials placements of its workspace (~0.25 s each, once).  They need a warm-up step to
+    # fall into (else they would run inside the timed region) and one rank; the line says what was asked for.
+    trials = args.placement_trials if (args.warmup > 0 and world == 1) else 1
+    api.set_placement_trials(trials)
     # N > 1 measures the RCCL path or nothing: the built-in communicator is created strictly (no silent fall-back to host
     # all-gathers through torch.distributed; VCLUST_COMM / VCLUST_DIST_BACKEND=gloo override it for tests on one GPU)
     kind = os.environ.get('VCLUST_COMM') or ('rccl-strict' if world > 1 and dist is not None and dist.get_backend() == 'nccl' else None)
@@ -314,55 +448,29 @@ def main():
         n_pairs = state['n_pairs']
         tk = state['tasks']
         step_s = dt / args.steps
-        # SURVEY 8(d) algorithmic bytes, by stage
-        n_pos = float(np.sum(np.maximum(lens - args.k + 1, 0)))
-        stage_bytes = {
-            'extract': float(np.sum(lens)) / 4.0 + 8.0 * n_pos,        # read the packed bases, write each position's u64 k-mer
-            'index': 16.0 * n_pos,                                    # the join's key stream: written once, read once
-            'join': 8.0 * n_pos + 16.0 * n_pairs,                     # read each k-mer once for the join, 16 B per emitted pair
-            'align': float(np.sum((lens[tk['q']] + lens[tk['r']]) / 4.0 + 20.0)),
-        }
-        b_pre = float(np.sum(lens / 4.0 + 16.0 * np.maximum(lens - args.k + 1, 0))) + 16.0 * n_pairs
-        b_aln = stage_bytes['align']
-        per_step = {e['name']: e['total_ms'] / args.steps for e in prof}
-        roofline = None
-        if prof:
-            dom = max((e for e in prof if e['name'] != 'exchange'), key=lambda e: e['total_ms'])      # (a kernel of this rank, not a collective)
-            kern, stage = SCOPES.get(dom['name'], (dom['name'], 'align'))
-            launches_per_step = dom['launches'] / args.steps
-            avg_ms = dom['total_ms'] / dom['launches']
-            stage_ms = sum(v for k, v in per_step.items() if SCOPES.get(k, (k, 'align'))[1] == stage)
-            stage_frac = stage_bytes[stage] / max(world, 1) / (stage_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-            if stage == 'index':
-                # the inverted index is ONE logical pass of SURVEY 8(d) (16 B per position) implemented as several
-                # kernels (partition levels + bucket sort): a kernel of it is priced with its time share of the stage
-                alg = stage_bytes[stage] / max(world, 1) * (dom['total_ms'] / args.steps / stage_ms) / launches_per_step
-                basis = ('SURVEY 8(d) bytes of the "index" stage (16 B per position) x this kernel\'s share of the stage time, per launch, '
-                         '/ its HIP-event time on the library stream: equals the stage\'s fraction')
-            else:
-                alg = stage_bytes[stage] / launches_per_step / max(world, 1)
-                basis = f'SURVEY 8(d) bytes of the "{stage}" stage, per launch, / this kernel\'s HIP-event time on the library stream'
-            achieved = alg / (avg_ms * 1e-3) / 1e9
-            impl = dom['bytes'] / dom['launches']
-            traffic, src = pmc_traffic(args.workload if args.count is None else f'{args.workload}/{args.count}', kern, launches_per_step) if world == 1 else (None, None)
-            roofline = dict(
-                bound='hbm', kernel=kern, scope=dom['name'], achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit='GB/s',
-                frac=round(achieved / HBM_PEAK_GBS, 6), traffic=traffic, traffic_source=src,
-                avg_launch_ms=round(avg_ms, 4), launches_per_step=round(launches_per_step, 3),
-                algorithmic_bytes_per_launch=round(alg), basis=basis,
-                stage=dict(name=stage, ms_per_step=round(stage_ms, 3), algorithmic_bytes_per_step=round(stage_bytes[stage] / max(world, 1)),
-                           frac=round(stage_frac, 6)),
-                implementation_bytes_per_launch=round(impl),
-                implementation_frac=round(impl / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
-                ms_per_step_by_scope={k: round(v, 3) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
-                host_ms_per_step=round(step_s * 1e3 - sum(per_step.values()), 3),
-                path=dict(algorithmic_bytes_per_step=round(b_pre + b_aln), achieved=round((b_pre + b_aln) / step_s / 1e9, 3),
-                          frac=round((b_pre + b_aln) / step_s / 1e9 / HBM_PEAK_GBS, 6),
-                          note='B_pre + B_aln of SURVEY 8(d) / whole step incl. host time' + (', all ranks' if world > 1 else '')))
+        stage_bytes, b_pre, b_aln = stage_bytes_of(lens, tk, n_pairs, args.k)
+        roofline = roofline_of(prof, args.steps, step_s, stage_bytes, b_pre, b_aln, world,
+                               args.workload if args.count is None else f'{args.workload}/{args.count}')
+        # -- behind the timed region (nothing below touches `value`): --out-aln from one parse at this size, then configs[1] / [2]
+        out_aln = None
+        if world == 1 and not args.no_out_aln:
+            try:
+                plain = next((e['total_ms'] / args.steps for e in prof if e['name'] == 'lz_parse'), 0.0)
+                out_aln = out_aln_leg(gs, tk, plain)
+            except Exception as exc:
+                out_aln = dict(error=str(exc))
+        others = None
+        if world == 1 and not args.no_other_workloads and args.workload == 'phage-100k' and args.count is None:
+            others = {}
+            for name in ('phage-1k', 'imgvr-10k'):
+                try:
+                    others[name] = side_workload(name, comm, args.k, args.min_ident)
+                except Exception as exc:
+                    others[name] = dict(error=str(exc))
         cpu = None
         if world == 1 and not args.no_cpu_baseline and wl['kind'] == 'families':
             cpu = cpu_baseline(min(args.cpu_sample_families, n_units), wl['members'], wl['length'], wl['seed'],
-                               min(os.cpu_count() or 1, 256), args.k, min_kmers, args.min_ident, n_units)
+                               min(os.cpu_count() or 1, 256), args.k, min_kmers, args.min_ident, n_units, reps=args.cpu_reps)
         out = {
             'metric': 'genome pairs/sec through prefilter+align (ani.tsv)',
             'value': round(n_pairs * args.steps / dt, 3),
@@ -385,7 +493,9 @@ def main():
             'roofline': roofline,
             'cpu_baseline': cpu,
             'cli_wall': e2e,
-            'placement_trials': args.warmup > 0 and world == 1,
+            'out_aln': out_aln,
+            'other_workloads': others,
+            'placement_trials': trials,
             'comm': dict(kind=comm.kind, rccl_ranks=comm.rccl_ranks, strict=(kind == 'rccl-strict'), rccl_failure=rccl_failure,
                          backend=(dist.get_backend() if dist is not None else None)) if world > 1 else None,
             'per_rank': per_rank if world > 1 else None,
@@ -396,7 +506,7 @@ def main():
             out['vs_cpu_baseline'] = dict(
                 device_resident=round(out['value'] / cpu['value'], 1),
                 end_to_end_cli=round(e2e['pairs_per_s'] / cpu['value'], 1) if e2e and 'pairs_per_s' in e2e else None,
-                label='GPU pairs/s / cpu_baseline.value: vs OWN CPU port (oracle/, every stage on cpu_baseline.cores threads), sample-extrapolated -- not the upstream binaries')
+                label='GPU pairs/s / cpu_baseline.value (median of its repetitions): vs OWN CPU port (oracle/, every stage on cpu_baseline.cores threads), sample-extrapolated -- not the upstream binaries')
         print(json.dumps(out))
     comm.close()
     if dist:

@@ -12,6 +12,7 @@
  *   L8  alignment table (example/output/ani.aln.tsv), per pair sorted by alnlen desc, qstart asc.
  */
 #include "vclust_oracle.h"
+#include <time.h>
 #include <omp.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -286,6 +287,7 @@ static int path_rows_impl(const vo_genome_set* s, int k, int min_kmers, double m
     if (mt) vo_shared_all_mt(s, k, 1.0, sizes, &pairs, &np, stage_s, threads_used);
     else vo_shared_all(s, k, 1.0, sizes, &pairs, &np);
     const double t_lz0 = omp_get_wtime();
+    struct timespec c_lz0; clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &c_lz0);
     int64_t kept = 0;
     for (int64_t i = 0; i < np; ++i) {
         if ((int64_t)pairs[i].shared < min_kmers) continue;
@@ -325,6 +327,7 @@ static int path_rows_impl(const vo_genome_set* s, int k, int min_kmers, double m
     }
     free(roff); free(rtask);
     if (mt && stage_s) stage_s[3] = omp_get_wtime() - t_lz0;
+    { struct timespec c1; clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &c1); vo_note_stage_cpu(3, (double)(c1.tv_sec - c_lz0.tv_sec) + 1e-9 * (double)(c1.tv_nsec - c_lz0.tv_nsec)); }
     *rows_out = st; *n_rows = nt;
     return 0;
 }

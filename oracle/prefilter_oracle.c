@@ -162,8 +162,17 @@ int vo_shared_all(const vo_genome_set* s, int k, double fraction,
  *              its own thread (sort + reduce).
  * stage_s (may be NULL) receives the wall seconds of {sets, index, pair count}; *threads_used the OpenMP team size. ---- */
 #include <omp.h>
+#include <malloc.h>
+#include <time.h>
 static double now_s(void) { return omp_get_wtime(); }
+static double cpu_s(void) { struct timespec ts; clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 void vo_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+/* CPU seconds (all threads of the process) of the four stages of the last vo_shared_all_mt / vo_path_rows_mt call: CPU / wall
+ * of a stage = the threads that were actually busy in it (bench.py prints it beside the wall seconds) */
+static double g_stage_cpu[4];
+void vo_last_stage_cpu(double* out4) { for (int i = 0; i < 4; ++i) out4[i] = g_stage_cpu[i]; }
+void vo_note_stage_cpu(int stage, double seconds) { if (stage >= 0 && stage < 4) g_stage_cpu[stage] = seconds; }
+static void* big_alloc(size_t bytes) { return malloc(bytes ? bytes : 1); }     /* (2 MiB pages by madvise were measured: their first touch is 4 x SLOWER in this VM) */
 static int cmp_kg(const void* x, const void* y) {
     const kg_t* a = (const kg_t*)x; const kg_t* b = (const kg_t*)y;
     return a->kmer < b->kmer ? -1 : (a->kmer > b->kmer);
@@ -199,11 +208,15 @@ int vo_shared_all_mt(const vo_genome_set* s, int k, double fraction, int64_t* se
         T = omp_get_num_threads();
     }
     if (threads_used) *threads_used = T;
-    double t0 = now_s();
+    /* a k-mer set is 320 kB: above malloc's default mmap threshold every set would be an mmap + munmap of its own, 100 000 of
+     * them from 256 threads through one address-space lock; from the per-thread arenas they are pointer bumps */
+    static int tuned = 0;
+    if (!tuned) { tuned = 1; mallopt(M_MMAP_THRESHOLD, 32 << 20); mallopt(M_TRIM_THRESHOLD, 1 << 30);      /* (32 MiB is the largest threshold glibc accepts) */ }
+    double t0 = now_s(), c0 = cpu_s();
     uint64_t** sets = (uint64_t**)calloc(n > 0 ? n : 1, sizeof(uint64_t*));
     #pragma omp parallel for schedule(dynamic)
     for (int g = 0; g < n; ++g) set_sizes[g] = vo_kmer_set_f(s->g[g].seq, s->g[g].len, k, fraction, &sets[g]);
-    double t1 = now_s();
+    double t1 = now_s(), c1 = cpu_s();
     /* index: partition by hash, then sort every partition */
     int PB = 6; while ((1 << PB) < 16 * T && PB < 14) ++PB;
     const int NP = 1 << PB;
@@ -222,7 +235,7 @@ int vo_shared_all_mt(const vo_genome_set* s, int k, double fraction, int64_t* se
         for (int t = 0; t < T; ++t) { int64_t c = cnt[(size_t)t * NP + p]; cnt[(size_t)t * NP + p] = total; total += c; }
     }
     pstart[NP] = total;
-    kg_t* a = (kg_t*)malloc(sizeof(kg_t) * (total > 0 ? total : 1));
+    kg_t* a = (kg_t*)big_alloc(sizeof(kg_t) * (size_t)(total > 0 ? total : 1));
     #pragma omp parallel num_threads(T)
     {
         const int t = omp_get_thread_num();
@@ -240,7 +253,7 @@ int vo_shared_all_mt(const vo_genome_set* s, int k, double fraction, int64_t* se
         const int bits = (2 * k + 7) / 8 * 8, passes = bits / 8;
         #pragma omp parallel num_threads(T)
         {
-            kg_t* tmp = (kg_t*)malloc(sizeof(kg_t) * (pmax > 0 ? pmax : 1));
+            kg_t* tmp = (kg_t*)big_alloc(sizeof(kg_t) * (size_t)(pmax > 0 ? pmax : 1));
             #pragma omp for schedule(dynamic, 1)
             for (int p = 0; p < NP; ++p) {
                 const int64_t m = pstart[p + 1] - pstart[p];
@@ -250,7 +263,7 @@ int vo_shared_all_mt(const vo_genome_set* s, int k, double fraction, int64_t* se
             free(tmp);
         }
     }
-    double t2 = now_s();
+    double t2 = now_s(), c2 = cpu_s();
     /* pair counts: per-thread tables over the partitions */
     ptab_t* tabs = (ptab_t*)calloc((size_t)T, sizeof(ptab_t));
     for (int t = 0; t < T; ++t) { tabs[t].cap = 1 << 12; tabs[t].tab = (pc_t*)calloc(tabs[t].cap, sizeof(pc_t)); }
@@ -304,7 +317,8 @@ int vo_shared_all_mt(const vo_genome_set* s, int k, double fraction, int64_t* se
         pr[m].a = (uint32_t)(e->key >> 32); pr[m].b = (uint32_t)e->key; pr[m].shared = e->cnt; ++m;
     }
     free(ent); free(bstart); free(bout);
-    double t3 = now_s();
+    double t3 = now_s(), c3 = cpu_s();
+    g_stage_cpu[0] = c1 - c0; g_stage_cpu[1] = c2 - c1; g_stage_cpu[2] = c3 - c2;
     if (stage_s) { stage_s[0] = t1 - t0; stage_s[1] = t2 - t1; stage_s[2] = t3 - t2; }
     *out_pairs = pr; *n_pairs = np;
     return 0;

@@ -65,6 +65,8 @@ int vo_shared_all(const vo_genome_set* s, int k, double fraction,
 /* the same counts with every stage on all OpenMP threads (bench.py's cpu_baseline; vo_shared_all is the checker);
  * stage_s[3] = seconds of {sets, index, pair count} */
 void vo_set_threads(int n);      /* OpenMP team size of the calls that follow */
+void vo_last_stage_cpu(double* out4);           /* CPU seconds (all threads) of {sets, index, pair count, lz} of the last *_mt call */
+void vo_note_stage_cpu(int stage, double seconds);
 int vo_shared_all_mt(const vo_genome_set* s, int k, double fraction, int64_t* set_sizes, vo_pair_count** out_pairs,
                      int64_t* n_pairs, double* stage_s, int* threads_used);
 int vo_write_fltr(const vo_genome_set* s, int k, double fraction, int min_kmers, double min_ident,

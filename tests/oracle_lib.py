@@ -48,7 +48,7 @@ def lib():
         if not LIB.exists():
             build()
         L = C.CDLL(str(LIB))
-        if not hasattr(L, 'vo_path_rows_mt'):          # a library built from older sources
+        if not hasattr(L, 'vo_last_stage_cpu'):          # a library built from older sources
             build()
             L = C.CDLL(str(LIB))
         L.vo_read_fasta.argtypes = [C.c_char_p, C.c_int, C.POINTER(GenomeSet)]
@@ -73,6 +73,8 @@ def lib():
         L.vo_path_rows_mt.restype = C.c_int
         L.vo_set_threads.argtypes = [C.c_int]
         L.vo_set_threads.restype = None
+        L.vo_last_stage_cpu.argtypes = [C.POINTER(C.c_double)]
+        L.vo_last_stage_cpu.restype = None
         L.vo_fmt_num.argtypes = [C.c_double, C.c_char_p]
         L.vo_fmt_num.restype = C.c_int
         L.vo_fmt_len_ratio.argtypes = [C.c_int64, C.c_int64, C.c_char_p]
@@ -204,3 +206,10 @@ def path_rows_mt(codes, offsets, k=25, min_kmers=20, min_ident=0.7, lz=None, thr
     out = np.ctypeslib.as_array(C.cast(pp, C.POINTER(C.c_uint32)), shape=(max(n.value, 1) * 5,))[:n.value * 5].copy().view(dt)
     lib().free(C.cast(pp, C.c_void_p))
     return out, dict(zip(('sets', 'index', 'pair_count', 'lz'), (round(float(x), 3) for x in st))), thr.value
+
+
+def last_stage_cpu():
+    """CPU seconds (all threads) of the stages of the last *_mt call: {stage: seconds}."""
+    c = (C.c_double * 4)()
+    lib().vo_last_stage_cpu(c)
+    return dict(zip(('sets', 'index', 'pair_count', 'lz'), (round(float(x), 3) for x in c)))

@@ -379,6 +379,37 @@ comm.close(); dist.destroy_process_group()
     assert p.returncode == 0 and p.stdout.count('masks ok rank') == nproc, (p.stdout[-500:], p.stderr[:3000])
 
 
+def test_eight_processes_write_the_files_of_one(tmp_path):
+    """World 8 as EIGHT REAL PROCESSES (sharing the one GPU of the test box, exchanges over gloo through the callback
+    communicator): configs[1] -- phage-1k, 1 000 x 40 kb -- through `torchrun ... vclust.py prefilter` / `align --filter` =
+    vg_prefilter_sharded / vg_align_sharded.  The prefilter takes the sliced scan (every rank scans an eighth of the bases, the
+    kept masks and level-1 counts travel in the all-to-all, nominations / union / counts in all-gathers), the align stage
+    deals the references into eight ranges and gathers rows (and, with --out-aln, regions).  fltr.txt, ani.tsv and the
+    ids file must be the bytes one process writes; the alignment table the same multiset of lines."""
+    import filecmp
+    sys.path.insert(0, str(ROOT))
+    from vclust_amd import synth
+    codes, offsets, names, _ = synth.make_workload('phage-1k')
+    fa = tmp_path / 'phage1k.fna'
+    synth.write_fasta(fa, codes, offsets, names)
+    f1, a1, l1 = tmp_path / 'f1.txt', tmp_path / 'a1.tsv', tmp_path / 'l1.tsv'
+    assert run('prefilter', '-i', fa, '-o', f1, '-v', '0').returncode == 0
+    assert run('align', '-i', fa, '-o', a1, '--filter', f1, '--out-aln', l1, '-v', '0').returncode == 0
+    f8, a8, l8, b8 = tmp_path / 'f8.txt', tmp_path / 'a8.tsv', tmp_path / 'l8.tsv', tmp_path / 'b8.tsv'
+    p = _torchrun(8, VCLUST, 'prefilter', '-i', fa, '-o', f8, '-v', '0')
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert filecmp.cmp(f1, f8, shallow=False)
+    p = _torchrun(8, VCLUST, 'align', '-i', fa, '-o', a8, '--filter', f8, '--out-aln', l8, '-v', '0')
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert filecmp.cmp(a1, a8, shallow=False) and filecmp.cmp(str(a1)[:-4] + '.ids.tsv', str(a8)[:-4] + '.ids.tsv', shallow=False)
+    assert sum(1 for _ in open(a8)) == 9001
+    assert sorted(open(l1).read().splitlines()) == sorted(open(l8).read().splitlines())
+    # without --out-aln the ranks start from the candidate pairs (vg_lz_align_pairs_sharded)
+    p = _torchrun(8, VCLUST, 'align', '-i', fa, '-o', b8, '--filter', f8, '-v', '0')
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert filecmp.cmp(a1, b8, shallow=False)
+
+
 def test_two_ranks_align_from_many_pairs(tmp_path):
     """vg_lz_align_pairs_sharded with more than 2^17 candidate pairs (80 families of 60 short genomes): the listing of a
     rank's tasks and their positions in the owners' lists runs on several host threads; every rank must still receive

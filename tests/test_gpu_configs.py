@@ -14,6 +14,8 @@ from vclust_amd import api, synth
 
 pytestmark = pytest.mark.gpu
 
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+
 
 def _rows_dict(tasks, stats):
     return {(int(t['q']), int(t['r'])): (int(s['n_match']), int(s['aln_len']), int(s['n_regions'])) for t, s in zip(tasks, stats)}
@@ -148,6 +150,45 @@ def test_many_regions_per_task(tmp_path):
     orc.run_cli('align', '-o', tmp_path / 'o.tsv', '--out-aln', tmp_path / 'o_aln.tsv', fa)
     assert filecmp.cmp(tmp_path / 'ani.tsv', tmp_path / 'o.tsv', shallow=False)
     assert sorted(open(tmp_path / 'aln.tsv').read().splitlines()) == sorted(open(tmp_path / 'o_aln.tsv').read().splitlines())
+
+
+def test_out_aln_one_parse_against_its_checkers(tmp_path):
+    """--out-aln comes from ONE parse (regions written into chunks behind a cursor, placed once the rows are known).  Its
+    checkers, each in a process of its own (developer switches are read once): the two-pass scheme it replaces (rows first,
+    then a second parse into an arena of known size), the general kernel instead of the specialised one, and a first arena
+    far too small (64 records), which makes the batch repeat itself with the size the cursor reported.  Regions (in the order
+    the library returns them: sorted task list, query order) and rows must be the same arrays in all four, and the rows must
+    equal those of a call without regions."""
+    import os
+    import subprocess
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+from vclust_amd import api, synth
+codes, offsets, names = synth.make_families(40, 6, length=30000, seed=29, p_lo=0.02, p_hi=0.16, n_indels=25)
+gs = api.GenomeSet.from_codes(codes, offsets, names)
+tasks = gs.align_tasks(synth.family_pairs(40, 6))
+plain = gs.lz_align(tasks)
+stats, regions = gs.lz_align(tasks, want_regions=True)
+assert np.array_equal(plain, stats), 'rows with and without regions differ'
+assert len(regions) == int(stats['n_regions'].sum())
+np.savez(sys.argv[1], stats=stats, regions=regions)
+""" % str(ROOT)
+    out = {}
+    for tag, env in (('one_parse', {}), ('two_pass', dict(VG_LZ_REGIONS='two-pass')), ('general', dict(VG_LZ_KERNEL='general')),
+                     ('tiny_arena', dict(VG_LZ_ARENA='64'))):
+        f = tmp_path / f'{tag}.npz'
+        p = subprocess.run([sys.executable, '-c', code, str(f)], env=dict(os.environ, VG_DEV_SWITCHES='1', **env), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        assert p.returncode == 0, (tag, p.stderr[-2000:])
+        d = np.load(f); out[tag] = (d['stats'], d['regions'])
+    base = out['one_parse']
+    assert len(base[1]) > 20 * len(base[0])
+    # within a task the regions come in query order and do not overlap
+    rg = base[1]
+    same = rg['task'][1:] == rg['task'][:-1]
+    assert np.all(rg['qstart'][1:][same] > rg['qend'][:-1][same])
+    for tag, (st, rgs) in out.items():
+        assert np.array_equal(st, base[0]) and np.array_equal(rgs, base[1]), tag
 
 
 @pytest.mark.parametrize('k', [15, 30])

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer tool: the LZ parse alone on the phage-100k set (NF families), REPS times: ms of the lz_parse scope and a hash
 of the rows -- run once per kernel variant (the switches are read once per process) and compare:
-  VG_DEV_SWITCHES=1 VG_LZ_KERNEL=one python tools/micro/parse_ab.py ; VG_DEV_SWITCHES=1 VG_LZ_KERNEL=two python tools/micro/parse_ab.py"""
+  VG_DEV_SWITCHES=1 python tools/micro/parse_ab.py ; VG_DEV_SWITCHES=1 VG_LZ_INDEX=fused python tools/micro/parse_ab.py"""
 import hashlib, os, sys, pathlib
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent.parent))
 from vclust_amd import api, synth
@@ -16,4 +16,4 @@ api.profile_enable(True); api.profile_reset()
 for _ in range(REPS):
     st = gs.lz_align(tasks)
 prof = {e['name']: round(e['total_ms'] / REPS, 2) for e in api.profile_get()}
-print(os.environ.get('VG_LZ_KERNEL', 'default'), len(tasks), 'tasks', prof, hashlib.sha256(st.tobytes()).hexdigest()[:16], flush=True)
+print(os.environ.get('VG_LZ_KERNEL', 'default'), 'index=' + os.environ.get('VG_LZ_INDEX', 'default'), len(tasks), 'tasks', prof, hashlib.sha256(st.tobytes()).hexdigest()[:16], flush=True)

@@ -27,6 +27,7 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <optional>
 
 namespace {
 
@@ -1026,6 +1027,16 @@ struct task_dev { uint32_t q, r_slot, out_idx, pad; };
 constexpr int SEG_LOG_CAP = 250;          // (4 x 250 records + the hand-over words: 20 KiB of LDS per workgroup, eight workgroups per CU)
 constexpr int PW_AFTER_EVENT = 32;
 struct seg_rec { int i_ev, ev_pos; uint32_t VM, VA, VN; };     // VN: bit 31 = open region already spans >= reg
+// --out-aln in ONE parse: a wave writes its kept regions into chunks of RCHUNK records it takes from a global cursor
+// (one atomic per chunk); a record carries the task's place in the sorted list and the region's number inside the task,
+// so a placing pass (k_regions_place) moves it to its final slot once the rows -- hence every task's region count -- are
+// known.  The unused tail of a wave's last chunk is marked.  A cursor beyond the arena's capacity = nothing was written
+// there: the host repeats the batch with an arena of exactly the size the cursor reports (the count of chunks a parse
+// takes is a function of its rows).
+constexpr int FUSED_SLOTS = 16384;         // EXPERIMENT (VG_LZ_INDEX=fused): 4^msl slots of eight words per reference (msl = 7)
+constexpr int RCHUNK = 8;
+struct region_rec { uint32_t task; int32_t qstart, qend, rstart, rend, n_match; uint32_t k, t; };     // 32 bytes; task = ~0u: unused slot
+static_assert(sizeof(region_rec) == 32, "arena record");
 
 #define PARSE_ARGS \
     const task_dev* __restrict__ tasks, int64_t n_tasks, const ref_desc* __restrict__ refs, \
@@ -1034,14 +1045,16 @@ struct seg_rec { int i_ev, ev_pos; uint32_t VM, VA, VN; };     // VN: bit 31 = o
     const uint32_t* __restrict__ rr_pool, const uint32_t* __restrict__ mask_pool, \
     const uint32_t* __restrict__ stab_pool, const uint32_t* __restrict__ sent_pool, \
     lz_dev_params P, vg_pair_stat* __restrict__ stats, \
-    vg_region* __restrict__ regions, const unsigned long long* __restrict__ region_off
+    region_rec* __restrict__ arena, unsigned long long* __restrict__ arena_cursor, unsigned long long arena_cap, \
+    const uint32_t* __restrict__ fslots
 #define PARSE_ARG_NAMES tasks, n_tasks, refs, planes, nmask, base_off, glen, g_has_n, rr_pool, mask_pool, \
-    stab_pool, sent_pool, P, stats, regions, region_off
+    stab_pool, sent_pool, P, stats, arena, arena_cursor, arena_cap, fslots
 
 // FAST: the default LZ-ANI parameters and a set without N as compile-time constants (shift counts, loop bounds
 // and the mask paths fold away); the host launches it when both hold.
-template <int S, bool DEV, bool FAST = false>
+template <int S, bool DEV, bool FAST = false, bool REG = false, bool FUSED = false>
 __device__ __forceinline__ void lz_parse_body(PARSE_ARGS) {
+    static_assert(!REG || S == 1, "regions are emitted by the one-wave parse (query order)");
     if (FAST) { P.mal = 11; P.msl = 7; P.mrd = 40; P.mqd = 40; P.reg = 35; P.aw = 15; P.am = 7; P.ar = 3; P.ablate = 0; P.weak_ratio = 3; P.margin = 6; P.seed_choice = 3; }
     const int ABL = DEV ? P.ablate : 0;           // developer timing knobs: compiled out of the production kernels
     __shared__ seg_rec s_log[S > 1 ? S * SEG_LOG_CAP : 1];
@@ -1079,20 +1092,28 @@ __device__ __forceinline__ void lz_parse_body(PARSE_ARGS) {
     bool in_region = false; int r_qstart = 0, r_rstart = 0, r_qend = 0, r_rend = -1, r_match = 0, vend = 0;
     int kept_end = seg_start;
     uint32_t M = 0, A = 0, NR = 0;
+    unsigned long long chunk_base = 0;
 
     auto close_region = [&]() {
         if (in_region) {
             int span = r_qend - r_qstart + 1;
             if (span >= P.reg) {
                 M += (uint32_t)r_match; A += (uint32_t)span; NR += 1; kept_end = r_qend + 1;
-                if (regions && lane == 0) {
-                    // slot = this task's offset (prefix sum of the stats pass) + regions kept so far: exact size, fixed order
-                    vg_region rg; rg.task = tk.out_idx; rg.qstart = r_qstart; rg.qend = r_qend;
-                    rg.rstart = r_rstart; rg.rend = r_rend; rg.n_match = r_match;
-                    // (the slots were sized by the counting pass: a region beyond them -- the two passes disagreeing -- is
-                    // dropped here and reported by the host, which compares the region counts of the two passes)
-                    const unsigned long long at = region_off[t] + (NR - 1);
-                    if (at < region_off[t + 1]) regions[at] = rg;
+                if (REG) {
+                    const uint32_t kk = NR - 1;
+                    if ((kk & (RCHUNK - 1)) == 0) {
+                        // a new chunk: one atomic on the cursor by the wave's first lane, broadcast through SGPRs
+                        unsigned long long b = 0;
+                        if (lane == 0) b = atomicAdd(arena_cursor, (unsigned long long)RCHUNK);
+                        chunk_base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32)) << 32) |
+                                     (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+                    }
+                    const unsigned long long at = chunk_base + (kk & (RCHUNK - 1));
+                    if (lane == 0 && at < arena_cap) {
+                        region_rec rg; rg.task = tk.out_idx; rg.qstart = r_qstart; rg.qend = r_qend;
+                        rg.rstart = r_rstart; rg.rend = r_rend; rg.n_match = r_match; rg.k = kk; rg.t = (uint32_t)t;
+                        arena[at] = rg;
+                    }
                 }
             }
             in_region = false;
@@ -1125,9 +1146,16 @@ __device__ __forceinline__ void lz_parse_body(PARSE_ARGS) {
             uint32_t s_u = 0, s_e = 0;
             const uint32_t posmask = (rd.pos_bits >= 32) ? 0xffffffffu : ((1u << rd.pos_bits) - 1u);
             const uint32_t qtag = tag_of(xq.lo, xq.hi, P.msl, rd.tag_bits);
-            if ((do_a || do_s) && q_ok_s) {
+            const bool probing = (do_a || do_s) && q_ok_s;
+            const uint32_t b = bucket_of(xq.lo, xq.hi, P.msl);
+            uint4 f0 = make_uint4(~0u, ~0u, ~0u, ~0u), f1 = f0;
+            if (FUSED) {
+                // EXPERIMENT (VG_LZ_INDEX=fused): the bucket's first entries sit in a fixed 32-byte slot -- no bounds word in
+                // front of them, ONE line per probing lane; a word with bit 31 set ends the list (all ones) or, as the slot's
+                // last word, points at the bucket's remaining entries in the ordinary entry array
+                if (probing) { const uint32_t* sl = fslots + ((size_t)tk.r_slot * FUSED_SLOTS + b) * 8; __builtin_memcpy(&f0, sl, 16); __builtin_memcpy(&f1, sl + 4, 16); }
+            } else if (probing) {
                 // bucket bounds = two neighbouring table words: one 8-byte load
-                const uint32_t b = bucket_of(xq.lo, xq.hi, P.msl);
                 uint2 bb; __builtin_memcpy(&bb, stab + (b ? b - 1 : 0u), 8);
                 s_u = b ? bb.x : 0u; s_e = b ? bb.y : bb.x;
             }
@@ -1140,11 +1168,8 @@ __device__ __forceinline__ void lz_parse_body(PARSE_ARGS) {
             int sbest_len = 0, sbest_pos = 0, sbest_ad = 0, ncap_a = 0, ncap_s = 0;
             const uint32_t win_span = (uint32_t)(win_hi - win_lo);                  // window test: one unsigned compare
             const bool win_any = win_hi >= win_lo;
-            while (s_u < s_e) {
-                if (DEV) { ++n_ab; }
-                // four consecutive entries = one 16-byte load (the pool carries four entries of slack; entries past
-                // the bucket end are ignored below)
-                uint4 v; __builtin_memcpy(&v, sent + s_u, 16);
+            // four entries of the bucket (vm: which of them exist): anchor candidates by tag, seed candidates by window, each verified once
+            auto scan4 = [&](const uint4 v, const unsigned vm) {
                 const uint32_t e4[4] = { v.x, v.y, v.z, v.w };
                 unsigned am = 0, sm = 0;
                 // (all four entries are tested without a branch; those past the bucket end are masked out afterwards)
@@ -1154,8 +1179,6 @@ __device__ __forceinline__ void lz_parse_body(PARSE_ARGS) {
                     am |= (uint32_t)(rd.tag_bits == 0 || (e4[j] >> rd.pos_bits) == qtag) << j;
                     sm |= (uint32_t)(ps - (uint32_t)win_lo <= win_span) << j;
                 }
-                const uint32_t left = s_e - s_u;
-                const unsigned vm = left >= 4u ? 0xfu : ((1u << left) - 1u);
                 am &= do_a ? vm : 0u; sm &= (do_s && win_any) ? vm : 0u;
                 unsigned cm = am | sm;
                 while (cm) {
@@ -1193,6 +1216,30 @@ __device__ __forceinline__ void lz_parse_body(PARSE_ARGS) {
                         }
                     }
                 }
+            };
+            if (FUSED) {
+                if (DEV) { ++n_ab; }
+                // (a slot's words with bit 31 set are not entries: padding or the pointer)
+                const unsigned vm0 = (unsigned)(!(f0.x >> 31)) | ((unsigned)(!(f0.y >> 31)) << 1) | ((unsigned)(!(f0.z >> 31)) << 2) | ((unsigned)(!(f0.w >> 31)) << 3);
+                const unsigned vm1 = (unsigned)(!(f1.x >> 31)) | ((unsigned)(!(f1.y >> 31)) << 1) | ((unsigned)(!(f1.z >> 31)) << 2) | ((unsigned)(!(f1.w >> 31)) << 3);
+                if (vm0) scan4(f0, vm0);
+                if (vm1) scan4(f1, vm1);
+                if ((f1.w >> 31) && f1.w != ~0u) {
+                    // the rest of a bucket of more than eight entries: count << 23 | first entry; count 255 = ask the bounds table
+                    s_u = f1.w & 0x7fffffu; const uint32_t cnt = (f1.w >> 23) & 0xffu;
+                    if (cnt == 255u) { uint2 bb; __builtin_memcpy(&bb, stab + (b ? b - 1 : 0u), 8); s_e = b ? bb.y : bb.x; }
+                    else s_e = s_u + cnt;
+                }
+                const unsigned long long hit0 = __ballot(best_len > 0 || sbest_len > 0);
+                if (hit0 && lane > __builtin_ctzll(hit0)) s_u = s_e;
+            }
+            while (s_u < s_e) {
+                if (DEV) { ++n_ab; }
+                // four consecutive entries = one 16-byte load (the pool carries four entries of slack; entries past
+                // the bucket end are ignored below)
+                uint4 v; __builtin_memcpy(&v, sent + s_u, 16);
+                const uint32_t left = s_e - s_u;
+                scan4(v, left >= 4u ? 0xfu : ((1u << left) - 1u));
                 s_u += 4;
                 // positions behind the first one that already has a match cannot become the event: stop their walks
                 const unsigned long long hit = __ballot(best_len > 0 || sbest_len > 0);
@@ -1348,21 +1395,70 @@ __device__ __forceinline__ void lz_parse_body(PARSE_ARGS) {
         M = (uint32_t)n_iter; A = (uint32_t)n_events; if (ABL & 2048) { M = (uint32_t)mab; A = (uint32_t)msb; }
     }
     if (ABL & (32 | 1024)) NR = (uint32_t)((long long)wall_clock64() - t_start);        // developer timing: 100 MHz ticks
+    if (REG && (NR & (RCHUNK - 1)) != 0) {
+        // the unused tail of the last chunk: marked, one slot per lane
+        const uint32_t used = NR & (RCHUNK - 1);
+        const unsigned long long at = chunk_base + used + (uint32_t)lane;
+        if (used + (uint32_t)lane < (uint32_t)RCHUNK && at < arena_cap) arena[at].task = ~0u;
+    }
     if (lane == 0) { vg_pair_stat st; st.n_match = M; st.aln_len = A; st.n_regions = NR; stats[tk.out_idx] = st; }
 }
 
 // The parse is bound by dependent memory round trips, so resident waves are throughput: the
 // register budget is capped for the occupancy named in each kernel (waves per SIMD).
-#define PARSE_KERNEL(NAME, S, DEV, WAVES, FAST) \
+#define PARSE_KERNEL(NAME, S, DEV, WAVES, FAST, REG, ...) \
     __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) NAME(PARSE_ARGS) { \
-        lz_parse_body<S, DEV, FAST>(PARSE_ARG_NAMES); }
-PARSE_KERNEL(k_lz_parse, 1, false, 8, false)
-PARSE_KERNEL(k_lz_parse_fast, 1, false, 8, true)
-PARSE_KERNEL(k_lz_parse_seg, 4, false, 8, false)
-PARSE_KERNEL(k_lz_parse_seg_fast, 4, false, 8, true)
+        lz_parse_body<S, DEV, FAST, REG, ##__VA_ARGS__>(PARSE_ARG_NAMES); }
+PARSE_KERNEL(k_lz_parse, 1, false, 8, false, false)
+PARSE_KERNEL(k_lz_parse_fast, 1, false, 8, true, false)
+PARSE_KERNEL(k_lz_parse_seg, 4, false, 8, false, false)
+PARSE_KERNEL(k_lz_parse_seg_fast, 4, false, 8, true, false)
+PARSE_KERNEL(k_lz_parse_regions, 1, false, 8, false, true)            // --out-aln: rows AND regions from one parse
+PARSE_KERNEL(k_lz_parse_fast_regions, 1, false, 8, true, true)
+PARSE_KERNEL(k_lz_parse_fast_fused, 1, false, 8, true, false, true)     // EXPERIMENT: probes read fused bucket slots (VG_LZ_INDEX=fused)
+// EXPERIMENT: the fused slots of a batch's references made FROM the ordinary index (a conversion pass, so that the probe
+// side can be measured before a build kernel writes this layout itself): one workgroup per reference, a thread per bucket
+__global__ void __launch_bounds__(256)
+k_index_fuse(const ref_desc* __restrict__ refs, int first_ref, int n_refs, const uint32_t* __restrict__ stab_pool, const uint32_t* __restrict__ sent_pool,
+             uint32_t* __restrict__ fslots) {
+    for (int r = blockIdx.x; r < n_refs; r += gridDim.x) {
+        const ref_desc rd = refs[first_ref + r];
+        const uint32_t* stab = stab_pool + rd.stab; const uint32_t* sent = sent_pool + rd.sent;
+        uint32_t* out = fslots + (size_t)(first_ref + r) * FUSED_SLOTS * 8;
+        for (int b = threadIdx.x; b < FUSED_SLOTS; b += blockDim.x) {
+            const uint32_t lo = b ? stab[b - 1] : 0u, hi = stab[b], n = hi - lo;
+            uint32_t w[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[j] = (uint32_t)j < n ? sent[lo + j] : ~0u;
+            if (n > 8) w[7] = 0x80000000u | (((n - 7) < 255u ? (n - 7) : 255u) << 23) | (lo + 7);
+            uint4 a = make_uint4(w[0], w[1], w[2], w[3]), c2 = make_uint4(w[4], w[5], w[6], w[7]);
+            __builtin_memcpy(out + (size_t)b * 8, &a, 16); __builtin_memcpy(out + (size_t)b * 8 + 4, &c2, 16);
+        }
+    }
+}
 #ifdef VG_DEV_KERNELS      // developer build only (VG_DEV=1 python -m vclust_amd.build --force): timing knobs and counters
-PARSE_KERNEL(k_lz_parse_dev, 1, true, 3, false)
+PARSE_KERNEL(k_lz_parse_dev, 1, true, 3, false, false)
 #endif
+
+// --out-aln, behind the parse: region counts of a batch's tasks in sorted-list order (the scan of them = every task's first
+// slot), and the move of every arena record to slot first[t] + k
+__global__ void __launch_bounds__(256)
+k_region_counts(const task_dev* __restrict__ tasks, int64_t n_tasks, const vg_pair_stat* __restrict__ stats, unsigned long long* __restrict__ cnt) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t <= n_tasks; t += (int64_t)gridDim.x * blockDim.x)
+        cnt[t] = t < n_tasks ? (unsigned long long)stats[tasks[t].out_idx].n_regions : 0ULL;
+}
+__global__ void __launch_bounds__(256)
+k_regions_place(const region_rec* __restrict__ arena, unsigned long long n_slots, const unsigned long long* __restrict__ first,
+                unsigned long long n_out, vg_region* __restrict__ out, unsigned int* __restrict__ bad) {
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += (unsigned long long)gridDim.x * blockDim.x) {
+        const region_rec r = arena[i];
+        if (r.task == ~0u) continue;
+        const unsigned long long at = first[r.t] + r.k;
+        if (at >= first[r.t + 1] || at >= n_out) { atomicAdd(bad, 1u); continue; }      // (rows and records of one parse cannot disagree: reported, never written)
+        vg_region o; o.task = r.task; o.qstart = r.qstart; o.qend = r.qend; o.rstart = r.rstart; o.rend = r.rend; o.n_match = r.n_match;
+        out[at] = o;
+    }
+}
 
 inline int grid_for(int64_t n, int block = 256, int max_blocks = 256 * 16) {
     int64_t b = (n + block - 1) / block; if (b < 1) b = 1;
@@ -1534,7 +1630,8 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
     // group tasks by reference ON THE DEVICE (k_task_count, a stable radix sort on the reference id, k_task_records):
     // device task records (query, ordinal of the reference among the references that have tasks, position in
     // the caller's list); the host gets the per-reference counts back and plans the batches from them.
-    std::vector<task_dev> td;                                 // host copy, fetched for --out-aln only
+    static const bool two_pass_regions = [] { const char* e = vg_dev_getenv("VG_LZ_REGIONS"); return e && !strcmp(e, "two-pass"); }();      // developer switch: the checker of the one-parse --out-aln
+    std::vector<task_dev> td;                                 // host copy, fetched for the two-pass --out-aln only
     std::vector<int64_t> ref_first((size_t)g->n + 1, 0);     // first sorted task of reference r
     std::vector<uint32_t> ref_ids;                            // references that have tasks, ascending
     int64_t q_max = 0; double q_sum = 0, bytes_alg_all = 0;
@@ -1566,7 +1663,7 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
         dbuf<uint32_t> d_ord((size_t)g->n); d_ord.upload(ord.data(), ord.size(), s);
         hipLaunchKernelGGL(k_task_records, dim3(grid_for(n_tasks)), dim3(256), 0, s, (const vg_task*)d_raw.p, (const uint32_t*)d_vals2.p, n_tasks,
                            (const uint32_t*)d_ord.p, d_tasks.p);
-        if (regions) { td.resize((size_t)n_tasks); d_tasks.download(td.data(), td.size(), s); }
+        if (regions && two_pass_regions) { td.resize((size_t)n_tasks); d_tasks.download(td.data(), td.size(), s); }
         VG_HIP(hipStreamSynchronize(s));                      // the scratch buffers go out of scope
     }
     vg_host_mark("lz: tasks grouped");
@@ -1591,6 +1688,7 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
     for (int i = 0; fast_params && i < g->n; ++i) if (g->has_n[(size_t)i] || g->len[(size_t)i] >= (1 << 22)) fast_params = false;   // (tag: 8 bits beside <= 24 position bits)
 
     dbuf<vg_pair_stat> d_stats((size_t)n_tasks);
+    dbuf<uint32_t> fused_pool;                        // EXPERIMENT VG_LZ_INDEX=fused: 32-byte bucket slots of all references of the call
     const bool want_regions = regions != nullptr;
     std::vector<vg_region> h_regions;                 // all kept regions, batch after batch
     std::vector<vg_pair_stat> h_stats;                // host copy of the rows (sizes the region buffer)
@@ -1638,69 +1736,144 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
         if (!(bi == 0 && plan->batch0_built)) lz_build_batch(g, p, *plan, bi, sb);
         {
             const int64_t nt = B.end - B.pos;
-            vg_prof_scope ps("lz_parse", B.bytes_alg);
+            std::optional<vg_prof_scope> ps; ps.emplace("lz_parse", B.bytes_alg);
             // Four waves per pair (segments) shorten the critical path: worth it when the launch would
             // otherwise last as long as its slowest pair -- few tasks, or queries several times longer than
             // the average one (mixed contig sets).  With many uniform tasks one wave per pair keeps every
             // SIMD busy without the duplicated stretches.
             const bool uneven = B.q_max * nt > 3 * B.q_sum;
-            const bool segments = seg_env ? atoi(seg_env) > 1 : ((n_tasks <= g_segment_task_limit && nt <= g_segment_task_limit) || uneven);
-            const unsigned long long* no_off = nullptr;
+            const bool segments = !want_regions && (seg_env ? atoi(seg_env) > 1 : ((n_tasks <= g_segment_task_limit && nt <= g_segment_task_limit) || uneven));
+            if (want_regions && !two_pass_regions) {
+                // --out-aln: rows and regions from ONE parse (one wave per pair: regions leave in query order).  The arena is
+                // sized from the batch (a chunk per task + a region per 256 query symbols: four times what diverged phage
+                // families produce); should a batch need more, the cursor says exactly how much and the batch is repeated.
+                const int64_t nblk = ((nt + 3) / 4 + 7) / 8 * 8;
+                unsigned long long cap = (unsigned long long)nt * RCHUNK + (unsigned long long)(B.q_sum / 256) + 1024;
+                static const long long cap_env = [] { const char* e = vg_dev_getenv("VG_LZ_ARENA"); return e ? atoll(e) : 0LL; }();      // developer switch (tests): a first arena of that many records
+                if (cap_env > 0) cap = (unsigned long long)cap_env;
+                dbuf<unsigned long long> d_cur(1), d_first((size_t)nt + 1);
+                dbuf<unsigned int> d_bad(1);
+                for (int attempt = 0;; ++attempt) {
+                    dbuf<region_rec> d_arena((size_t)cap);
+                    d_cur.zero(s); d_bad.zero(s);
+                    if (!ps) ps.emplace("lz_parse", B.bytes_alg);
+                    if (fast_params) hipLaunchKernelGGL(k_lz_parse_fast_regions, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p + B.pos, nt, d_refs.p, d_planes, g->d_nmask.p,
+                                       g->d_base_off.p, g->d_len.p, g->d_has_n.p, L.rr_pool.p, L.mask_pool.p, L.stab_pool.p,
+                                       L.sent_pool.p, P, d_stats.p, d_arena.p, d_cur.p, cap, (const uint32_t*)nullptr);
+                    else hipLaunchKernelGGL(k_lz_parse_regions, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p + B.pos, nt, d_refs.p, d_planes, g->d_nmask.p,
+                                       g->d_base_off.p, g->d_len.p, g->d_has_n.p, L.rr_pool.p, L.mask_pool.p, L.stab_pool.p,
+                                       L.sent_pool.p, P, d_stats.p, d_arena.p, d_cur.p, cap, (const uint32_t*)nullptr);
+                    ps.reset();                                   // (the scope times the parse; what follows is the placing pass)
+                    vg_prof_scope ps2("lz_regions_place", 0);
+                    hipLaunchKernelGGL(k_region_counts, dim3(grid_for(nt + 1)), dim3(256), 0, s, (const task_dev*)(d_tasks.p + B.pos), nt, (const vg_pair_stat*)d_stats.p, d_first.p);
+                    size_t tb = 0;
+                    VG_HIP(rocprim::exclusive_scan(nullptr, tb, d_first.p, d_first.p, 0ULL, (size_t)nt + 1, rocprim::plus<unsigned long long>(), s));
+                    dbuf<char> tmp(tb);
+                    VG_HIP(rocprim::exclusive_scan((void*)tmp.p, tb, d_first.p, d_first.p, 0ULL, (size_t)nt + 1, rocprim::plus<unsigned long long>(), s));
+                    unsigned long long used = 0, nr = 0;
+                    d_cur.download(&used, 1, s);
+                    VG_HIP(hipMemcpyAsync(&nr, d_first.p + nt, sizeof nr, hipMemcpyDeviceToHost, s));
+                    VG_HIP(hipStreamSynchronize(s));
+                    if (used > cap) {
+                        if (attempt) throw vg_error(VG_EHIP, "internal error: the region arena of the LZ parse overflowed twice");
+                        cap = used; continue;                     // (records beyond the arena were not written: once more, with room for all)
+                    }
+                    if (nr) {
+                        dbuf<vg_region> d_regions((size_t)nr);
+                        hipLaunchKernelGGL(k_regions_place, dim3(grid_for((int64_t)used)), dim3(256), 0, s, (const region_rec*)d_arena.p, used,
+                                           (const unsigned long long*)d_first.p, nr, d_regions.p, d_bad.p);
+                        unsigned int bad = 0; d_bad.download(&bad, 1, s);
+                        const size_t at = h_regions.size();
+                        h_regions.resize(at + (size_t)nr);
+                        d_regions.download(h_regions.data() + at, (size_t)nr, s);
+                        VG_HIP(hipStreamSynchronize(s));
+                        if (bad) throw vg_error(VG_EHIP, "internal error: region records of the LZ parse disagree with its rows");
+                    }
+                    break;
+                }
+                continue;
+            }
             if (segments && P.ablate == 0 && nt < (1LL << 31)) {
                 const int64_t nblk = (nt + 7) / 8 * 8;
                 if (fast_params) hipLaunchKernelGGL(k_lz_parse_seg_fast, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p + B.pos, nt, d_refs.p, d_planes, g->d_nmask.p,
                                    g->d_base_off.p, g->d_len.p, g->d_has_n.p, L.rr_pool.p, L.mask_pool.p, L.stab_pool.p,
-                                   L.sent_pool.p, P, d_stats.p, (vg_region*)nullptr, no_off);
+                                   L.sent_pool.p, P, d_stats.p, (region_rec*)nullptr, (unsigned long long*)nullptr, 0ULL, (const uint32_t*)nullptr);
                 else hipLaunchKernelGGL(k_lz_parse_seg, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p + B.pos, nt, d_refs.p, d_planes, g->d_nmask.p,
                                    g->d_base_off.p, g->d_len.p, g->d_has_n.p, L.rr_pool.p, L.mask_pool.p, L.stab_pool.p,
-                                   L.sent_pool.p, P, d_stats.p, (vg_region*)nullptr, no_off);
+                                   L.sent_pool.p, P, d_stats.p, (region_rec*)nullptr, (unsigned long long*)nullptr, 0ULL, (const uint32_t*)nullptr);
             } else {
                 const int64_t nblk = ((nt + 3) / 4 + 7) / 8 * 8;
 #ifdef VG_DEV_KERNELS
                 if (P.ablate) {
                     hipLaunchKernelGGL(k_lz_parse_dev, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p + B.pos, nt, d_refs.p, d_planes, g->d_nmask.p,
                                    g->d_base_off.p, g->d_len.p, g->d_has_n.p, L.rr_pool.p, L.mask_pool.p, L.stab_pool.p,
-                                   L.sent_pool.p, P, d_stats.p, (vg_region*)nullptr, no_off);
+                                   L.sent_pool.p, P, d_stats.p, (region_rec*)nullptr, (unsigned long long*)nullptr, 0ULL, (const uint32_t*)nullptr);
                 } else
 #endif
+                static const bool fused_index = [] { const char* e = vg_dev_getenv("VG_LZ_INDEX"); return e && !strcmp(e, "fused"); }();      // EXPERIMENT
+                if (fast_params && fused_index && p->msl == 7) {
+                    // EXPERIMENT (profiles/r06_parse_fused_slots.md): the probes read fixed 32-byte bucket slots made from the
+                    // ordinary index by a conversion pass of its own scope -- the probe side of a layout measured before any
+                    // build kernel writes it
+                    ps.reset();
+                    if (!fused_pool.p) fused_pool.alloc((size_t)plan->all_refs.size() * FUSED_SLOTS * 8 + 8);
+                    {
+                        vg_prof_scope pf("lz_index_fuse", (double)B.n_refs * FUSED_SLOTS * 32.0);
+                        hipLaunchKernelGGL(k_index_fuse, dim3((unsigned)std::min(B.n_refs, 256 * 16)), dim3(256), 0, s, (const ref_desc*)d_refs.p, B.first_ref, B.n_refs,
+                                           (const uint32_t*)L.stab_pool.p, (const uint32_t*)L.sent_pool.p, fused_pool.p);
+                    }
+                    ps.emplace("lz_parse", B.bytes_alg);
+                    hipLaunchKernelGGL(k_lz_parse_fast_fused, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p + B.pos, nt, d_refs.p, d_planes, g->d_nmask.p,
+                                   g->d_base_off.p, g->d_len.p, g->d_has_n.p, L.rr_pool.p, L.mask_pool.p, L.stab_pool.p,
+                                   L.sent_pool.p, P, d_stats.p, (region_rec*)nullptr, (unsigned long long*)nullptr, 0ULL, (const uint32_t*)fused_pool.p);
+                } else
                 if (fast_params) {
                     // (developer experiment: VG_LZ_OCC_KB reserves that much unused LDS per workgroup, i.e. caps the resident waves)
                     static const size_t occ_lds = [] { const char* e = vg_dev_getenv("VG_LZ_OCC_KB"); return e ? (size_t)atoi(e) * 1024 : (size_t)0; }();
                     hipLaunchKernelGGL(k_lz_parse_fast, dim3((unsigned)nblk), dim3(256), occ_lds, s, d_tasks.p + B.pos, nt, d_refs.p, d_planes, g->d_nmask.p,
                                    g->d_base_off.p, g->d_len.p, g->d_has_n.p, L.rr_pool.p, L.mask_pool.p, L.stab_pool.p,
-                                   L.sent_pool.p, P, d_stats.p, (vg_region*)nullptr, no_off);
+                                   L.sent_pool.p, P, d_stats.p, (region_rec*)nullptr, (unsigned long long*)nullptr, 0ULL, (const uint32_t*)nullptr);
                 } else {
                     hipLaunchKernelGGL(k_lz_parse, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p + B.pos, nt, d_refs.p, d_planes, g->d_nmask.p,
                                    g->d_base_off.p, g->d_len.p, g->d_has_n.p, L.rr_pool.p, L.mask_pool.p, L.stab_pool.p,
-                                   L.sent_pool.p, P, d_stats.p, (vg_region*)nullptr, no_off);
+                                   L.sent_pool.p, P, d_stats.p, (region_rec*)nullptr, (unsigned long long*)nullptr, 0ULL, (const uint32_t*)nullptr);
                 }
             }
             if (want_regions) {
-                // --out-aln: the rows just computed give every task's region count, so the region buffer is
-                // sized exactly (prefix sum) and every region has a fixed slot; the parse runs a second time
-                // and writes them (one wave per pair: regions are emitted in query order)
+                // VG_LZ_REGIONS=two-pass (developer switch, the checker of the one-parse path): the rows just computed give
+                // every task's region count, the parse runs a SECOND time into an arena that is known to fit, and the same
+                // placing pass orders the records
                 h_stats.resize((size_t)n_tasks);
                 d_stats.download(h_stats.data(), (size_t)n_tasks, s);
                 VG_HIP(hipStreamSynchronize(s));
                 std::vector<unsigned long long> off((size_t)nt + 1, 0);
                 if (first_pass.empty()) first_pass.resize((size_t)n_tasks);
+                unsigned long long chunks = 0;
                 for (int64_t t = 0; t < nt; ++t) {
                     const uint32_t oi = td[(size_t)(B.pos + t)].out_idx;
                     first_pass[oi] = h_stats[oi];
                     off[(size_t)t + 1] = off[(size_t)t] + h_stats[oi].n_regions;
+                    chunks += (h_stats[oi].n_regions + RCHUNK - 1) / RCHUNK;
                 }
                 const unsigned long long nr = off[(size_t)nt];
                 if (nr) {
-                    dbuf<unsigned long long> d_off((size_t)nt + 1); d_off.upload(off.data(), off.size(), s);
+                    const unsigned long long cap = chunks * RCHUNK;
+                    dbuf<unsigned long long> d_off((size_t)nt + 1), d_cur(1); d_off.upload(off.data(), off.size(), s);
+                    dbuf<unsigned int> d_bad(1); d_cur.zero(s); d_bad.zero(s);
+                    dbuf<region_rec> d_arena((size_t)cap);
                     dbuf<vg_region> d_regions((size_t)nr);
                     const int64_t nblk = ((nt + 3) / 4 + 7) / 8 * 8;
-                    hipLaunchKernelGGL(k_lz_parse, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p + B.pos, nt, d_refs.p, d_planes, g->d_nmask.p,
+                    hipLaunchKernelGGL(k_lz_parse_regions, dim3((unsigned)nblk), dim3(256), 0, s, d_tasks.p + B.pos, nt, d_refs.p, d_planes, g->d_nmask.p,
                                    g->d_base_off.p, g->d_len.p, g->d_has_n.p, L.rr_pool.p, L.mask_pool.p, L.stab_pool.p,
-                                   L.sent_pool.p, P, d_stats.p, d_regions.p, (const unsigned long long*)d_off.p);
+                                   L.sent_pool.p, P, d_stats.p, d_arena.p, d_cur.p, cap, (const uint32_t*)nullptr);
+                    hipLaunchKernelGGL(k_regions_place, dim3(grid_for((int64_t)cap)), dim3(256), 0, s, (const region_rec*)d_arena.p, cap,
+                                       (const unsigned long long*)d_off.p, nr, d_regions.p, d_bad.p);
+                    unsigned int bad = 0; d_bad.download(&bad, 1, s);
                     const size_t at = h_regions.size();
                     h_regions.resize(at + (size_t)nr);
                     d_regions.download(h_regions.data() + at, (size_t)nr, s);
                     VG_HIP(hipStreamSynchronize(s));
+                    if (bad) throw vg_error(VG_EHIP, "internal error: the region pass and the counting pass of the LZ parse disagree");
                 }
             }
         }
