@@ -5,11 +5,17 @@
 set -u
 REPO=$(pwd); OUT=$REPO/${1:-gpurun_out/r5_parse_pmc}; export NF=${2:-10000} REPS=1 VG_DEV_SWITCHES=1 TMPDIR=/tmp
 mkdir -p "$OUT"; cd /tmp
+# SHORT=1: the instruction counters and the L2 hit / miss / request counters only (two passes per variant)
+if [ "${SHORT:-0}" = 1 ]; then
+  SETS=("SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum")
+else
+  SETS=("SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
+        "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_SCA SQ_INSTS_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU" \
+        "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_STALL_sum TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum")
+fi
 for K in ${KERNELS:-default}; do
   i=0
-  for SET in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
-             "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_SCA SQ_INSTS_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU" \
-             "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_STALL_sum TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum"; do
+  for SET in "${SETS[@]}"; do
     i=$((i+1))
     IDX=default; KK=$K; if [ "$K" = fused ]; then IDX=fused; KK=default; fi
     VG_LZ_INDEX=$IDX VG_LZ_KERNEL=$KK rocprofv3 --pmc $SET --kernel-trace --output-format csv -d "$OUT/$K/set$i" -- python $REPO/tools/micro/parse_ab.py > "$OUT/$K.set$i.log" 2>&1

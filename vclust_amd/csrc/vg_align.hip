@@ -1764,12 +1764,13 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
                                        g->d_base_off.p, g->d_len.p, g->d_has_n.p, L.rr_pool.p, L.mask_pool.p, L.stab_pool.p,
                                        L.sent_pool.p, P, d_stats.p, d_arena.p, d_cur.p, cap, (const uint32_t*)nullptr);
                     ps.reset();                                   // (the scope times the parse; what follows is the placing pass)
-                    vg_prof_scope ps2("lz_regions_place", 0);
+                    std::optional<vg_prof_scope> ps2; ps2.emplace("lz_regions_place", 0);      // (its kernels, not the downloads)
                     hipLaunchKernelGGL(k_region_counts, dim3(grid_for(nt + 1)), dim3(256), 0, s, (const task_dev*)(d_tasks.p + B.pos), nt, (const vg_pair_stat*)d_stats.p, d_first.p);
                     size_t tb = 0;
                     VG_HIP(rocprim::exclusive_scan(nullptr, tb, d_first.p, d_first.p, 0ULL, (size_t)nt + 1, rocprim::plus<unsigned long long>(), s));
                     dbuf<char> tmp(tb);
                     VG_HIP(rocprim::exclusive_scan((void*)tmp.p, tb, d_first.p, d_first.p, 0ULL, (size_t)nt + 1, rocprim::plus<unsigned long long>(), s));
+                    ps2.reset();
                     unsigned long long used = 0, nr = 0;
                     d_cur.download(&used, 1, s);
                     VG_HIP(hipMemcpyAsync(&nr, d_first.p + nt, sizeof nr, hipMemcpyDeviceToHost, s));
@@ -1780,8 +1781,10 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
                     }
                     if (nr) {
                         dbuf<vg_region> d_regions((size_t)nr);
+                        ps2.emplace("lz_regions_place", (double)used * 32.0 + (double)nr * 24.0);
                         hipLaunchKernelGGL(k_regions_place, dim3(grid_for((int64_t)used)), dim3(256), 0, s, (const region_rec*)d_arena.p, used,
                                            (const unsigned long long*)d_first.p, nr, d_regions.p, d_bad.p);
+                        ps2.reset();
                         unsigned int bad = 0; d_bad.download(&bad, 1, s);
                         const size_t at = h_regions.size();
                         h_regions.resize(at + (size_t)nr);
