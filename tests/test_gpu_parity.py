@@ -346,9 +346,13 @@ def test_accuracy_against_known_truth():
     # the fitted constants on the HIP path = the CPU restatement, to the integer
     codes, offsets, names, prs = acc.make_set()
     assert acc.tani_hip(codes, offsets, names, prs[:6], {}) == acc.tani_oracle(codes, offsets, names, prs[:6], {})
+    # where the thin constants CAN act (full mutation model): they change rows, and tANI by far less than the criterion
+    sens = acc.knob_sensitivity()
+    assert any(v[0] > 0 for d in sens.values() for v in d.values()), 'no thin constant changed a single row: the sensitivity sets exercise nothing'
+    assert all(v[2] < acc.TOLERANCE for d in sens.values() for v in d.values()), sens
     out = ROOT / 'gpurun_out'
     try:
         out.mkdir(exist_ok=True)
-        (out / 'r06_accuracy_vs_truth.md').write_text(acc.markdown(res, False))
+        (out / 'r06_accuracy_vs_truth.md').write_text(acc.markdown(res, False, sens))
     except OSError:
         pass

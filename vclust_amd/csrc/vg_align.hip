@@ -1554,21 +1554,44 @@ struct lz_plan {
     std::vector<ref_desc> all_refs;           // indexed by the reference ordinal the task records carry
     dbuf<ref_desc> d_refs;
     lz_slot slot;
-    int64_t budget = 0; int mal = 0, msl = 0; const vg_genomes* g = nullptr;
+    int64_t budget = 0; int mal = 0, msl = 0; const vg_genomes* g = nullptr; int n_genomes = 0;
     bool batch0_built = false;
     hipEvent_t built_ev = nullptr;            // batch 0 was queued on another queue than the library's: vg_lz_align waits for it
     ~lz_plan() { if (built_ev) { (void)hipEventSynchronize(built_ev); (void)hipEventDestroy(built_ev); } }
 };
 int64_t lz_batch_budget(const vg_genomes* g, const vg_lz_params* p, const std::vector<uint32_t>& ref_ids);
 void lz_plan_references(const vg_genomes* g, const vg_lz_params* p, lz_plan& P);
+void lz_plan_alloc(lz_plan& P);
 void lz_build_batch(const vg_genomes* g, const vg_lz_params* p, lz_plan& P, size_t bi, hipStream_t sb);
 std::mutex g_prep_mu;
 std::unique_ptr<lz_plan> g_prepared;          // left by vg_lz_prepare for the next vg_lz_align
+// The HOST side of the last plan (batches, descriptors, build lists: 1-2 ms of bookkeeping per 100 000 references), kept
+// without its device pools: a long-lived process that aligns against the same references again -- the steps of a
+// resident service, bench.py -- takes it back instead of cutting the batches anew.  It depends on (set, parameters, budget,
+// reference ids) only; it is dropped with the set (vg_genomes_free), by vg_release_device_memory, and never kept by the
+// cold one-shot calls.  Results do not depend on it.
+std::unique_ptr<lz_plan> g_plan_cache;
+// (under g_prep_mu) the cached plan when it is the plan of exactly these references, with fresh pools; else nullptr
+std::unique_ptr<lz_plan> lz_take_cached_plan(const vg_genomes* g, const vg_lz_params* p, const std::vector<uint32_t>& ref_ids) {
+    if (!g_plan_cache) return nullptr;
+    lz_plan& Q = *g_plan_cache;
+    if (Q.g != g || Q.mal != p->mal || Q.msl != p->msl || Q.n_genomes != g->n || Q.ref_ids != ref_ids || Q.budget != lz_batch_budget(g, p, ref_ids)) { g_plan_cache.reset(); return nullptr; }
+    return std::move(g_plan_cache);
+}
+void lz_keep_plan_host_side(std::unique_ptr<lz_plan>& plan) {
+    if (!plan || vg_one_shot()) return;
+    plan->slot = lz_slot(); plan->d_refs.release();            // (the pools go back to the allocator: nothing of the device is pinned)
+    plan->batch0_built = false;
+    if (plan->built_ev) { (void)hipEventSynchronize(plan->built_ev); (void)hipEventDestroy(plan->built_ev); plan->built_ev = nullptr; }
+    std::lock_guard<std::mutex> lk(g_prep_mu);
+    g_plan_cache = std::move(plan);
+}
 }
 void vg_lz_drop_prepared(const vg_genomes* g) {
     std::lock_guard<std::mutex> lk(g_prep_mu);
     // (a build deferred to the next SpGEMM -- developer experiment -- holds a raw pointer to the plan: it goes with it)
     if (g_prepared && (!g || g_prepared->g == g)) { vg_set_spgemm_hook(nullptr); (void)hipStreamSynchronize(vg_stream()); g_prepared.reset(); }
+    if (g_plan_cache && (!g || g_plan_cache->g == g)) g_plan_cache.reset();
 }
 
 // The genome set as bit planes (what the parse reads its queries from): made once per resident set, on the library's
@@ -1711,9 +1734,13 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
         }
     }
     if (!plan) {
-        plan.reset(new lz_plan);
-        plan->g = g; plan->ref_ids = ref_ids;
-        lz_plan_references(g, p, *plan);
+        { std::lock_guard<std::mutex> lk(g_prep_mu); plan = lz_take_cached_plan(g, p, ref_ids); }
+        if (plan) lz_plan_alloc(*plan);
+        else {
+            plan.reset(new lz_plan);
+            plan->g = g; plan->ref_ids = ref_ids;
+            lz_plan_references(g, p, *plan);
+        }
     }
     if (plan->built_ev) VG_HIP(hipStreamWaitEvent(s, plan->built_ev, 0));
     std::vector<lz_batch>& batches = plan->batches;
@@ -1899,6 +1926,7 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
         if (!h_regions.empty()) memcpy(o, h_regions.data(), sizeof(vg_region) * h_regions.size());
         *regions = o; if (n_regions) *n_regions = (int64_t)h_regions.size();
     }
+    lz_keep_plan_host_side(plan);
     VG_API_END
 }
 
@@ -1933,7 +1961,7 @@ void lz_plan_references(const vg_genomes* g, const vg_lz_params* p, lz_plan& P) 
     hipStream_t s = vg_stream();
     const std::vector<uint32_t>& ref_ids = P.ref_ids;
     const int64_t stab_n = 1LL << (2 * p->msl);
-    P.mal = p->mal; P.msl = p->msl; P.g = g;
+    P.mal = p->mal; P.msl = p->msl; P.g = g; P.n_genomes = g->n;
     const int64_t batch_budget = P.budget = lz_batch_budget(g, p, ref_ids);
     std::vector<lz_batch>& batches = P.batches;
     std::vector<ref_desc>& all_refs = P.all_refs;
@@ -2009,8 +2037,14 @@ void lz_plan_references(const vg_genomes* g, const vg_lz_params* p, lz_plan& P) 
         }
     }
     vg_host_mark("lz plan: batches cut");
-    // ---- the reference descriptors of the whole call go up once; one set of index buffers, sized for the largest
-    // batch, is reused by every batch
+    lz_plan_alloc(P);
+}
+// the device side of a plan: the reference descriptors of the whole call go up once; one set of index buffers, sized for
+// the largest batch, is reused by every batch.  (Also what a plan taken from the host-side cache still needs.)
+void lz_plan_alloc(lz_plan& P) {
+    hipStream_t s = vg_stream();
+    std::vector<lz_batch>& batches = P.batches;
+    std::vector<ref_desc>& all_refs = P.all_refs;
     P.d_refs.alloc(std::max<size_t>(1, all_refs.size()));
     if (!all_refs.empty()) P.d_refs.upload(all_refs.data(), all_refs.size(), s);
     vg_host_mark("lz plan: descriptors queued");
@@ -2089,12 +2123,19 @@ extern "C" int vg_lz_prepare(vg_genomes* g, const vg_pair_count* pairs, int64_t 
         if (pairs[i].a >= (uint32_t)g->n || pairs[i].b >= (uint32_t)g->n) throw vg_error(VG_EINVAL, "pair id out of range");
         is_ref[pairs[i].a] = 1; is_ref[pairs[i].b] = 1;
     }
-    std::unique_ptr<lz_plan> plan(new lz_plan);
-    for (int i = 0; i < g->n; ++i) if (is_ref[(size_t)i]) plan->ref_ids.push_back((uint32_t)i);
-    plan->g = g;
+    std::vector<uint32_t> ref_ids;
+    for (int i = 0; i < g->n; ++i) if (is_ref[(size_t)i]) ref_ids.push_back((uint32_t)i);
     vg_host_mark("lz prepare: references listed");
-    lz_plan_references(g, p, *plan);
-    vg_host_mark("lz prepare: planned");
+    std::unique_ptr<lz_plan> plan;
+    { std::lock_guard<std::mutex> lk(g_prep_mu); plan = lz_take_cached_plan(g, p, ref_ids); }
+    if (plan) { lz_plan_alloc(*plan); vg_host_mark("lz prepare: plan of the last call taken over"); }
+    else {
+        plan.reset(new lz_plan);
+        plan->ref_ids = std::move(ref_ids);
+        plan->g = g;
+        lz_plan_references(g, p, *plan);
+        vg_host_mark("lz prepare: planned");
+    }
     // (developer experiment VG_LZ_PREPARE_QUEUE=own: the build runs on a queue of its own, beside whatever the caller
     // launches next on the library's queue -- a prefilter pass, if the references are known before it)
     static const bool own_queue = [] { const char* e = vg_dev_getenv("VG_LZ_PREPARE_QUEUE"); return e && !strcmp(e, "own"); }();
