@@ -113,6 +113,32 @@ def cpu_baseline(sample_families, members, length, seed, threads, k, min_kmers, 
                        'own CPU restatement (oracle/), not upstream: kmer-db / lz-ani sources are absent from the reference checkout')
 
 
+def host_cpus():
+    """CPUs this process may actually use: the smallest of the visible CPUs, the affinity mask and the cgroup CPU quota (a
+    container on a 256-thread host may be allowed 16: a team of 256 OpenMP threads then time-slices 16 cores)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            txt = open(path).read().split()
+            if path.endswith('cpu.max'):
+                if txt[0] != 'max':
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0]); per = float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+                if q > 0:
+                    quota = q / per
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return dict(visible=os.cpu_count() or 1, usable=n, cgroup_quota=round(quota, 2) if quota else None,
+                threads=max(1, min(n, 256, int(quota + 0.5) if quota else n)))
+
+
 def _run_traced(cmd, env):
     """One CLI process with the library's host-side phase marks (VG_HOST_TRACE): wall seconds, marks {name: ms since
     the previous mark}, and the two stretches the library cannot see (process start -> first mark, last mark -> gone)."""
@@ -323,6 +349,7 @@ def main():
     ap.add_argument('--min-kmers', type=int, default=None, help='default 20 (30 for contigs-1M, large.yml:65-72)')
     ap.add_argument('--min-ident', type=float, default=0.7)
     ap.add_argument('--cpu-sample-families', type=int, default=2000, help='families of the set the CPU baseline runs on (2 000 = 20 000 genomes: a fifth of phage-100k)')
+    ap.add_argument('--cpu-threads', type=int, default=0, help='OpenMP threads of the CPU baseline (default: what the process may use: affinity and cgroup quota)')
     ap.add_argument('--cpu-reps', type=int, default=3, help='repetitions of the CPU baseline (value = the median run)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-cli-wall', action='store_true')
@@ -469,8 +496,10 @@ def main():
                     others[name] = dict(error=str(exc))
         cpu = None
         if world == 1 and not args.no_cpu_baseline and wl['kind'] == 'families':
+            hc = host_cpus()
             cpu = cpu_baseline(min(args.cpu_sample_families, n_units), wl['members'], wl['length'], wl['seed'],
-                               min(os.cpu_count() or 1, 256), args.k, min_kmers, args.min_ident, n_units, reps=args.cpu_reps)
+                               args.cpu_threads or hc['threads'], args.k, min_kmers, args.min_ident, n_units, reps=args.cpu_reps)
+            cpu['host_cpus'] = hc
         out = {
             'metric': 'genome pairs/sec through prefilter+align (ani.tsv)',
             'value': round(n_pairs * args.steps / dt, 3),

@@ -10,7 +10,7 @@ OUT=$REPO/gpurun_out/pmc_${TAG}_${WL}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 export VG_DEV_SWITCHES=1 VG_PLACEMENT_TRIALS=1      # (one prefilter pass per step in the traces)
-CMD="python $REPO/bench.py --workload $WL --steps 1 --warmup 1 --no-cpu-baseline --no-cli-wall"
+CMD="python $REPO/bench.py --workload $WL --steps 1 --warmup 1 --no-cpu-baseline --no-cli-wall --no-other-workloads --no-out-aln"
 cd /tmp
 rocprofv3 -L > "$OUT/counters_available.txt" 2>&1
 i=0

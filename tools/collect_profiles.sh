@@ -14,7 +14,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 # (one prefilter pass per step in the traces: the placement trials of a process's first pass -- DESIGN section 4 -- are off)
 export VG_DEV_SWITCHES=1 VG_PLACEMENT_TRIALS=1
-CMD="python $REPO/bench.py --workload $WL ${N:+--count $N} --steps $STEPS --warmup 1 --no-cpu-baseline --no-cli-wall"
+CMD="python $REPO/bench.py --workload $WL ${N:+--count $N} --steps $STEPS --warmup 1 --no-cpu-baseline --no-cli-wall --no-other-workloads --no-out-aln"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $CMD > "$OUT/stats.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -- $CMD > "$OUT/fetch.log" 2>&1

@@ -11,7 +11,7 @@ a = ap.parse_args()
 rows = []
 for f in glob.glob(os.path.join(a.dir, '**', '*kernel_trace.csv'), recursive=True):
     for r in csv.DictReader(open(f, newline='')):
-        rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), re.sub(r'\(.*', '', r['Kernel_Name'])[:60]))
+        rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), (re.search(r'k_\w+(<[^>(]*>)?|rocprim::\w+|__amd_\w+', r['Kernel_Name']) or re.search(r'\S+', r['Kernel_Name'])).group(0)[:60]))
 rows.sort()
 starts = [i for i, r in enumerate(rows) if a.first in r[2] and (i == 0 or a.first not in rows[i - 1][2])]
 for si in starts[-a.passes:]:

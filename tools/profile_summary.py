@@ -68,7 +68,7 @@ def main():
         kernels[k] = dict(launches=max(nf, nw), FETCH_SIZE_KB_per_launch=round(fk, 1), WRITE_SIZE_KB_per_launch=round(wk, 1),
                           fetch_factor=fetch_factor(k), hbm_bytes_per_launch=round((fetch_factor(k) * fk + wk) * 1024),
                           hbm_bytes_per_launch_raw=round((fk + wk) * 1024))
-    doc = dict(workload=workload, command=f'python bench.py --workload ... --steps {steps} --warmup 1 --no-cpu-baseline --no-cli-wall (1 MI355X)',
+    doc = dict(workload=workload, command=f'python bench.py --workload ... --steps {steps} --warmup 1 --no-cpu-baseline --no-cli-wall --no-other-workloads --no-out-aln (1 MI355X)',
                steps_in_run=steps + 1,
                correction='separate --pmc passes for FETCH_SIZE and WRITE_SIZE (TCC slot limits); rocprofv3 units are KB; '
                           'hbm_bytes_per_launch = (fetch_factor x FETCH_SIZE + WRITE_SIZE) x 1024: factor 2 for streaming reads (gfx950 '
