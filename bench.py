@@ -258,6 +258,19 @@ def roofline_of(prof, steps, step_s, stage_bytes, b_pre, b_aln, world, workload_
         basis = f'SURVEY 8(d) bytes of the "{stage}" stage, per launch, / this kernel\'s HIP-event time on the library stream'
     achieved = alg / (avg_ms * 1e-3) / 1e9
     impl = dom['bytes'] / dom['launches']
+    # the same pricing for every scope of the step (which kernel is the longest flips between k_lz_parse_fast and k_bucket_runs
+    # with the placement state of the box: the reader finds both here whichever leads)
+    def priced(e):
+        kn, stg = SCOPES.get(e['name'], (e['name'], 'align'))
+        lps = e['launches'] / steps; a_ms = e['total_ms'] / e['launches']
+        s_ms = sum(v for k_, v in per_step.items() if SCOPES.get(k_, (k_, 'align'))[1] == stg)
+        # (a kernel of a stage that is ONE logical pass of SURVEY 8(d) implemented as several kernels is priced with its time share of the stage)
+        ab = stage_bytes[stg] / max(world, 1) * (e['total_ms'] / steps / s_ms) / lps
+        if stg == 'align' and e['name'] == 'lz_parse':
+            ab = stage_bytes[stg] / max(world, 1) / lps      # (the parse alone carries B_aln, as the headline kernel of rounds 2-5 did)
+        return dict(scope=e['name'], kernel=kn, stage=stg, avg_launch_ms=round(a_ms, 4), launches_per_step=round(lps, 3),
+                    algorithmic_bytes_per_launch=round(ab), achieved=round(ab / (a_ms * 1e-3) / 1e9, 3), frac=round(ab / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6))
+    all_kernels = [priced(e) for e in sorted((e for e in prof if e['name'] != 'exchange'), key=lambda e: -e['total_ms'])]
     traffic, src = pmc_traffic(workload_key, kern, launches_per_step) if world == 1 else (None, None)
     return dict(
         bound='hbm', kernel=kern, scope=dom['name'], achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit='GB/s',
@@ -268,6 +281,7 @@ def roofline_of(prof, steps, step_s, stage_bytes, b_pre, b_aln, world, workload_
                    frac=round(stage_frac, 6)),
         implementation_bytes_per_launch=round(impl),
         implementation_frac=round(impl / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+        kernels=all_kernels,
         ms_per_step_by_scope={k: round(v, 3) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
         host_ms_per_step=round(step_s * 1e3 - sum(per_step.values()), 3),
         path=dict(algorithmic_bytes_per_step=round(b_pre + b_aln), achieved=round((b_pre + b_aln) / step_s / 1e9, 3),
