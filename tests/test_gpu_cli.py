@@ -410,6 +410,40 @@ def test_eight_processes_write_the_files_of_one(tmp_path):
     assert filecmp.cmp(a1, b8, shallow=False)
 
 
+def test_ranks_that_plan_differently_are_stopped_before_the_exchange(tmp_path):
+    """How a rank cuts its shard (sliced scan or not, RANGE or HASH shards) follows from PROCESS-LOCAL knobs (vg_set_subshards,
+    VG_RANGE_SCAN, VG_INDEX_PATH).  Two ranks on a set that takes the sliced scan; rank 1 forces sub-shards, which switches ITS
+    sliced scan off: without the agreement in front of the exchange rank 0 would wait inside the all-to-all for a peer that
+    never comes.  Both ranks must return the same error, naming the cause, and the communicator must still work afterwards."""
+    script = tmp_path / 'plan_mismatch.py'
+    script.write_text("""
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+from vclust_amd import api, synth, distributed as D, _lib
+dist, dev = D.init_process_group()
+api.set_device(0)
+comm = D.make_comm(dist, dev)
+lib = _lib.load()
+codes, offsets, names = synth.make_families(100, 5, length=9000, seed=31)
+gs = api.GenomeSet.from_codes(codes, offsets, names)
+if dist.get_rank() == 1:
+    lib.vg_set_subshards(2)
+try:
+    D.prefilter_counts(gs, comm, 25, 1.0, min_shared=20); raise SystemExit('ranks with different plans went on')
+except _lib.VclustGpuError as e:
+    assert 'plan the prefilter shard differently' in str(e), str(e)
+lib.vg_set_subshards(0)
+sizes, pairs = D.prefilter_counts(gs, comm, 25, 1.0, min_shared=20)
+s0, p0 = gs.kmer_shared(k=25, min_shared=20)
+assert np.array_equal(sizes, s0) and np.array_equal(pairs, np.sort(p0, order=['a', 'b'])) and len(p0) > 500
+print('mismatch ok rank', dist.get_rank(), flush=True)
+comm.close(); dist.destroy_process_group()
+""" % str(ROOT))
+    p = _torchrun(2, script)
+    assert p.returncode == 0 and p.stdout.count('mismatch ok rank') == 2, (p.stdout[-500:], p.stderr[-3000:])
+
+
 def test_two_ranks_align_from_many_pairs(tmp_path):
     """vg_lz_align_pairs_sharded with more than 2^17 candidate pairs (80 families of 60 short genomes): the listing of a
     rank's tasks and their positions in the owners' lists runs on several host threads; every rank must still receive

@@ -152,6 +152,33 @@ def test_many_regions_per_task(tmp_path):
     assert sorted(open(tmp_path / 'aln.tsv').read().splitlines()) == sorted(open(tmp_path / 'o_aln.tsv').read().splitlines())
 
 
+def test_placement_trials_are_opt_in_and_change_nothing(tmp_path):
+    """vg_set_placement_trials: by default the first dense pass of a process over a large set (>= 2^30 padded bases) runs ONCE;
+    a process that opts in repeats it on fresh workspaces (the allocator trace shows the trials) and returns the same sizes and
+    pairs.  27 000 x 40 kb genomes, each variant in a process of its own."""
+    import os
+    import subprocess
+    code = r"""
+import sys, hashlib, numpy as np
+sys.path.insert(0, %r)
+from vclust_amd import api, synth
+codes, offsets, names, _ = synth.make_workload('phage-100k', 2700)
+gs = api.GenomeSet.from_codes(codes, offsets, names)
+api.set_placement_trials(int(sys.argv[1]))
+sizes, pairs = gs.kmer_shared(k=25, min_shared=20)
+pairs = np.sort(pairs, order=['a', 'b'])
+assert len(pairs) == 2700 * 45
+print('digest', hashlib.sha256(sizes.tobytes() + pairs.tobytes()).hexdigest())
+""" % str(ROOT)
+    out = {}
+    for trials in (1, 3):
+        p = subprocess.run([sys.executable, '-c', code, str(trials)], env=dict(os.environ, VG_ALLOC_TRACE='1'), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-2000:]
+        out[trials] = (p.stdout.strip().splitlines()[-1], p.stderr.count('[vg placement] trial'))
+    assert out[1][1] == 0 and out[3][1] >= 1, out          # (no trial unless asked for)
+    assert out[1][0] == out[3][0] and out[1][0].startswith('digest')
+
+
 def test_out_aln_one_parse_against_its_checkers(tmp_path):
     """--out-aln comes from ONE parse (regions written into chunks behind a cursor, placed once the rows are known).  Its
     checkers, each in a process of its own (developer switches are read once): the two-pass scheme it replaces (rows first,

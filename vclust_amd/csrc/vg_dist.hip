@@ -115,8 +115,9 @@ void gather_device(const vg_comm* c, const void* send, void* recv, int64_t bytes
 void agree(const vg_comm* c, int my_rc, const char* what) {
     std::vector<int32_t> all((size_t)c->world, 0); int32_t mine = my_rc;
     gather_host(c, &mine, all.data(), sizeof(int32_t));
+    // (the first failed rank names the error code; a rank that failed itself -- whether or not it is that first one -- says why)
     for (int r = 0; r < c->world; ++r) if (all[(size_t)r] != 0)
-        throw vg_error(all[(size_t)r], std::string(what) + ": rank " + std::to_string(r) + " failed" + (r == c->rank ? std::string(": ") + vg_last_error() : std::string()));
+        throw vg_error(all[(size_t)r], std::string(what) + ": rank " + std::to_string(r) + " failed" + (my_rc != 0 ? std::string(": ") + vg_last_error() : std::string()));
 }
 // the same agreement carrying a checksum every rank must hold alike (e.g. of an input list all ranks are to pass identically)
 void agree_same(const vg_comm* c, int my_rc, uint32_t checksum, const char* what, const char* mismatch) {
