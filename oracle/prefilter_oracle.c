@@ -235,7 +235,11 @@ int vo_shared_all_mt(const vo_genome_set* s, int k, double fraction, int64_t* se
         for (int t = 0; t < T; ++t) { int64_t c = cnt[(size_t)t * NP + p]; cnt[(size_t)t * NP + p] = total; total += c; }
     }
     pstart[NP] = total;
-    kg_t* a = (kg_t*)big_alloc(sizeof(kg_t) * (size_t)(total > 0 ? total : 1));
+    /* the (k-mer, genome) records are GBs: the block is kept between calls (returning 13 GB to the kernel and faulting them in
+     * again costs the port a second per call, serially, inside the timed stages -- the GPU side caches its blocks too) */
+    static kg_t* a_keep = NULL; static size_t a_cap = 0;
+    if ((size_t)total > a_cap) { free(a_keep); a_cap = (size_t)total + (size_t)total / 8 + 1; a_keep = (kg_t*)big_alloc(sizeof(kg_t) * a_cap); }
+    kg_t* a = a_keep;
     #pragma omp parallel num_threads(T)
     {
         const int t = omp_get_thread_num();
@@ -284,7 +288,7 @@ int vo_shared_all_mt(const vo_genome_set* s, int k, double fraction, int64_t* se
             }
         }
     }
-    free(a); free(pstart);
+    free(pstart);
     /* merge: entries dealt by a hash of the pair into T buckets, every bucket summed on its own thread */
     int64_t* bc = (int64_t*)calloc((size_t)T * T + 1, sizeof(int64_t));           /* [source thread][bucket] */
     #pragma omp parallel for schedule(static, 1) num_threads(T)

@@ -1778,6 +1778,14 @@ extern "C" int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks,
                 unsigned long long cap = (unsigned long long)nt * RCHUNK + (unsigned long long)(B.q_sum / 256) + 1024;
                 static const long long cap_env = [] { const char* e = vg_dev_getenv("VG_LZ_ARENA"); return e ? atoll(e) : 0LL; }();      // developer switch (tests): a first arena of that many records
                 if (cap_env > 0) cap = (unsigned long long)cap_env;
+                {   // (a generous first arena must not be what makes a large call fail: at most an eighth of the free device memory;
+                    // a batch that needs more says so through the cursor and is repeated with exactly what it needs)
+                    size_t fr = 0, tot = 0;
+                    if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr > 0) {
+                        const unsigned long long most = std::max<unsigned long long>((unsigned long long)nt * RCHUNK / 4 + 1024, (unsigned long long)(fr / 8) / sizeof(region_rec));
+                        if (cap > most) cap = most;
+                    } else (void)hipGetLastError();
+                }
                 dbuf<unsigned long long> d_cur(1), d_first((size_t)nt + 1);
                 dbuf<unsigned int> d_bad(1);
                 for (int attempt = 0;; ++attempt) {
