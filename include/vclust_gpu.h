@@ -151,7 +151,9 @@ typedef struct { int weak_seed_ratio, anchor_margin, seed_choice; } vg_lz_fit;
 void vg_set_lz_fit(const vg_lz_fit* f);
 
 /* LZ parse of every task on the GPU.  stats: n_tasks entries (caller-owned).
- * regions/n_regions may be NULL; otherwise all kept regions (unordered), vg_free(). */
+ * regions/n_regions may be NULL; otherwise all kept regions, vg_free(): rows and regions come from ONE parse (round 6); the
+ * regions of a task are contiguous and in query order (tasks in the library's reference-grouped order: sort on `task` if
+ * the caller's order is needed -- vg_write_ani does). */
 int vg_lz_align(vg_genomes* g, const vg_task* tasks, int64_t n_tasks, const vg_lz_params* p,
                 vg_pair_stat* stats, vg_region** regions, int64_t* n_regions);
 
